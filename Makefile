@@ -1,0 +1,28 @@
+# Build libdagr_hip.so (gfx950 only) and the CPU oracle.  No cmake: one hipcc invocation per TU.
+HIPCC      ?= hipcc
+ARCH       ?= gfx950
+# -ffp-contract=off: several integer decisions (voxel ids, denormalised coordinates) hang on
+# separately-rounded fp32 multiply/add/divide exactly as torch computes them (SURVEY QUIRK-2).
+HIPFLAGS   ?= --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Iinclude
+SRC        := $(wildcard dagr_amd/csrc/*.hip)
+OBJ        := $(patsubst dagr_amd/csrc/%.hip,build/%.o,$(SRC))
+LIB        := dagr_amd/lib/libdagr_hip.so
+
+all: $(LIB) oracle
+
+$(LIB): $(OBJ)
+	@mkdir -p dagr_amd/lib
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJ)
+
+build/%.o: dagr_amd/csrc/%.hip dagr_amd/csrc/common.hpp include/dagr_hip.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf build $(LIB)
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean

@@ -1,0 +1,82 @@
+"""ctypes binding of libdagr_hip.so (the C ABI declared in include/dagr_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a call fails, a
+RuntimeError is raised (the reference raises RuntimeError through AT_ASSERTM for bad inputs,
+``src/dagr/graph/ev_graph.cu:9-12``).  PyTorch only supplies device memory and streams here; every
+argument crossing this boundary is a raw pointer or an integer.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdagr_hip.so")
+
+c_void_p = ctypes.c_void_p
+c_i32 = ctypes.c_int32
+c_i64 = ctypes.c_int64
+c_size_t = ctypes.c_size_t
+c_float = ctypes.c_float
+
+
+class GraphDesc(ctypes.Structure):
+    """``dagr_graph_desc`` (include/dagr_hip.h)."""
+    _fields_ = [("width", c_i32), ("height", c_i32), ("batch_size", c_i32), ("max_neighbors", c_i32),
+                ("queue_size", c_i32), ("radius", c_i32), ("delta_t_us", c_i32), ("time_window", c_i32),
+                ("max_events", c_i64)]
+
+
+# name -> (restype, argtypes); the single source of truth for the symbols we bind.  The CPU-only
+# test-suite checks that every function declared in include/dagr_hip.h appears here and resolves.
+SIGNATURES = {
+    "dagr_last_error": (ctypes.c_char_p, []),
+    "dagr_version": (ctypes.c_int, []),
+    "dagr_device_count": (ctypes.c_int, []),
+    "dagr_format_events": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i32, c_i32, c_i32,
+                                          c_void_p, c_void_p, c_void_p]),
+    "dagr_graph_workspace_bytes": (c_size_t, [ctypes.POINTER(GraphDesc)]),
+    "dagr_graph_workspace_init": (ctypes.c_int, [ctypes.POINTER(GraphDesc), c_void_p, c_size_t, c_void_p]),
+    "dagr_graph_build_window": (ctypes.c_int, [ctypes.POINTER(GraphDesc), c_void_p, c_void_p, c_i32, c_void_p,
+                                               c_i32, c_i64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dagr_graph_status": (ctypes.c_int, [ctypes.POINTER(GraphDesc), c_void_p, ctypes.POINTER(c_i64),
+                                         ctypes.POINTER(c_i32), c_void_p]),
+    "dagr_scan_scratch_elems": (c_size_t, [c_i64]),
+    "dagr_graph_edge_index": (ctypes.c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p,
+                                             c_i64, c_void_p]),
+    "dagr_spiral_offsets": (ctypes.c_int, [c_i32, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libdagr_hip.so once; fail loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"dagr_amd: {LIB_PATH} not found -- build it with `make` (or __graft_entry__.build()). "
+                "There is no CPU fallback for the event-graph hot path.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().dagr_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libdagr_hip {what} failed (status {rc}): {msg}")
+
+
+def ptr(t):
+    """Raw device/host pointer of a torch tensor (or None)."""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def cur_stream(device=None):
+    """hipStream_t of torch's current stream, as void*."""
+    import torch
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,74 @@
+// common.hpp -- shared host/device helpers for libdagr_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "dagr_hip.h"
+
+namespace dagr {
+
+void set_error(const std::string &msg);
+
+#define DAGR_CHECK_ARG(cond, msg)                                             \
+    do {                                                                      \
+        if (!(cond)) {                                                        \
+            ::dagr::set_error(std::string(__func__) + ": " + (msg));          \
+            return DAGR_ERR_INVALID_ARG;                                      \
+        }                                                                     \
+    } while (0)
+
+#define DAGR_CHECK_HIP(expr)                                                  \
+    do {                                                                      \
+        hipError_t _e = (expr);                                               \
+        if (_e != hipSuccess) {                                               \
+            ::dagr::set_error(std::string(__func__) + ": " #expr " -> " +     \
+                              hipGetErrorString(_e));                         \
+            return DAGR_ERR_HIP;                                              \
+        }                                                                     \
+    } while (0)
+
+#define DAGR_CHECK_LAUNCH() DAGR_CHECK_HIP(hipGetLastError())
+
+constexpr int kBlock = 256;  // 4 waves of 64
+constexpr int kWave = 64;
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- device-side wave / block primitives (wave = 64 lanes) -------------------------------
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int n = __shfl_up(v, d, 64);
+        if (lane >= d) v += n;
+    }
+    return v;
+}
+
+// Exclusive scan over a 256-thread block. `smem` must hold >= 4 ints. Returns the exclusive
+// prefix of `v` for this thread and the block total in `total`.
+__device__ __forceinline__ int block_exclusive_scan(int v, int *smem, int &total) {
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    int incl = wave_inclusive_scan(v);
+    if (lane == 63) smem[wid] = incl;
+    __syncthreads();
+    int w0 = smem[0], w1 = smem[1], w2 = smem[2], w3 = smem[3];
+    __syncthreads();
+    int base = (wid > 0 ? w0 : 0) + (wid > 1 ? w1 : 0) + (wid > 2 ? w2 : 0);
+    total = w0 + w1 + w2 + w3;
+    return base + incl - v;
+}
+
+// ---- generic int32 exclusive scan over n elements (3 launches) --------------------------
+constexpr int kScanTile = 2048;  // elements per block: 256 threads x 8
+size_t scan_scratch_elems(int64_t n);
+// out[i] = sum_{j<i} in[j]; if zero_input, in[] is cleared after being consumed. in may alias out
+// only if !zero_input.  scratch: scan_scratch_elems(n) ints.
+hipError_t exclusive_scan_i32(int32_t *in, int32_t *out, int64_t n, int32_t *scratch, bool zero_input,
+                              hipStream_t stream);
+
+}  // namespace dagr

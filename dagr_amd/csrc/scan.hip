@@ -1,0 +1,97 @@
+// scan.hip -- int32 exclusive prefix sum (tile reduce -> scan of tile sums -> tile rescan).
+// Used for the per-pixel event offsets (P = B*H*W bins), the neighbour-list row pointers and the
+// occupied-voxel relabelling.  HBM traffic: 2 reads + 1 write of n ints (+ optional re-zero).
+#include "common.hpp"
+
+namespace dagr {
+
+size_t scan_scratch_elems(int64_t n) { return (size_t)ceil_div(n, kScanTile) + 8; }
+
+namespace {
+
+__global__ __launch_bounds__(kBlock) void scan_tile_reduce(const int32_t *__restrict__ in, int64_t n,
+                                                          int32_t *__restrict__ tile_sums) {
+    __shared__ int smem[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + threadIdx.x * 8;
+    int s = 0;
+    if (base + 8 <= n) {
+        const int4 a = *reinterpret_cast<const int4 *>(in + base);
+        const int4 b = *reinterpret_cast<const int4 *>(in + base + 4);
+        s = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+    } else {
+        for (int k = 0; k < 8; k++)
+            if (base + k < n) s += in[base + k];
+    }
+    int total;
+    block_exclusive_scan(s, smem, total);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+
+// single block: in-place exclusive scan of tile_sums[0..m)
+__global__ __launch_bounds__(kBlock) void scan_tile_sums(int32_t *__restrict__ tile_sums, int m) {
+    __shared__ int smem[4];
+    int carry = 0;
+    for (int base = 0; base < m; base += kBlock) {
+        int i = base + threadIdx.x;
+        int v = i < m ? tile_sums[i] : 0;
+        int total;
+        int ex = block_exclusive_scan(v, smem, total);
+        if (i < m) tile_sums[i] = carry + ex;
+        carry += total;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void scan_tile_apply(int32_t *__restrict__ in, int32_t *__restrict__ out,
+                                                         int64_t n, const int32_t *__restrict__ tile_sums,
+                                                         int zero_input) {
+    __shared__ int smem[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + threadIdx.x * 8;
+    int v[8];
+    const bool full = base + 8 <= n;
+    if (full) {
+        const int4 a = *reinterpret_cast<const int4 *>(in + base);
+        const int4 b = *reinterpret_cast<const int4 *>(in + base + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = (base + k < n) ? in[base + k] : 0;
+    }
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) s += v[k];
+    int total;
+    int ex = block_exclusive_scan(s, smem, total) + tile_sums[blockIdx.x];
+    int o[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { o[k] = ex; ex += v[k]; }
+    if (full) {
+        *reinterpret_cast<int4 *>(out + base) = make_int4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<int4 *>(out + base + 4) = make_int4(o[4], o[5], o[6], o[7]);
+        if (zero_input) {
+            *reinterpret_cast<int4 *>(in + base) = make_int4(0, 0, 0, 0);
+            *reinterpret_cast<int4 *>(in + base + 4) = make_int4(0, 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (base + k < n) {
+                out[base + k] = o[k];
+                if (zero_input) in[base + k] = 0;
+            }
+    }
+}
+
+}  // namespace
+
+hipError_t exclusive_scan_i32(int32_t *in, int32_t *out, int64_t n, int32_t *scratch, bool zero_input,
+                              hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    const int tiles = (int)ceil_div(n, kScanTile);
+    scan_tile_reduce<<<tiles, kBlock, 0, stream>>>(in, n, scratch);
+    scan_tile_sums<<<1, kBlock, 0, stream>>>(scratch, tiles);
+    scan_tile_apply<<<tiles, kBlock, 0, stream>>>(in, out, n, scratch, zero_input ? 1 : 0);
+    return hipGetLastError();
+}
+
+}  // namespace dagr

@@ -1,0 +1,205 @@
+"""Host-side mirror of the reference's graph builder classes over libdagr_hip.
+
+Mirrors ``src/dagr/graph/ev_graph.py`` (``AsyncGraph`` :18-103, ``SlidingWindowGraph`` :106-166):
+same constructor arguments, ``forward`` / ``reset`` / ``delete_nodes`` names and return shapes
+(``int64[2, E]`` in the order of ``edges[:, edges[1] >= 0]``, graph/utils.py:22).
+
+Difference by design: the reference keeps a ``B x Q x H x W`` FIFO volume and can append events to
+it call after call (``reset=False``); this round implements the *window* mode every evaluation
+script uses (``reset=True`` before each call: ``model/networks/dagr.py:74,90``,
+``model/layers/ev_tgn.py:45-49``), as one fused device pipeline (csrc/graph_build.hip).  Calling
+``forward`` twice without ``reset`` raises ``NotImplementedError`` instead of silently diverging.
+"""
+import ctypes
+
+import torch
+
+from .. import _lib
+
+
+class WindowGraphBuilder:
+    """Thin owner of a ``dagr_graph_desc`` + device workspace; neighbour-list output.
+
+    ``build(pos, batch)`` -> ``(nbr_src int32[N,K], nbr_code int16[N,K], deg int32[N])`` on the
+    current stream, no host synchronisation.
+    """
+
+    def __init__(self, width, height, batch_size, max_num_neighbors, max_queue_size, radius, delta_t_us,
+                 time_window=1000000, max_events=1 << 16, device="cuda"):
+        self.device = torch.device(device)
+        self.params = dict(width=int(width), height=int(height), batch_size=int(batch_size),
+                           max_neighbors=int(max_num_neighbors), queue_size=int(max_queue_size),
+                           radius=int(radius), delta_t_us=int(delta_t_us), time_window=int(time_window))
+        self.desc = None
+        self.workspace = None
+        self._alloc(int(max_events))
+
+    def _alloc(self, max_events):
+        L = _lib.lib()
+        self.desc = _lib.GraphDesc(max_events=max_events, **self.params)
+        nbytes = L.dagr_graph_workspace_bytes(ctypes.byref(self.desc))
+        if nbytes == 0:
+            raise RuntimeError("libdagr_hip: " + L.dagr_last_error().decode())
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        _lib.check(L.dagr_graph_workspace_init(ctypes.byref(self.desc), _lib.ptr(self.workspace), nbytes,
+                                               _lib.cur_stream(self.device)), "graph_workspace_init")
+
+    @property
+    def K(self):
+        return self.params["max_neighbors"]
+
+    def build(self, pos, batch, out=None):
+        N = int(pos.shape[0])
+        assert pos.is_cuda and pos.is_contiguous() and pos.shape[1] == 3
+        if pos.dtype not in (torch.float32, torch.int32):
+            raise RuntimeError(f"pos must be float32 (normalised) or int32 (x,y,t_us), got {pos.dtype}")
+        if batch.dtype not in (torch.int32, torch.int64):
+            raise RuntimeError(f"batch must be int32 or int64, got {batch.dtype}")
+        assert batch.is_cuda and batch.is_contiguous() and batch.shape[0] == N
+        if N > self.desc.max_events:  # grow like ev_graph.py:78-80
+            self._alloc(max(N, 2 * int(self.desc.max_events)))
+        K = self.K
+        if out is None:
+            nbr_src = torch.empty((N, K), dtype=torch.int32, device=self.device)
+            nbr_code = torch.empty((N, K), dtype=torch.int16, device=self.device)
+            deg = torch.empty((N,), dtype=torch.int32, device=self.device)
+        else:
+            nbr_src, nbr_code, deg = out
+        L = _lib.lib()
+        _lib.check(L.dagr_graph_build_window(ctypes.byref(self.desc), _lib.ptr(self.workspace), _lib.ptr(pos),
+                                             1 if pos.dtype == torch.int32 else 0, _lib.ptr(batch),
+                                             1 if batch.dtype == torch.int64 else 0, N, _lib.ptr(nbr_src),
+                                             _lib.ptr(nbr_code), _lib.ptr(deg), _lib.cur_stream(self.device)),
+                   "graph_build_window")
+        return nbr_src, nbr_code, deg
+
+    def status(self):
+        """(num_edges, flags) of the last build; synchronises the current stream."""
+        ne, fl = ctypes.c_int64(0), ctypes.c_int32(0)
+        _lib.check(_lib.lib().dagr_graph_status(ctypes.byref(self.desc), _lib.ptr(self.workspace),
+                                                ctypes.byref(ne), ctypes.byref(fl), _lib.cur_stream(self.device)),
+                   "graph_status")
+        return ne.value, fl.value
+
+    def edge_index(self, nbr_src, deg):
+        """Reference-shaped ``int64[2,E]`` (synchronises to learn E) + rowptr int32[N+1]."""
+        N = int(deg.shape[0])
+        if N == 0:
+            return torch.zeros((2, 0), dtype=torch.int64, device=self.device), \
+                torch.zeros((1,), dtype=torch.int32, device=self.device)
+        L = _lib.lib()
+        K = self.K
+        rowptr = torch.empty((N + 1,), dtype=torch.int32, device=self.device)
+        scratch = torch.empty((L.dagr_scan_scratch_elems(N + 1),), dtype=torch.int32, device=self.device)
+        stream = _lib.cur_stream(self.device)
+        _lib.check(L.dagr_graph_edge_index(_lib.ptr(nbr_src), _lib.ptr(deg), N, K, _lib.ptr(rowptr),
+                                           _lib.ptr(scratch), None, 0, stream), "graph_edge_index(rowptr)")
+        E = int(rowptr[-1].item())
+        edge_index = torch.empty((2, E), dtype=torch.int64, device=self.device)
+        if E > 0:
+            _lib.check(L.dagr_graph_edge_index(_lib.ptr(nbr_src), _lib.ptr(deg), N, K, _lib.ptr(rowptr),
+                                               _lib.ptr(scratch), _lib.ptr(edge_index), E, stream),
+                       "graph_edge_index")
+        return edge_index, rowptr
+
+
+class AsyncGraph:
+    """Mirror of ``ev_graph.py:18-103`` (window mode only, see module docstring)."""
+
+    def __init__(self, width=640, height=480, batch_size=1, max_num_neighbors=16, max_queue_size=512, radius=7,
+                 delta_t_us=600000):
+        self.radius = radius
+        self.delta_t_us = delta_t_us
+        self.max_index = 0
+        self.min_index = 0
+        self.max_queue_size = max_queue_size
+        self.max_num_neighbors = max_num_neighbors
+        self.width = width
+        self.height = height
+        self.batch_size = batch_size
+        self.device = None
+        self.edges = torch.zeros((2, 0), dtype=torch.long)
+        self.all_timestamps = torch.zeros((0,), dtype=torch.int32)
+        self._builder = None
+        self.last_neighbors = None  # (nbr_src, nbr_code, deg) of the last forward
+
+    def initialize(self, n_ev, device):
+        self.edges = torch.zeros((2, 0), dtype=torch.long, device=device)
+        self.all_timestamps = torch.zeros((0,), dtype=torch.int32, device=device)
+        self._builder = WindowGraphBuilder(self.width, self.height, self.batch_size, self.max_num_neighbors,
+                                           self.max_queue_size, int(self.radius), int(self.delta_t_us),
+                                           max_events=max(n_ev, 1024), device=device)
+
+    def reset(self):
+        self.edges = torch.zeros((2, 0), dtype=torch.long, device=self.device)
+        self.all_timestamps = torch.zeros((0,), dtype=torch.int32, device=self.device)
+        self.max_index = 0
+        self.min_index = 0
+
+    def _forward(self, batch, pos, collect_edges=True):
+        n_ev = len(batch)
+        if not batch.is_cuda:  # the reference asserts CUDA tensors (ev_graph.cu:9-11)
+            raise RuntimeError("batch must be a CUDA (HIP) tensor")
+        if self.device is None:
+            self.device = batch.device
+            self.initialize(n_ev, self.device)
+        if n_ev == 0:
+            return torch.zeros((2, 0), device=self.device, dtype=torch.int32)
+        assert type(batch) is torch.Tensor and batch.dtype == torch.int32, [type(batch), batch.dtype]
+        if self.max_index != 0:
+            raise NotImplementedError(
+                "incremental graph updates (forward without reset()) are not implemented; "
+                "the window engine rebuilds the graph per reset=True call")
+        pos = pos.int().contiguous()
+        self.all_timestamps = torch.cat([self.all_timestamps, pos[:, 2]])
+        self.max_index += n_ev
+        nbr_src, nbr_code, deg = self._builder.build(pos, batch.contiguous())
+        self.last_neighbors = (nbr_src, nbr_code, deg)
+        edge_indices, _ = self._builder.edge_index(nbr_src, deg)
+        if collect_edges:
+            self.edges = torch.cat([self.edges, edge_indices], dim=-1)
+        return edge_indices
+
+    def forward(self, batch, pos, collect_edges=True):
+        return self._forward(batch, pos, collect_edges=collect_edges)
+
+
+class SlidingWindowGraph(AsyncGraph):
+    """Mirror of ``ev_graph.py:106-166``."""
+
+    def __init__(self, width=640, height=480, batch_size=1, max_num_neighbors=16, max_queue_size=1024, radius=7,
+                 delta_t_us=600000):
+        AsyncGraph.__init__(self, width, height, batch_size, max_num_neighbors, max_queue_size, radius, delta_t_us)
+
+    @property
+    def init(self):
+        return len(self.all_timestamps) > 0
+
+    def delete_nodes(self, n_delete, delete_edges=True, return_edges=True):
+        self.all_timestamps = self.all_timestamps[n_delete:]
+        self.min_index += n_delete
+        deleted_edges = None
+        if delete_edges:
+            mask = (self.edges[0] < n_delete) | (self.edges[1] < n_delete)
+            deleted_edges = self.edges[:, mask].clone()
+            self.edges = self.edges[:, ~mask]
+        self.edges.add_(-n_delete)
+        if delete_edges and return_edges:
+            return deleted_edges
+
+    def forward(self, batch, pos, return_node_counts=False, return_total_edges=False, delete_nodes=True,
+                collect_edges=True):
+        n_delete = len(batch) if self.init else 0
+        edges = AsyncGraph._forward(self, batch, pos, collect_edges=collect_edges)
+        ret = [edges]
+        if return_total_edges:
+            total_edges = self.edges.clone()
+        if return_node_counts:
+            tot_nodes = len(self.all_timestamps)
+        if delete_nodes:
+            ret.append(self.delete_nodes(n_delete))
+        if return_total_edges:
+            ret.append(total_edges)
+        if return_node_counts:
+            ret.append([n_delete, len(batch), tot_nodes])
+        return ret[0] if len(ret) == 1 else ret

@@ -1,0 +1,69 @@
+"""Shared graph-builder test cases (inputs only) for the CPU and GPU suites and the golden maker."""
+import numpy as np
+
+from dagr_amd.utils import synthetic as syn
+
+
+def _case(name, x, y, t, b, W, H, B, r, dt, K=16, Q=128):
+    return dict(name=name, x=np.asarray(x, np.int32), y=np.asarray(y, np.int32), t=np.asarray(t, np.int32),
+                b=np.asarray(b, np.int32), W=W, H=H, B=B, r=r, dt=dt, K=K, Q=Q)
+
+
+def small_cases():
+    """Edge cases of SURVEY.md section 4 / 8d (S-edge-cases) + small random windows."""
+    cases = []
+    W, H = 64, 48
+    cases.append(_case("empty", [], [], [], [], W, H, 1, 4, 10000))
+    cases.append(_case("single", [5], [7], [1000000], [0], W, H, 1, 4, 10000))
+    cases.append(_case("single_b1", [5], [7], [1000000], [1], W, H, 2, 4, 10000))  # QUIRK-5
+    cases.append(_case("two_same_pixel", [5, 5], [7, 7], [999000, 1000000], [0, 0], W, H, 1, 4, 10000))
+    # dt boundary: 10000 is an edge, 10001 is not (ev_graph.cu:69)
+    cases.append(_case("dt_boundary", [10, 11, 12], [10, 10, 10], [989999, 990000, 1000000], [0, 0, 0], W, H, 1, 4, 10000))
+    # identical timestamps
+    rng = np.random.default_rng(3)
+    n = 200
+    cases.append(_case("same_t", rng.integers(0, W, n), rng.integers(0, H, n), np.full(n, 1000000), np.zeros(n), W, H, 1, 4, 10000))
+    # hot pixel: 300 events on one pixel (> Q=128) + neighbours around it
+    n = 300
+    t = np.sort(rng.integers(990000, 1000001, n + 40))
+    x = np.concatenate([np.full(n, 20), rng.integers(17, 24, 40)])
+    y = np.concatenate([np.full(n, 20), rng.integers(17, 24, 40)])
+    perm = rng.permutation(n + 40)
+    cases.append(_case("hot_pixel", x[perm], y[perm], t, np.zeros(n + 40), W, H, 1, 4, 10000))
+    # hot pixel with small FIFO (Q=8) and mid-size segments (exercise long path with Q < 64 < n)
+    cases.append(_case("hot_pixel_q8", x[perm], y[perm], t, np.zeros(n + 40), W, H, 1, 4, 10000, Q=8))
+    # border events
+    bx = np.array([0, 0, W - 1, W - 1, 0, W - 1, 1, W - 2] * 5)
+    by = np.array([0, H - 1, 0, H - 1, 1, H - 2, 0, H - 1] * 5)
+    cases.append(_case("border", bx, by, np.sort(rng.integers(995000, 1000001, len(bx))), np.zeros(len(bx)), W, H, 1, 4, 10000))
+    # dense blob: saturates K=16 in the first ring
+    n = 1500
+    cases.append(_case("dense_blob", rng.integers(28, 36, n), rng.integers(20, 28, n),
+                       np.sort(rng.integers(990000, 1000001, n)), np.zeros(n), W, H, 1, 4, 10000))
+    # unsorted timestamps (negative dt is admitted by the reference's `dt > delta` test)
+    n = 400
+    cases.append(_case("unsorted_t", rng.integers(0, W, n), rng.integers(0, H, n), rng.integers(950000, 1000001, n),
+                       np.zeros(n), W, H, 1, 4, 10000))
+    # small K, radius 0 and radius 1
+    n = 500
+    xx, yy, tt = rng.integers(0, 16, n), rng.integers(0, 16, n), np.sort(rng.integers(950000, 1000001, n))
+    cases.append(_case("k4", xx, yy, tt, np.zeros(n), 16, 16, 1, 2, 20000, K=4))
+    cases.append(_case("r0", xx, yy, tt, np.zeros(n), 16, 16, 1, 0, 20000))
+    cases.append(_case("r1", xx, yy, tt, np.zeros(n), 16, 16, 1, 1, 20000))
+    # batched random windows (B=3), DSEC-like geometry scaled down
+    x, y, t, p, b = syn.batch_windows(syn.uniform_window, 1500, 3, 80, 60, seed=11)
+    cases.append(_case("uniform_b3", x, y, t, b, 80, 60, 3, 4, 10000))
+    x, y, t, p, b = syn.batch_windows(syn.edges_window, 3000, 2, 80, 60, seed=21)
+    cases.append(_case("edges_b2", x, y, t, b, 80, 60, 2, 4, 10000))
+    return cases
+
+
+def medium_cases():
+    cases = []
+    x, y, t, p, b = syn.batch_windows(syn.uniform_window, 20000, 2, 320, 215, seed=101)
+    cases.append(_case("dsec_uniform_b2", x, y, t, b, 320, 215, 2, 4, 10000))
+    x, y, t, p, b = syn.batch_windows(syn.edges_window, 30000, 1, 320, 215, seed=201)
+    cases.append(_case("dsec_edges_b1", x, y, t, b, 320, 215, 1, 4, 10000))
+    x, y, t, p, b = syn.batch_windows(syn.edges_window, 50000, 1, 640, 480, seed=301)
+    cases.append(_case("vga_edges_b1", x, y, t, b, 640, 480, 1, 7, 10000))
+    return cases

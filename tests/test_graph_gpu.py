@@ -1,0 +1,80 @@
+"""GPU parity of the HIP window graph builder against the CPU oracle (bit-exact, integers)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import graph as og
+from tests.graph_cases import small_cases, medium_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_hip(case, use_float_pos=False):
+    from dagr_amd.graph.ev_graph import WindowGraphBuilder
+    from dagr_amd.utils.synthetic import format_data_np
+    dev = torch.device("cuda:0")
+    N = len(case["x"])
+    g = WindowGraphBuilder(case["W"], case["H"], case["B"], case["K"], case["Q"], case["r"], case["dt"],
+                           max_events=max(N, 16), device=dev)
+    if use_float_pos:
+        pos = torch.from_numpy(format_data_np(case["x"], case["y"], case["t"], case["W"], case["H"])).to(dev)
+    else:
+        pos = torch.from_numpy(np.stack([case["x"], case["y"], case["t"]], -1).astype(np.int32).reshape(N, 3)).to(dev)
+    batch = torch.from_numpy(case["b"].astype(np.int64)).to(dev)
+    outs = []
+    for rep in range(2):  # second build checks the "counters are zero again" invariant
+        nbr_src, nbr_code, deg = g.build(pos, batch)
+        ei, rowptr = g.edge_index(nbr_src, deg)
+        ne, flags = g.status()
+        outs.append((ei.cpu().numpy(), nbr_src.cpu().numpy(), nbr_code.cpu().numpy(), deg.cpu().numpy(), ne, flags))
+    assert (outs[0][0] == outs[1][0]).all()
+    return outs[1]
+
+
+def _oracle(case):
+    return og.build_window_graph(case["x"], case["y"], case["t"], case["b"], case["W"], case["H"], case["B"],
+                                 case["r"], case["dt"], K=case["K"], Q=case["Q"])
+
+
+def _check_codes(case, nbr_src, nbr_code, deg):
+    r = case["r"]
+    side = 2 * r + 1
+    for e in range(0, len(deg), max(1, len(deg) // 200)):
+        for j in range(deg[e]):
+            s = nbr_src[e, j]
+            dx, dy = case["x"][s] - case["x"][e], case["y"][s] - case["y"][e]
+            assert nbr_code[e, j] == (dx + r) * side + (dy + r)
+
+
+@pytest.mark.parametrize("case", small_cases(), ids=lambda c: c["name"])
+def test_small_cases_bit_exact(case):
+    ei, nbr_src, nbr_code, deg, ne, flags = _run_hip(case)
+    ref = _oracle(case)
+    assert flags == 0
+    assert ei.shape == ref.shape, (ei.shape, ref.shape)
+    assert (ei == ref).all()
+    assert ne == ref.shape[1]
+    _check_codes(case, nbr_src, nbr_code, deg)
+
+
+@pytest.mark.parametrize("case", medium_cases(), ids=lambda c: c["name"])
+def test_medium_cases_bit_exact_float_pos(case):
+    """normalised fp32 pos in (format_data -> denormalize_pos round trip fused in the kernel)."""
+    ei, nbr_src, nbr_code, deg, ne, flags = _run_hip(case, use_float_pos=True)
+    pos = og.denormalize_pos(__import__("dagr_amd.utils.synthetic", fromlist=["x"]).format_data_np(
+        case["x"], case["y"], case["t"], case["W"], case["H"]), case["W"], case["H"], 1000000)
+    ref = og.build_window_graph(pos[:, 0], pos[:, 1], pos[:, 2], case["b"], case["W"], case["H"], case["B"],
+                                case["r"], case["dt"], K=case["K"], Q=case["Q"])
+    assert flags == 0
+    assert ei.shape == ref.shape
+    assert (ei == ref).all()
+    # invariants stated by the reference (ev_tgn.py:52-54): src <= dst, dst non-decreasing
+    assert (ei[0] <= ei[1]).all() and (np.diff(ei[1]) >= 0).all()
+    assert deg.max() <= case["K"] and deg.min() >= 1
+
+
+def test_out_of_range_event_is_flagged():
+    case = small_cases()[3].copy()
+    case["x"] = case["x"].copy(); case["x"][0] = case["W"] + 3
+    ei, nbr_src, nbr_code, deg, ne, flags = _run_hip(case)
+    assert flags & 1
