@@ -18,6 +18,14 @@ c_size_t = ctypes.c_size_t
 c_float = ctypes.c_float
 
 
+class PoolDesc(ctypes.Structure):
+    """``dagr_pool_desc`` (include/dagr_hip.h)."""
+    _fields_ = [("batch_size", c_i32), ("channels", c_i32), ("gx", c_i32), ("gy", c_i32), ("vx", c_float),
+                ("vy", c_float), ("inv_w", c_float), ("inv_h", c_float), ("two_max", c_float), ("r00", c_float),
+                ("r02", c_float), ("r11", c_float), ("r12", c_float), ("rx", c_i32), ("ry", c_i32), ("aggr", c_i32),
+                ("append_pos", c_i32)]
+
+
 class GraphDesc(ctypes.Structure):
     """``dagr_graph_desc`` (include/dagr_hip.h)."""
     _fields_ = [("width", c_i32), ("height", c_i32), ("batch_size", c_i32), ("max_neighbors", c_i32),
@@ -43,6 +51,29 @@ SIGNATURES = {
     "dagr_graph_edge_index": (ctypes.c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p,
                                              c_i64, c_void_p]),
     "dagr_spiral_offsets": (ctypes.c_int, [c_i32, c_void_p, c_void_p]),
+    "dagr_spline_tap_window": (ctypes.c_int, [c_i32, c_float, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
+    "dagr_spline_l0_table": (ctypes.c_int, [c_i32, c_i32, c_float, c_float, c_i32, c_i32, c_i32, c_i32, c_void_p,
+                                            c_void_p, c_void_p]),
+    "dagr_spline_conv_l0": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i64, c_i32, c_i32, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_i32, c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_i32,
+                                           c_void_p, c_i32, c_void_p]),
+    "dagr_spline_tap_aggregate": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_i32,
+                                                 c_i32, c_void_p, c_i32, c_i32, c_i32, c_i32, c_float, c_float,
+                                                 c_void_p, c_i32, c_void_p]),
+    "dagr_pool_workspace_bytes": (c_size_t, [ctypes.POINTER(PoolDesc)]),
+    "dagr_pool_workspace_init": (ctypes.c_int, [ctypes.POINTER(PoolDesc), c_void_p, c_size_t, c_void_p]),
+    "dagr_pool_l0": (ctypes.c_int, [ctypes.POINTER(PoolDesc), c_void_p, ctypes.POINTER(GraphDesc), c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_void_p, c_i32, c_i64, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_void_p]),
+    "dagr_pool_csr": (ctypes.c_int, [ctypes.POINTER(PoolDesc), c_void_p, c_void_p, c_i32, c_void_p, c_i32, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_void_p]),
+    "dagr_pool_status": (ctypes.c_int, [ctypes.POINTER(PoolDesc), c_void_p, ctypes.POINTER(c_i32), c_void_p]),
+    "dagr_to_dense": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_i32, c_i32, c_void_p, c_void_p, c_float, c_float,
+                                     c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dagr_gemm_bias_act": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_i32, c_void_p, c_i32, c_void_p, c_void_p,
+                                          c_i32, c_i32, c_i32, c_i32, c_void_p]),
 }
 
 _lib = None

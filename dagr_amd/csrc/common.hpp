@@ -71,4 +71,7 @@ size_t scan_scratch_elems(int64_t n);
 hipError_t exclusive_scan_i32(int32_t *in, int32_t *out, int64_t n, int32_t *scratch, bool zero_input,
                               hipStream_t stream);
 
+
+void graph_ws_views(const dagr_graph_desc *desc, void *workspace, const int32_t **start, const int2 **slot_it);
+
 }  // namespace dagr

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kBlock) void k_order_long(int Q, const int32_t *__r
                                                       const int32_t *__restrict__ status) {
     __shared__ int hist[256];
     __shared__ int sel[kMaxQueue];
-    __shared__ int sh_prefix, sh_remaining, sh_nsel;
+    __shared__ int sh_prefix, sh_remaining, sh_nsel, sh_nrest;
     int n_long = status[0];
     if (n_long > long_cap) n_long = long_cap;
     for (int li = blockIdx.x; li < n_long; li += gridDim.x) {
@@ -203,11 +203,14 @@ __global__ __launch_bounds__(kBlock) void k_order_long(int Q, const int32_t *__r
             }
             thr = (unsigned)sh_prefix;
         }
-        if (threadIdx.x == 0) sh_nsel = 0;
+        if (threadIdx.x == 0) { sh_nsel = 0; sh_nrest = 0; }
         __syncthreads();
         for (int k = threadIdx.x; k < n; k += kBlock) {
             const int v = slot_tmp[a + k];
             if ((unsigned)v >= thr) sel[atomicAdd(&sh_nsel, 1)] = v;
+            // older events are invisible to the search (beyond the FIFO depth) but remain graph nodes:
+            // keep them, in any order, in the head of the segment (voxel pooling walks the segment)
+            else slot_it[a + atomicAdd(&sh_nrest, 1)] = make_int2(v, ev_t[v]);
         }
         __syncthreads();
         // sh_nsel == m (ids are unique)
@@ -217,7 +220,6 @@ __global__ __launch_bounds__(kBlock) void k_order_long(int Q, const int32_t *__r
             for (int j = 0; j < m; j++) rank += (sel[j] < v) ? 1 : 0;
             slot_it[a + (n - m) + rank] = make_int2(v, ev_t[v]);
         }
-        for (int k = threadIdx.x; k < n - m; k += kBlock) slot_it[a + k] = make_int2(-1, 0);  // never visible
         __syncthreads();
     }
 }
@@ -373,6 +375,16 @@ __global__ void k_format_events(const int16_t *__restrict__ xy, const int32_t *_
 }  // namespace dagr
 
 using namespace dagr;
+
+namespace dagr {
+// views into the builder workspace for the level-0 pooling kernel (pooling.hip)
+void graph_ws_views(const dagr_graph_desc *desc, void *workspace, const int32_t **start, const int2 **slot_it) {
+    GraphWs ws;
+    carve(*desc, (char *)workspace, &ws);
+    *start = ws.start;
+    *slot_it = ws.slot_it;
+}
+}  // namespace dagr
 
 extern "C" {
 

@@ -1,0 +1,601 @@
+// pooling.hip -- voxel-grid pooling of the event graph (fp32 features, exact integer decisions).
+//
+// Reference: Pooling.forward (src/dagr/model/layers/pooling.py:51-97) =
+//   torch_cluster.grid_cluster -> torch.unique relabel (consecutive_cluster :12-16, host sync) ->
+//   cluster[edge_index], drop self loops, unique(dim=-1) (host sync, lexicographic sort) ->
+//   scatter-mean of pos (pool_pos), scatter-max / mean of x, round_to_pixel (:47-49), T.Cartesian.
+//
+// Here (no host sync, nothing sorted):
+//   * cluster id = cx + gx*(cy + gy*(ct + b)) from the same fp32 divisions (IEEE, this TU is built with
+//     -ffp-contract=off; SURVEY QUIRK-2), including the t == 1.0 leak into the next sample's id range
+//     (QUIRK-1).  Ids index a dense table of T = gx*gy*(B+1) slots; an exclusive scan over the
+//     occupancy flags gives the consecutive ids torch.unique(sorted=True) would give.
+//   * reductions are order-independent and therefore deterministic: max through an order-preserving
+//     int mapping, means through exact 64-bit fixed-point sums (2^-40 for positions, 2^-32 for
+//     features) divided once at the end.
+//   * level 0 (N events): one wave per voxel walks the CSR-by-pixel index of the graph builder
+//     (pixel rows of a voxel are contiguous slot ranges) -- no atomics except for the rare leak events.
+//     Coarser levels (<= 2240*(B+1) nodes): atomics into the same accumulators.
+//   * coarse edges: per destination cluster a 64-slot open-addressing set of source clusters
+//     (atomicCAS), then one wave per cluster sorts its row; rows -> CSR; each edge gets the integer
+//     LUT coordinate the next SplineConv needs, computed with the reference's float formula
+//     (T.Cartesian then spline_conv.py:41-42).
+#include "common.hpp"
+
+namespace dagr {
+namespace {
+
+constexpr int kRowSlots = 64;           // coarse in-degree bound per cluster (flagged if exceeded)
+constexpr int kMaxChunks = 9;           // up to 144 feature channels at level 0
+constexpr double kPosScale = 1099511627776.0;  // 2^40
+constexpr double kFeatScale = 4294967296.0;    // 2^32
+
+struct PoolWs {
+    int32_t *occupied;   // [T+1] flags, zero between calls
+    int32_t *newid;      // [T+1] exclusive scan (newid[T] = number of clusters)
+    int32_t *scan_tmp;
+    long long *possum;   // [T][3] fixed point 2^-40
+    int32_t *cnt;        // [T]
+    int32_t *perm;       // [T] max member index (consecutive_cluster's perm on CPU)
+    long long *xacc;     // [T][C]: ordered-int max (low 32 bits) or fixed-point sum
+    int32_t *rows;       // [T][64] source-cluster sets, -1 = empty
+    int32_t *rowcnt;     // [T+1]
+    int32_t *status;     // [4]: 0 flags
+};
+
+__host__ __device__ inline size_t pool_carve(const dagr_pool_desc &d, char *base, PoolWs *ws) {
+    const int64_t T = (int64_t)d.gx * d.gy * (d.batch_size + 1);
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off = (off + bytes + 255) / 256 * 256;
+        return base ? base + o : nullptr;
+    };
+    PoolWs w;
+    w.occupied = (int32_t *)take((T + 9) * 4);
+    w.newid = (int32_t *)take((T + 9) * 4);
+    w.scan_tmp = (int32_t *)take(((T + 1 + kScanTile - 1) / kScanTile + 8) * 4);
+    w.possum = (long long *)take(T * 3 * 8);
+    w.cnt = (int32_t *)take(T * 4);
+    w.perm = (int32_t *)take(T * 4);
+    w.xacc = (long long *)take(T * (size_t)d.channels * 8);
+    w.rows = (int32_t *)take(T * (size_t)kRowSlots * 4);
+    w.rowcnt = (int32_t *)take((T + 9) * 4);
+    w.status = (int32_t *)take(16);
+    if (ws) *ws = w;
+    return off;
+}
+
+__device__ __forceinline__ int enc_f(float f) {
+    const int i = __float_as_int(f);
+    return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__device__ __forceinline__ float dec_f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+constexpr int kEncMin = (int)0x80000000;
+
+// grid_cluster (torch_cluster): trunc((pos - 0) / size) per dimension; time voxel = 1, batch voxel = 1.
+__device__ __forceinline__ int cluster_raw(float px, float py, float pt, int b, const dagr_pool_desc &d, bool &ok) {
+    const int cx = (int)(px / d.vx);
+    const int cy = (int)(py / d.vy);
+    const int ct = (int)(pt / 1.0f);
+    ok = (cx >= 0 && cx < d.gx && cy >= 0 && cy < d.gy && ct >= 0 && ct <= 1 && b >= 0 && b < d.batch_size);
+    return cx + d.gx * (cy + d.gy * (ct + b));
+}
+
+// torch.div(a, b, rounding_mode='floor') for floats (c10::div_floor_floating)
+__device__ __forceinline__ float div_floor(float a, float b) {
+    if (b == 0.0f) return a / b;
+    const float mod = fmodf(a, b);
+    float div = (a - mod) / b;
+    if ((mod != 0.0f) && ((b < 0.0f) != (mod < 0.0f))) div -= 1.0f;
+    float floordiv;
+    if (div != 0.0f) {
+        floordiv = floorf(div);
+        if (div - floordiv > 0.5f) floordiv += 1.0f;
+    } else {
+        floordiv = copysignf(0.0f, a / b);
+    }
+    return floordiv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic level: one thread per (node, channel)
+__global__ __launch_bounds__(kBlock) void k_pool_accumulate(dagr_pool_desc d, const int32_t *__restrict__ n_ptr,
+                                                           int n_max, const float *__restrict__ x, int ldx,
+                                                           const float *__restrict__ pos,
+                                                           const int32_t *__restrict__ batch, PoolWs ws,
+                                                           int32_t *__restrict__ cluster_raw_out) {
+    const int n_nodes = n_ptr ? min(*n_ptr, n_max) : n_max;
+    const int C = d.channels;
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int n = (int)(gid / C), ch = (int)(gid % C);
+    if (n >= n_nodes) return;
+    bool ok;
+    const int raw = cluster_raw(pos[3 * n], pos[3 * n + 1], pos[3 * n + 2], batch[n], d, ok);
+    if (!ok) {
+        if (ch == 0) { atomicOr(&ws.status[0], 1); cluster_raw_out[n] = -1; }
+        return;
+    }
+    const float v = x[(size_t)n * ldx + ch];
+    if (d.aggr == 0)
+        atomicMax(reinterpret_cast<int *>(ws.xacc + (size_t)raw * C + ch), enc_f(v));
+    else
+        atomicAdd(reinterpret_cast<unsigned long long *>(ws.xacc + (size_t)raw * C + ch),
+                  (unsigned long long)(long long)llrint((double)v * kFeatScale));
+    if (ch == 0) {
+        cluster_raw_out[n] = raw;
+        ws.occupied[raw] = 1;
+        atomicAdd(&ws.cnt[raw], 1);
+        atomicMax(&ws.perm[raw], n);
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            atomicAdd(reinterpret_cast<unsigned long long *>(ws.possum + (size_t)raw * 3 + k),
+                      (unsigned long long)(long long)llrint((double)pos[3 * n + k] * kPosScale));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// level 0: one wave per source voxel (cx, cy, b); 4 events in flight (16 lanes = 16 channels each)
+__global__ __launch_bounds__(kBlock) void k_pool_l0_cells(dagr_pool_desc d, int W, int H,
+                                                         const int32_t *__restrict__ xlo,  // [gx+1] pixel bounds
+                                                         const int32_t *__restrict__ ylo,  // [gy+1]
+                                                         const int32_t *__restrict__ start,
+                                                         const int2 *__restrict__ slot_it,
+                                                         const float *__restrict__ x, int ldx,
+                                                         const float *__restrict__ pos, PoolWs ws) {
+    const int lane = threadIdx.x & 63, l = lane & 15, g = lane >> 4;
+    const int cell = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int ncell = d.gx * d.gy * d.batch_size;
+    if (cell >= ncell) return;
+    const int cx = cell % d.gx, cy = (cell / d.gx) % d.gy, b = cell / (d.gx * d.gy);
+    const int x0 = xlo[cx], x1 = xlo[cx + 1] - 1, y0 = ylo[cy], y1 = ylo[cy + 1] - 1;
+    const int C = d.channels;
+    const int nchk = (C + 15) >> 4;
+    float mx[kMaxChunks];
+    double sm[kMaxChunks];
+#pragma unroll
+    for (int c = 0; c < kMaxChunks; c++) { mx[c] = -INFINITY; sm[c] = 0.0; }
+    long long ps0 = 0, ps1 = 0, ps2 = 0;
+    int cnt = 0, pmax = -1;
+    const int raw = cx + d.gx * (cy + d.gy * b);
+    if (x1 >= x0) {
+        for (int y = y0; y <= y1; y++) {
+            const int base = W * (y + H * b);
+            const int a = start[base + x0], bnd = start[base + x1 + 1];
+            for (int s = a + g; s < bnd; s += 4) {
+                const int id = slot_it[s].x;
+                const float px = pos[3 * (size_t)id], py = pos[3 * (size_t)id + 1], pt = pos[3 * (size_t)id + 2];
+                if (pt >= 1.0f) {
+                    // QUIRK-1: t == 1.0 lands in the next sample's id range -> rare, atomics
+                    const int rl = raw + d.gx * d.gy;
+#pragma unroll
+                    for (int c = 0; c < kMaxChunks; c++) {
+                        const int ch = c * 16 + l;
+                        if (c < nchk && ch < C) {
+                            const float v = x[(size_t)id * ldx + ch];
+                            if (d.aggr == 0)
+                                atomicMax(reinterpret_cast<int *>(ws.xacc + (size_t)rl * C + ch), enc_f(v));
+                            else
+                                atomicAdd(reinterpret_cast<unsigned long long *>(ws.xacc + (size_t)rl * C + ch),
+                                          (unsigned long long)(long long)llrint((double)v * kFeatScale));
+                        }
+                    }
+                    if (l == 0) {
+                        ws.occupied[rl] = 1;
+                        atomicAdd(&ws.cnt[rl], 1);
+                        atomicMax(&ws.perm[rl], id);
+                        atomicAdd(reinterpret_cast<unsigned long long *>(ws.possum + (size_t)rl * 3 + 0),
+                                  (unsigned long long)(long long)llrint((double)px * kPosScale));
+                        atomicAdd(reinterpret_cast<unsigned long long *>(ws.possum + (size_t)rl * 3 + 1),
+                                  (unsigned long long)(long long)llrint((double)py * kPosScale));
+                        atomicAdd(reinterpret_cast<unsigned long long *>(ws.possum + (size_t)rl * 3 + 2),
+                                  (unsigned long long)(long long)llrint((double)pt * kPosScale));
+                    }
+                    continue;
+                }
+#pragma unroll
+                for (int c = 0; c < kMaxChunks; c++) {
+                    const int ch = c * 16 + l;
+                    if (c < nchk && ch < C) {
+                        const float v = x[(size_t)id * ldx + ch];
+                        mx[c] = fmaxf(mx[c], v);
+                        sm[c] += (double)(long long)llrint((double)v * kFeatScale);
+                    }
+                }
+                ps0 += (long long)llrint((double)px * kPosScale);
+                ps1 += (long long)llrint((double)py * kPosScale);
+                ps2 += (long long)llrint((double)pt * kPosScale);
+                cnt++;
+                pmax = max(pmax, id);
+            }
+        }
+    }
+    // combine the 4 event groups (lanes l, l+16, l+32, l+48 hold the same channel)
+#pragma unroll
+    for (int off = 16; off < 64; off <<= 1) {
+#pragma unroll
+        for (int c = 0; c < kMaxChunks; c++) {
+            if (c < nchk) {
+                mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], off, 64));
+                sm[c] += __shfl_xor(sm[c], off, 64);
+            }
+        }
+        ps0 += __shfl_xor(ps0, off, 64);
+        ps1 += __shfl_xor(ps1, off, 64);
+        ps2 += __shfl_xor(ps2, off, 64);
+        cnt += __shfl_xor(cnt, off, 64);
+        pmax = max(pmax, __shfl_xor(pmax, off, 64));
+    }
+    if (cnt > 0 && g == 0) {
+        // this wave is the only non-atomic writer of slot `raw`; leak events of sample b-1 may hit it
+        // concurrently with atomics, so merge with atomics as well (exactly-once per channel).
+#pragma unroll
+        for (int c = 0; c < kMaxChunks; c++) {
+            const int ch = c * 16 + l;
+            if (c < nchk && ch < C) {
+                if (d.aggr == 0)
+                    atomicMax(reinterpret_cast<int *>(ws.xacc + (size_t)raw * C + ch), enc_f(mx[c]));
+                else
+                    atomicAdd(reinterpret_cast<unsigned long long *>(ws.xacc + (size_t)raw * C + ch),
+                              (unsigned long long)(long long)sm[c]);
+            }
+        }
+        if (l == 0) {
+            ws.occupied[raw] = 1;
+            atomicAdd(&ws.cnt[raw], cnt);
+            atomicMax(&ws.perm[raw], pmax);
+            atomicAdd(reinterpret_cast<unsigned long long *>(ws.possum + (size_t)raw * 3 + 0), (unsigned long long)ps0);
+            atomicAdd(reinterpret_cast<unsigned long long *>(ws.possum + (size_t)raw * 3 + 1), (unsigned long long)ps1);
+            atomicAdd(reinterpret_cast<unsigned long long *>(ws.possum + (size_t)raw * 3 + 2), (unsigned long long)ps2);
+        }
+    }
+}
+
+// level 0: cluster of every event (for the coarse edges)
+__global__ __launch_bounds__(kBlock) void k_pool_l0_event_cluster(dagr_pool_desc d, int N,
+                                                                 const float *__restrict__ pos,
+                                                                 const int32_t *__restrict__ batch32,
+                                                                 const int64_t *__restrict__ batch64,
+                                                                 int32_t *__restrict__ cluster_raw_out,
+                                                                 int32_t *__restrict__ status) {
+    const int n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    bool ok;
+    const int b = batch32 ? batch32[n] : (int)batch64[n];
+    const int raw = cluster_raw(pos[3 * (size_t)n], pos[3 * (size_t)n + 1], pos[3 * (size_t)n + 2], b, d, ok);
+    if (!ok) atomicOr(status, 1);
+    cluster_raw_out[n] = ok ? raw : -1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// finalize: one thread per (table slot, channel).  Writes the pooled node and re-arms the slot.
+__global__ __launch_bounds__(kBlock) void k_pool_finalize(dagr_pool_desc d, PoolWs ws,
+                                                         const int32_t *__restrict__ batch32,
+                                                         const int64_t *__restrict__ batch64,
+                                                         float *__restrict__ x_out, int ldo, int xoff,
+                                                         float *__restrict__ pos_out, int32_t *__restrict__ batch_out,
+                                                         int32_t *__restrict__ n_out) {
+    const int T = d.gx * d.gy * (d.batch_size + 1);
+    const int C = d.channels;
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int raw = (int)(gid / C), ch = (int)(gid % C);
+    if (raw >= T) return;
+    if (gid == 0) *n_out = ws.newid[T];
+    const int cnt = ws.cnt[raw];
+    long long *acc = ws.xacc + (size_t)raw * C + ch;
+    if (cnt > 0) {
+        const int c = ws.newid[raw];
+        float v;
+        if (d.aggr == 0) v = dec_f((int)(*acc));
+        else v = (float)(((double)(*acc) / kFeatScale) / (double)cnt);
+        x_out[(size_t)c * ldo + xoff + ch] = v;
+        if (ch == 0) {
+            float p[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) p[k] = (float)(((double)ws.possum[(size_t)raw * 3 + k] / kPosScale) / (double)cnt);
+            // round_to_pixel (pooling.py:47-49): floor((pos + 1e-5) / wh_inv) * wh_inv on x, y
+            p[0] = div_floor(p[0] + 1e-5f, d.inv_w) * d.inv_w;
+            p[1] = div_floor(p[1] + 1e-5f, d.inv_h) * d.inv_h;
+            pos_out[3 * c] = p[0]; pos_out[3 * c + 1] = p[1]; pos_out[3 * c + 2] = p[2];
+            const int pm = ws.perm[raw];
+            batch_out[c] = batch32 ? batch32[pm] : (int)batch64[pm];
+            // Net.forward concatenates pos[:, :2] to x before the next Layer (net.py:137-138): the
+            // caller asks for it by reserving the two columns after the C channels.
+            if (d.append_pos) {
+                x_out[(size_t)c * ldo + xoff + C] = p[0];
+                x_out[(size_t)c * ldo + xoff + C + 1] = p[1];
+            }
+        }
+    }
+    // re-arm this thread's own accumulator words for the next window
+    *acc = 0ll;
+    if (d.aggr == 0) *reinterpret_cast<int *>(acc) = kEncMin;
+    if (ch == 0) {
+        ws.possum[(size_t)raw * 3] = 0; ws.possum[(size_t)raw * 3 + 1] = 0; ws.possum[(size_t)raw * 3 + 2] = 0;
+    }
+}
+
+__global__ void k_fill_enc_min(long long *p, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { p[i] = 0ll; *reinterpret_cast<int *>(p + i) = kEncMin; }
+}
+
+// second half of the re-arm (cnt / perm are read by every channel thread above, so clear them later)
+__global__ __launch_bounds__(kBlock) void k_pool_rearm(int T, PoolWs ws) {
+    const int raw = blockIdx.x * kBlock + threadIdx.x;
+    if (raw >= T) return;
+    ws.cnt[raw] = 0;
+    ws.perm[raw] = -1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// coarse edges: insert (source cluster -> destination cluster) into the destination's slot set
+__device__ __forceinline__ void row_insert(int32_t *__restrict__ rows, int cd, int cs, int32_t *status) {
+    int32_t *row = rows + (size_t)cd * kRowSlots;
+    unsigned h = ((unsigned)cs * 2654435761u) >> 26;  // 6 bits
+    for (int probe = 0; probe < kRowSlots; probe++) {
+        const int cur = row[h];
+        if (cur == cs) return;
+        if (cur == -1) {
+            const int old = atomicCAS(&row[h], -1, cs);
+            if (old == -1 || old == cs) return;
+        }
+        h = (h + 1) & (kRowSlots - 1);
+    }
+    atomicOr(status, 2);  // more than 64 distinct sources
+}
+
+// level 0: fixed-stride neighbour lists; one thread per slot
+__global__ __launch_bounds__(kBlock) void k_coarse_edges_ell(int N, int K, const int32_t *__restrict__ nbr_src,
+                                                            const int32_t *__restrict__ deg,
+                                                            const int32_t *__restrict__ cluster_raw_in,
+                                                            const int32_t *__restrict__ newid, int32_t *rows,
+                                                            int32_t *status) {
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int n = (int)(gid / K), j = (int)(gid % K);
+    if (n >= N || j >= deg[n]) return;
+    const int rd = cluster_raw_in[n];
+    const int rs = cluster_raw_in[nbr_src[(size_t)n * K + j]];
+    if (rd == rs || rd < 0 || rs < 0) return;
+    row_insert(rows, newid[rd], newid[rs], status);
+}
+
+// pooled levels: CSR; one thread per destination node
+__global__ __launch_bounds__(kBlock) void k_coarse_edges_csr(const int32_t *__restrict__ n_ptr, int n_max,
+                                                            const int32_t *__restrict__ rowptr,
+                                                            const int32_t *__restrict__ col,
+                                                            const int32_t *__restrict__ cluster_raw_in,
+                                                            const int32_t *__restrict__ newid, int32_t *rows,
+                                                            int32_t *status) {
+    const int n_nodes = n_ptr ? min(*n_ptr, n_max) : n_max;
+    const int n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= n_nodes) return;
+    const int rd = cluster_raw_in[n];
+    if (rd < 0) return;
+    const int cd = newid[rd];
+    for (int e = rowptr[n]; e < rowptr[n + 1]; e++) {
+        const int rs = cluster_raw_in[col[e]];
+        if (rs == rd || rs < 0) continue;
+        row_insert(rows, cd, newid[rs], status);
+    }
+}
+
+// one wave per cluster row: sort the occupied slots ascending, count them
+__global__ __launch_bounds__(kBlock) void k_rows_sort(int T, const int32_t *__restrict__ newid, int32_t *rows,
+                                                     int32_t *__restrict__ rowcnt) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (c > T) return;
+    const int nc = newid[T];
+    if (c >= nc) {
+        if (lane == 0 && c <= T) rowcnt[c] = 0;
+        return;
+    }
+    int32_t *row = rows + (size_t)c * kRowSlots;
+    const int v = row[lane];
+    const bool valid = v >= 0;
+    int rank = 0;
+    for (int k = 0; k < 64; k++) {
+        const int o = __shfl(v, k, 64);
+        rank += (o >= 0 && o < v) ? 1 : 0;
+    }
+    const int count = __popcll(__ballot(valid));
+    row[lane] = -1;
+    __builtin_amdgcn_wave_barrier();
+    if (valid) row[rank] = v;   // all reads happened before (shuffles above), same-wave ordering
+    if (lane == 0) rowcnt[c] = count;
+}
+
+// rows -> CSR + LUT coordinates; re-arms the slot sets
+__global__ __launch_bounds__(kBlock) void k_rows_emit(dagr_pool_desc d, int T, const int32_t *__restrict__ newid,
+                                                     int32_t *rows, const int32_t *__restrict__ rowptr,
+                                                     const float *__restrict__ pos_out, int32_t *__restrict__ col,
+                                                     int32_t *__restrict__ code, int32_t *__restrict__ e_out,
+                                                     int e_cap, int32_t *status) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int nc = newid[T];
+    if (c == 0 && lane == 0) *e_out = rowptr[nc];
+    if (c >= nc) return;
+    int32_t *row = rows + (size_t)c * kRowSlots;
+    const int cnt = rowptr[c + 1] - rowptr[c];
+    const int v = row[lane];
+    row[lane] = -1;
+    if (lane >= cnt) return;
+    const int o = rowptr[c] + lane;
+    if (o >= e_cap) { atomicOr(status, 4); return; }
+    // T.Cartesian(norm=True, max_value=M): (pos[src] - pos[dst]) / (2M) + 0.5 ; then the LUT index
+    // of message_lut (spline_conv.py:41-42): trunc(attr * R00 + R02 + 1e-3)
+    const float ax = (pos_out[3 * v] - pos_out[3 * c]) / d.two_max + 0.5f;
+    const float ay = (pos_out[3 * v + 1] - pos_out[3 * c + 1]) / d.two_max + 0.5f;
+    const int ix = (int)((ax * d.r00 + d.r02) + 1e-3f);
+    const int iy = (int)((ay * d.r11 + d.r12) + 1e-3f);
+    if (ix < 0 || ix > 2 * d.rx || iy < 0 || iy > 2 * d.ry) atomicOr(status, 8);
+    col[o] = v;
+    code[o] = (ix & 0xffff) | (iy << 16);
+}
+
+}  // namespace
+}  // namespace dagr
+
+using namespace dagr;
+
+namespace {
+int validate_pool(const dagr_pool_desc *d) {
+    DAGR_CHECK_ARG(d != nullptr, "desc is NULL");
+    DAGR_CHECK_ARG(d->gx > 0 && d->gy > 0 && d->batch_size > 0 && d->channels > 0, "bad sizes");
+    DAGR_CHECK_ARG((int64_t)d->gx * d->gy * (d->batch_size + 1) < (1 << 28), "voxel table too large");
+    DAGR_CHECK_ARG(d->aggr == 0 || d->aggr == 1, "aggr must be 0 (max) or 1 (mean)");
+    DAGR_CHECK_ARG(d->vx > 0 && d->vy > 0 && d->two_max > 0, "bad voxel size / cartesian max");
+    return DAGR_OK;
+}
+}  // namespace
+
+extern "C" {
+
+size_t dagr_pool_workspace_bytes(const dagr_pool_desc *desc) {
+    if (validate_pool(desc) != DAGR_OK) return 0;
+    return pool_carve(*desc, nullptr, nullptr);
+}
+
+int dagr_pool_workspace_init(const dagr_pool_desc *desc, void *workspace, size_t bytes, void *stream_) {
+    int rc = validate_pool(desc);
+    if (rc != DAGR_OK) return rc;
+    DAGR_CHECK_ARG(workspace, "workspace is NULL");
+    PoolWs ws;
+    if (pool_carve(*desc, (char *)workspace, &ws) > bytes) {
+        set_error("dagr_pool_workspace_init: workspace too small");
+        return DAGR_ERR_WORKSPACE;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t T = (int64_t)desc->gx * desc->gy * (desc->batch_size + 1);
+    DAGR_CHECK_HIP(hipMemsetAsync(ws.occupied, 0, (T + 9) * 4, stream));
+    DAGR_CHECK_HIP(hipMemsetAsync(ws.newid, 0, (T + 9) * 4, stream));
+    DAGR_CHECK_HIP(hipMemsetAsync(ws.possum, 0, T * 3 * 8, stream));
+    DAGR_CHECK_HIP(hipMemsetAsync(ws.cnt, 0, T * 4, stream));
+    DAGR_CHECK_HIP(hipMemsetAsync(ws.perm, 0xff, T * 4, stream));
+    DAGR_CHECK_HIP(hipMemsetAsync(ws.rows, 0xff, T * (size_t)kRowSlots * 4, stream));
+    DAGR_CHECK_HIP(hipMemsetAsync(ws.rowcnt, 0, (T + 9) * 4, stream));
+    DAGR_CHECK_HIP(hipMemsetAsync(ws.status, 0, 16, stream));
+    // feature accumulators: ordered-int minimum for max, 0 for mean
+    {
+        const size_t n = T * (size_t)desc->channels;
+        if (desc->aggr == 0) {
+            k_fill_enc_min<<<(unsigned)ceil_div(n, 256), 256, 0, stream>>>(ws.xacc, n);
+            DAGR_CHECK_LAUNCH();
+        } else {
+            DAGR_CHECK_HIP(hipMemsetAsync(ws.xacc, 0, n * 8, stream));
+        }
+    }
+    return DAGR_OK;
+}
+
+
+static int pool_tail(const dagr_pool_desc *d, PoolWs &ws, const int32_t *batch32, const int64_t *batch64,
+                     float *x_out, int ldo, int xoff, float *pos_out, int32_t *batch_out, int32_t *n_out,
+                     int32_t *rowptr_out, int32_t *col_out, int32_t *code_out, int32_t *e_out, int e_cap,
+                     hipStream_t stream) {
+    const int T = d->gx * d->gy * (d->batch_size + 1);
+    const int wpb = kBlock / 64;
+    k_rows_sort<<<(unsigned)ceil_div(T + 1, wpb), kBlock, 0, stream>>>(T, ws.newid, ws.rows, ws.rowcnt);
+    DAGR_CHECK_LAUNCH();
+    DAGR_CHECK_HIP(exclusive_scan_i32(ws.rowcnt, rowptr_out, T + 1, ws.scan_tmp, false, stream));
+    k_rows_emit<<<(unsigned)ceil_div(T, wpb), kBlock, 0, stream>>>(*d, T, ws.newid, ws.rows, rowptr_out, pos_out,
+                                                                  col_out, code_out, e_out, e_cap, ws.status);
+    DAGR_CHECK_LAUNCH();
+    k_pool_rearm<<<(unsigned)ceil_div(T, kBlock), kBlock, 0, stream>>>(T, ws);
+    DAGR_CHECK_LAUNCH();
+    (void)batch32; (void)batch64; (void)x_out; (void)ldo; (void)xoff; (void)batch_out; (void)n_out;
+    return DAGR_OK;
+}
+
+int dagr_pool_l0(const dagr_pool_desc *desc, void *pool_ws, const dagr_graph_desc *gdesc, void *graph_ws,
+                 const int32_t *xlo, const int32_t *ylo, const float *x, int32_t ldx, const float *pos,
+                 const void *batch, int32_t batch_is_int64, int64_t N, const int32_t *nbr_src, const int32_t *deg,
+                 int32_t *cluster_scratch, float *x_out, int32_t ldo, int32_t xoff, float *pos_out,
+                 int32_t *batch_out, int32_t *n_out, int32_t *rowptr_out, int32_t *col_out, int32_t *code_out,
+                 int32_t *e_out, int32_t e_cap, void *stream_) {
+    int rc = validate_pool(desc);
+    if (rc != DAGR_OK) return rc;
+    DAGR_CHECK_ARG(pool_ws && gdesc && graph_ws, "NULL workspace/desc");
+    DAGR_CHECK_ARG(desc->channels <= 16 * kMaxChunks, "too many channels for the level-0 pooling kernel");
+    DAGR_CHECK_ARG(desc->batch_size == gdesc->batch_size, "batch_size mismatch");
+    DAGR_CHECK_ARG(n_out && rowptr_out && e_out, "NULL output");
+    hipStream_t stream = (hipStream_t)stream_;
+    PoolWs ws;
+    pool_carve(*desc, (char *)pool_ws, &ws);
+    const int T = desc->gx * desc->gy * (desc->batch_size + 1);
+    const int32_t *b32 = batch_is_int64 ? nullptr : (const int32_t *)batch;
+    const int64_t *b64 = batch_is_int64 ? (const int64_t *)batch : nullptr;
+    if (N > 0) {
+        DAGR_CHECK_ARG(xlo && ylo && x && pos && batch && nbr_src && deg && cluster_scratch, "NULL input");
+        const int32_t *start; const int2 *slot_it;
+        graph_ws_views(gdesc, graph_ws, &start, &slot_it);
+        const int ncell = desc->gx * desc->gy * desc->batch_size;
+        k_pool_l0_cells<<<(unsigned)ceil_div(ncell, kBlock / 64), kBlock, 0, stream>>>(
+            *desc, gdesc->width, gdesc->height, xlo, ylo, start, slot_it, x, ldx, pos, ws);
+        DAGR_CHECK_LAUNCH();
+    }
+    DAGR_CHECK_HIP(exclusive_scan_i32(ws.occupied, ws.newid, T + 1, ws.scan_tmp, true, stream));
+    k_pool_finalize<<<(unsigned)ceil_div((int64_t)T * desc->channels, kBlock), kBlock, 0, stream>>>(
+        *desc, ws, b32, b64, x_out, ldo, xoff, pos_out, batch_out, n_out);
+    DAGR_CHECK_LAUNCH();
+    if (N > 0) {
+        k_pool_l0_event_cluster<<<(unsigned)ceil_div(N, kBlock), kBlock, 0, stream>>>(*desc, (int)N, pos, b32, b64,
+                                                                                   cluster_scratch, ws.status);
+        DAGR_CHECK_LAUNCH();
+        const int K = gdesc->max_neighbors;
+        k_coarse_edges_ell<<<(unsigned)ceil_div(N * K, kBlock), kBlock, 0, stream>>>((int)N, K, nbr_src, deg,
+                                                                                   cluster_scratch, ws.newid,
+                                                                                   ws.rows, ws.status);
+        DAGR_CHECK_LAUNCH();
+    }
+    return pool_tail(desc, ws, b32, b64, x_out, ldo, xoff, pos_out, batch_out, n_out, rowptr_out, col_out, code_out,
+                     e_out, e_cap, stream);
+}
+
+int dagr_pool_csr(const dagr_pool_desc *desc, void *pool_ws, const int32_t *n_ptr, int32_t n_max, const float *x,
+                  int32_t ldx, const float *pos, const int32_t *batch, const int32_t *rowptr, const int32_t *col,
+                  int32_t *cluster_scratch, float *x_out, int32_t ldo, int32_t xoff, float *pos_out,
+                  int32_t *batch_out, int32_t *n_out, int32_t *rowptr_out, int32_t *col_out, int32_t *code_out,
+                  int32_t *e_out, int32_t e_cap, void *stream_) {
+    int rc = validate_pool(desc);
+    if (rc != DAGR_OK) return rc;
+    DAGR_CHECK_ARG(pool_ws, "NULL workspace");
+    DAGR_CHECK_ARG(n_out && rowptr_out && e_out, "NULL output");
+    hipStream_t stream = (hipStream_t)stream_;
+    PoolWs ws;
+    pool_carve(*desc, (char *)pool_ws, &ws);
+    const int T = desc->gx * desc->gy * (desc->batch_size + 1);
+    if (n_max > 0) {
+        DAGR_CHECK_ARG(x && pos && batch && rowptr && col && cluster_scratch, "NULL input");
+        k_pool_accumulate<<<(unsigned)ceil_div((int64_t)n_max * desc->channels, kBlock), kBlock, 0, stream>>>(
+            *desc, n_ptr, n_max, x, ldx, pos, batch, ws, cluster_scratch);
+        DAGR_CHECK_LAUNCH();
+    }
+    DAGR_CHECK_HIP(exclusive_scan_i32(ws.occupied, ws.newid, T + 1, ws.scan_tmp, true, stream));
+    k_pool_finalize<<<(unsigned)ceil_div((int64_t)T * desc->channels, kBlock), kBlock, 0, stream>>>(
+        *desc, ws, batch, nullptr, x_out, ldo, xoff, pos_out, batch_out, n_out);
+    DAGR_CHECK_LAUNCH();
+    if (n_max > 0) {
+        k_coarse_edges_csr<<<(unsigned)ceil_div(n_max, kBlock), kBlock, 0, stream>>>(n_ptr, n_max, rowptr, col,
+                                                                                   cluster_scratch, ws.newid, ws.rows,
+                                                                                   ws.status);
+        DAGR_CHECK_LAUNCH();
+    }
+    return pool_tail(desc, ws, batch, nullptr, x_out, ldo, xoff, pos_out, batch_out, n_out, rowptr_out, col_out,
+                     code_out, e_out, e_cap, stream);
+}
+
+int dagr_pool_status(const dagr_pool_desc *desc, void *pool_ws, int32_t *flags_host, void *stream) {
+    int rc = validate_pool(desc);
+    if (rc != DAGR_OK) return rc;
+    DAGR_CHECK_ARG(pool_ws && flags_host, "NULL pointer");
+    PoolWs ws;
+    pool_carve(*desc, (char *)pool_ws, &ws);
+    DAGR_CHECK_HIP(hipMemcpyAsync(flags_host, ws.status, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    DAGR_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return DAGR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,81 @@
+"""Minimal stand-ins for ``torch_geometric.data.Data`` / ``Batch`` (torch_geometric is not part of
+this stack).  Attribute bag with the few behaviours the reference's hot path relies on:
+``clone``, ``cuda``/``to``, ``num_graphs``, ``Batch.from_data_list`` with ``follow_batch``."""
+import copy
+
+import torch
+
+
+class Data:
+    def __init__(self, **kwargs):
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+    def keys(self):
+        return [k for k in self.__dict__.keys() if not k.startswith("_")]
+
+    def __contains__(self, key):
+        return key in self.__dict__
+
+    def _apply(self, fn):
+        out = copy.copy(self)
+        for k in self.keys():
+            v = getattr(self, k)
+            if torch.is_tensor(v):
+                setattr(out, k, fn(v))
+        return out
+
+    def to(self, device, non_blocking=False):
+        return self._apply(lambda t: t.to(device, non_blocking=non_blocking))
+
+    def cuda(self, non_blocking=False):
+        return self.to("cuda", non_blocking=non_blocking)
+
+    def cpu(self):
+        return self.to("cpu")
+
+    def clone(self):
+        return self._apply(lambda t: t.clone())
+
+    @property
+    def num_nodes(self):
+        for k in ("x", "pos"):
+            v = getattr(self, k, None)
+            if torch.is_tensor(v):
+                return v.shape[0]
+        return 0
+
+    @property
+    def num_graphs(self):
+        if getattr(self, "_num_graphs", None) is not None:
+            return self._num_graphs
+        b = getattr(self, "batch", None)
+        if b is None or b.numel() == 0:
+            return 1
+        return int(b.max().item()) + 1
+
+
+class Batch(Data):
+    @classmethod
+    def from_data_list(cls, data_list, follow_batch=()):
+        """Concatenate node-level tensors along dim 0 (PyG collation): x, pos, t, bbox, bbox0;
+        ``image`` along dim 0; scalar attributes (width, height, time_window, ...) become 1-D tensors;
+        strings become lists.  ``batch`` / ``<key>_batch`` hold the sample index."""
+        out = cls()
+        keys = data_list[0].keys()
+        n_nodes = [d.num_nodes for d in data_list]
+        for k in keys:
+            vals = [getattr(d, k) for d in data_list]
+            v0 = vals[0]
+            if torch.is_tensor(v0) and v0.dim() > 0:
+                setattr(out, k, torch.cat(vals, dim=0))
+                if k in follow_batch:
+                    setattr(out, k + "_batch", torch.cat([torch.full((v.shape[0],), i, dtype=torch.long)
+                                                          for i, v in enumerate(vals)]))
+            elif torch.is_tensor(v0) or isinstance(v0, (int, float)):
+                setattr(out, k, torch.as_tensor([float(v) if isinstance(v, float) else int(v) for v in vals]))
+            else:
+                setattr(out, k, list(vals))
+        out.batch = torch.cat([torch.full((n,), i, dtype=torch.long) for i, n in enumerate(n_nodes)])
+        out._num_graphs = len(data_list)
+        return out

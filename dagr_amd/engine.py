@@ -1,0 +1,391 @@
+"""WindowEngine -- sequences the HIP kernels of libdagr_hip for one batch of event windows.
+
+Mirrors the control flow of ``Net.forward`` (src/dagr/model/networks/net.py:108-190) and the eval
+branch of ``GNNHead.forward`` (src/dagr/model/networks/dagr.py:192-236,283-312), but every graph
+level lives in pre-sized device buffers with device-side node/edge counts, so a window runs without
+host synchronisation: graph build -> fused level-0 convs -> voxel pooling -> (tap aggregation +
+GEMM) per pooled conv -> dense head maps.  PyTorch supplies memory and the stream only.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .graph.ev_graph import WindowGraphBuilder
+
+
+def _f32(v):
+    """Value of ``v`` (python float or 0-dim tensor) as the fp32 torch would compute with."""
+    return float(torch.as_tensor(v, dtype=torch.float32))
+
+
+def _bn_affine(bn):
+    m = bn.module
+    scale = (m.weight / torch.sqrt(m.running_var + m.eps)).detach().float()
+    shift = (m.bias - m.running_mean * scale).detach().float()
+    return scale, shift
+
+
+class _ConvPack:
+    """Packed weights of one fused contraction: Wm[K, N], bias[N] (BN folded), plus shape info."""
+
+    def __init__(self, cin, cskip, Wm, bias, relu):
+        self.cin, self.cskip, self.Wm, self.bias, self.relu = cin, cskip, Wm.contiguous(), bias.contiguous(), relu
+        self.K, self.N = Wm.shape
+
+
+def _pack_generic(convs, norms, skip=None, relu=True, device="cuda"):
+    """Columns of several convs that read the same input are concatenated (N = sum of couts).
+    rows: [25*cin taps (kx + 5*ky major, then input channel) | cin root | cskip skip]."""
+    cols, biases = [], []
+    cin = convs[0].in_channels
+    for conv, norm in zip(convs, norms):
+        W = conv.weight.detach().float()            # [25, cin, cout]
+        root = conv.lin.weight.detach().float()     # [cout, cin]
+        cout = W.shape[2]
+        if norm is not None:
+            scale, shift = _bn_affine(norm)
+        else:
+            scale, shift = torch.ones(cout, device=W.device), torch.zeros(cout, device=W.device)
+        if conv.bias is not None:
+            shift = shift + conv.bias.detach().float() * scale
+        block = torch.cat([W.reshape(25 * cin, cout), root.t()], 0) * scale.view(1, -1)
+        if skip is not None:
+            lin, norm_skip = skip
+            s_scale, s_shift = _bn_affine(norm_skip)
+            block = torch.cat([block, lin.mlp.weight.detach().float().t() * s_scale.view(1, -1)], 0)
+            shift = shift + s_shift
+        cols.append(block)
+        biases.append(shift)
+    cskip = skip[0].mlp.in_features if skip is not None else 0
+    return _ConvPack(cin, cskip, torch.cat(cols, 1).to(device), torch.cat(biases).to(device), relu)
+
+
+def _pack_l0(conv, norm, win, skip=None, device="cuda"):
+    """Level-0 packing: rows [(a + tx*b)*cin + i | root | skip] x 16 over the tx x ty tap window."""
+    win_x, tx, win_y, ty = win
+    W = conv.weight.detach().float()
+    cin, cout = W.shape[1], W.shape[2]
+    assert cout == 16, "level-0 kernel is specialised for 16 output channels (int(base_width*32))"
+    scale, shift = _bn_affine(norm)
+    rows = []
+    for b in range(ty):
+        for a in range(tx):
+            rows.append(W[(win_x + a) + 5 * (win_y + b)] * scale.view(1, -1))
+    rows.append(conv.lin.weight.detach().float().t() * scale.view(1, -1))
+    cskip = 0
+    if skip is not None:
+        lin, norm_skip = skip
+        s_scale, s_shift = _bn_affine(norm_skip)
+        rows.append(lin.mlp.weight.detach().float().t() * s_scale.view(1, -1))
+        shift = shift + s_shift
+        cskip = lin.mlp.in_features
+    return cin, cskip, torch.cat(rows, 0).contiguous().to(device), shift.contiguous().to(device)
+
+
+class _Level:
+    """Device buffers of one pooled graph level (capacity T = gx*gy*(B+1) nodes)."""
+
+    def __init__(self, T, cin, cout, device):
+        self.T = T
+        self.e_cap = T * 64
+        i32 = dict(dtype=torch.int32, device=device)
+        f32 = dict(dtype=torch.float32, device=device)
+        self.x = torch.zeros((T, cin), **f32)        # pooled features + pos[:, :2]
+        self.pos = torch.zeros((T, 3), **f32)
+        self.batch = torch.zeros((T,), **i32)
+        self.rowptr = torch.zeros((T + 2,), **i32)
+        self.col = torch.zeros((self.e_cap,), **i32)
+        self.code = torch.zeros((self.e_cap,), **i32)
+        self.counts = torch.zeros((2,), **i32)       # [n_nodes, n_edges]
+        self.cluster = torch.zeros((T,), **i32)      # scratch for the next pooling
+        self.h1 = torch.zeros((T, cout), **f32)
+        self.h2 = torch.zeros((T, cout), **f32)
+
+
+class WindowEngine:
+    def __init__(self, model, max_events=1 << 17, device="cuda"):
+        self.model = model
+        self.device = torch.device(device)
+        args = model.args
+        bb, head = model.backbone, model.head
+        self.args = args
+        self.B = int(args.batch_size)
+        self.W, self.H = int(model.width), int(model.height)
+        self.time_window = int(getattr(args, "time_window_us", 1000000))
+        self.num_classes = bb.num_classes
+        self.num_scales = int(args.num_scales)
+        self.use_image = bool(args.use_image)
+        if self.use_image:
+            raise NotImplementedError("--use_image fusion is not wired into the engine yet")
+        if bb.conv_block1.conv_block1.conv.lut_domain is None:
+            model.cache_luts(width=self.W, height=self.H, radius=args.radius)
+            model._engine = self
+        self.L = _lib.lib()
+        if self.L.dagr_device_count() < 1:
+            raise RuntimeError("dagr_amd: no HIP device visible; the event-graph path has no CPU fallback")
+        self._prepare(bb, head)
+        self.max_events = 0
+        self._alloc_events(int(max_events))
+
+    # ------------------------------------------------------------------------------------ plan
+    def _prepare(self, bb, head):
+        dev = self.device
+        L = self.L
+        stream = _lib.cur_stream(dev)
+        layers = [bb.conv_block1, bb.layer2, bb.layer3, bb.layer4, bb.layer5]
+        pools = [bb.pool1, bb.pool2, bb.pool3, bb.pool4]
+        self.dom = [layer.conv_block1.conv.lut_domain for layer in layers]
+        # ---- level 0
+        d0 = self.dom[0]
+        assert d0["rx"] == d0["ry"]
+        win = []
+        for r, den in ((d0["rx"], d0["den_x"]), (d0["ry"], d0["den_y"])):
+            lo, cnt = ctypes.c_int32(0), ctypes.c_int32(0)
+            _lib.check(L.dagr_spline_tap_window(r, den, ctypes.byref(lo), ctypes.byref(cnt)), "tap_window")
+            if cnt.value <= 3:      # 3-tap window (clamped into the 5-tap kernel), else all 5 taps
+                win += [min(lo.value, 2), 3]
+            else:
+                win += [0, 5]
+        self.win0 = tuple(win)      # (win_x, tx, win_y, ty)
+        self.ntaps0 = win[1] * win[3]
+        ntp = (self.ntaps0 + 3) // 4 * 4
+        self.ncodes0 = (2 * d0["rx"] + 1) * (2 * d0["ry"] + 1)
+        self.tab0 = torch.zeros((self.ncodes0, ntp), dtype=torch.float32, device=dev)
+        bad = torch.zeros((1,), dtype=torch.int32, device=dev)
+        _lib.check(L.dagr_spline_l0_table(d0["rx"], d0["ry"], d0["den_x"], d0["den_y"], win[0], win[1], win[2], win[3],
+                                          _lib.ptr(self.tab0), _lib.ptr(bad), stream), "l0_table")
+        if int(bad.item()) != 0:
+            raise RuntimeError("level-0 offset table: an offset needs a kernel tap outside the chosen window")
+        l0 = layers[0]
+        self.l0_conv1 = _pack_l0(l0.conv_block1.conv, l0.conv_block1.norm, self.win0, device=dev)
+        self.l0_conv2 = _pack_l0(l0.conv_block2.conv, l0.conv_block2.norm, self.win0,
+                                 skip=(l0.conv_block2.lin, l0.conv_block2.norm_skip), device=dev)
+        # ---- pooled levels 1..4
+        self.packs = []
+        for layer in layers[1:]:
+            c1 = _pack_generic([layer.conv_block1.conv], [layer.conv_block1.norm], device=dev)
+            c2 = _pack_generic([layer.conv_block2.conv], [layer.conv_block2.norm],
+                               skip=(layer.conv_block2.lin, layer.conv_block2.norm_skip), device=dev)
+            self.packs.append((c1, c2))
+        # ---- poolings
+        self.pool_desc, self.pool_ws, self.levels = [], [], []
+        B = self.B
+        chans = [l.out_channel for l in layers]
+        for k, pool in enumerate(pools):
+            vs = pool.voxel_size.detach().float().cpu()
+            end = torch.Tensor([0.9999999, 0.9999999])
+            g = ((end - 0) / vs[:2]).to(torch.int64) + 1            # grid_cluster num_voxels
+            nd = self.dom[k + 1]
+            remap = nd["remap"]
+            desc = _lib.PoolDesc(batch_size=B, channels=chans[k], gx=int(g[0]), gy=int(g[1]), vx=float(vs[0]),
+                                 vy=float(vs[1]), inv_w=float(pool.wh_inv[0, 0]), inv_h=float(pool.wh_inv[0, 1]),
+                                 two_max=_f32(2 * pool.transform.max), r00=float(remap[0, 0]),
+                                 r02=float(remap[0, 2]), r11=float(remap[1, 1]), r12=float(remap[1, 2]),
+                                 rx=nd["rx"], ry=nd["ry"], aggr=0 if pool.aggr == "max" else 1, append_pos=1)
+            nbytes = L.dagr_pool_workspace_bytes(ctypes.byref(desc))
+            if nbytes == 0:
+                raise RuntimeError("libdagr_hip: " + L.dagr_last_error().decode())
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            _lib.check(L.dagr_pool_workspace_init(ctypes.byref(desc), _lib.ptr(ws), nbytes, stream), "pool_ws_init")
+            self.pool_desc.append(desc)
+            self.pool_ws.append(ws)
+            T = int(g[0]) * int(g[1]) * (B + 1)
+            self.levels.append(_Level(T, chans[k] + 2, chans[k + 1], dev))
+        # voxel -> first pixel tables for the level-0 pooling (same fp32 division as grid_cluster)
+        vs = pools[0].voxel_size.detach().float().cpu()
+        d = self.pool_desc[0]
+        cellx = ((torch.arange(self.W).float() / self.W) / vs[0]).to(torch.int64)
+        celly = ((torch.arange(self.H).float() / self.H) / vs[1]).to(torch.int64)
+        self.xlo = torch.searchsorted(cellx, torch.arange(d.gx + 1)).to(torch.int32).to(dev)
+        self.ylo = torch.searchsorted(celly, torch.arange(d.gy + 1)).to(torch.int32).to(dev)
+        # ---- head
+        self.head_packs = []
+        first_level = 5 - self.num_scales   # levels feeding scale 1..num_scales (3,4 or 4)
+        self.head_levels = list(range(first_level, 5))
+        for s in range(1, self.num_scales + 1):
+            g = lambda n: getattr(head, n + str(s))
+            stem = _pack_generic([g("stem").conv], [g("stem").norm], device=dev)
+            cr = _pack_generic([g("cls_conv").conv, g("reg_conv").conv], [g("cls_conv").norm, g("reg_conv").norm],
+                               device=dev)
+            cls = _pack_generic([g("cls_pred")], [None], relu=False, device=dev)
+            ro = _pack_generic([g("reg_pred"), g("obj_pred")], [None, None], relu=False, device=dev)
+            self.head_packs.append((stem, cr, cls, ro))
+        self.n_reg = head.stem1.conv.out_channels
+        osz = bb.get_output_sizes()[-self.num_scales:]
+        self.out_sizes = osz                                   # [[H,W], ...]
+        self.strides = list(bb.strides)
+        self.head_vox = [pools[2].voxel_size[:2].detach().float().cpu(), pools[3].voxel_size[:2].detach().float().cpu()][-self.num_scales:]
+        # scratch for the head / aggregation
+        lda_max = 0
+        for k, (c1, c2) in enumerate(self.packs):
+            lda_max = max(lda_max, self.levels[k].T * max(c1.K, c2.K))
+        for i, lvl in enumerate(self.head_levels):
+            for p in self.head_packs[i]:
+                lda_max = max(lda_max, self.levels[lvl - 1].T * p.K)
+        self.A = torch.zeros((lda_max,), dtype=torch.float32, device=dev)
+        self.head_buf = []
+        for i, lvl in enumerate(self.head_levels):
+            T = self.levels[lvl - 1].T
+            Hc, Wc = self.out_sizes[i]
+            self.head_buf.append(dict(
+                stem=torch.zeros((T, self.n_reg), dtype=torch.float32, device=dev),
+                cr=torch.zeros((T, 2 * self.n_reg), dtype=torch.float32, device=dev),
+                pred=torch.zeros((T, 5 + self.num_classes), dtype=torch.float32, device=dev),
+                winner=torch.zeros((self.B * Hc * Wc,), dtype=torch.int32, device=dev),
+                dense=torch.zeros((self.B, 5 + self.num_classes, Hc, Wc), dtype=torch.float32, device=dev)))
+        self.status = torch.zeros((4,), dtype=torch.int32, device=dev)
+        # grid / stride cache of decode_outputs (model/utils.py:119-134)
+        grids, strides = [], []
+        for (hs, ws_), stride in zip(self.out_sizes, self.strides):
+            yv, xv = torch.meshgrid(torch.arange(hs), torch.arange(ws_), indexing="ij")
+            grid = torch.stack((xv, yv), 2).view(1, -1, 2)
+            grids.append(grid)
+            strides.append(torch.full((1, grid.shape[1], 1), stride))
+        self.grid_cache = torch.cat(grids, dim=1).float().to(dev)
+        self.stride_cache = torch.cat(strides, dim=1).float().to(dev)
+
+    def _alloc_events(self, n):
+        if n <= self.max_events:
+            return
+        dev = self.device
+        n = max(n, 1024)
+        self.max_events = n
+        bb = self.model.backbone
+        tgn = bb.events_to_graph
+        self.graph = tgn.init_graph_creator(self.W, self.H, self.time_window, self.B, dev, max_events=n)
+        K = self.graph.K
+        self.nbr_src = torch.zeros((n, K), dtype=torch.int32, device=dev)
+        self.nbr_code = torch.zeros((n, K), dtype=torch.int16, device=dev)
+        self.deg = torch.zeros((n,), dtype=torch.int32, device=dev)
+        self.h1 = torch.zeros((n, 16), dtype=torch.float32, device=dev)
+        self.h2 = torch.zeros((n, 16), dtype=torch.float32, device=dev)
+        self.cluster0 = torch.zeros((n,), dtype=torch.int32, device=dev)
+
+    # ------------------------------------------------------------------------------- kernels
+    def _conv_generic(self, lvl, pack, x, ldx, xskip, ldskip, out, ldo, dom, stream):
+        L = self.L
+        P = _lib.ptr
+        lda = pack.K
+        _lib.check(L.dagr_spline_tap_aggregate(P(lvl.counts), lvl.T, P(lvl.rowptr), P(lvl.col), P(lvl.code),
+                                               x, ldx, pack.cin, xskip, ldskip, pack.cskip, dom["rx"], dom["ry"],
+                                               dom["den_x"], dom["den_y"], P(self.A), lda, stream), "tap_aggregate")
+        _lib.check(L.dagr_gemm_bias_act(P(lvl.counts), lvl.T, P(self.A), lda, P(pack.Wm), pack.N, P(pack.bias),
+                                        out, ldo, pack.K, pack.N, 1 if pack.relu else 0, stream), "gemm")
+
+    def forward_raw(self, pos, feat, batch, trace=None):
+        """pos fp32[N,3] normalised (format_data), feat fp32[N,1], batch int32/int64[N] on the device.
+        Returns decoded head outputs [B, n_anchors, 5+num_classes] (GNNHead.forward eval)."""
+        L, P, dev = self.L, _lib.ptr, self.device
+        N = int(pos.shape[0])
+        self._alloc_events(N)
+        stream = _lib.cur_stream(dev)
+        pos = pos.contiguous()
+        batch = batch.contiguous()
+        b64 = 1 if batch.dtype == torch.int64 else 0
+        g = self.graph
+        nbr_src, nbr_code, deg = self.nbr_src[:N], self.nbr_code[:N], self.deg[:N]
+        g.build(pos, batch, out=(nbr_src, nbr_code, deg))
+        K = g.K
+        # ---- level 0: Layer(3 -> 16)  (net.py:124-126)
+        x0 = torch.cat((feat.float().reshape(N, feat.shape[1] if feat.dim() > 1 else 1), pos[:, :2]), dim=1).contiguous()
+        c0 = x0.shape[1]
+        cin, cskip, w1, s1 = self.l0_conv1
+        assert cin == c0
+        _lib.check(L.dagr_spline_conv_l0(cin, 0, self.ntaps0, N, K, self.ncodes0, P(nbr_src), P(nbr_code), P(deg), P(x0), c0,
+                                         None, 0, P(self.tab0), P(w1), P(s1), 1, P(self.h1), 16, stream), "conv_l0")
+        cin, cskip, w2, s2 = self.l0_conv2
+        _lib.check(L.dagr_spline_conv_l0(cin, cskip, self.ntaps0, N, K, self.ncodes0, P(nbr_src), P(nbr_code), P(deg), P(self.h1),
+                                         16, P(x0), c0, P(self.tab0), P(w2), P(s2), 1, P(self.h2), 16, stream),
+                   "conv_l0")
+        if trace is not None:
+            trace["nbr"] = (nbr_src.clone(), nbr_code.clone(), deg.clone())
+            trace["layer1"] = self.h2[:N].clone()
+        # ---- pool1 (net.py:131)
+        l1 = self.levels[0]
+        d = self.pool_desc[0]
+        _lib.check(L.dagr_pool_l0(ctypes.byref(d), P(self.pool_ws[0]), ctypes.byref(g.desc), P(g.workspace),
+                                  P(self.xlo), P(self.ylo), P(self.h2), 16, P(pos), P(batch), b64, N, P(nbr_src),
+                                  P(deg), P(self.cluster0), P(l1.x), l1.x.shape[1], 0, P(l1.pos), P(l1.batch),
+                                  P(l1.counts), P(l1.rowptr), P(l1.col), P(l1.code),
+                                  ctypes.c_void_p(l1.counts.data_ptr() + 4), l1.e_cap, stream), "pool_l0")
+        # ---- levels 1..4
+        for k in range(4):
+            lvl = self.levels[k]
+            c1, c2 = self.packs[k]
+            dom = self.dom[k + 1]
+            ldx = lvl.x.shape[1]
+            self._conv_generic(lvl, c1, P(lvl.x), ldx, None, 0, P(lvl.h1), c1.N, dom, stream)
+            self._conv_generic(lvl, c2, P(lvl.h1), c1.N, P(lvl.x), ldx, P(lvl.h2), c2.N, dom, stream)
+            if trace is not None:
+                trace[f"pool{k + 1}"] = self._level_snapshot(lvl, lvl.x)
+                trace[f"layer{k + 2}"] = self._level_snapshot(lvl, lvl.h2)
+            if k < 3:
+                nxt = self.levels[k + 1]
+                d = self.pool_desc[k + 1]
+                _lib.check(L.dagr_pool_csr(ctypes.byref(d), P(self.pool_ws[k + 1]), P(lvl.counts), lvl.T, P(lvl.h2),
+                                           c2.N, P(lvl.pos), P(lvl.batch), P(lvl.rowptr), P(lvl.col),
+                                           P(lvl.cluster), P(nxt.x), nxt.x.shape[1], 0, P(nxt.pos), P(nxt.batch),
+                                           P(nxt.counts), P(nxt.rowptr), P(nxt.col), P(nxt.code),
+                                           ctypes.c_void_p(nxt.counts.data_ptr() + 4), nxt.e_cap, stream), "pool_csr")
+        # ---- head (dagr.py:179-236)
+        outs = []
+        for i, lvln in enumerate(self.head_levels):
+            lvl = self.levels[lvln - 1]
+            stem, cr, cls, ro = self.head_packs[i]
+            hb = self.head_buf[i]
+            dom = self.dom[lvln]
+            nr = self.n_reg
+            self._conv_generic(lvl, stem, P(lvl.h2), lvl.h2.shape[1], None, 0, P(hb["stem"]), nr, dom, stream)
+            self._conv_generic(lvl, cr, P(hb["stem"]), nr, None, 0, P(hb["cr"]), 2 * nr, dom, stream)
+            pred = hb["pred"]
+            npred = pred.shape[1]
+            # pred columns: [reg(4) | obj(1) | cls(num_classes)] = order of collect_outputs (dagr.py:300-302)
+            self._conv_generic(lvl, ro, ctypes.c_void_p(hb["cr"].data_ptr() + 4 * nr), 2 * nr, None, 0, P(pred), npred,
+                               dom, stream)
+            self._conv_generic(lvl, cls, P(hb["cr"]), 2 * nr, None, 0, ctypes.c_void_p(pred.data_ptr() + 4 * 5), npred,
+                               dom, stream)
+            Hc, Wc = self.out_sizes[i]
+            vox = self.head_vox[i]
+            _lib.check(L.dagr_to_dense(P(lvl.counts), lvl.T, P(pred), npred, npred, P(lvl.pos), P(lvl.batch),
+                                       float(vox[0]), float(vox[1]), self.B, Hc, Wc, P(hb["winner"]), P(hb["dense"]),
+                                       P(self.status), stream), "to_dense")
+            outs.append(hb["dense"])
+        if trace is not None:
+            trace["head_dense"] = [o.clone() for o in outs]
+        return self._decode(outs)
+
+    def _decode(self, dense_maps):
+        """collect_outputs + decode_outputs (dagr.py:283-312) on the tiny dense maps (torch ops)."""
+        hybrid = [torch.cat([o[:, :4], o[:, 4:].sigmoid()], 1) for o in dense_maps]
+        outputs = torch.cat([o.flatten(start_dim=2) for o in hybrid], dim=2).permute(0, 2, 1).contiguous()
+        outputs[..., :2] = (outputs[..., :2] + self.grid_cache) * self.stride_cache
+        outputs[..., 2:4] = torch.exp(outputs[..., 2:4]) * self.stride_cache
+        return outputs
+
+    def _level_snapshot(self, lvl, x):
+        n, e = [int(v) for v in lvl.counts.tolist()]
+        return dict(x=x[:n].clone(), pos=lvl.pos[:n].clone(), batch=lvl.batch[:n].clone(),
+                    rowptr=lvl.rowptr[:n + 1].clone(), col=lvl.col[:e].clone(), code=lvl.code[:e].clone())
+
+    def check_status(self):
+        """Raise if any kernel flagged an inconsistency (synchronises)."""
+        ne, fl = self.graph.status()
+        if fl:
+            raise RuntimeError(f"graph builder flagged {fl:#x} (events outside the sensor / batch range)")
+        for k, (d, ws) in enumerate(zip(self.pool_desc, self.pool_ws)):
+            f = ctypes.c_int32(0)
+            _lib.check(self.L.dagr_pool_status(ctypes.byref(d), _lib.ptr(ws), ctypes.byref(f),
+                                               _lib.cur_stream(self.device)), "pool_status")
+            if f.value:
+                raise RuntimeError(f"pool{k + 1} flagged {f.value:#x}")
+        if int(self.status[0].item()):
+            raise RuntimeError("to_dense: node outside the output map")
+
+    def forward_data(self, data):
+        """``DAGR.forward`` input contract: ``data`` after ``format_data`` (pos fp32[N,3] normalised,
+        x fp32[N,1], batch)."""
+        batch = data.batch if getattr(data, "batch", None) is not None else \
+            torch.zeros(data.pos.shape[0], dtype=torch.int64, device=data.pos.device)
+        return self.forward_raw(data.pos.float(), data.x.float(), batch)

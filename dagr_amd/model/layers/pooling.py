@@ -1,0 +1,25 @@
+"""Mirror of ``src/dagr/model/layers/pooling.py:19-97`` (voxel-grid pooling).  Buffers are
+non-persistent exactly like the reference's, so they do not appear in the state_dict."""
+import torch
+
+
+class Pooling(torch.nn.Module):
+    def __init__(self, size, width, height, batch_size, transform, aggr="max", keep_temporal_ordering=False,
+                 dim=2, self_loop=False, in_channels=-1):
+        super().__init__()
+        assert aggr in ["mean", "max"]
+        assert not keep_temporal_ordering and not self_loop and in_channels <= 0, \
+            "only the default Pooling options used by Net (net.py:78-97) are implemented"
+        self.aggr = aggr
+        self.register_buffer("voxel_size", torch.cat([size, torch.Tensor([1])]), persistent=False)
+        self.transform = transform
+        self.dim = dim
+        self.register_buffer("start", torch.Tensor([0, 0, 0, 0]), persistent=False)
+        self.register_buffer("end", torch.Tensor([0.9999999, 0.9999999, 0.9999999, batch_size - 1]), persistent=False)
+        self.register_buffer("wh_inv", 1 / torch.Tensor([[width, height]]), persistent=False)
+        self.batch_size = batch_size
+        self.max_num_voxels = batch_size * self.num_grid_cells
+
+    @property
+    def num_grid_cells(self):
+        return int((1 / self.voxel_size + 1e-3).int().prod())

@@ -1,0 +1,125 @@
+"""Mirror of ``src/dagr/model/networks/dagr.py``: ``DAGR`` (:14-103, a YOLOX with ``backbone`` = Net
+and ``head`` = GNNHead), ``CNNHead`` (:106-122), ``GNNHead`` (:125-312, eval branch).  Sub-module
+names and parameter shapes follow the reference so ``ModelEMA(model).ema.load_state_dict(ckpt['ema'])``
+(scripts/run_test.py:57-58) works.  The forward pass is executed by ``dagr_amd.engine.WindowEngine``
+(hand-written HIP kernels behind include/dagr_hip.h); training losses are out of scope."""
+import torch
+
+from ..layers.conv import ConvBlock
+from ..layers.spline_conv import SplineConvToDense
+from ..utils import voxel_size_to_params, postprocess_network_output, convert_to_evaluation_format
+from .net import Net
+from .yolox_min import YOLOXHeadParams
+
+
+class CNNHead(YOLOXHeadParams):
+    """dagr.py:106-122 -- dense YOLOX head on the (resized) image features; PyTorch-ROCm."""
+
+    def forward(self, xin):
+        outputs = dict(cls_output=[], reg_output=[], obj_output=[])
+        for k, (cls_conv, reg_conv, x) in enumerate(zip(self.cls_convs, self.reg_convs, xin)):
+            x = self.stems[k](x)
+            cls_feat = cls_conv(x)
+            reg_feat = reg_conv(x)
+            outputs["cls_output"].append(self.cls_preds[k](cls_feat))
+            outputs["reg_output"].append(self.reg_preds[k](reg_feat))
+            outputs["obj_output"].append(self.obj_preds[k](reg_feat))
+        return outputs
+
+
+class GNNHead(YOLOXHeadParams):
+    def __init__(self, num_classes, strides=(8, 16, 32), in_channels=(256, 512, 1024),
+                 in_channels_cnn=(256, 512, 1024), act="silu", depthwise=False, pretrain_cnn=False, args=None):
+        YOLOXHeadParams.__init__(self, num_classes, args.yolo_stem_width, strides, in_channels, act)
+        self.pretrain_cnn = pretrain_cnn
+        self.num_scales = args.num_scales
+        self.use_image = bool(args.use_image)
+        self.batch_size = args.batch_size
+        self.no_events = bool(args.no_events)
+        self.in_channels = list(in_channels)
+        self.n_anchors = 1
+        self.num_classes = num_classes
+        n_reg = max(in_channels)
+        self.stem1 = ConvBlock(in_channels=in_channels[0], out_channels=n_reg, args=args)
+        self.cls_conv1 = ConvBlock(in_channels=n_reg, out_channels=n_reg, args=args)
+        self.cls_pred1 = SplineConvToDense(n_reg, self.n_anchors * self.num_classes, bias=True, args=args)
+        self.reg_conv1 = ConvBlock(in_channels=n_reg, out_channels=n_reg, args=args)
+        self.reg_pred1 = SplineConvToDense(n_reg, 4, bias=True, args=args)
+        self.obj_pred1 = SplineConvToDense(n_reg, self.n_anchors, bias=True, args=args)
+        if self.num_scales > 1:
+            self.stem2 = ConvBlock(in_channels=in_channels[1], out_channels=n_reg, args=args)
+            self.cls_conv2 = ConvBlock(in_channels=n_reg, out_channels=n_reg, args=args)
+            self.cls_pred2 = SplineConvToDense(n_reg, self.n_anchors * self.num_classes, bias=True, args=args)
+            self.reg_conv2 = ConvBlock(in_channels=n_reg, out_channels=n_reg, args=args)
+            self.reg_pred2 = SplineConvToDense(n_reg, 4, bias=True, args=args)
+            self.obj_pred2 = SplineConvToDense(n_reg, self.n_anchors, bias=True, args=args)
+        if self.use_image:
+            self.cnn_head = CNNHead(num_classes=num_classes, strides=strides, in_channels=in_channels_cnn)
+        self.strides = list(strides)
+
+
+class DAGR(torch.nn.Module):
+    def __init__(self, args, height, width):
+        super().__init__()
+        self.conf_threshold = 0.001
+        self.nms_threshold = 0.65
+        self.height = height
+        self.width = width
+        self.args = args
+        self.backbone = Net(args, height=height, width=width)
+        self.head = GNNHead(num_classes=self.backbone.num_classes, in_channels=self.backbone.out_channels,
+                            in_channels_cnn=self.backbone.out_channels_cnn, strides=self.backbone.strides,
+                            pretrain_cnn=args.pretrain_cnn, args=args)
+        self._engine = None
+        if "img_net_checkpoint" in vars(args):
+            from ..utils import init_subnetwork
+            state_dict = torch.load(args.img_net_checkpoint)
+            init_subnetwork(self, state_dict["ema"], "backbone.net.", freeze=True)
+            init_subnetwork(self, state_dict["ema"], "head.cnn_head.")
+
+    # -- dagr.py:37-72 -------------------------------------------------------------------------
+    def cache_luts(self, width, height, radius):
+        M = 2 * float(int(radius * width + 2) / width)
+        r = int(radius * width + 1)
+        b, h = self.backbone, self.head
+        for blk in (b.conv_block1.conv_block1, b.conv_block1.conv_block2):
+            blk.conv.init_lut(height=height, width=width, Mx=M, rx=r)
+        levels = [(b.pool1, [b.layer2]), (b.pool2, [b.layer3]), (b.pool3, [b.layer4]), (b.pool4, [b.layer5])]
+        for k, (pool, layers) in enumerate(levels):
+            rx, ry, M = voxel_size_to_params(pool, height, width)
+            for layer in layers:
+                layer.conv_block1.conv.init_lut(height=height, width=width, Mx=M, rx=rx, ry=ry)
+                layer.conv_block2.conv.init_lut(height=height, width=width, Mx=M, rx=rx, ry=ry)
+            s = {2: "1", 3: "2"}.get(k)
+            if s is not None and (s == "1" or h.num_scales > 1):
+                for name in ("stem", "cls_conv", "reg_conv"):
+                    getattr(h, name + s).conv.init_lut(height=height, width=width, Mx=M, rx=rx, ry=ry)
+                for name in ("cls_pred", "reg_pred", "obj_pred"):
+                    getattr(h, name + s).init_lut(height=height, width=width, Mx=M, rx=rx, ry=ry)
+        self._engine = None  # parameters / domains changed: rebuild the device-side plan lazily
+
+    def engine(self):
+        if self._engine is None:
+            from ...engine import WindowEngine
+            self._engine = WindowEngine(self)
+        return self._engine
+
+    def load_state_dict(self, *a, **kw):
+        r = super().load_state_dict(*a, **kw)
+        self._engine = None
+        return r
+
+    # -- dagr.py:74-103 (eval branch) ----------------------------------------------------------
+    def forward(self, x, reset=True, return_targets=True, filtering=True):
+        if self.training:
+            raise NotImplementedError("training (losses, backward) is outside this round's scope")
+        if not reset:
+            raise NotImplementedError("incremental (reset=False) inference is not implemented")
+        outputs = self.engine().forward_data(x)
+        detections = postprocess_network_output(outputs, self.backbone.num_classes, self.conf_threshold,
+                                                self.nms_threshold, filtering=filtering, height=self.height,
+                                                width=self.width)
+        ret = [detections]
+        if return_targets and hasattr(x, "bbox"):
+            ret.append(convert_to_evaluation_format(x))
+        return ret

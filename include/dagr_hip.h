@@ -111,6 +111,101 @@ int dagr_graph_edge_index(const int32_t *nbr_src, const int32_t *deg, int64_t N,
                           int32_t *rowptr, int32_t *scan_scratch,
                           int64_t *edge_index, int64_t row_stride, void *stream);
 
+/* ------------------------------------------------------------------------ *
+ * SplineConv (degree-1 open B-spline, 5x5 kernel, sum aggregation)
+ *   replaces MySplineConv.forward/_forward/message_lut          model/layers/spline_conv.py:39-78
+ *   over  torch_geometric SplineConv + ToSparseTensor, torch_spline_conv spline_basis /
+ *   spline_weighting, torch_scatter segment_csr  (third-party, un-vendored: SURVEY.md 2.3),
+ *   fused with BatchNorm(eval)+ReLU (model/layers/conv.py:23-28) and the skip branch (:47-56).
+ *
+ *   Edge offsets are integer LUT coordinates (ix, iy) in [0,2rx] x [0,2ry], exactly the index the
+ *   reference's message_lut derives (spline_conv.py:41-42); den_x = fp32(2*Mx*width),
+ *   den_y = fp32(2*My*height) as in init_lut (spline_conv.py:29-30).
+ *   Weight packing (host side, BN folded: W*scale[o], shift[o]):
+ *     level 0  : wpack[(tx*ty*cin taps | cin root | cskip skip)][16], taps = tx x ty window starting
+ *                at (win_x, win_y) of the 5x5 kernel, tap row = (a + tx*b)*cin + i
+ *     generic  : Wm[(25*cin taps | cin root | cskip skip)][cout], tap row = (kx + 5*ky)*cin + i
+ * ------------------------------------------------------------------------ */
+/* first kernel tap (0..4) and number of taps touched by offsets -r..r on one axis (host) */
+int dagr_spline_tap_window(int32_t r, float den, int32_t *first_tap_host, int32_t *num_taps_host);
+/* tab[(2rx+1)*(2ry+1)][ntp], ntp = round_up(tx*ty, 4): per offset code = ix*(2ry+1)+iy the window
+ * products bx[a]*by[b] at [a + tx*b]; window = taps [win_x, win_x+tx) x [win_y, win_y+ty);
+ * bad_flag (device int32) is set if an offset needs a tap outside the window */
+int dagr_spline_l0_table(int32_t rx, int32_t ry, float den_x, float den_y, int32_t win_x, int32_t tx,
+                         int32_t win_y, int32_t ty, float *tab, int32_t *bad_flag, void *stream);
+/* fused level-0 conv on the builder's neighbour lists; cout is 16 (Net: int(base_width*32)).
+ * out[n,0:16] = act(sum_j x[src_j] . What(code_j) + x[n] . root + xskip[n] . skip + shift) */
+int dagr_spline_conv_l0(int32_t cin, int32_t cskip, int32_t ntaps /* tx*ty: 9, 15 or 25 */,
+                        int64_t N, int32_t K, int32_t ncodes,
+                        const int32_t *nbr_src, const int16_t *nbr_code, const int32_t *deg,
+                        const float *x, int32_t ldx, const float *xskip, int32_t ldskip,
+                        const float *tab, const float *wpack, const float *shift, int32_t relu,
+                        float *out, int32_t ldo, void *stream);
+/* generic step 1: A[n] = [sum_j basis*x_j per tap (25*cin) | x[n] (cin) | xskip[n] (cskip)] over a
+ * CSR-by-destination graph; code[e] = ix | iy<<16.  n_nodes_ptr (device, may be NULL) bounds the
+ * rows actually processed (<= n_nodes_max) without a host sync. */
+int dagr_spline_tap_aggregate(const int32_t *n_nodes_ptr, int32_t n_nodes_max, const int32_t *rowptr,
+                              const int32_t *col, const int32_t *code, const float *x, int32_t ldx,
+                              int32_t cin, const float *xskip, int32_t ldskip, int32_t cskip,
+                              int32_t rx, int32_t ry, float den_x, float den_y,
+                              float *A, int32_t lda, void *stream);
+/* generic step 2: C[M,N] = act(A[M,K] . Wm[K,N] + bias[N]); M = min(*m_ptr, m_max) */
+int dagr_gemm_bias_act(const int32_t *m_ptr, int32_t m_max, const float *A, int32_t lda,
+                       const float *Wm, int32_t ldw, const float *bias, float *C, int32_t ldc,
+                       int32_t K, int32_t N, int32_t relu, void *stream);
+
+/* ------------------------------------------------------------------------ *
+ * Voxel-grid pooling
+ *   replaces Pooling.forward / consecutive_cluster / round_to_pixel   model/layers/pooling.py:12-97
+ *   over torch_cluster.grid_cluster, torch_scatter.scatter_max, PyG pool_pos / _avg_pool_x,
+ *   T.Cartesian (third-party, un-vendored), plus the LUT index of the consuming SplineConvs
+ *   (spline_conv.py:41-42).  Output graph: CSR by destination cluster, sources ascending,
+ *   code[e] = ix | iy<<16.  All counts stay on the device (n_out, e_out; rowptr_out[n_out] = e_out).
+ * ------------------------------------------------------------------------ */
+typedef struct {
+    int32_t batch_size;   /* B                                                          */
+    int32_t channels;     /* C: feature channels pooled                                 */
+    int32_t gx, gy;       /* voxels per axis = trunc(0.9999999/size)+1 (grid_cluster)   */
+    float vx, vy;         /* voxel_size[0], voxel_size[1]  (pooling.py:24)              */
+    float inv_w, inv_h;   /* wh_inv = 1/W, 1/H in fp32      (pooling.py:32)             */
+    float two_max;        /* fp32(2*max_value) of this pooling's Cartesian transform    */
+    float r00, r02, r11, r12; /* attr_remapping_matrix of the consuming convs (spline_conv.py:23-24) */
+    int32_t rx, ry;       /* their LUT offset domain                                    */
+    int32_t aggr;         /* 0 = max, 1 = mean                                          */
+    int32_t append_pos;   /* also write pos[:, :2] into columns C, C+1 of each output row (net.py:137-138) */
+} dagr_pool_desc;
+
+size_t dagr_pool_workspace_bytes(const dagr_pool_desc *desc);
+int dagr_pool_workspace_init(const dagr_pool_desc *desc, void *workspace, size_t workspace_bytes, void *stream);
+/* level 0: pools the events of the window whose graph was just built on (gdesc, graph_ws).
+ * xlo[gx+1] / ylo[gy+1]: first pixel column/row of each voxel (device int32; from the same fp32
+ * division as grid_cluster).  x_out rows start at column xoff; outputs sized for
+ * T = gx*gy*(B+1) clusters; rowptr_out has T+2 entries; e_cap = capacity of col_out/code_out. */
+int dagr_pool_l0(const dagr_pool_desc *desc, void *pool_ws, const dagr_graph_desc *gdesc, void *graph_ws,
+                 const int32_t *xlo, const int32_t *ylo, const float *x, int32_t ldx, const float *pos,
+                 const void *batch, int32_t batch_is_int64, int64_t N, const int32_t *nbr_src, const int32_t *deg,
+                 int32_t *cluster_scratch /*[N]*/, float *x_out, int32_t ldo, int32_t xoff, float *pos_out,
+                 int32_t *batch_out, int32_t *n_out, int32_t *rowptr_out, int32_t *col_out, int32_t *code_out,
+                 int32_t *e_out, int32_t e_cap, void *stream);
+/* coarser levels: input graph in CSR; n_ptr (device) = number of valid input nodes (<= n_max) */
+int dagr_pool_csr(const dagr_pool_desc *desc, void *pool_ws, const int32_t *n_ptr, int32_t n_max, const float *x,
+                  int32_t ldx, const float *pos, const int32_t *batch, const int32_t *rowptr, const int32_t *col,
+                  int32_t *cluster_scratch /*[n_max]*/, float *x_out, int32_t ldo, int32_t xoff, float *pos_out,
+                  int32_t *batch_out, int32_t *n_out, int32_t *rowptr_out, int32_t *col_out, int32_t *code_out,
+                  int32_t *e_out, int32_t e_cap, void *stream);
+/* flags bit0: node outside the voxel grid; bit1: > 64 distinct sources for one cluster;
+ * bit2: edge capacity exceeded; bit3: LUT coordinate out of range.  Synchronises `stream`. */
+int dagr_pool_status(const dagr_pool_desc *desc, void *pool_ws, int32_t *flags_host, void *stream);
+
+/* ------------------------------------------------------------------------ *
+ * to_dense  -- model/layers/spline_conv.py:80-107 (SplineConvToDense tail)
+ *   dense[B,C,Hc,Wc] (fully written, zeros where no node); cell = trunc(pos_xy / voxel_xy);
+ *   winner_scratch int32[B*Hc*Wc]; status (device int32) bit0 = node outside the map.
+ * ------------------------------------------------------------------------ */
+int dagr_to_dense(const int32_t *n_ptr, int32_t n_max, const float *x, int32_t ldx, int32_t channels,
+                  const float *pos, const int32_t *batch, float vx, float vy, int32_t batch_size,
+                  int32_t Hc, int32_t Wc, int32_t *winner_scratch, float *dense, int32_t *status, void *stream);
+
 /* Host-side helper: first n offsets of the search spiral (spiral.h:1-15), the closed form the
  * search kernel uses.  dx/dy are HOST arrays.  Lets CPU-only tests pin the visiting order. */
 int dagr_spiral_offsets(int32_t n, int32_t *dx_host, int32_t *dy_host);

@@ -1,0 +1,265 @@
+"""CPU oracle (torch fp32, CPU tensors) for the floating-point ops of the hot path.
+
+TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py.  **Parity unpinned** for the third-party ops:
+torch_spline_conv / torch_scatter / torch_cluster / torch_sparse / torch_geometric are not vendored
+in /root/reference, are unpinned by ``install_env.sh:3-11`` and absent from this image, and the
+reference ships no tests or golden vectors.  Each function restates the published algorithm and
+cites the reference call site (paths relative to /root/reference/src/dagr/) it stands in for.
+"""
+import torch
+
+KERNEL_SIZE = 5   # config/dagr-s-dsec.yaml:18
+DEGREE = 1        # conv.py:17 / spline_conv.py:10
+DIM = 2           # edge_attr_dim, config:16
+
+
+# --------------------------------------------------------------------------- T.Cartesian
+def cartesian(pos, edge_index, max_value):
+    """``T.Cartesian(norm=True, cat=False, max_value=M)`` [torch_geometric] as used by
+    ``model/layers/components.py:25-35`` and ``pooling.py:88-92``; restated in the reference itself at
+    ``asynchronous/cartesian.py:6-16``: ``cart = pos[row] - pos[col]; cart / (2*max) + 0.5`` with
+    (row, col) = (source, destination).  ``max_value`` may be a python float (the product 2*max is
+    formed in double, then the division happens in fp32) or a 0-dim fp32 tensor."""
+    if edge_index.shape[1] == 0:
+        return torch.zeros((0, pos.shape[1]), dtype=pos.dtype)
+    row, col = edge_index[0], edge_index[1]
+    cart = pos[row] - pos[col]
+    return cart / (2 * max_value) + 0.5
+
+
+# --------------------------------------------------------------------------- torch_spline_conv
+def spline_basis(pseudo, kernel_size=KERNEL_SIZE, is_open_spline=1, degree=DEGREE):
+    """``torch_spline_conv.spline_basis`` (call site ``model/layers/spline_conv.py:32``).
+    Published algorithm (torch_spline_conv/csrc/cpu/basis_cpu.cpp, degree-1 branch): for each of the
+    S=(degree+1)^D combinations s, per dimension d: k_mod = (s / (degree+1)^d) % (degree+1),
+    v = pseudo[e,d] * (kernel_size - degree*is_open_spline), frac = v - floor(v),
+    basis *= 1 - frac - k_mod + 2*frac*k_mod, index += ((int(floor(v)) + k_mod) % kernel_size) * offset,
+    offset *= kernel_size (dimension 0 fastest)."""
+    E, D = pseudo.shape
+    S = (degree + 1) ** D
+    basis = torch.ones((E, S), dtype=pseudo.dtype)
+    index = torch.zeros((E, S), dtype=torch.int64)
+    for s in range(S):
+        k = s
+        wi_offset = 1
+        for d in range(D):
+            k_mod = k % (degree + 1)
+            k //= (degree + 1)
+            v = pseudo[:, d] * (kernel_size - degree * is_open_spline)
+            fl = torch.floor(v)
+            frac = v - fl
+            basis[:, s] = basis[:, s] * (1 - frac - k_mod + 2 * frac * k_mod)
+            index[:, s] += ((fl.to(torch.int64) + k_mod) % kernel_size) * wi_offset
+            wi_offset *= kernel_size
+    return basis, index
+
+
+def spline_weighting(x_j, weight, basis, index):
+    """``torch_spline_conv.spline_weighting``: out[e,o] = sum_s basis[e,s] * sum_i x_j[e,i] W[index[e,s],i,o]
+    (the non-LUT message of PyG ``SplineConv.message``)."""
+    out = torch.zeros((x_j.shape[0], weight.shape[2]), dtype=x_j.dtype)
+    for s in range(basis.shape[1]):
+        out += basis[:, s:s + 1] * torch.einsum("ei,eio->eo", x_j, weight[index[:, s]])
+    return out
+
+
+# --------------------------------------------------------------------------- MySplineConv
+class SplineConvParams:
+    """Parameters of one ``MySplineConv`` (``spline_conv.py:9-15`` over PyG ``SplineConv``):
+    weight[25,Cin,Cout], root lin.weight[Cout,Cin] (bias-free), optional bias[Cout]."""
+
+    def __init__(self, weight, root_weight, bias=None):
+        self.weight = weight
+        self.root = root_weight
+        self.bias = bias
+        self.lut = None
+        self.remap = None
+
+    def init_lut(self, height, width, rx, Mx, ry=None, My=None):
+        """``spline_conv.py:16-37``.  The reference materialises ``lut_weights[(2rx+1),(2ry+1),Cin,Cout]``
+        (GBs at the coarse levels); the oracle keeps the parameters and evaluates, with the same
+        arithmetic, only the cells that ``message_lut`` actually indexes (``lut_cells``).
+        ``full_lut`` builds the whole table for small domains."""
+        ry = ry or rx
+        My = My or Mx
+        self.remap = torch.Tensor([[2 * Mx * width, 0, -Mx * width + rx],
+                                   [0, 2 * My * height, -My * height + ry]])
+        self.rx, self.ry = rx, ry
+        self._den = (2 * Mx * width, 2 * My * height)
+        self.lut = True
+
+    def lut_cells(self, dx_index, dy_index):
+        """Rows ``lut_weights[dx_index, dy_index]`` computed as ``spline_conv.py:27-34`` does."""
+        dxy = torch.stack([(dx_index - self.rx), (dy_index - self.ry)]).float()
+        dxy[0] = dxy[0] / self._den[0] + 0.5
+        dxy[1] = dxy[1] / self._den[1] + 0.5
+        edge_attr = dxy.view((2, -1)).t()
+        bil_w, indices = spline_basis(edge_attr)
+        return (bil_w[..., None, None] * self.weight[indices]).sum(1)
+
+    def full_lut(self):
+        gx, gy = torch.meshgrid(torch.arange(0, 2 * self.rx + 1), torch.arange(0, 2 * self.ry + 1), indexing="ij")
+        cells = self.lut_cells(gx.reshape(-1), gy.reshape(-1))
+        return cells.view(2 * self.rx + 1, 2 * self.ry + 1, cells.shape[1], cells.shape[2])
+
+    def lut_index(self, edge_attr):
+        """``spline_conv.py:41-42``."""
+        dx = (edge_attr[:, 0] * self.remap[0, 0] + self.remap[0, -1] + 1e-3).long()
+        dy = (edge_attr[:, 1] * self.remap[1, 1] + self.remap[1, -1] + 1e-3).long()
+        return dx, dy
+
+    def message(self, x_j, edge_attr):
+        if self.lut is not None:  # message_lut, spline_conv.py:39-47
+            dx, dy = self.lut_index(edge_attr)
+            assert (dx >= 0).all() and (dx <= 2 * self.rx).all() and (dy >= 0).all() and (dy <= 2 * self.ry).all(), \
+                "LUT index out of range (the reference would wrap / fault here)"
+            key = dx * (2 * self.ry + 1) + dy
+            ukey, inv = torch.unique(key, return_inverse=True)
+            cells = self.lut_cells(ukey // (2 * self.ry + 1), ukey % (2 * self.ry + 1))
+            out = torch.empty((x_j.shape[0], self.weight.shape[2]), dtype=x_j.dtype)
+            step = 1 << 16
+            for s in range(0, x_j.shape[0], step):  # weights = lut[dx, dy]; einsum("nio,ni->no")
+                out[s:s + step] = torch.einsum("nio,ni->no", cells[inv[s:s + step]], x_j[s:s + step])
+            return out
+        basis, index = spline_basis(edge_attr)  # PyG SplineConv.message
+        return spline_weighting(x_j, self.weight, basis, index)
+
+
+def to_sparse(edge_index, edge_attr, num_nodes):
+    """``ToSparseTensor(attr="edge_attr")`` [torch_geometric + torch_sparse] (``spline_conv.py:12,52-54``):
+    edges sorted by (destination, source); returns rowptr over destinations, col=source, value."""
+    row, col = edge_index[0], edge_index[1]  # row = source, col = destination
+    key = col * num_nodes + row
+    perm = torch.argsort(key, stable=True)
+    dst = col[perm]
+    src = row[perm]
+    val = edge_attr[perm]
+    counts = torch.bincount(dst, minlength=num_nodes)
+    rowptr = torch.zeros(num_nodes + 1, dtype=torch.int64)
+    rowptr[1:] = torch.cumsum(counts, 0)
+    return rowptr, src, val, dst
+
+
+def segment_csr_sum(inputs, rowptr):
+    """``torch_scatter.segment_csr(reduce='sum')``: sequential per-destination sum in stored order."""
+    n = rowptr.numel() - 1
+    out = torch.zeros((n, inputs.shape[1]), dtype=inputs.dtype)
+    dst = torch.repeat_interleave(torch.arange(n), rowptr[1:] - rowptr[:-1])
+    out.index_add_(0, dst, inputs)  # CPU index_add_ accumulates in index order
+    return out
+
+
+def spline_conv(p, x, adj):
+    """``MySplineConv._forward`` (``spline_conv.py:64-78``) with the sparse-tensor path of
+    ``forward`` (:49-56); in-repo restatement of the op sequence: ``asynchronous/conv.py:11-26``."""
+    rowptr, src, val, _ = adj
+    n = x.shape[0]
+    if src.numel() > 0:
+        msg = p.message(x[src], val)
+        out = segment_csr_sum(msg, rowptr)
+    else:
+        out = torch.zeros((n, p.weight.shape[2]), dtype=x.dtype)
+    out = out + x @ p.root.t()
+    if p.bias is not None:
+        out = out + p.bias
+    return out
+
+
+def batch_norm_eval(x, bn):
+    """PyG ``BatchNorm`` wraps ``nn.BatchNorm1d`` as ``.module`` (``components.py:9-12``); eval mode,
+    eps 1e-5 (restated at ``asynchronous/batch_norm.py:9-10`` and ``asy_tools/main.cu:66``)."""
+    return torch.nn.functional.batch_norm(x, bn["running_mean"], bn["running_var"], bn["weight"], bn["bias"],
+                                          training=False, eps=1e-5)
+
+
+# --------------------------------------------------------------------------- pooling
+def grid_cluster(pos, size, start, end):
+    """``torch_cluster.grid_cluster`` (call site ``pooling.py:56``), published algorithm
+    (torch_cluster/csrc/cpu/grid_cpu.cpp): all fp32 until the cast to int64."""
+    pos = pos - start.unsqueeze(0)
+    num_voxels = ((end - start) / size).to(torch.int64) + 1
+    num_voxels = num_voxels.cumprod(0)
+    num_voxels = torch.cat([torch.ones(1, dtype=torch.int64), num_voxels], 0)[: size.numel()]
+    out = (pos / size.view(1, -1)).to(torch.int64)
+    out = out * num_voxels.view(1, -1)
+    return out.sum(1)
+
+
+def consecutive_cluster(src):
+    """``pooling.py:12-16``; ``scatter_`` with duplicate indices: on CPU the last occurrence wins."""
+    unique, inv, counts = torch.unique(src, sorted=True, return_inverse=True, return_counts=True)
+    perm = torch.arange(inv.size(0), dtype=inv.dtype)
+    perm = inv.new_empty(unique.size(0)).scatter_(0, inv, perm)
+    return unique, inv, perm, counts
+
+
+def scatter_mean(src, index, n):
+    """``torch_scatter.scatter(reduce='mean')`` = sum / count (``pool_pos`` / ``_avg_pool_x``, pooling.py:67,77)."""
+    out = torch.zeros((n,) + tuple(src.shape[1:]), dtype=src.dtype)
+    out.index_add_(0, index, src)
+    cnt = torch.bincount(index, minlength=n).clamp(min=1).to(src.dtype)
+    return out / cnt.view(-1, *([1] * (src.dim() - 1)))
+
+
+def scatter_max(src, index, n):
+    """``torch_scatter.scatter_max`` values (pooling.py:75)."""
+    out = torch.full((n, src.shape[1]), float("-inf"), dtype=src.dtype)
+    out = out.scatter_reduce(0, index.view(-1, 1).expand_as(src), src, reduce="amax", include_self=True)
+    return out
+
+
+def round_to_pixel(pos, wh_inv):
+    """``pooling.py:47-49``."""
+    pos = torch.div(pos + 1e-5, wh_inv, rounding_mode="floor")
+    return pos * wh_inv
+
+
+class PoolingParams:
+    """Buffers of ``Pooling.__init__`` (``pooling.py:19-40``)."""
+
+    def __init__(self, size, width, height, batch_size, cart_max, aggr="max"):
+        self.aggr = aggr
+        self.voxel_size = torch.cat([size, torch.Tensor([1])])
+        self.start = torch.Tensor([0, 0, 0, 0])
+        self.end = torch.Tensor([0.9999999, 0.9999999, 0.9999999, batch_size - 1])
+        self.wh_inv = 1 / torch.Tensor([[width, height]])
+        self.cart_max = cart_max
+
+
+def pooling(pp, x, pos, batch, edge_index):
+    """``Pooling.forward`` (``pooling.py:51-97``), self_loop=False, keep_temporal_ordering=False,
+    bn=None.  Returns (x, pos, batch, edge_index, edge_attr[E,3])."""
+    if x.shape[0] == 0:
+        return None
+    pos4 = torch.cat([pos, batch.float().view(-1, 1)], dim=-1)
+    cluster = grid_cluster(pos4, pp.voxel_size, pp.start, pp.end)
+    unique_clusters, cluster, perm, _ = consecutive_cluster(cluster)
+    n = unique_clusters.numel()
+    ei = cluster[edge_index]
+    ei = ei[:, ei[0] != ei[1]]
+    if ei.shape[1] > 0:
+        ei = ei.unique(dim=-1)
+    new_batch = batch[perm]
+    new_pos = scatter_mean(pos, cluster, n)
+    if pp.aggr == "max":
+        new_x = scatter_max(x, cluster, n)
+    else:
+        new_x = scatter_mean(x, cluster, n)
+    new_pos[:, :2] = round_to_pixel(new_pos[:, :2], pp.wh_inv)
+    if ei.numel() > 0:
+        edge_attr = cartesian(new_pos, ei, pp.cart_max)
+    else:
+        edge_attr = torch.zeros((0, new_pos.shape[1]), dtype=new_pos.dtype)
+    return new_x, new_pos, new_batch, ei, edge_attr
+
+
+# --------------------------------------------------------------------------- to_dense
+def to_dense(x, pos, pooling_size, batch, batch_size):
+    """``spline_conv.py:80-107``: zeroed [B,C,H,W]; ``dense[batch, :, est_y, est_x] = x`` (index_put,
+    duplicates: last writer wins on CPU)."""
+    W, H = (1 / pooling_size[:2] + 1e-3).long()
+    C = x.shape[-1]
+    dense = torch.zeros((batch_size, C, int(H), int(W)), dtype=x.dtype)
+    est_x, est_y = (pos[:, :2] / pooling_size[:2]).t().long()
+    dense[batch.long(), :, est_y, est_x] = x
+    return dense

@@ -1,0 +1,120 @@
+"""GPU parity of the whole events-only hot path (graph -> SplineConv stack -> pooling -> head maps)
+against the CPU oracle, stage by stage.  Tolerance for fp32 features / head outputs: 1e-4
+(BASELINE.json north_star); graph indices, cluster assignments, pooled positions: exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as om
+from dagr_amd.utils import synthetic as syn
+from dagr_amd.utils.testing_weights import randomize_
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _setup(W, H, B, seed=0):
+    from dagr_amd.model.networks.dagr import DAGR
+    torch.manual_seed(seed)
+    args = om.default_args(batch_size=B)
+    model = randomize_(DAGR(args, height=H, width=W), seed=seed).eval()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.cuda()
+    model.cache_luts(width=W, height=H, radius=args.radius)
+    return args, model, sd
+
+
+def _events(gen, n, B, W, H, seed):
+    x, y, t, p, b = syn.batch_windows(gen, n, B, W, H, seed=seed)
+    pos = syn.format_data_np(x, y, t, W, H)
+    return x, y, t, p, b, pos
+
+
+def _edges_from_csr(rowptr, col):
+    rowptr, col = rowptr.cpu().numpy(), col.cpu().numpy()
+    dst = np.repeat(np.arange(len(rowptr) - 1), np.diff(rowptr))
+    return np.stack([col, dst])
+
+
+def _sorted_cols(e):
+    e = np.asarray(e)
+    order = np.lexsort((e[1], e[0]))
+    return e[:, order]
+
+
+def _compare(args, model, sd, W, H, B, x, y, t, p, b, pos):
+    dev = torch.device("cuda:0")
+    eng = model.engine()
+    tr_h = {}
+    out_h = eng.forward_raw(torch.from_numpy(pos).to(dev), torch.from_numpy(p.astype(np.float32)).view(-1, 1).to(dev),
+                            torch.from_numpy(b).to(dev), trace=tr_h)
+    eng.check_status()
+    tr_o = {}
+    out_o, raw_o = om.forward_events(sd, args, H, W, x, y, t, p, b, B, trace=tr_o)
+    # level 0 features
+    d = (tr_h["layer1"].cpu() - tr_o["layer1"]["x"]).abs().max().item()
+    assert d < TOL, f"layer1 features differ by {d}"
+    # pooled levels
+    for k in range(1, 5):
+        ho, oo = tr_h[f"pool{k}"], tr_o[f"pool{k}"]
+        assert ho["x"].shape[0] == oo["x"].shape[0], f"pool{k}: cluster count {ho['x'].shape[0]} vs {oo['x'].shape[0]}"
+        c = oo["x"].shape[1]
+        assert (ho["batch"].cpu().long() == oo["batch"]).all(), f"pool{k}: batch"
+        dp = (ho["pos"].cpu() - oo["pos"]).abs().max().item()
+        assert dp < 1e-6, f"pool{k}: pos differs by {dp}"
+        assert (ho["pos"].cpu()[:, :2] == oo["pos"][:, :2]).all(), f"pool{k}: rounded xy not identical"
+        dx = (ho["x"].cpu()[:, :c] - oo["x"]).abs().max().item()
+        assert dx < TOL, f"pool{k}: x differs by {dx}"
+        assert (ho["x"].cpu()[:, c:c + 2] == ho["pos"].cpu()[:, :2]).all()
+        eh = _sorted_cols(_edges_from_csr(ho["rowptr"], ho["col"]))
+        eo = _sorted_cols(oo["edge_index"].numpy())
+        assert eh.shape == eo.shape and (eh == eo).all(), f"pool{k}: coarse edges differ"
+        hl, ol = tr_h[f"layer{k + 1}"], tr_o[f"layer{k + 1}"]
+        dl = (hl["x"].cpu() - ol["x"]).abs().max().item()
+        assert dl < TOL, f"layer{k + 1} features differ by {dl}"
+    # dense head maps (raw logits) and decoded outputs
+    for i, dm in enumerate(tr_h["head_dense"]):
+        cls_o, reg_o, obj_o = raw_o[i]
+        ref = torch.cat([reg_o, obj_o, cls_o], 1)
+        dd = (dm.cpu() - ref).abs().max().item()
+        assert dd < TOL, f"head scale {i + 1} differs by {dd}"
+    rel = ((out_h.cpu() - out_o).abs() / (1 + out_o.abs())).max().item()
+    assert rel < TOL, f"decoded outputs differ by {rel}"
+    return out_h
+
+
+def test_small_uniform_b2():
+    W, H, B = 320, 215, 2
+    args, model, sd = _setup(W, H, B)
+    _compare(args, model, sd, W, H, B, *_events(syn.uniform_window, 6000, B, W, H, seed=5))
+
+
+def test_small_edges_b3_repeatable():
+    W, H, B = 320, 215, 3
+    args, model, sd = _setup(W, H, B, seed=1)
+    ev = _events(syn.edges_window, 8000, B, W, H, seed=7)
+    o1 = _compare(args, model, sd, W, H, B, *ev).clone()
+    o2 = _compare(args, model, sd, W, H, B, *ev)      # same buffers, second window: bit-identical
+    assert torch.equal(o1, o2)
+
+
+def test_vga_uniform_b1():
+    W, H, B = 640, 480, 1
+    args, model, sd = _setup(W, H, B, seed=2)
+    _compare(args, model, sd, W, H, B, *_events(syn.uniform_window, 25000, B, W, H, seed=9))
+
+
+def test_empty_and_tiny_windows():
+    W, H, B = 320, 215, 2
+    args, model, sd = _setup(W, H, B, seed=3)
+    dev = torch.device("cuda:0")
+    eng = model.engine()
+    out = eng.forward_raw(torch.zeros((0, 3), device=dev), torch.zeros((0, 1), device=dev),
+                          torch.zeros((0,), dtype=torch.int64, device=dev))
+    eng.check_status()
+    assert out.shape == (B, 175, 7)
+    # all-zero dense maps -> decode of zeros: sigmoid(0)=0.5
+    assert torch.allclose(out[..., 4:], torch.full_like(out[..., 4:], 0.5))
+    x = np.array([10, 11, 300], np.int64); y = np.array([20, 20, 200], np.int64)
+    t = np.array([999000, 1000000, 1000000], np.int64); p = np.array([1, -1, 1], np.int8); b = np.array([0, 0, 1], np.int64)
+    _compare(args, model, sd, W, H, B, x, y, t, p, b, syn.format_data_np(x, y, t, W, H))
