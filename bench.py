@@ -1,0 +1,217 @@
+#!/usr/bin/env python
+"""bench.py -- events/sec of the DAGR event-graph hot path on MI355X.
+
+One "step" = one pass of the hot path (format_data'd events -> graph build -> SplineConv stack +
+voxel pooling -> decoded detection-head outputs [B,175,5+C]) over one batch of B synthetic 50 ms
+event windows already resident in HBM.  `python bench.py --gpus N --steps K --warmup W`; for N > 1
+the driver launches it under torch.distributed.run (one rank per GPU); windows are independent so
+ranks share nothing on the data path (weak scaling) and RCCL is used once, to all-gather the
+detections of the run.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--events-per-window", type=int, default=100000)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--stream", choices=["uniform", "edges"], default="uniform")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-windows", type=int, default=4)
+    return ap.parse_args()
+
+
+def make_model(W, H, B):
+    from oracle.model import default_args  # argument defaults only (config/dagr-s-dsec.yaml values)
+    from dagr_amd.model.networks.dagr import DAGR
+    from dagr_amd.utils.testing_weights import randomize_
+    torch.manual_seed(0)
+    args = default_args(batch_size=B)
+    model = randomize_(DAGR(args, height=H, width=W)).eval()
+    return args, model
+
+
+def algorithmic_bytes(N, E, r, levels):
+    """SURVEY.md 8(d) per-window algorithmic bytes (int32 indices, fp32 features, no LUT)."""
+    def conv(cin, cout, nn, ee):
+        return 4 * cin * ee + 8 * ee + 4 * (nn + 1) + 4 * cin * nn + 4 * cout * nn + 104 * cin * cout
+    out = {}
+    out["graph"] = 16 * N + 4 * (2 * r + 1) ** 2 * N + 12 * E + 4 * (N + 1)
+    out["l0_conv1"] = conv(3, 16, N, E)
+    out["l0_conv2"] = conv(16, 16, N, E) + 4 * 3 * N
+    n1, e1 = levels[0]
+    out["pool1"] = 4 * (16 + 5) * N + 8 * E + 4 * (16 + 4) * n1 + 12 * e1
+    tail = 0
+    chans = [(18, 64), (66, 64), (66, 64), (66, 64)]
+    for (nn, ee), (cin, cout) in zip(levels, chans):
+        tail += conv(cin, cout, nn, ee) + conv(cout, cout, nn, ee) + 4 * cin * nn
+    for k in range(1, 4):
+        nn, ee = levels[k - 1]
+        nc, ec = levels[k]
+        tail += 4 * (64 + 5) * nn + 8 * ee + 4 * (64 + 4) * nc + 12 * ec
+    out["tail"] = tail
+    return out
+
+
+def time_gpu(fn, iters, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(iters):
+        fn()
+    ev1.record()
+    torch.cuda.synchronize()
+    return ev0.elapsed_time(ev1) / iters  # ms
+
+
+def cpu_baseline(args_ns, model_sd, W, H, n_events, n_windows, stream):
+    """The oracle (op-for-op CPU restatement, `port`) on a bounded sample: B=1 windows of the same
+    synthetic stream.  Graph build: single-threaded C; conv/pool: torch CPU on all host threads."""
+    from oracle import model as om
+    from dagr_amd.utils import synthetic as syn
+    gen = syn.uniform_window if stream == "uniform" else syn.edges_window
+    a = om.default_args(batch_size=1)
+    tot_ev, t0 = 0, time.perf_counter()
+    for w in range(n_windows):
+        x, y, t, p = gen(n_events, W, H, seed=1234 + w)
+        b = np.zeros(len(x), np.int64)
+        om.forward_events(model_sd, a, H, W, x, y, t, p, b, 1)
+        tot_ev += len(x)
+    dt = time.perf_counter() - t0
+    return dict(value=tot_ev / dt, unit="events/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n_windows} windows x {n_events} events, {W}x{H}, B=1, events-only dagr-s, "
+                       f"oracle/model.py (torch-CPU fp32 + C graph builder), {dt:.1f} s")
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    from dagr_amd.utils import synthetic as syn
+
+    W, H, B, NPW = a.width, a.height, a.batch, a.events_per_window
+    args, model = make_model(W, H, B)
+    sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(dev)
+    model.cache_luts(width=W, height=H, radius=args.radius)
+    eng = model.engine()
+
+    # synthetic inputs, resident in HBM before the timed region (distinct per rank and per slot)
+    gen = syn.uniform_window if a.stream == "uniform" else syn.edges_window
+    slots = []
+    for s in range(4):
+        x, y, t, p, b = syn.batch_windows(gen, NPW, B, W, H, seed=1234 + 1000 * rank + 10 * s)
+        pos = torch.from_numpy(syn.format_data_np(x, y, t, W, H)).to(dev)
+        feat = torch.from_numpy(p.astype(np.float32)).view(-1, 1).to(dev)
+        batch = torch.from_numpy(b).to(dev)
+        slots.append((pos, feat, batch))
+    n_events_step = B * NPW
+
+    def step(i):
+        pos, feat, batch = slots[i % len(slots)]
+        return eng.forward_raw(pos, feat, batch)
+
+    for i in range(a.warmup):
+        step(i)
+    eng.check_status()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outs = []
+    for i in range(a.steps):
+        outs.append(step(i))
+    if dist is not None:  # the only collective of the job: gather the run's detections (RCCL)
+        mine = outs[-1].contiguous()
+        gathered = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=dev)
+        dist.all_gather_into_tensor(gathered, mine)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    eng.check_status()
+
+    result = None
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / a.steps
+        value = world * n_events_step * a.steps / elapsed
+        # ---- per-stage / per-kernel timing on the stream the kernels run on (HIP events)
+        pos, feat, batch = slots[0]
+        eng.forward_raw(pos, feat, batch)
+        ne, _ = eng.graph.status()
+        levels = [tuple(int(v) for v in lvl.counts.tolist()) for lvl in eng.levels]
+        r = eng.graph.params["radius"]
+        ab = algorithmic_bytes(n_events_step, ne, r, levels)
+        iters = 20
+        stages = {}
+        stages["graph"] = time_gpu(lambda: eng.stage_graph(pos, batch), iters)
+        eng.stage_l0_input(feat)
+        stages["l0_conv1"] = time_gpu(eng.stage_l0_conv1, iters)
+        stages["l0_conv2"] = time_gpu(eng.stage_l0_conv2, iters)
+        stages["pool1"] = time_gpu(eng.stage_pool1, iters)
+        stages["tail"] = time_gpu(eng.stage_tail, iters)
+        stages["head"] = time_gpu(lambda: eng._decode(eng.stage_head()), iters)
+        kernels = {k: dict(ms=round(v, 4), alg_MB=round(ab[k] / 1e6, 2) if k in ab else None,
+                           alg_GBs=round(ab[k] / 1e9 / (v / 1e3), 1) if k in ab else None)
+                   for k, v in stages.items()}
+        dom = max(("l0_conv1", "l0_conv2"), key=lambda k: stages[k])  # single-launch stages
+        achieved = ab[dom] / 1e9 / (stages[dom] / 1e3)
+        roofline = dict(kernel={"l0_conv1": "k_conv_l0<3,0,NT>", "l0_conv2": "k_conv_l0<16,3,NT>"}[dom],
+                        bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                        alg_bytes_per_launch=int(ab[dom]), launch_ms=round(stages[dom], 4))
+        result = {
+            "metric": "events_per_sec", "value": round(value, 1), "unit": "events/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"dagr-s events-only, {W}x{H} synthetic S-{a.stream}, B={B} windows/step x "
+                                   f"{NPW} events (50 ms each), r={r}, K=16, graph+GNN+head maps",
+                       "events_per_step_per_gpu": n_events_step, "edges_per_step": int(ne),
+                       "level_nodes_edges": levels, "window_latency_ms": round(ms_per_step, 4)},
+            "roofline": roofline, "stages": kernels,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args, sd_cpu, W, H, NPW, a.cpu_windows, a.stream)
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    main()

@@ -274,43 +274,62 @@ class WindowEngine:
         _lib.check(L.dagr_gemm_bias_act(P(lvl.counts), lvl.T, P(self.A), lda, P(pack.Wm), pack.N, P(pack.bias),
                                         out, ldo, pack.K, pack.N, 1 if pack.relu else 0, stream), "gemm")
 
-    def forward_raw(self, pos, feat, batch, trace=None):
-        """pos fp32[N,3] normalised (format_data), feat fp32[N,1], batch int32/int64[N] on the device.
-        Returns decoded head outputs [B, n_anchors, 5+num_classes] (GNNHead.forward eval)."""
-        L, P, dev = self.L, _lib.ptr, self.device
+    # -------------------------------------------------------------------------------- stages
+    def stage_graph(self, pos, batch):
+        """events -> neighbour lists (EV_TGN.forward, layers/ev_tgn.py:39-58)."""
         N = int(pos.shape[0])
         self._alloc_events(N)
-        stream = _lib.cur_stream(dev)
-        pos = pos.contiguous()
-        batch = batch.contiguous()
-        b64 = 1 if batch.dtype == torch.int64 else 0
-        g = self.graph
-        nbr_src, nbr_code, deg = self.nbr_src[:N], self.nbr_code[:N], self.deg[:N]
-        g.build(pos, batch, out=(nbr_src, nbr_code, deg))
-        K = g.K
-        # ---- level 0: Layer(3 -> 16)  (net.py:124-126)
-        x0 = torch.cat((feat.float().reshape(N, feat.shape[1] if feat.dim() > 1 else 1), pos[:, :2]), dim=1).contiguous()
-        c0 = x0.shape[1]
+        self._N = N
+        self._pos, self._batch = pos, batch
+        self._nbr = (self.nbr_src[:N], self.nbr_code[:N], self.deg[:N])
+        self.graph.build(pos, batch, out=self._nbr)
+
+    def stage_l0_input(self, feat):
+        """x = cat(x, pos[:, :2]) (net.py:124-125)."""
+        N = self._N
+        self._x0 = torch.cat((feat.float().reshape(N, feat.shape[1] if feat.dim() > 1 else 1), self._pos[:, :2]),
+                             dim=1).contiguous()
+
+    def stage_l0_conv1(self):
+        """conv_block1.conv_block1: SplineConv(3->16)+BN+ReLU (conv.py:23-28)."""
+        L, P = self.L, _lib.ptr
+        nbr_src, nbr_code, deg = self._nbr
         cin, cskip, w1, s1 = self.l0_conv1
+        c0 = self._x0.shape[1]
         assert cin == c0
-        _lib.check(L.dagr_spline_conv_l0(cin, 0, self.ntaps0, N, K, self.ncodes0, P(nbr_src), P(nbr_code), P(deg), P(x0), c0,
-                                         None, 0, P(self.tab0), P(w1), P(s1), 1, P(self.h1), 16, stream), "conv_l0")
+        _lib.check(L.dagr_spline_conv_l0(cin, 0, self.ntaps0, self._N, self.graph.K, self.ncodes0, P(nbr_src),
+                                         P(nbr_code), P(deg), P(self._x0), c0, None, 0, P(self.tab0), P(w1), P(s1), 1,
+                                         P(self.h1), 16, _lib.cur_stream(self.device)), "conv_l0")
+
+    def stage_l0_conv2(self):
+        """conv_block1.conv_block2: SplineConv(16->16)+BN + skip Linear+BN, ReLU (conv.py:47-56)."""
+        L, P = self.L, _lib.ptr
+        nbr_src, nbr_code, deg = self._nbr
         cin, cskip, w2, s2 = self.l0_conv2
-        _lib.check(L.dagr_spline_conv_l0(cin, cskip, self.ntaps0, N, K, self.ncodes0, P(nbr_src), P(nbr_code), P(deg), P(self.h1),
-                                         16, P(x0), c0, P(self.tab0), P(w2), P(s2), 1, P(self.h2), 16, stream),
-                   "conv_l0")
-        if trace is not None:
-            trace["nbr"] = (nbr_src.clone(), nbr_code.clone(), deg.clone())
-            trace["layer1"] = self.h2[:N].clone()
-        # ---- pool1 (net.py:131)
+        c0 = self._x0.shape[1]
+        _lib.check(L.dagr_spline_conv_l0(cin, cskip, self.ntaps0, self._N, self.graph.K, self.ncodes0, P(nbr_src),
+                                         P(nbr_code), P(deg), P(self.h1), 16, P(self._x0), c0, P(self.tab0), P(w2),
+                                         P(s2), 1, P(self.h2), 16, _lib.cur_stream(self.device)), "conv_l0")
+
+    def stage_pool1(self):
+        """pool1 (net.py:131) on the event graph."""
+        L, P = self.L, _lib.ptr
+        g = self.graph
+        nbr_src, nbr_code, deg = self._nbr
         l1 = self.levels[0]
         d = self.pool_desc[0]
+        b64 = 1 if self._batch.dtype == torch.int64 else 0
         _lib.check(L.dagr_pool_l0(ctypes.byref(d), P(self.pool_ws[0]), ctypes.byref(g.desc), P(g.workspace),
-                                  P(self.xlo), P(self.ylo), P(self.h2), 16, P(pos), P(batch), b64, N, P(nbr_src),
-                                  P(deg), P(self.cluster0), P(l1.x), l1.x.shape[1], 0, P(l1.pos), P(l1.batch),
-                                  P(l1.counts), P(l1.rowptr), P(l1.col), P(l1.code),
-                                  ctypes.c_void_p(l1.counts.data_ptr() + 4), l1.e_cap, stream), "pool_l0")
-        # ---- levels 1..4
+                                  P(self.xlo), P(self.ylo), P(self.h2), 16, P(self._pos), P(self._batch), b64, self._N,
+                                  P(nbr_src), P(deg), P(self.cluster0), P(l1.x), l1.x.shape[1], 0, P(l1.pos),
+                                  P(l1.batch), P(l1.counts), P(l1.rowptr), P(l1.col), P(l1.code),
+                                  ctypes.c_void_p(l1.counts.data_ptr() + 4), l1.e_cap, _lib.cur_stream(self.device)),
+                   "pool_l0")
+
+    def stage_tail(self, trace=None):
+        """layer2..layer5 with pool2..pool4 (net.py:137-184)."""
+        L, P = self.L, _lib.ptr
+        stream = _lib.cur_stream(self.device)
         for k in range(4):
             lvl = self.levels[k]
             c1, c2 = self.packs[k]
@@ -329,7 +348,11 @@ class WindowEngine:
                                            P(lvl.cluster), P(nxt.x), nxt.x.shape[1], 0, P(nxt.pos), P(nxt.batch),
                                            P(nxt.counts), P(nxt.rowptr), P(nxt.col), P(nxt.code),
                                            ctypes.c_void_p(nxt.counts.data_ptr() + 4), nxt.e_cap, stream), "pool_csr")
-        # ---- head (dagr.py:179-236)
+
+    def stage_head(self):
+        """GNNHead.process_feature per scale + to_dense (dagr.py:179-236)."""
+        L, P = self.L, _lib.ptr
+        stream = _lib.cur_stream(self.device)
         outs = []
         for i, lvln in enumerate(self.head_levels):
             lvl = self.levels[lvln - 1]
@@ -352,6 +375,21 @@ class WindowEngine:
                                        float(vox[0]), float(vox[1]), self.B, Hc, Wc, P(hb["winner"]), P(hb["dense"]),
                                        P(self.status), stream), "to_dense")
             outs.append(hb["dense"])
+        return outs
+
+    def forward_raw(self, pos, feat, batch, trace=None):
+        """pos fp32[N,3] normalised (format_data), feat fp32[N,1], batch int32/int64[N] on the device.
+        Returns decoded head outputs [B, n_anchors, 5+num_classes] (GNNHead.forward eval)."""
+        self.stage_graph(pos.contiguous(), batch.contiguous())
+        self.stage_l0_input(feat)
+        self.stage_l0_conv1()
+        self.stage_l0_conv2()
+        if trace is not None:
+            trace["nbr"] = tuple(t.clone() for t in self._nbr)
+            trace["layer1"] = self.h2[:self._N].clone()
+        self.stage_pool1()
+        self.stage_tail(trace)
+        outs = self.stage_head()
         if trace is not None:
             trace["head_dense"] = [o.clone() for o in outs]
         return self._decode(outs)
