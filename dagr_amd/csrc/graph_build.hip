@@ -251,6 +251,12 @@ __device__ __forceinline__ int group16_inclusive_scan(int v) {
     return v;
 }
 
+// kTile = true (2r+2 <= 16): the segment offsets of an event's (2r+1)^2 neighbourhood are fetched
+// row by row -- per instruction the 16 lanes of an event read the 2r+2 consecutive offsets of one
+// pixel row (1-2 cache lines, instead of one line per probed pixel on the vertical spiral legs) --
+// and parked in LDS; the spiral then runs out of LDS and only touches global memory for the
+// {id, t} pairs of non-empty pixels.  kTile = false: generic path, probes go to global memory.
+template <bool kTile>
 __global__ __launch_bounds__(kBlock) void k_search(int N, int W, int H, int K, int Q, int r, float delta_t,
                                                   const int32_t *__restrict__ ev_xyb,
                                                   const int32_t *__restrict__ ev_t,
@@ -258,12 +264,11 @@ __global__ __launch_bounds__(kBlock) void k_search(int N, int W, int H, int K, i
                                                   const int2 *__restrict__ slot_it,
                                                   int32_t *__restrict__ nbr_src, int16_t *__restrict__ nbr_code,
                                                   int32_t *__restrict__ deg, int32_t *__restrict__ status) {
-    __shared__ int16_t sp_tab[kMaxSpiral];  // (sx + 64) | (sy + 64) << 8, spiral.h:1-15 order
+    __shared__ int16_t sp_tab[kTile ? 256 : kMaxSpiral];  // (sx + 64) | (sy + 64) << 8, spiral.h:1-15 order
+    __shared__ int tile[kTile ? (kBlock / 16) * 16 * 17 : 1];  // per event: segment offsets [row][col], row stride 17
     __shared__ int blk_edges;
     const int side = 2 * r + 1;
     const int S = side * side;
-    // Closed form of SpiralOut: position s>0 lies on ring rho = ceil((sqrt(s+1)-1)/2); the ring
-    // starts at (rho, -(rho-1)) ... walked +y, -x, -y, +x.  Filled once per block.
     for (int s = threadIdx.x; s < S; s += kBlock) {
         int sx, sy;
         spiral_offset(s, sx, sy);
@@ -273,6 +278,7 @@ __global__ __launch_bounds__(kBlock) void k_search(int N, int W, int H, int K, i
     __syncthreads();
 
     const int l = threadIdx.x & 15;
+    const int grp = threadIdx.x >> 4;
     const int e = (blockIdx.x * kBlock + threadIdx.x) >> 4;
     int total = 0;
     if (e < N) {
@@ -287,47 +293,99 @@ __global__ __launch_bounds__(kBlock) void k_search(int N, int W, int H, int K, i
         if (c >= 0) {
             const int x = c & 4095, y = (c >> 12) & 4095, b = c >> 24;
             const int plane = W * H * b;
-            for (int s0 = 0; s0 < S && total < K; s0 += 16) {
-                const int s = s0 + l;
-                int bnd = 0, vis = 0, sx = 0, sy = 0;
-                if (s < S) {
-                    const int code = sp_tab[s];
-                    sx = (code & 255) - 64;
-                    sy = ((code >> 8) & 255) - 64;
-                    const int xn = x + sx, yn = y + sy;
-                    if (xn >= 0 && yn >= 0 && xn < W && yn < H) {  // out of FOV: skip this pixel only
-                        const int p = plane + yn * W + xn;
-                        const int a = start[p];
-                        bnd = start[p + 1];
-                        vis = bnd - a;
-                        if (vis > Q) vis = Q;  // FIFO depth
+            int *my_tile = tile + (kTile ? grp * 16 * 17 : 0);
+            if (kTile) {
+                // lane l owns neighbourhood column x - r + l (clamped into the row, so that pixels
+                // outside the sensor read two equal offsets = empty); one instruction per row: the 16
+                // lanes of an event read 16 consecutive offsets (1-2 cache lines).
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int yn = y + i - r;
+                    int val = 0;
+                    if (i < side && yn >= 0 && yn < H) {
+                        // columns left of the sensor clamp to the first in-range pixel, columns right
+                        // of it to the row end: both give zero-length segments
+                        const int lo = max(x - r, 0), hi = min(x + r, W - 1) + 1;
+                        val = start[plane + yn * W + min(max(x - r + l, lo), hi)];
+                    }
+                    if (i < side) my_tile[i * 17 + l] = val;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            // Positions are consumed in batches of kRounds x 16 (first batch: 1 round = ring 0, ring 1
+            // and the start of ring 2, where dense scenes already fill their K slots).  Inside a batch
+            // every lane first collects the segment bounds of all its positions, then the newest
+            // {id, t} of every non-empty pixel, and only then evaluates them.
+            constexpr int kRounds = 8;
+            for (int s0 = 0; s0 < S && total < K;) {
+                const int rounds = (s0 == 0) ? 1 : min(kRounds, (S - s0 + 15) >> 4);
+                int bnd[kRounds], vis[kRounds], ecode[kRounds];
+#pragma unroll
+                for (int m = 0; m < kRounds; m++) {
+                    bnd[m] = 0; vis[m] = 0; ecode[m] = 0;
+                    const int s = s0 + 16 * m + l;
+                    if (m < rounds && s < S) {
+                        const int code = sp_tab[s];
+                        const int sx = (code & 255) - 64, sy = ((code >> 8) & 255) - 64;
+                        ecode[m] = (sx + r) * side + (sy + r);
+                        if (kTile) {
+                            const int cur = my_tile[(sy + r) * 17 + (sx + r)];
+                            bnd[m] = my_tile[(sy + r) * 17 + (sx + r) + 1];
+                            vis[m] = min(bnd[m] - cur, Q);                  // FIFO depth
+                        } else {
+                            const int xn = x + sx, yn = y + sy;
+                            if (xn >= 0 && yn >= 0 && xn < W && yn < H) {  // out of FOV: skip this pixel only
+                                const int p = plane + yn * W + xn;
+                                const int a = start[p];
+                                bnd[m] = start[p + 1];
+                                vis[m] = min(bnd[m] - a, Q);                // FIFO depth
+                            }
+                        }
                     }
                 }
-                // pass 1: count admissible sources of this pixel, newest first
-                int v = 0;
-                for (int k = 0; k < vis && v < K; k++) {
-                    const int2 it = slot_it[bnd - 1 - k];
-                    if (it.x >= e) continue;                          // ev_graph.cu:64 (newer or self)
-                    if ((float)(t - it.y) > delta_t) continue;        // ev_graph.cu:69 (continue, not break)
-                    v++;
+                int2 it0[kRounds];
+#pragma unroll
+                for (int m = 0; m < kRounds; m++) {
+                    it0[m] = make_int2(0x7fffffff, 0);
+                    if (vis[m] > 0) it0[m] = slot_it[bnd[m] - 1];
                 }
-                const int incl = group16_inclusive_scan(v);
-                const int excl = incl - v;
-                const int chunk_total = __shfl(incl, 15, 16);
-                // pass 2: emit, cut at K
-                int slot = total + excl;
-                if (v > 0 && slot < K) {
-                    const int16_t ecode = (int16_t)((sx + r) * side + (sy + r));
-                    for (int k = 0; k < vis && slot < K; k++) {
-                        const int2 it = slot_it[bnd - 1 - k];
-                        if (it.x >= e) continue;
-                        if ((float)(t - it.y) > delta_t) continue;
-                        nbr_src[row + slot] = it.x;
-                        nbr_code[row + slot] = ecode;
-                        slot++;
+                // admissible sources per position, newest first:
+                //   skip ids >= e (newer or self, ev_graph.cu:64); skip dt > delta (continue, :69)
+                int v[kRounds];
+#pragma unroll
+                for (int m = 0; m < kRounds; m++) {
+                    int cnt = 0;
+                    if (vis[m] > 0) {
+                        cnt = (it0[m].x < e && !((float)(t - it0[m].y) > delta_t)) ? 1 : 0;
+                        for (int k = 1; k < vis[m] && cnt < K; k++) {
+                            const int2 it = slot_it[bnd[m] - 1 - k];
+                            if (it.x >= e) continue;
+                            if ((float)(t - it.y) > delta_t) continue;
+                            cnt++;
+                        }
+                    }
+                    v[m] = cnt;
+                }
+                // sequential cut in spiral order: round by round, lane by lane
+#pragma unroll
+                for (int m = 0; m < kRounds; m++) {
+                    if (m < rounds) {   // uniform across the 16-lane group
+                        const int incl = group16_inclusive_scan(v[m]);
+                        int slot = total + incl - v[m];
+                        total += __shfl(incl, 15, 16);
+                        if (v[m] > 0 && slot < K) {
+                            for (int k = 0; k < vis[m] && slot < K; k++) {
+                                const int2 it = (k == 0) ? it0[m] : slot_it[bnd[m] - 1 - k];
+                                if (it.x >= e) continue;
+                                if ((float)(t - it.y) > delta_t) continue;
+                                nbr_src[row + slot] = it.x;
+                                nbr_code[row + slot] = (int16_t)ecode[m];
+                                slot++;
+                            }
+                        }
                     }
                 }
-                total += chunk_total;
+                s0 += 16 * rounds;
             }
             if (total > K) total = K;
         }
@@ -462,9 +520,14 @@ int dagr_graph_build_window(const dagr_graph_desc *desc, void *workspace, const 
                                             ws.long_list, long_cap, ws.status);
     DAGR_CHECK_LAUNCH();
     const unsigned gS = (unsigned)ceil_div(N * 16, kBlock);
-    k_search<<<gS, kBlock, 0, stream>>>(n, W, H, desc->max_neighbors, desc->queue_size, desc->radius,
-                                        (float)desc->delta_t_us, ws.ev_xyb, ws.ev_t, ws.start, ws.slot_it,
-                                        nbr_src, nbr_code, deg, ws.status);
+    if (2 * desc->radius + 2 <= 16)
+        k_search<true><<<gS, kBlock, 0, stream>>>(n, W, H, desc->max_neighbors, desc->queue_size, desc->radius,
+                                                  (float)desc->delta_t_us, ws.ev_xyb, ws.ev_t, ws.start, ws.slot_it,
+                                                  nbr_src, nbr_code, deg, ws.status);
+    else
+        k_search<false><<<gS, kBlock, 0, stream>>>(n, W, H, desc->max_neighbors, desc->queue_size, desc->radius,
+                                                   (float)desc->delta_t_us, ws.ev_xyb, ws.ev_t, ws.start, ws.slot_it,
+                                                   nbr_src, nbr_code, deg, ws.status);
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;
 }

@@ -172,7 +172,7 @@ constexpr int kL0Out = 16;
 constexpr int kL0RowStride = 20;
 
 template <int CIN, int CSKIP, int NT>
-__global__ __launch_bounds__(kBlock) void k_conv_l0(int N, int K, int ncodes, const int32_t *__restrict__ nbr_src,
+__global__ __launch_bounds__(kBlock, 4) void k_conv_l0(int N, int K, int ncodes, const int32_t *__restrict__ nbr_src,
                                                    const int16_t *__restrict__ nbr_code,
                                                    const int32_t *__restrict__ deg, const float *__restrict__ x,
                                                    int ldx, const float *__restrict__ xskip, int ldskip,
@@ -202,28 +202,39 @@ __global__ __launch_bounds__(kBlock) void k_conv_l0(int N, int K, int ncodes, co
         for (int c = 0; c < NCH; c++)
 #pragma unroll
             for (int k = 0; k < NTP; k++) A[c][k] = 0.0f;
-        // neighbour slots are read 16 at a time by the 16 lanes, then broadcast slot by slot
+        // neighbour slots are read 16 at a time by the 16 lanes; all (up to 16) source rows are
+        // requested before the first one is consumed (the gathers are the latency that matters here)
         for (int j0 = 0; j0 < d; j0 += 16) {
             int my_src = 0, my_code = 0;
             if (j0 + l < d) { my_src = nbr_src[row + j0 + l]; my_code = nbr_code[row + j0 + l]; }
             const int cnt = min(16, d - j0);
-            for (int j = 0; j < cnt; j++) {
-                const int src = __shfl(my_src, j, 16);
-                const int code = __shfl(my_code, j, 16);
-                float t[NTP];
+            float v[NCH][16];
 #pragma unroll
-                for (int q = 0; q < NTP / 4; q++) {
-                    const float4 tq = *reinterpret_cast<const float4 *>(tab_s + code * NTP + 4 * q);
-                    t[4 * q] = tq.x; t[4 * q + 1] = tq.y; t[4 * q + 2] = tq.z; t[4 * q + 3] = tq.w;
-                }
+            for (int j = 0; j < 16; j++) {
+                const int src = __shfl(my_src, j, 16);
                 const float *xs = x + (size_t)src * ldx;
 #pragma unroll
                 for (int c = 0; c < NCH; c++) {
                     const int ch = c * 16 + l;
-                    const float v = (ch < CIN) ? xs[ch] : 0.0f;
-#pragma unroll
-                    for (int k = 0; k < NT; k++) A[c][k] = fmaf(t[k], v, A[c][k]);
+                    v[c][j] = (j < cnt && ch < CIN) ? xs[ch] : 0.0f;
                 }
+            }
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                if (j < cnt) {
+                    const int code = __shfl(my_code, j, 16);
+                    float t[NTP];
+#pragma unroll
+                    for (int q = 0; q < NTP / 4; q++) {
+                        const float4 tq = *reinterpret_cast<const float4 *>(tab_s + code * NTP + 4 * q);
+                        t[4 * q] = tq.x; t[4 * q + 1] = tq.y; t[4 * q + 2] = tq.z; t[4 * q + 3] = tq.w;
+                    }
+#pragma unroll
+                    for (int c = 0; c < NCH; c++)
+#pragma unroll
+                        for (int k = 0; k < NT; k++) A[c][k] = fmaf(t[k], v[c][j], A[c][k]);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // keep the table reads of later slots from piling up in VGPRs
             }
         }
         // contraction: lane i owns rows (k*CIN + i); 16 partial outputs per lane
@@ -418,6 +429,11 @@ int dagr_gemm_bias_act(const int32_t *m_ptr, int32_t m_max, const float *A, int3
     DAGR_CHECK_ARG(m_max >= 0 && K >= 1 && N >= 1, "bad sizes");
     if (m_max == 0) return DAGR_OK;
     DAGR_CHECK_ARG(A && Wm && C, "NULL pointer");
+    // wide outputs with 16-byte aligned rows go to the exact-fp32 MFMA kernel (gemm.hip)
+    if (ldw % 8 == 0 && ldw >= N && lda % 4 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)Wm % 16) == 0) {
+        DAGR_CHECK_HIP(launch_gemm_mfma(m_ptr, m_max, A, lda, Wm, ldw, bias, C, ldc, K, N, relu, (hipStream_t)stream));
+        return DAGR_OK;
+    }
     dim3 grid((unsigned)ceil_div(m_max, GM), (unsigned)ceil_div(N, GN));
     k_gemm_bias_act<<<grid, kBlock, 0, (hipStream_t)stream>>>(m_ptr, m_max, A, lda, Wm, ldw, bias, C, ldc, K, N, relu);
     DAGR_CHECK_LAUNCH();

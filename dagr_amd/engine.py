@@ -31,8 +31,11 @@ class _ConvPack:
     """Packed weights of one fused contraction: Wm[K, N], bias[N] (BN folded), plus shape info."""
 
     def __init__(self, cin, cskip, Wm, bias, relu):
-        self.cin, self.cskip, self.Wm, self.bias, self.relu = cin, cskip, Wm.contiguous(), bias.contiguous(), relu
         self.K, self.N = Wm.shape
+        self.ldw = (self.N + 7) // 8 * 8      # zero-padded columns: rows stay 32-byte aligned for the MFMA GEMM
+        if self.ldw != self.N:
+            Wm = torch.cat([Wm, torch.zeros((self.K, self.ldw - self.N), dtype=Wm.dtype, device=Wm.device)], 1)
+        self.cin, self.cskip, self.Wm, self.bias, self.relu = cin, cskip, Wm.contiguous(), bias.contiguous(), relu
 
 
 def _pack_generic(convs, norms, skip=None, relu=True, device="cuda"):
@@ -220,10 +223,10 @@ class WindowEngine:
         # scratch for the head / aggregation
         lda_max = 0
         for k, (c1, c2) in enumerate(self.packs):
-            lda_max = max(lda_max, self.levels[k].T * max(c1.K, c2.K))
+            lda_max = max(lda_max, self.levels[k].T * (max(c1.K, c2.K) + 3))
         for i, lvl in enumerate(self.head_levels):
             for p in self.head_packs[i]:
-                lda_max = max(lda_max, self.levels[lvl - 1].T * p.K)
+                lda_max = max(lda_max, self.levels[lvl - 1].T * (p.K + 3))
         self.A = torch.zeros((lda_max,), dtype=torch.float32, device=dev)
         self.head_buf = []
         for i, lvl in enumerate(self.head_levels):
@@ -267,11 +270,11 @@ class WindowEngine:
     def _conv_generic(self, lvl, pack, x, ldx, xskip, ldskip, out, ldo, dom, stream):
         L = self.L
         P = _lib.ptr
-        lda = pack.K
+        lda = (pack.K + 3) // 4 * 4    # 16-byte aligned rows for the MFMA GEMM's float4 loads
         _lib.check(L.dagr_spline_tap_aggregate(P(lvl.counts), lvl.T, P(lvl.rowptr), P(lvl.col), P(lvl.code),
                                                x, ldx, pack.cin, xskip, ldskip, pack.cskip, dom["rx"], dom["ry"],
                                                dom["den_x"], dom["den_y"], P(self.A), lda, stream), "tap_aggregate")
-        _lib.check(L.dagr_gemm_bias_act(P(lvl.counts), lvl.T, P(self.A), lda, P(pack.Wm), pack.N, P(pack.bias),
+        _lib.check(L.dagr_gemm_bias_act(P(lvl.counts), lvl.T, P(self.A), lda, P(pack.Wm), pack.ldw, P(pack.bias),
                                         out, ldo, pack.K, pack.N, 1 if pack.relu else 0, stream), "gemm")
 
     # -------------------------------------------------------------------------------- stages
