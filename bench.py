@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--stream", choices=["uniform", "edges"], default="uniform")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay each input slot through a captured hipGraph")
     ap.add_argument("--cpu-windows", type=int, default=4)
     return ap.parse_args()
 
@@ -135,9 +136,23 @@ def main():
         slots.append((pos, feat, batch))
     n_events_step = B * NPW
 
+    graphs = {}
+
     def step(i):
-        pos, feat, batch = slots[i % len(slots)]
-        return eng.forward_raw(pos, feat, batch)
+        s = i % len(slots)
+        pos, feat, batch = slots[s]
+        if not a.graph:
+            return eng.forward_raw(pos, feat, batch)
+        if s not in graphs:   # capture once per input slot (fixed buffers and event count)
+            eng.forward_raw(pos, feat, batch)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = eng.forward_raw(pos, feat, batch)
+            graphs[s] = (g, out)
+        g, out = graphs[s]
+        g.replay()
+        return out
 
     for i in range(a.warmup):
         step(i)

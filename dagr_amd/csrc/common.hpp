@@ -35,6 +35,21 @@ constexpr int kBlock = 256;  // 4 waves of 64
 constexpr int kWave = 64;
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Grid of a persistent (grid-stride) kernel: exactly the number of blocks that are co-resident, so
+// that every block gets the same share of the work (an over-sized grid runs in uneven waves).
+template <typename Kern>
+inline unsigned persistent_grid(Kern kernel, int block, size_t dyn_lds, int64_t max_useful_blocks) {
+    int per_cu = 0, dev = 0, cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, dyn_lds) != hipSuccess || per_cu < 1)
+        per_cu = 1;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+        cus = prop.multiProcessorCount;
+    int64_t g = (int64_t)per_cu * cus;
+    if (g > max_useful_blocks) g = max_useful_blocks;
+    return (unsigned)(g < 1 ? 1 : g);
+}
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ---- device-side wave / block primitives (wave = 64 lanes) -------------------------------
@@ -62,6 +77,28 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *smem, int &total
     total = w0 + w1 + w2 + w3;
     return base + incl - v;
 }
+
+// ---- XCD-aware work split.  Workgroup b is (observed, not contractual) placed on XCD b % 8 and each
+// XCD has a private 4 MiB L2.  Event ids are time-ordered per sample and samples are concatenated, so
+// giving every XCD one contiguous eighth of the items keeps an item's neighbours (earlier events of the
+// same sample / the same pixel plane) in that XCD's L2 instead of pulling the whole array into all
+// eight.  Pure performance mapping: any placement yields the same result.
+struct XcdSplit {
+    int first, end, stride;
+};
+__device__ __forceinline__ XcdSplit xcd_split(int n_items, int items_per_block, int item_in_block) {
+    const int G = gridDim.x;
+    const int nx = (G % 8 == 0) ? 8 : 1;
+    const int xcd = blockIdx.x % nx, lb = blockIdx.x / nx, bpx = G / nx;
+    const int chunk = (n_items + nx - 1) / nx;
+    const int begin = xcd * chunk;
+    XcdSplit s;
+    s.end = min(n_items, begin + chunk);
+    s.first = begin + lb * items_per_block + item_in_block;
+    s.stride = bpx * items_per_block;
+    return s;
+}
+inline unsigned round_grid8(int64_t g) { return (unsigned)(g <= 8 ? (g < 1 ? 1 : g) : (g + 7) / 8 * 8); }
 
 // ---- generic int32 exclusive scan over n elements (3 launches) --------------------------
 constexpr int kScanTile = 2048;  // elements per block: 256 threads x 8

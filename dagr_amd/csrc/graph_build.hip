@@ -22,6 +22,8 @@
 //     no -1 fill, no compaction pass, no host sync; the offset code is the SplineConv LUT index.
 #include "common.hpp"
 
+#include <type_traits>
+
 namespace dagr {
 namespace {
 
@@ -399,6 +401,138 @@ __global__ __launch_bounds__(kBlock) void k_search(int N, int W, int H, int K, i
 }
 
 // ---------------------------------------------------------------------------------------------
+// K6 (r <= 7): LDS-tiled, persistent variant of k_search<true>.  Same cut semantics, fewer
+// instructions per probed pixel:
+//   * a 16-lane group loops over events; the spiral position of (round m, lane l) does not depend on
+//     the event, so its tile offset and offset code live in registers for the whole kernel;
+//   * most pixels hold 0 or 1 visible events: a round in which no lane has more than one takes a
+//     ballot/popcount cut (the sequential "first K in spiral order" becomes a prefix popcount);
+//     rounds with a multi-event pixel fall back to the exact prefix-sum walk.
+constexpr int kTileRounds = 15;  // ceil(15*15 / 16)
+
+__global__ __launch_bounds__(kBlock) void k_search_tiled(int N, int W, int H, int K, int Q, int r, float delta_t,
+                                                        const int32_t *__restrict__ ev_xyb,
+                                                        const int32_t *__restrict__ ev_t,
+                                                        const int32_t *__restrict__ start,
+                                                        const int2 *__restrict__ slot_it,
+                                                        int32_t *__restrict__ nbr_src,
+                                                        int16_t *__restrict__ nbr_code, int32_t *__restrict__ deg,
+                                                        int32_t *__restrict__ status) {
+    __shared__ int tile[(kBlock / 16) * 16 * 17];
+    const int side = 2 * r + 1;
+    const int S = side * side;
+    const int l = threadIdx.x & 15;
+    const int grp = threadIdx.x >> 4;
+    const int gshift = threadIdx.x & 48;  // bit offset of this group inside the wave ballot
+    int *my_tile = tile + grp * 16 * 17;
+    // per-lane constants: position s = 16*m + l -> (tile offset | offset code << 16), -1 if s >= S
+    int pc[kTileRounds];
+#pragma unroll
+    for (int m = 0; m < kTileRounds; m++) {
+        const int s = 16 * m + l;
+        int sx, sy;
+        spiral_offset(s, sx, sy);
+        pc[m] = (s < S) ? (((sy + r) * 17 + (sx + r)) | (((sx + r) * side + (sy + r)) << 16)) : -1;
+    }
+    long long edges_acc = 0;
+    const XcdSplit xs = xcd_split(N, kBlock / 16, grp);
+    for (int e = xs.first; e < xs.end; e += xs.stride) {
+        const int c = ev_xyb[e];
+        const int t = ev_t[e];
+        const int64_t row = (int64_t)e * K;
+        int total = 1;
+        if (l == 0) {
+            nbr_src[row] = e;  // self loop first (ev_graph.cu:44-46)
+            nbr_code[row] = (int16_t)(r * side + r);
+        }
+        if (c >= 0) {
+            const int x = c & 4095, y = (c >> 12) & 4095, b = c >> 24;
+            const int plane = W * H * b;
+            const int lo = max(x - r, 0), hi = min(x + r, W - 1) + 1;
+            const int col = plane + min(max(x - r + l, lo), hi);
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int yn = y + i - r;
+                int val = 0;
+                if (i < side && yn >= 0 && yn < H) val = start[col + yn * W];
+                my_tile[i * 17 + l] = val;
+            }
+            __builtin_amdgcn_wave_barrier();
+
+            auto batch = [&](auto first_c, auto count_c) {
+                constexpr int m0 = decltype(first_c)::value, nr = decltype(count_c)::value;
+                int bnd[nr], vis[nr];
+                int2 it0[nr];
+#pragma unroll
+                for (int j = 0; j < nr; j++) {
+                    const int p = pc[m0 + j];
+                    bnd[j] = 0; vis[j] = 0;
+                    if (p >= 0) {
+                        const int cur = my_tile[p & 0xffff];
+                        bnd[j] = my_tile[(p & 0xffff) + 1];
+                        vis[j] = min(bnd[j] - cur, Q);   // FIFO depth
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < nr; j++) {
+                    it0[j] = make_int2(0x7fffffff, 0);
+                    if (vis[j] > 0) it0[j] = slot_it[bnd[j] - 1];
+                }
+#pragma unroll
+                for (int j = 0; j < nr; j++) {
+                    if (total >= K) break;                               // group-uniform
+                    if (16 * (m0 + j) >= S) break;
+                    // newest entry: skip ids >= e (ev_graph.cu:64), skip dt > delta (:69)
+                    const bool ok0 = vis[j] > 0 && it0[j].x < e && !((float)(t - it0[j].y) > delta_t);
+                    const unsigned multi = (unsigned)(__ballot(vis[j] > 1) >> gshift) & 0xffffu;
+                    const int ecode = pc[m0 + j] >> 16;
+                    if (multi == 0) {
+                        const unsigned bits = (unsigned)(__ballot(ok0) >> gshift) & 0xffffu;
+                        const int slot = total + __popc(bits & ((1u << l) - 1u));
+                        if (ok0 && slot < K) {
+                            nbr_src[row + slot] = it0[j].x;
+                            nbr_code[row + slot] = (int16_t)ecode;
+                        }
+                        total += __popc(bits);
+                    } else {
+                        int v = 0;
+                        if (vis[j] > 0) {
+                            v = ok0 ? 1 : 0;
+                            for (int k = 1; k < vis[j] && v < K; k++) {
+                                const int2 it = slot_it[bnd[j] - 1 - k];
+                                if (it.x >= e) continue;
+                                if ((float)(t - it.y) > delta_t) continue;
+                                v++;
+                            }
+                        }
+                        const int incl = group16_inclusive_scan(v);
+                        int slot = total + incl - v;
+                        total += __shfl(incl, 15, 16);
+                        if (v > 0 && slot < K) {
+                            for (int k = 0; k < vis[j] && slot < K; k++) {
+                                const int2 it = (k == 0) ? it0[j] : slot_it[bnd[j] - 1 - k];
+                                if (it.x >= e) continue;
+                                if ((float)(t - it.y) > delta_t) continue;
+                                nbr_src[row + slot] = it.x;
+                                nbr_code[row + slot] = (int16_t)ecode;
+                                slot++;
+                            }
+                        }
+                    }
+                }
+            };
+            batch(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+            if (total < K && S > 16) batch(std::integral_constant<int, 1>{}, std::integral_constant<int, 7>{});
+            if (total < K && S > 128) batch(std::integral_constant<int, 8>{}, std::integral_constant<int, 7>{});
+            if (total > K) total = K;
+            __builtin_amdgcn_wave_barrier();  // tile reads of this event precede the next event's writes
+        }
+        if (l == 0) { deg[e] = total; edges_acc += total; }
+    }
+    if (l == 0 && edges_acc) atomicAdd(reinterpret_cast<unsigned long long *>(status + 2), (unsigned long long)edges_acc);
+}
+
+// ---------------------------------------------------------------------------------------------
 // reference-shaped edge_index from the neighbour lists (graph/utils.py:22 order)
 __global__ __launch_bounds__(kBlock) void k_edge_index(int N, int K, const int32_t *__restrict__ nbr_src,
                                                       const int32_t *__restrict__ deg,
@@ -520,10 +654,13 @@ int dagr_graph_build_window(const dagr_graph_desc *desc, void *workspace, const 
                                             ws.long_list, long_cap, ws.status);
     DAGR_CHECK_LAUNCH();
     const unsigned gS = (unsigned)ceil_div(N * 16, kBlock);
-    if (2 * desc->radius + 2 <= 16)
-        k_search<true><<<gS, kBlock, 0, stream>>>(n, W, H, desc->max_neighbors, desc->queue_size, desc->radius,
+    if (2 * desc->radius + 2 <= 16) {
+        static const unsigned resident = persistent_grid(k_search_tiled, kBlock, 0, 1 << 30);
+        const unsigned gT = round_grid8(std::min<int64_t>(ceil_div(N * 16, kBlock), resident));
+        k_search_tiled<<<gT, kBlock, 0, stream>>>(n, W, H, desc->max_neighbors, desc->queue_size, desc->radius,
                                                   (float)desc->delta_t_us, ws.ev_xyb, ws.ev_t, ws.start, ws.slot_it,
                                                   nbr_src, nbr_code, deg, ws.status);
+    }
     else
         k_search<false><<<gS, kBlock, 0, stream>>>(n, W, H, desc->max_neighbors, desc->queue_size, desc->radius,
                                                    (float)desc->delta_t_us, ws.ev_xyb, ws.ev_t, ws.start, ws.slot_it,
