@@ -1,98 +1,103 @@
-// gemm.hip -- C[M,N] = act(A[M,K] . Wm[K,N] + bias[N]) with exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
+// gemm.hip -- C[M,N] = act(A[M,K] . Wm[K,N] + bias[N]) with exact-fp32 MFMA (v_mfma_f32_16x16x4_f32).
 //
 // The pooled-level SplineConvs are contractions of the tap-aggregated rows A[n] (K = 26*Cin (+Cskip),
 // up to 1682) with a packed weight matrix (N = 64 / 128): GEMM-shaped, so they run on the matrix
 // cores.  The f32-input MFMA is bit-exact fp32 FMA at the vector rate (MI355X_MICROARCH.md), which keeps
 // the 1e-4 parity bar with no precision trade.
 //
-// Shape of the problem: M is small (<= 2240*(B+1) rows, often a few hundred) and K is long, so the
-// critical path of a 64x64 output tile is its K-chain (K/2 dependent 64-cycle MFMAs).  A block is
-// therefore 16 waves: 2x2 waves tile the 64x64 output and 4 wave-quads split K (each quad owns a
-// 32-wide slice of every 128-wide K step); the four partial tiles are summed through LDS in a fixed
-// order (deterministic).  Operands are staged in LDS as [k][m] / [k][n] so that a lane's MFMA operand
-// (i = lane&31, k = lane>>5) is a conflict-free row read; the next K step is prefetched into registers
-// while the current one is multiplied.  M is bounded by a device-side count: no host sync.
+// Shape of the problem: M is small (<= 2240*(B+1) rows, often a few hundred) and K is long, so what
+// matters is (i) enough workgroups to occupy 256 CUs and (ii) a short dependent K-chain per wave.
+// Block tile BM x 64 with BM = 16 (one accumulator per wave) or 32 (two accumulators, picked when
+// M/32 already yields >= 2 blocks per CU); 16 waves: wave w of a quad owns output columns
+// [16w, 16w+16) and the 4 quads split K (chain = K/16 MFMAs per wave, four load streams in flight).  Operands are staged in LDS as [k][m] / [k][n] with row strides = 16 mod 32
+// dwords so that a lane's MFMA operand (i = lane&15, k = lane>>4) is a conflict-free read; the next
+// 32-wide K stage is prefetched into registers while the current one is multiplied.  M is bounded by a
+// device-side count: no host sync.  Summation order is fixed: results are run-to-run identical.
 #include "common.hpp"
 
 namespace dagr {
 namespace {
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-constexpr int MB = 64, NB = 64, KB = 32, KSPLIT = 4;
-constexpr int AS_STRIDE = MB + 1;   // [k][m]: reads are 32 consecutive m; odd stride spreads the transposed stores
-constexpr int WS_STRIDE = NB + 4;   // [k][n]: 16-byte aligned rows for b128 stores
-constexpr int kGemmThreads = 256 * KSPLIT;
-constexpr int kStageFloats = KSPLIT * KB * (AS_STRIDE + WS_STRIDE);
-constexpr int kReduceFloats = KSPLIT * MB * NB;
-constexpr int kLdsFloats = kStageFloats > kReduceFloats ? kStageFloats : kReduceFloats;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int NB = 64, KB = 32, KSPLIT = 4;
+constexpr int WS_STRIDE = NB + 16;  // 80 = 16 (mod 32)
+constexpr int kGemmThreads = kBlock * KSPLIT;
 
+template <int BM>
 __global__ __launch_bounds__(kGemmThreads) void k_gemm_mfma(const int32_t *__restrict__ m_ptr, int m_max,
-                                                           const float *__restrict__ A, int lda,
-                                                           const float *__restrict__ Wm, int ldw,
-                                                           const float *__restrict__ bias, float *__restrict__ C,
-                                                           int ldc, int K, int N, int relu) {
-    __shared__ __align__(16) float lds[kLdsFloats];
+                                                     const float *__restrict__ A, int lda,
+                                                     const float *__restrict__ Wm, int ldw,
+                                                     const float *__restrict__ bias, float *__restrict__ C, int ldc,
+                                                     int K, int N, int relu) {
+    constexpr int RT = BM / 16;            // 16-row tiles per wave
+    constexpr int AS_STRIDE = BM + 16;     // 32 or 48 = 0/16 (mod 32) alternating with k
+    constexpr int A_THREADS = BM * (KB / 4);
+    // the 4 wave quads of a block each own a 32-wide slice of every 128-wide K step (their K-chains and
+    // their global-load latencies overlap); partial tiles are summed through LDS in a fixed order
+    constexpr int kStage = KSPLIT * KB * (AS_STRIDE + WS_STRIDE);
+    constexpr int kReduce = KSPLIT * BM * NB;
+    __shared__ __align__(16) float lds[kStage > kReduce ? kStage : kReduce];
     const int M = m_ptr ? min(*m_ptr, m_max) : m_max;
-    const int m0 = blockIdx.x * MB, n0 = blockIdx.y * NB;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * NB;
     if (m0 >= M) return;
-    const int tid = threadIdx.x;
-    const int ks = tid >> 8;            // K slice of this wave quad
-    const int t = tid & 255, l = t & 63, w = t >> 6;
-    const int wm = w & 1, wn = w >> 1;
+    const int ks = threadIdx.x >> 8;
     float *As = lds + ks * KB * AS_STRIDE;
     float *Ws = lds + KSPLIT * KB * AS_STRIDE + ks * KB * WS_STRIDE;
-    // staging roles inside the slice
-    const int a_row = t >> 2, a_kq = (t & 3) * 8;   // A: 64 rows x 32 k, 8 consecutive k per thread
-    const int w_k = t >> 3, w_nq = (t & 7) * 8;     // W: 32 k x 64 n, 8 consecutive n per thread
-    const bool a_ok = (m0 + a_row) < M;
-    const float *a_src = A + (size_t)(m0 + a_row) * lda + a_kq;
-    const bool w_ok = (n0 + w_nq + 8) <= ldw;       // weight rows are zero-padded to a multiple of 8 columns
-    float4 ra0, ra1, rw0, rw1;
-    auto load_tile = [&](int k0) {   // k0 = first k of this slice in this step
-        ra0 = ra1 = rw0 = rw1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int t = threadIdx.x & 255, l = t & 63, w = t >> 6;
+    // staging roles
+    const int a_row = t >> 3, a_kq = (t & 7) * 4;    // A: BM rows x 32 k, 4 consecutive k per thread
+    const bool a_thr = t < A_THREADS;
+    const bool a_ok = a_thr && (m0 + a_row) < M;
+    const float *a_src = A + (size_t)(m0 + (a_thr ? a_row : 0)) * lda + a_kq;
+    const int w_k = t >> 4, w_nq = (t & 15) * 4;     // W: 32 k x 64 n, two float4 per thread (k, k+16)
+    const bool w_ok = (n0 + w_nq + 4) <= ldw;        // weight rows are zero-padded to a multiple of 8 columns
+    float4 ra, rw0, rw1;
+    auto load_tile = [&](int k0) {
+        ra = rw0 = rw1 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (a_ok) {
-            if (k0 + a_kq + 8 <= K) {
-                ra0 = *reinterpret_cast<const float4 *>(a_src + k0);
-                ra1 = *reinterpret_cast<const float4 *>(a_src + k0 + 4);
+            if (k0 + a_kq + 4 <= K) {
+                ra = *reinterpret_cast<const float4 *>(a_src + k0);
             } else if (k0 + a_kq < K) {
-                float tmp[8];
+                float tmp[4];
 #pragma unroll
-                for (int j = 0; j < 8; j++) tmp[j] = (k0 + a_kq + j < K) ? a_src[k0 + j] : 0.f;
-                ra0 = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
-                ra1 = make_float4(tmp[4], tmp[5], tmp[6], tmp[7]);
+                for (int j = 0; j < 4; j++) tmp[j] = (k0 + a_kq + j < K) ? a_src[k0 + j] : 0.f;
+                ra = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
             }
         }
-        if (w_ok && k0 + w_k < K) {
-            const float *ws = Wm + (size_t)(k0 + w_k) * ldw + n0 + w_nq;
-            rw0 = *reinterpret_cast<const float4 *>(ws);
-            rw1 = *reinterpret_cast<const float4 *>(ws + 4);
+        if (w_ok) {
+            if (k0 + w_k < K) rw0 = *reinterpret_cast<const float4 *>(Wm + (size_t)(k0 + w_k) * ldw + n0 + w_nq);
+            if (k0 + w_k + 16 < K)
+                rw1 = *reinterpret_cast<const float4 *>(Wm + (size_t)(k0 + w_k + 16) * ldw + n0 + w_nq);
         }
     };
     auto store_tile = [&]() {
-        float *as = As + a_kq * AS_STRIDE + a_row;
-        as[0 * AS_STRIDE] = ra0.x; as[1 * AS_STRIDE] = ra0.y; as[2 * AS_STRIDE] = ra0.z; as[3 * AS_STRIDE] = ra0.w;
-        as[4 * AS_STRIDE] = ra1.x; as[5 * AS_STRIDE] = ra1.y; as[6 * AS_STRIDE] = ra1.z; as[7 * AS_STRIDE] = ra1.w;
-        float4 *wsd = reinterpret_cast<float4 *>(Ws + w_k * WS_STRIDE + w_nq);
-        wsd[0] = rw0;
-        wsd[1] = rw1;
+        if (a_thr) {
+            float *as = As + a_kq * AS_STRIDE + a_row;
+            as[0 * AS_STRIDE] = ra.x; as[1 * AS_STRIDE] = ra.y; as[2 * AS_STRIDE] = ra.z; as[3 * AS_STRIDE] = ra.w;
+        }
+        *reinterpret_cast<float4 *>(Ws + w_k * WS_STRIDE + w_nq) = rw0;
+        *reinterpret_cast<float4 *>(Ws + (w_k + 16) * WS_STRIDE + w_nq) = rw1;
     };
-    f32x16 acc;
+    f32x4 acc[RT];
 #pragma unroll
-    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    for (int r = 0; r < RT; r++) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
     constexpr int KSTEP = KB * KSPLIT;
     load_tile(ks * KB);
     store_tile();
     __syncthreads();
-    const float *a_rd = As + (l >> 5) * AS_STRIDE + wm * 32 + (l & 31);
-    const float *w_rd = Ws + (l >> 5) * WS_STRIDE + wn * 32 + (l & 31);
+    const float *a_rd = As + (l >> 4) * AS_STRIDE + (l & 15);
+    const float *w_rd = Ws + (l >> 4) * WS_STRIDE + w * 16 + (l & 15);
     for (int k0 = 0; k0 < K; k0 += KSTEP) {
         const bool more = (k0 + KSTEP) < K;
         if (more) load_tile(k0 + KSTEP + ks * KB);
 #pragma unroll
-        for (int kk = 0; kk < KB; kk += 2) {
-            const float a = a_rd[kk * AS_STRIDE];
+        for (int kk = 0; kk < KB; kk += 4) {
             const float b = w_rd[kk * WS_STRIDE];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < RT; r++) {
+                const float a = a_rd[kk * AS_STRIDE + r * 16];
+                acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[r], 0, 0, 0);
+            }
         }
         __syncthreads();
         if (more) {
@@ -100,24 +105,20 @@ __global__ __launch_bounds__(kGemmThreads) void k_gemm_mfma(const int32_t *__res
             __syncthreads();
         }
     }
-    // split-K reduction through LDS (staging buffers are dead after the last barrier above)
-    float *red = lds + ks * MB * NB;
+    // split-K reduction (staging buffers are dead after the last barrier above)
+    float *red = lds + ks * BM * NB;
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-        red[row * NB + wn * 32 + (l & 31)] = acc[r];
-    }
+    for (int r = 0; r < RT; r++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) red[(r * 16 + (l >> 4) * 4 + q) * NB + w * 16 + (l & 15)] = acc[r][q];
     __syncthreads();
-#pragma unroll
-    for (int q = 0; q < (MB * NB) / kGemmThreads; q++) {
-        const int idx = q * kGemmThreads + tid;
-        const int row = idx / NB, col = idx % NB;
-        float v = ((lds[idx] + lds[MB * NB + idx]) + lds[2 * MB * NB + idx]) + lds[3 * MB * NB + idx];
-        const int gm = m0 + row, gn = n0 + col;
-        if (gm < M && gn < N) {
-            v += bias ? bias[gn] : 0.f;
+    for (int idx = threadIdx.x; idx < BM * NB; idx += kGemmThreads) {
+        const int row = m0 + idx / NB, col = n0 + idx % NB;
+        if (row < M && col < N) {
+            float v = ((lds[idx] + lds[BM * NB + idx]) + lds[2 * BM * NB + idx]) + lds[3 * BM * NB + idx];
+            v += bias ? bias[col] : 0.f;
             if (relu) v = fmaxf(v, 0.f);
-            C[(size_t)gm * ldc + gn] = v;
+            C[(size_t)row * ldc + col] = v;
         }
     }
 }
@@ -126,14 +127,14 @@ __global__ __launch_bounds__(kGemmThreads) void k_gemm_mfma(const int32_t *__res
 
 hipError_t launch_gemm_mfma(const int32_t *m_ptr, int m_max, const float *A, int lda, const float *Wm, int ldw,
                             const float *bias, float *C, int ldc, int K, int N, int relu, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_gemm_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 0);
-        (void)e;
-        attr_set = true;
+    const unsigned gy = (unsigned)ceil_div(N, NB);
+    if (ceil_div(m_max, 32) * gy >= 512) {
+        dim3 grid((unsigned)ceil_div(m_max, 32), gy);
+        k_gemm_mfma<32><<<grid, kGemmThreads, 0, stream>>>(m_ptr, m_max, A, lda, Wm, ldw, bias, C, ldc, K, N, relu);
+    } else {
+        dim3 grid((unsigned)ceil_div(m_max, 16), gy);
+        k_gemm_mfma<16><<<grid, kGemmThreads, 0, stream>>>(m_ptr, m_max, A, lda, Wm, ldw, bias, C, ldc, K, N, relu);
     }
-    dim3 grid((unsigned)ceil_div(m_max, MB), (unsigned)ceil_div(N, NB));
-    k_gemm_mfma<<<grid, kGemmThreads, 0, stream>>>(m_ptr, m_max, A, lda, Wm, ldw, bias, C, ldc, K, N, relu);
     return hipGetLastError();
 }
 

@@ -82,11 +82,55 @@ __global__ __launch_bounds__(kBlock) void scan_tile_apply(int32_t *__restrict__ 
     }
 }
 
+// whole scan in one workgroup (n <= 64 Ki): the voxel tables and cluster rows of the pooled levels
+// are a few thousand entries, where three dependent launches cost more than the work
+__global__ __launch_bounds__(1024) void scan_single_block(int32_t *__restrict__ in, int32_t *__restrict__ out,
+                                                         int n, int zero_input) {
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024 * 4) {
+        const int i0 = base + threadIdx.x * 4;
+        int v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = (i0 + k < n) ? in[i0 + k] : 0;
+        const int s = v[0] + v[1] + v[2] + v[3];
+        const int incl = wave_inclusive_scan(s);
+        if (lane == 63) wsum[wid] = incl;
+        __syncthreads();
+        int wbase = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int ws = wsum[k];
+            if (k < wid) wbase += ws;
+            total += ws;
+        }
+        int ex = carry_s + wbase + incl - s;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (i0 + k < n) {
+                out[i0 + k] = ex;
+                if (zero_input) in[i0 + k] = 0;
+            }
+            ex += v[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s += total;
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 hipError_t exclusive_scan_i32(int32_t *in, int32_t *out, int64_t n, int32_t *scratch, bool zero_input,
                               hipStream_t stream) {
     if (n <= 0) return hipSuccess;
+    if (n <= 65536) {
+        scan_single_block<<<1, 1024, 0, stream>>>(in, out, (int)n, zero_input ? 1 : 0);
+        return hipGetLastError();
+    }
     const int tiles = (int)ceil_div(n, kScanTile);
     scan_tile_reduce<<<tiles, kBlock, 0, stream>>>(in, n, scratch);
     scan_tile_sums<<<1, kBlock, 0, stream>>>(scratch, tiles);
