@@ -35,38 +35,51 @@ def parse():
     ap.add_argument("--stream", choices=["uniform", "edges"], default="uniform")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay each input slot through a captured hipGraph")
+    ap.add_argument("--events-only", action="store_true",
+                    help="BASELINE config 1 shape (no --use_image) instead of config 2 (ResNet-50 image branch)")
+    ap.add_argument("--img-net", default="resnet50")
+    ap.add_argument("--no-pipeline-image", dest="pipeline_image", action="store_false",
+                    help="run the image branch in-line instead of one step ahead on a side stream")
     ap.add_argument("--cpu-windows", type=int, default=4)
     return ap.parse_args()
 
 
-def make_model(W, H, B):
+def make_model(W, H, B, use_image=False, img_net="resnet50"):
     from oracle.model import default_args  # argument defaults only (config/dagr-s-dsec.yaml values)
     from dagr_amd.model.networks.dagr import DAGR
     from dagr_amd.utils.testing_weights import randomize_
     torch.manual_seed(0)
-    args = default_args(batch_size=B)
+    args = default_args(batch_size=B, use_image=use_image, img_net=img_net)
     model = randomize_(DAGR(args, height=H, width=W)).eval()
     return args, model
 
 
-def algorithmic_bytes(N, E, r, levels):
-    """SURVEY.md 8(d) per-window algorithmic bytes (int32 indices, fp32 features, no LUT)."""
+def algorithmic_bytes(N, E, r, levels, use_image=False):
+    """SURVEY.md 8(d) per-step algorithmic bytes (int32 indices, fp32 features, no LUT)."""
     def conv(cin, cout, nn, ee):
         return 4 * cin * ee + 8 * ee + 4 * (nn + 1) + 4 * cin * nn + 4 * cout * nn + 104 * cin * cout
+
+    def sample(cf, nn):  # 4 taps read + write
+        return 16 * cf * nn + 4 * cf * nn
+    fch = [16, 64, 64, 64, 64] if use_image else [0] * 5
+    c0 = 3 + fch[0]
     out = {}
     out["graph"] = 16 * N + 4 * (2 * r + 1) ** 2 * N + 12 * E + 4 * (N + 1)
-    out["l0_conv1"] = conv(3, 16, N, E)
-    out["l0_conv2"] = conv(16, 16, N, E) + 4 * 3 * N
+    out["l0_input"] = sample(fch[0], N) + 4 * 3 * N
+    out["l0_conv1"] = conv(c0, 16, N, E)
+    out["l0_conv2"] = conv(16, 16, N, E) + 4 * c0 * N + sample(fch[1], N)
     n1, e1 = levels[0]
-    out["pool1"] = 4 * (16 + 5) * N + 8 * E + 4 * (16 + 4) * n1 + 12 * e1
+    cp = 16 + fch[1]
+    out["pool1"] = 4 * (cp + 5) * N + 8 * E + 4 * (cp + 4) * n1 + 12 * e1
     tail = 0
-    chans = [(18, 64), (66, 64), (66, 64), (66, 64)]
-    for (nn, ee), (cin, cout) in zip(levels, chans):
-        tail += conv(cin, cout, nn, ee) + conv(cout, cout, nn, ee) + 4 * cin * nn
-    for k in range(1, 4):
-        nn, ee = levels[k - 1]
-        nc, ec = levels[k]
-        tail += 4 * (64 + 5) * nn + 8 * ee + 4 * (64 + 4) * nc + 12 * ec
+    for k, (nn, ee) in enumerate(levels):
+        cin = (16 if k == 0 else 64) + fch[k + 1] + 2
+        tail += conv(cin, 64, nn, ee) + conv(64, 64, nn, ee) + 4 * cin * nn
+        if k < 3:
+            tail += sample(fch[k + 2], nn)
+            nc, ec = levels[k + 1]
+            cpk = 64 + fch[k + 2]
+            tail += 4 * (cpk + 5) * nn + 8 * ee + 4 * (cpk + 4) * nc + 12 * ec
     out["tail"] = tail
     return out
 
@@ -85,22 +98,33 @@ def time_gpu(fn, iters, warm=3):
     return ev0.elapsed_time(ev1) / iters  # ms
 
 
-def cpu_baseline(args_ns, model_sd, W, H, n_events, n_windows, stream):
+def cpu_baseline(model_cpu, model_sd, W, H, n_events, n_windows, stream, use_image, img_net):
     """The oracle (op-for-op CPU restatement, `port`) on a bounded sample: B=1 windows of the same
-    synthetic stream.  Graph build: single-threaded C; conv/pool: torch CPU on all host threads."""
+    synthetic stream.  Graph build: single-threaded C; conv/pool (and, with the image branch, the same
+    torch ResNet/CNN-head modules) on all host threads."""
     from oracle import model as om
     from dagr_amd.utils import synthetic as syn
     gen = syn.uniform_window if stream == "uniform" else syn.edges_window
-    a = om.default_args(batch_size=1)
+    a = om.default_args(batch_size=1, use_image=use_image, img_net=img_net)
+    nc = om.NetConstants(a, H, W)
     tot_ev, t0 = 0, time.perf_counter()
-    for w in range(n_windows):
-        x, y, t, p = gen(n_events, W, H, seed=1234 + w)
-        b = np.zeros(len(x), np.int64)
-        om.forward_events(model_sd, a, H, W, x, y, t, p, b, 1)
-        tot_ev += len(x)
+    with torch.no_grad():
+        for w in range(n_windows):
+            x, y, t, p = gen(n_events, W, H, seed=1234 + w)
+            b = np.zeros(len(x), np.int64)
+            image_feat = cnn_out = None
+            if use_image:
+                img = torch.rand((1, 3, H, W), generator=torch.Generator().manual_seed(w))
+                feats, outs = model_cpu.backbone.net(img)
+                resized = [torch.nn.functional.interpolate(f, o) for f, o in zip(outs[-a.num_scales:], nc.output_sizes)]
+                cnn_out = model_cpu.head.cnn_head(resized)
+                image_feat = feats
+            om.forward_events(model_sd, a, H, W, x, y, t, p, b, 1, image_feat=image_feat, cnn_out=cnn_out)
+            tot_ev += len(x)
     dt = time.perf_counter() - t0
+    what = f"dagr-s + {img_net} image branch" if use_image else "events-only dagr-s"
     return dict(value=tot_ev / dt, unit="events/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{n_windows} windows x {n_events} events, {W}x{H}, B=1, events-only dagr-s, "
+                sample=f"{n_windows} windows x {n_events} events, {W}x{H}, B=1, {what}, "
                        f"oracle/model.py (torch-CPU fp32 + C graph builder), {dt:.1f} s")
 
 
@@ -110,6 +134,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    torch.backends.cudnn.benchmark = True   # MIOpen picks its fastest fp32 conv kernels for the image branch
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -119,8 +144,13 @@ def main():
     from dagr_amd.utils import synthetic as syn
 
     W, H, B, NPW = a.width, a.height, a.batch, a.events_per_window
-    args, model = make_model(W, H, B)
+    use_image = not a.events_only
+    args, model = make_model(W, H, B, use_image=use_image, img_net=a.img_net)
     sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model_cpu = None
+    if use_image and world == 1 and not a.no_cpu_baseline:
+        import copy
+        model_cpu = copy.deepcopy(model).eval()
     model = model.to(dev)
     model.cache_luts(width=W, height=H, radius=args.radius)
     eng = model.engine()
@@ -133,27 +163,37 @@ def main():
         pos = torch.from_numpy(syn.format_data_np(x, y, t, W, H)).to(dev)
         feat = torch.from_numpy(p.astype(np.float32)).view(-1, 1).to(dev)
         batch = torch.from_numpy(b).to(dev)
-        slots.append((pos, feat, batch))
+        image = None
+        if use_image:  # format_data'd frames (uint8/255, utils/buffers.py:37-38), resident like the events
+            image = torch.rand((B, 3, H, W), generator=torch.Generator().manual_seed(77 + s + 10 * rank)).to(dev)
+        slots.append((pos, feat, batch, image))
     n_events_step = B * NPW
 
     graphs = {}
+    pending = {}   # step index -> image-branch handle started one step ahead on the side stream
 
     def step(i):
         s = i % len(slots)
-        pos, feat, batch = slots[s]
+        pos, feat, batch, image = slots[s]
+        if use_image and a.pipeline_image and not a.graph:
+            h = pending.pop(i, None) or eng.image_async(image)
+            pending[i + 1] = eng.image_async(slots[(i + 1) % len(slots)][3])   # next batch's frames
+            return eng.forward_raw(pos, feat, batch, image_handle=h)
         if not a.graph:
-            return eng.forward_raw(pos, feat, batch)
+            return eng.forward_raw(pos, feat, batch, image=image)
         if s not in graphs:   # capture once per input slot (fixed buffers and event count)
-            eng.forward_raw(pos, feat, batch)
+            eng.forward_raw(pos, feat, batch, image=image)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                out = eng.forward_raw(pos, feat, batch)
+                out = eng.forward_raw(pos, feat, batch, image=image)
             graphs[s] = (g, out)
         g, out = graphs[s]
         g.replay()
         return out
 
+    ctx = torch.no_grad()
+    ctx.__enter__()
     for i in range(a.warmup):
         step(i)
     eng.check_status()
@@ -185,16 +225,19 @@ def main():
         ms_per_step = 1e3 * elapsed / a.steps
         value = world * n_events_step * a.steps / elapsed
         # ---- per-stage / per-kernel timing on the stream the kernels run on (HIP events)
-        pos, feat, batch = slots[0]
-        eng.forward_raw(pos, feat, batch)
+        pos, feat, batch, image = slots[0]
+        eng.forward_raw(pos, feat, batch, image=image)
         ne, _ = eng.graph.status()
         levels = [tuple(int(v) for v in lvl.counts.tolist()) for lvl in eng.levels]
         r = eng.graph.params["radius"]
-        ab = algorithmic_bytes(n_events_step, ne, r, levels)
+        ab = algorithmic_bytes(n_events_step, ne, r, levels, use_image)
         iters = 20
         stages = {}
+        if use_image:
+            stages["image_branch"] = time_gpu(lambda: eng.stage_image(image), 5, warm=1)
         stages["graph"] = time_gpu(lambda: eng.stage_graph(pos, batch), iters)
         eng.stage_l0_input(feat)
+        stages["l0_input"] = time_gpu(lambda: eng.stage_l0_input(feat), iters)
         stages["l0_conv1"] = time_gpu(eng.stage_l0_conv1, iters)
         stages["l0_conv2"] = time_gpu(eng.stage_l0_conv2, iters)
         stages["pool1"] = time_gpu(eng.stage_pool1, iters)
@@ -205,7 +248,7 @@ def main():
                    for k, v in stages.items()}
         dom = max(("l0_conv1", "l0_conv2"), key=lambda k: stages[k])  # single-launch stages
         achieved = ab[dom] / 1e9 / (stages[dom] / 1e3)
-        roofline = dict(kernel={"l0_conv1": "k_conv_l0<3,0,NT>", "l0_conv2": "k_conv_l0<16,3,NT>"}[dom],
+        roofline = dict(kernel={"l0_conv1": "k_conv_l0<C0,0,NT>", "l0_conv2": "k_conv_l0<16,C0,NT>"}[dom],
                         bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
                         alg_bytes_per_launch=int(ab[dom]), launch_ms=round(stages[dom], 4))
@@ -213,14 +256,18 @@ def main():
             "metric": "events_per_sec", "value": round(value, 1), "unit": "events/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"dagr-s events-only, {W}x{H} synthetic S-{a.stream}, B={B} windows/step x "
-                                   f"{NPW} events (50 ms each), r={r}, K=16, graph+GNN+head maps",
+            "config": {"workload": ("dagr-s + --use_image --img_net " + a.img_net if use_image else "dagr-s events-only")
+                                   + f", {W}x{H} synthetic S-{a.stream}, B={B} windows/step x {NPW} events (50 ms "
+                                   f"each), r={r}, K=16, events->graph->GNN(+image fusion)->decoded head outputs",
+                       "image_branch": ("one step ahead on a side stream" if (use_image and a.pipeline_image and not a.graph)
+                                        else ("in-line" if use_image else None)),
                        "events_per_step_per_gpu": n_events_step, "edges_per_step": int(ne),
                        "level_nodes_edges": levels, "window_latency_ms": round(ms_per_step, 4)},
             "roofline": roofline, "stages": kernels,
         }
         if world == 1 and not a.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(args, sd_cpu, W, H, NPW, a.cpu_windows, a.stream)
+            result["cpu_baseline"] = cpu_baseline(model_cpu, sd_cpu, W, H, NPW, a.cpu_windows, a.stream, use_image,
+                                                  a.img_net)
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

@@ -90,7 +90,7 @@ def _pack_l0(conv, norm, win, skip=None, device="cuda"):
 class _Level:
     """Device buffers of one pooled graph level (capacity T = gx*gy*(B+1) nodes)."""
 
-    def __init__(self, T, cin, cout, device):
+    def __init__(self, T, cin, cout, device, cf_next=0):
         self.T = T
         self.e_cap = T * 64
         i32 = dict(dtype=torch.int32, device=device)
@@ -104,7 +104,10 @@ class _Level:
         self.counts = torch.zeros((2,), **i32)       # [n_nodes, n_edges]
         self.cluster = torch.zeros((T,), **i32)      # scratch for the next pooling
         self.h1 = torch.zeros((T, cout), **f32)
-        self.h2 = torch.zeros((T, cout), **f32)
+        # Layer output h2 = hp[:, :cout]; with --use_image the image features sampled at this level's
+        # nodes are written into hp[:, cout:] (sampling_skip, net.py:142,155,171) and hp is what gets pooled
+        self.hp = torch.zeros((T, cout + cf_next), **f32)
+        self.cout = cout
 
 
 class WindowEngine:
@@ -120,14 +123,20 @@ class WindowEngine:
         self.num_classes = bb.num_classes
         self.num_scales = int(args.num_scales)
         self.use_image = bool(args.use_image)
-        if self.use_image:
-            raise NotImplementedError("--use_image fusion is not wired into the engine yet")
+        # channels of the image features concatenated before Layer k (net.py:47-50): [16,64,s,s,s]
+        self.feat_ch = list(bb.net.feature_channels) if self.use_image else [0] * 5
+        if self.use_image:   # channels-last image branch: its feature maps are then read as [B,h,w,C] rows
+            bb.net.to(memory_format=torch.channels_last)
+            head.cnn_head.to(memory_format=torch.channels_last)
         if bb.conv_block1.conv_block1.conv.lut_domain is None:
             model.cache_luts(width=self.W, height=self.H, radius=args.radius)
             model._engine = self
         self.L = _lib.lib()
         if self.L.dagr_device_count() < 1:
             raise RuntimeError("dagr_amd: no HIP device visible; the event-graph path has no CPU fallback")
+        self._keep = []
+        self._cnn_out = None
+        self._img_stream = None
         self._prepare(bb, head)
         self.max_events = 0
         self._alloc_events(int(max_events))
@@ -176,13 +185,14 @@ class WindowEngine:
         self.pool_desc, self.pool_ws, self.levels = [], [], []
         B = self.B
         chans = [l.out_channel for l in layers]
+        fch = self.feat_ch
         for k, pool in enumerate(pools):
             vs = pool.voxel_size.detach().float().cpu()
             end = torch.Tensor([0.9999999, 0.9999999])
             g = ((end - 0) / vs[:2]).to(torch.int64) + 1            # grid_cluster num_voxels
             nd = self.dom[k + 1]
             remap = nd["remap"]
-            desc = _lib.PoolDesc(batch_size=B, channels=chans[k], gx=int(g[0]), gy=int(g[1]), vx=float(vs[0]),
+            desc = _lib.PoolDesc(batch_size=B, channels=chans[k] + fch[k + 1], gx=int(g[0]), gy=int(g[1]), vx=float(vs[0]),
                                  vy=float(vs[1]), inv_w=float(pool.wh_inv[0, 0]), inv_h=float(pool.wh_inv[0, 1]),
                                  two_max=_f32(2 * pool.transform.max), r00=float(remap[0, 0]),
                                  r02=float(remap[0, 2]), r11=float(remap[1, 1]), r12=float(remap[1, 2]),
@@ -195,7 +205,8 @@ class WindowEngine:
             self.pool_desc.append(desc)
             self.pool_ws.append(ws)
             T = int(g[0]) * int(g[1]) * (B + 1)
-            self.levels.append(_Level(T, chans[k] + 2, chans[k + 1], dev))
+            self.levels.append(_Level(T, chans[k] + fch[k + 1] + 2, chans[k + 1], dev,
+                                      cf_next=fch[k + 2] if k + 2 < 5 else 0))
         # voxel -> first pixel tables for the level-0 pooling (same fp32 division as grid_cluster)
         vs = pools[0].voxel_size.detach().float().cpu()
         d = self.pool_desc[0]
@@ -263,7 +274,8 @@ class WindowEngine:
         self.nbr_code = torch.zeros((n, K), dtype=torch.int16, device=dev)
         self.deg = torch.zeros((n,), dtype=torch.int32, device=dev)
         self.h1 = torch.zeros((n, 16), dtype=torch.float32, device=dev)
-        self.h2 = torch.zeros((n, 16), dtype=torch.float32, device=dev)
+        self.hp0 = torch.zeros((n, 16 + self.feat_ch[1]), dtype=torch.float32, device=dev)  # [h2 | image feats]
+        self.x0buf = torch.zeros((n, 1 + self.feat_ch[0] + 2), dtype=torch.float32, device=dev)
         self.cluster0 = torch.zeros((n,), dtype=torch.int32, device=dev)
 
     # ------------------------------------------------------------------------------- kernels
@@ -287,14 +299,71 @@ class WindowEngine:
         self._nbr = (self.nbr_src[:N], self.nbr_code[:N], self.deg[:N])
         self.graph.build(pos, batch, out=self._nbr)
 
+    def _sample(self, n_ptr, n_max, pos, batch, b64, fmap, out, coff):
+        """sample_features (net.py:193-221) of one channels-last feature map into out[:, coff:coff+C]."""
+        Bf, C, h, w = fmap.shape
+        nhwc = fmap.permute(0, 2, 3, 1)
+        if not nhwc.is_contiguous():
+            nhwc = nhwc.contiguous()
+        self._keep.append(nhwc)
+        _lib.check(self.L.dagr_sample_features(n_ptr, n_max, _lib.ptr(pos), _lib.ptr(batch), b64, _lib.ptr(nhwc), Bf, h,
+                                               w, C, self.W, self.H, _lib.ptr(out), out.shape[1], coff,
+                                               _lib.cur_stream(self.device)), "sample_features")
+
+    def _image_branch(self, image):
+        bb, head = self.model.backbone, self.model.head
+        feats, outs = bb.net(image.contiguous(memory_format=torch.channels_last))
+        outs = outs[-self.num_scales:]
+        resized = [torch.nn.functional.interpolate(f, o) for f, o in zip(outs, self.out_sizes)]
+        return feats, head.cnn_head(resized)
+
+    def stage_image(self, image):
+        """HookModule + CNNHead on PyTorch-ROCm (net.py:110, dagr.py:205-206)."""
+        self._keep = []
+        self._img_feats, self._cnn_out = self._image_branch(image)
+
+    def image_async(self, image):
+        """Start the image branch of a *future* window batch on a side stream and return a handle for
+        ``forward_raw(..., image_handle=h)``.  Windows are independent, and a frame is available before
+        the 50 ms of events that follow it, so the dense CNN of batch i+1 can share the GPU with the
+        gather-bound event path of batch i."""
+        cur = torch.cuda.current_stream(self.device)
+        if self._img_stream is None:
+            self._img_stream = torch.cuda.Stream(self.device)
+        s = self._img_stream
+        s.wait_stream(cur)
+        with torch.cuda.stream(s):
+            feats, cnn_out = self._image_branch(image)
+            ev = torch.cuda.Event()
+            ev.record(s)
+        return feats, cnn_out, ev
+
+    def _consume_image_handle(self, handle):
+        feats, cnn_out, ev = handle
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(ev)
+        for t in list(feats) + [o for v in cnn_out.values() for o in v]:
+            t.record_stream(cur)   # allocated on the side stream, read on this one
+        self._keep = []
+        self._img_feats, self._cnn_out = feats, cnn_out
+
     def stage_l0_input(self, feat):
-        """x = cat(x, pos[:, :2]) (net.py:124-125)."""
+        """x = cat(x, [image feats,] pos[:, :2]) (net.py:118,124-125)."""
         N = self._N
-        self._x0 = torch.cat((feat.float().reshape(N, feat.shape[1] if feat.dim() > 1 else 1), self._pos[:, :2]),
-                             dim=1).contiguous()
+        f = feat.float().reshape(N, feat.shape[1] if feat.dim() > 1 else 1)
+        if not self.use_image:
+            self._x0 = torch.cat((f, self._pos[:, :2]), dim=1).contiguous()
+            return
+        x0 = self.x0buf[:N]
+        c = x0.shape[1]
+        x0[:, 0:1] = f
+        x0[:, c - 2:] = self._pos[:, :2]
+        b64 = 1 if self._batch.dtype == torch.int64 else 0
+        self._sample(None, N, self._pos, self._batch, b64, self._img_feats[0], x0, 1)
+        self._x0 = x0
 
     def stage_l0_conv1(self):
-        """conv_block1.conv_block1: SplineConv(3->16)+BN+ReLU (conv.py:23-28)."""
+        """conv_block1.conv_block1: SplineConv(3|19 -> 16)+BN+ReLU (conv.py:23-28)."""
         L, P = self.L, _lib.ptr
         nbr_src, nbr_code, deg = self._nbr
         cin, cskip, w1, s1 = self.l0_conv1
@@ -305,14 +374,19 @@ class WindowEngine:
                                          P(self.h1), 16, _lib.cur_stream(self.device)), "conv_l0")
 
     def stage_l0_conv2(self):
-        """conv_block1.conv_block2: SplineConv(16->16)+BN + skip Linear+BN, ReLU (conv.py:47-56)."""
+        """conv_block1.conv_block2: SplineConv(16->16)+BN + skip Linear+BN, ReLU (conv.py:47-56);
+        with --use_image followed by sampling_skip(image_feat[1]) (net.py:129)."""
         L, P = self.L, _lib.ptr
         nbr_src, nbr_code, deg = self._nbr
         cin, cskip, w2, s2 = self.l0_conv2
         c0 = self._x0.shape[1]
+        ldo = self.hp0.shape[1]
         _lib.check(L.dagr_spline_conv_l0(cin, cskip, self.ntaps0, self._N, self.graph.K, self.ncodes0, P(nbr_src),
                                          P(nbr_code), P(deg), P(self.h1), 16, P(self._x0), c0, P(self.tab0), P(w2),
-                                         P(s2), 1, P(self.h2), 16, _lib.cur_stream(self.device)), "conv_l0")
+                                         P(s2), 1, P(self.hp0), ldo, _lib.cur_stream(self.device)), "conv_l0")
+        if self.use_image:
+            b64 = 1 if self._batch.dtype == torch.int64 else 0
+            self._sample(None, self._N, self._pos, self._batch, b64, self._img_feats[1], self.hp0[:self._N], 16)
 
     def stage_pool1(self):
         """pool1 (net.py:131) on the event graph."""
@@ -323,11 +397,11 @@ class WindowEngine:
         d = self.pool_desc[0]
         b64 = 1 if self._batch.dtype == torch.int64 else 0
         _lib.check(L.dagr_pool_l0(ctypes.byref(d), P(self.pool_ws[0]), ctypes.byref(g.desc), P(g.workspace),
-                                  P(self.xlo), P(self.ylo), P(self.h2), 16, P(self._pos), P(self._batch), b64, self._N,
-                                  P(nbr_src), P(deg), P(self.cluster0), P(l1.x), l1.x.shape[1], 0, P(l1.pos),
-                                  P(l1.batch), P(l1.counts), P(l1.rowptr), P(l1.col), P(l1.code),
-                                  ctypes.c_void_p(l1.counts.data_ptr() + 4), l1.e_cap, _lib.cur_stream(self.device)),
-                   "pool_l0")
+                                  P(self.xlo), P(self.ylo), P(self.hp0), self.hp0.shape[1], P(self._pos),
+                                  P(self._batch), b64, self._N, P(nbr_src), P(deg), P(self.cluster0), P(l1.x),
+                                  l1.x.shape[1], 0, P(l1.pos), P(l1.batch), P(l1.counts), P(l1.rowptr), P(l1.col),
+                                  P(l1.code), ctypes.c_void_p(l1.counts.data_ptr() + 4), l1.e_cap,
+                                  _lib.cur_stream(self.device)), "pool_l0")
 
     def stage_tail(self, trace=None):
         """layer2..layer5 with pool2..pool4 (net.py:137-184)."""
@@ -339,15 +413,18 @@ class WindowEngine:
             dom = self.dom[k + 1]
             ldx = lvl.x.shape[1]
             self._conv_generic(lvl, c1, P(lvl.x), ldx, None, 0, P(lvl.h1), c1.N, dom, stream)
-            self._conv_generic(lvl, c2, P(lvl.h1), c1.N, P(lvl.x), ldx, P(lvl.h2), c2.N, dom, stream)
+            ldh = lvl.hp.shape[1]
+            self._conv_generic(lvl, c2, P(lvl.h1), c1.N, P(lvl.x), ldx, P(lvl.hp), ldh, dom, stream)
             if trace is not None:
                 trace[f"pool{k + 1}"] = self._level_snapshot(lvl, lvl.x)
-                trace[f"layer{k + 2}"] = self._level_snapshot(lvl, lvl.h2)
+                trace[f"layer{k + 2}"] = self._level_snapshot(lvl, lvl.hp[:, :lvl.cout])
             if k < 3:
+                if self.use_image:   # sampling_skip(image_feat[k+2]) (net.py:142,155,171)
+                    self._sample(P(lvl.counts), lvl.T, lvl.pos, lvl.batch, 0, self._img_feats[k + 2], lvl.hp, lvl.cout)
                 nxt = self.levels[k + 1]
                 d = self.pool_desc[k + 1]
-                _lib.check(L.dagr_pool_csr(ctypes.byref(d), P(self.pool_ws[k + 1]), P(lvl.counts), lvl.T, P(lvl.h2),
-                                           c2.N, P(lvl.pos), P(lvl.batch), P(lvl.rowptr), P(lvl.col),
+                _lib.check(L.dagr_pool_csr(ctypes.byref(d), P(self.pool_ws[k + 1]), P(lvl.counts), lvl.T, P(lvl.hp),
+                                           ldh, P(lvl.pos), P(lvl.batch), P(lvl.rowptr), P(lvl.col),
                                            P(lvl.cluster), P(nxt.x), nxt.x.shape[1], 0, P(nxt.pos), P(nxt.batch),
                                            P(nxt.counts), P(nxt.rowptr), P(nxt.col), P(nxt.code),
                                            ctypes.c_void_p(nxt.counts.data_ptr() + 4), nxt.e_cap, stream), "pool_csr")
@@ -363,7 +440,7 @@ class WindowEngine:
             hb = self.head_buf[i]
             dom = self.dom[lvln]
             nr = self.n_reg
-            self._conv_generic(lvl, stem, P(lvl.h2), lvl.h2.shape[1], None, 0, P(hb["stem"]), nr, dom, stream)
+            self._conv_generic(lvl, stem, P(lvl.hp), lvl.hp.shape[1], None, 0, P(hb["stem"]), nr, dom, stream)
             self._conv_generic(lvl, cr, P(hb["stem"]), nr, None, 0, P(hb["cr"]), 2 * nr, dom, stream)
             pred = hb["pred"]
             npred = pred.shape[1]
@@ -380,16 +457,27 @@ class WindowEngine:
             outs.append(hb["dense"])
         return outs
 
-    def forward_raw(self, pos, feat, batch, trace=None):
-        """pos fp32[N,3] normalised (format_data), feat fp32[N,1], batch int32/int64[N] on the device.
+    def forward_raw(self, pos, feat, batch, image=None, trace=None, image_handle=None):
+        """pos fp32[N,3] normalised (format_data), feat fp32[N,1], batch int32/int64[N] on the device;
+        image fp32[B,3,H,W] in [0,1] when the model was built with --use_image.
         Returns decoded head outputs [B, n_anchors, 5+num_classes] (GNNHead.forward eval)."""
+        self._cnn_out = None
+        if self.use_image:
+            if image_handle is not None:
+                self._consume_image_handle(image_handle)
+            elif image is None:
+                raise RuntimeError("model was built with --use_image: an image batch is required")
+            else:
+                self.stage_image(image)
         self.stage_graph(pos.contiguous(), batch.contiguous())
         self.stage_l0_input(feat)
         self.stage_l0_conv1()
         self.stage_l0_conv2()
         if trace is not None:
             trace["nbr"] = tuple(t.clone() for t in self._nbr)
-            trace["layer1"] = self.h2[:self._N].clone()
+            trace["layer1"] = self.hp0[:self._N, :16].clone()
+            if self.use_image:
+                trace["x0"] = self._x0.clone()
         self.stage_pool1()
         self.stage_tail(trace)
         outs = self.stage_head()
@@ -399,6 +487,13 @@ class WindowEngine:
 
     def _decode(self, dense_maps):
         """collect_outputs + decode_outputs (dagr.py:283-312) on the tiny dense maps (torch ops)."""
+        if self._cnn_out is not None:   # dagr.py:219-222,230-234: CNN-head logits are added to the GNN maps
+            fused = []
+            for k, o in enumerate(dense_maps):
+                c = self._cnn_out
+                fused.append(o + torch.cat([c["reg_output"][k], c["obj_output"][k], c["cls_output"][k]], 1))
+            dense_maps = fused
+            self._fused_dense = fused
         hybrid = [torch.cat([o[:, :4], o[:, 4:].sigmoid()], 1) for o in dense_maps]
         outputs = torch.cat([o.flatten(start_dim=2) for o in hybrid], dim=2).permute(0, 2, 1).contiguous()
         outputs[..., :2] = (outputs[..., :2] + self.grid_cache) * self.stride_cache
@@ -429,4 +524,4 @@ class WindowEngine:
         x fp32[N,1], batch)."""
         batch = data.batch if getattr(data, "batch", None) is not None else \
             torch.zeros(data.pos.shape[0], dtype=torch.int64, device=data.pos.device)
-        return self.forward_raw(data.pos.float(), data.x.float(), batch)
+        return self.forward_raw(data.pos.float(), data.x.float(), batch, image=getattr(data, "image", None))

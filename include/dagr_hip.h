@@ -206,6 +206,15 @@ int dagr_to_dense(const int32_t *n_ptr, int32_t n_max, const float *x, int32_t l
                   const float *pos, const int32_t *batch, float vx, float vy, int32_t batch_size,
                   int32_t Hc, int32_t Wc, int32_t *winner_scratch, float *dense, int32_t *status, void *stream);
 
+/* ------------------------------------------------------------------------ *
+ * sample_features (--use_image) -- model/networks/net.py:15-17,193-221
+ *   out[n, coff:coff+C] = trilinear grid_sample (align_corners=True) of feat at node n's position;
+ *   feat is channels-last fp32 [B,h,w,C]; width/height = sensor size used for normalisation.
+ * ------------------------------------------------------------------------ */
+int dagr_sample_features(const int32_t *n_ptr, int32_t n_max, const float *pos, const void *batch,
+                         int32_t batch_is_int64, const float *feat_nhwc, int32_t B, int32_t h, int32_t w, int32_t C,
+                         int32_t width, int32_t height, float *out, int32_t ldo, int32_t coff, void *stream);
+
 /* Host-side helper: first n offsets of the search spiral (spiral.h:1-15), the closed form the
  * search kernel uses.  dx/dy are HOST arrays.  Lets CPU-only tests pin the visiting order. */
 int dagr_spiral_offsets(int32_t n, int32_t *dx_host, int32_t *dy_host);

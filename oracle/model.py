@@ -184,6 +184,8 @@ def net_forward(sd, args, nc, pos, feat, batch, edge_index, use_lut=True, image_
     x = feat
     if image_feat is not None:
         x = torch.cat((x, sample_features(pos, batch, image_feat[0], W, H)), dim=1)
+        if trace is not None:
+            trace["x0_image"] = x.clone()
     edge_attr = ops.cartesian(pos, edge_index, nc.effective_radius)  # net.py:122
     edge_attr = torch.clamp(edge_attr, min=0, max=1)                 # net.py:123
     g = Graph(torch.cat((x, pos[:, :2]), dim=1), pos, batch, edge_index, edge_attr)
@@ -266,7 +268,7 @@ def head_forward(sd, args, nc, outs, batch_size, use_lut=True, cnn_out=None, tra
 
 
 def forward_events(sd, args, height, width, x, y, t, p, b, batch_size, use_lut=True, trace=None,
-                   time_window=1000000):
+                   time_window=1000000, image_feat=None, cnn_out=None):
     """Whole hot path for one window batch from raw events (int arrays): format_data
     (utils/buffers.py:33-44) -> EV_TGN (layers/ev_tgn.py:39-58) -> Net -> GNNHead eval."""
     nc = NetConstants(args, height, width)
@@ -282,5 +284,5 @@ def forward_events(sd, args, height, width, x, y, t, p, b, batch_size, use_lut=T
     ei = torch.from_numpy(ei)
     if trace is not None:
         trace["edge_index"] = ei.clone()
-    outs = net_forward(sd, args, nc, pos, feat, batch, ei, use_lut=use_lut, trace=trace)
-    return head_forward(sd, args, nc, outs, batch_size, use_lut=use_lut, trace=trace)
+    outs = net_forward(sd, args, nc, pos, feat, batch, ei, use_lut=use_lut, image_feat=image_feat, trace=trace)
+    return head_forward(sd, args, nc, outs, batch_size, use_lut=use_lut, cnn_out=cnn_out, trace=trace)

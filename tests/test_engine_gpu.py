@@ -13,10 +13,10 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-def _setup(W, H, B, seed=0):
+def _setup(W, H, B, seed=0, **over):
     from dagr_amd.model.networks.dagr import DAGR
     torch.manual_seed(seed)
-    args = om.default_args(batch_size=B)
+    args = om.default_args(batch_size=B, **over)
     model = randomize_(DAGR(args, height=H, width=W), seed=seed).eval()
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model = model.cuda()
@@ -42,15 +42,26 @@ def _sorted_cols(e):
     return e[:, order]
 
 
-def _compare(args, model, sd, W, H, B, x, y, t, p, b, pos):
+def _compare(args, model, sd, W, H, B, x, y, t, p, b, pos, image=None):
     dev = torch.device("cuda:0")
     eng = model.engine()
     tr_h = {}
     out_h = eng.forward_raw(torch.from_numpy(pos).to(dev), torch.from_numpy(p.astype(np.float32)).view(-1, 1).to(dev),
-                            torch.from_numpy(b).to(dev), trace=tr_h)
+                            torch.from_numpy(b).to(dev), image=image, trace=tr_h)
     eng.check_status()
     tr_o = {}
-    out_o, raw_o = om.forward_events(sd, args, H, W, x, y, t, p, b, B, trace=tr_o)
+    image_feat = cnn_out = None
+    if image is not None:
+        # the image branch is PyTorch on both sides; the oracle consumes the very feature maps the
+        # engine sampled, so this checks sample_features + fusion, not MIOpen-vs-CPU conv rounding
+        image_feat = [f.detach().float().cpu().contiguous() for f in eng._img_feats]
+        cnn_out = {k: [o.detach().float().cpu().contiguous() for o in v] for k, v in eng._cnn_out.items()}
+    out_o, raw_o = om.forward_events(sd, args, H, W, x, y, t, p, b, B, trace=tr_o, image_feat=image_feat,
+                                     cnn_out=cnn_out)
+    if image is not None:
+        c = tr_o["x0_image"].shape[1]
+        d0 = (tr_h["x0"].cpu()[:, :c] - tr_o["x0_image"]).abs().max().item()
+        assert d0 < 1e-5, f"sampled level-0 image features differ by {d0}"
     # level 0 features
     d = (tr_h["layer1"].cpu() - tr_o["layer1"]["x"]).abs().max().item()
     assert d < TOL, f"layer1 features differ by {d}"
@@ -73,7 +84,8 @@ def _compare(args, model, sd, W, H, B, x, y, t, p, b, pos):
         dl = (hl["x"].cpu() - ol["x"]).abs().max().item()
         assert dl < TOL, f"layer{k + 1} features differ by {dl}"
     # dense head maps (raw logits) and decoded outputs
-    for i, dm in enumerate(tr_h["head_dense"]):
+    dense_h = eng._fused_dense if image is not None else tr_h["head_dense"]
+    for i, dm in enumerate(dense_h):
         cls_o, reg_o, obj_o = raw_o[i]
         ref = torch.cat([reg_o, obj_o, cls_o], 1)
         dd = (dm.cpu() - ref).abs().max().item()
@@ -118,3 +130,12 @@ def test_empty_and_tiny_windows():
     x = np.array([10, 11, 300], np.int64); y = np.array([20, 20, 200], np.int64)
     t = np.array([999000, 1000000, 1000000], np.int64); p = np.array([1, -1, 1], np.int8); b = np.array([0, 0, 1], np.int64)
     _compare(args, model, sd, W, H, B, x, y, t, p, b, syn.format_data_np(x, y, t, W, H))
+
+
+def test_use_image_resnet18_b2():
+    """--use_image: sample_features at every level, 19/82/130-channel convs, CNN-head logit fusion."""
+    W, H, B = 320, 215, 2
+    args, model, sd = _setup(W, H, B, seed=4, use_image=True, img_net="resnet18")
+    image = torch.rand((B, 3, H, W), generator=torch.Generator().manual_seed(1)).cuda()
+    with torch.no_grad():
+        _compare(args, model, sd, W, H, B, *_events(syn.edges_window, 5000, B, W, H, seed=13), image=image)

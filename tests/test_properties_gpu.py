@@ -1,0 +1,89 @@
+"""GPU property tests at BASELINE sizes (640x480, B=8 x 100k events), where the CPU oracle is too slow
+to be the checker: size-independent properties of the path.
+  * invariants the reference states for the graph (ev_tgn.py:52-54): src <= dst, self loop first,
+    1 <= deg <= K, offsets within the radius, dt within delta, sources in the same sample;
+  * window independence (reset=True windows share no state): a batch of 8 windows gives, sample by
+    sample, exactly what each window gives alone (graph indices) -- the property the multi-GPU
+    sharding relies on;
+  * idempotence: the same buffers processed twice give bit-identical outputs (workspaces re-arm).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as om
+from dagr_amd.utils import synthetic as syn
+from dagr_amd.utils.testing_weights import randomize_
+
+pytestmark = pytest.mark.gpu
+W, H, B, NPW = 640, 480, 8, 100000
+
+
+@pytest.fixture(scope="module")
+def big():
+    from dagr_amd.model.networks.dagr import DAGR
+    torch.manual_seed(0)
+    args = om.default_args(batch_size=B)
+    model = randomize_(DAGR(args, height=H, width=W)).eval().cuda()
+    model.cache_luts(width=W, height=H, radius=args.radius)
+    x, y, t, p, b = syn.batch_windows(syn.edges_window, NPW, B, W, H, seed=4321)
+    dev = torch.device("cuda:0")
+    pos = torch.from_numpy(syn.format_data_np(x, y, t, W, H)).to(dev)
+    feat = torch.from_numpy(p.astype(np.float32)).view(-1, 1).to(dev)
+    batch = torch.from_numpy(b).to(dev)
+    return dict(model=model, args=args, x=x, y=y, t=t, b=b, pos=pos, feat=feat, batch=batch)
+
+
+def test_graph_invariants_full_size(big):
+    eng = big["model"].engine()
+    eng.stage_graph(big["pos"], big["batch"])
+    nbr_src, nbr_code, deg = [v.cpu().numpy() for v in eng._nbr]
+    ne, flags = eng.graph.status()
+    assert flags == 0
+    N, K, r = len(deg), 16, 7
+    assert deg.min() >= 1 and deg.max() <= K and ne == deg.sum()
+    assert (nbr_src[:, 0] == np.arange(N)).all()                       # self loop first
+    valid = np.arange(K)[None, :] < deg[:, None]
+    src = np.where(valid, nbr_src, 0)
+    dst = np.broadcast_to(np.arange(N)[:, None], src.shape)
+    assert (src[valid] <= dst[valid]).all()                            # sources are older events
+    assert (big["b"][src[valid]] == big["b"][dst[valid]]).all()        # same sample
+    dx = big["x"][src] - big["x"][dst]
+    dy = big["y"][src] - big["y"][dst]
+    assert (np.abs(dx[valid]) <= r).all() and (np.abs(dy[valid]) <= r).all()
+    assert (nbr_code[valid] == ((dx + r) * (2 * r + 1) + (dy + r))[valid]).all()
+    # t is compared after the fp32 round trip of format_data/denormalize_pos: allow 1 us of slack
+    dt = big["t"][dst].astype(np.int64) - big["t"][src]
+    assert (dt[valid] <= 10000 + 1).all()
+    # no duplicate sources per destination
+    s_sorted = np.sort(np.where(valid, nbr_src, -1 - np.arange(K)[None, :]), axis=1)
+    assert (np.diff(s_sorted, axis=1) != 0).all()
+
+
+def test_windows_are_independent(big):
+    """Sample s of the batch == the same window processed alone (graph indices, exactly)."""
+    from dagr_amd.graph.ev_graph import WindowGraphBuilder
+    eng = big["model"].engine()
+    eng.stage_graph(big["pos"], big["batch"])
+    nbr_src, _, deg = [v.clone() for v in eng._nbr]
+    dev = big["pos"].device
+    solo = WindowGraphBuilder(W, H, 1, 16, 128, 7, 10000, max_events=NPW, device=dev)
+    for s in (0, 3, 7):
+        sel = torch.nonzero(big["batch"] == s).flatten()
+        lo = int(sel[0])
+        s_src, _, s_deg = solo.build(big["pos"][sel].contiguous(), torch.zeros(len(sel), dtype=torch.int64, device=dev))
+        assert torch.equal(s_deg, deg[sel])
+        mask = torch.arange(16, device=dev)[None, :] < s_deg[:, None]
+        assert torch.equal(torch.where(mask, s_src + lo, 0), torch.where(mask, nbr_src[sel], 0))
+
+
+def test_idempotent_and_finite(big):
+    eng = big["model"].engine()
+    o1 = eng.forward_raw(big["pos"], big["feat"], big["batch"]).clone()
+    o2 = eng.forward_raw(big["pos"], big["feat"], big["batch"]).clone()
+    eng.check_status()
+    assert o1.shape == (B, 175, 7)
+    assert torch.isfinite(o1).all()
+    assert torch.equal(o1, o2)
+    n_lvl = [int(l.counts[0]) for l in eng.levels]
+    assert n_lvl[0] <= 2240 * (B + 1) and n_lvl[0] > n_lvl[1] > n_lvl[2] > n_lvl[3] > 0
