@@ -67,7 +67,8 @@ def algorithmic_bytes(N, E, r, levels, use_image=False):
     out["graph"] = 16 * N + 4 * (2 * r + 1) ** 2 * N + 12 * E + 4 * (N + 1)
     out["l0_input"] = sample(fch[0], N) + 4 * 3 * N
     out["l0_conv1"] = conv(c0, 16, N, E)
-    out["l0_conv2"] = conv(16, 16, N, E) + 4 * c0 * N + sample(fch[1], N)
+    out["l0_conv2"] = conv(16, 16, N, E) + 4 * c0 * N
+    out["l0_sample1"] = sample(fch[1], N)
     n1, e1 = levels[0]
     cp = 16 + fch[1]
     out["pool1"] = 4 * (cp + 5) * N + 8 * E + 4 * (cp + 4) * n1 + 12 * e1
@@ -239,7 +240,9 @@ def main():
         eng.stage_l0_input(feat)
         stages["l0_input"] = time_gpu(lambda: eng.stage_l0_input(feat), iters)
         stages["l0_conv1"] = time_gpu(eng.stage_l0_conv1, iters)
-        stages["l0_conv2"] = time_gpu(eng.stage_l0_conv2, iters)
+        stages["l0_conv2"] = time_gpu(lambda: eng.stage_l0_conv2(sample=False), iters)
+        if use_image:
+            stages["l0_sample1"] = time_gpu(lambda: (eng.stage_l0_conv2(sample=True)), iters) - stages["l0_conv2"]
         stages["pool1"] = time_gpu(eng.stage_pool1, iters)
         stages["tail"] = time_gpu(eng.stage_tail, iters)
         stages["head"] = time_gpu(lambda: eng._decode(eng.stage_head()), iters)

@@ -48,8 +48,11 @@ SIGNATURES = {
     "dagr_graph_status": (ctypes.c_int, [ctypes.POINTER(GraphDesc), c_void_p, ctypes.POINTER(c_i64),
                                          ctypes.POINTER(c_i32), c_void_p]),
     "dagr_scan_scratch_elems": (c_size_t, [c_i64]),
-    "dagr_graph_edge_index": (ctypes.c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p,
-                                             c_i64, c_void_p]),
+    "dagr_graph_edge_index": (ctypes.c_int, [ctypes.POINTER(GraphDesc), c_void_p, c_void_p, c_void_p, c_i64, c_void_p,
+                                             c_void_p, c_void_p, c_i64, c_void_p]),
+    "dagr_graph_node_order": (ctypes.c_int, [ctypes.POINTER(GraphDesc), c_void_p, c_i64, c_void_p, c_void_p, c_void_p]),
+    "dagr_graph_gather_inputs": (ctypes.c_int, [ctypes.POINTER(GraphDesc), c_void_p, c_void_p, c_void_p, c_i64,
+                                                c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_void_p]),
     "dagr_spiral_offsets": (ctypes.c_int, [c_i32, c_void_p, c_void_p]),
     "dagr_spline_tap_window": (ctypes.c_int, [c_i32, c_float, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
     "dagr_spline_l0_table": (ctypes.c_int, [c_i32, c_i32, c_float, c_float, c_i32, c_i32, c_i32, c_i32, c_void_p,
@@ -63,7 +66,8 @@ SIGNATURES = {
     "dagr_pool_workspace_bytes": (c_size_t, [ctypes.POINTER(PoolDesc)]),
     "dagr_pool_workspace_init": (ctypes.c_int, [ctypes.POINTER(PoolDesc), c_void_p, c_size_t, c_void_p]),
     "dagr_pool_l0": (ctypes.c_int, [ctypes.POINTER(PoolDesc), c_void_p, ctypes.POINTER(GraphDesc), c_void_p,
-                                    c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_void_p, c_i32, c_i64, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_i32, c_i64,
+                                    c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_void_p]),
     "dagr_pool_csr": (ctypes.c_int, [ctypes.POINTER(PoolDesc), c_void_p, c_void_p, c_i32, c_void_p, c_i32, c_void_p,
@@ -74,6 +78,7 @@ SIGNATURES = {
                                      c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dagr_sample_features": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_void_p, c_i32, c_void_p, c_i32, c_i32, c_i32,
                                             c_i32, c_i32, c_i32, c_void_p, c_i32, c_i32, c_void_p]),
+    "dagr_debug_calibrate": (ctypes.c_int, [c_i32, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p]),
     "dagr_gemm_bias_act": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_i32, c_void_p, c_i32, c_void_p, c_void_p,
                                           c_i32, c_i32, c_i32, c_i32, c_void_p]),
 }

@@ -111,6 +111,7 @@ hipError_t exclusive_scan_i32(int32_t *in, int32_t *out, int64_t n, int32_t *scr
 
 hipError_t launch_gemm_mfma(const int32_t *m_ptr, int m_max, const float *A, int lda, const float *Wm, int ldw,
                             const float *bias, float *C, int ldc, int K, int N, int relu, hipStream_t stream);
+const int32_t *graph_ws_node_count(const dagr_graph_desc *desc, void *workspace);
 void graph_ws_views(const dagr_graph_desc *desc, void *workspace, const int32_t **start, const int2 **slot_it);
 
 }  // namespace dagr

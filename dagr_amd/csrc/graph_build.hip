@@ -40,6 +40,8 @@ struct GraphWs {
     int32_t *ev_rank;   // [Nmax] arrival rank inside the pixel (arbitrary order)
     int32_t *slot_tmp;  // [Nmax] event id per CSR slot, arrival order
     int2 *slot_it;      // [Nmax] {event id, t} per CSR slot, ascending id inside a pixel
+    int32_t *slot_xyb;  // [Nmax] x | y<<12 | b<<24 per CSR slot
+    int32_t *ev_slot;   // [Nmax] CSR slot of every event (-1: dropped)
     int32_t *long_list; // [Nmax/kShortSeg + 1] pixels whose segment is longer than kShortSeg
     int32_t *status;    // [8]: 0 n_long, 1 flags, 2..3 num_edges (uint64), 4 last N
     int64_t P;
@@ -61,9 +63,11 @@ size_t carve(const dagr_graph_desc &d, char *base, GraphWs *ws) {
     int32_t *ev_rank = (int32_t *)take(d.max_events * 4);
     int32_t *slot_tmp = (int32_t *)take(d.max_events * 4);
     int2 *slot_it = (int2 *)take(d.max_events * 8);
+    int32_t *slot_xyb = (int32_t *)take(d.max_events * 4);
+    int32_t *ev_slot = (int32_t *)take(d.max_events * 4);
     int32_t *long_list = (int32_t *)take((d.max_events / kShortSeg + 2) * 4);
     int32_t *status = (int32_t *)take(8 * 4);
-    if (ws) *ws = GraphWs{cnt, start, scan_tmp, ev_xyb, ev_t, ev_rank, slot_tmp, slot_it, long_list, status, P};
+    if (ws) *ws = GraphWs{cnt, start, scan_tmp, ev_xyb, ev_t, ev_rank, slot_tmp, slot_it, slot_xyb, ev_slot, long_list, status, P};
     return off;
 }
 
@@ -123,11 +127,11 @@ __global__ __launch_bounds__(kBlock) void k_count(const void *__restrict__ pos_,
 __global__ __launch_bounds__(kBlock) void k_scatter(int N, int W, int H, const int32_t *__restrict__ ev_xyb,
                                                    const int32_t *__restrict__ ev_rank,
                                                    const int32_t *__restrict__ start,
-                                                   int32_t *__restrict__ slot_tmp) {
+                                                   int32_t *__restrict__ slot_tmp, int32_t *__restrict__ ev_slot) {
     const int e = blockIdx.x * kBlock + threadIdx.x;
     if (e >= N) return;
     const int c = ev_xyb[e];
-    if (c < 0) return;
+    if (c < 0) { ev_slot[e] = -1; return; }
     const int p = (c & 4095) + W * (((c >> 12) & 4095) + H * (c >> 24));
     slot_tmp[start[p] + ev_rank[e]] = e;
 }
@@ -138,6 +142,7 @@ __global__ __launch_bounds__(kBlock) void k_order(int N, int64_t P, int W, int H
                                                  const int32_t *__restrict__ ev_t,
                                                  const int32_t *__restrict__ start,
                                                  const int32_t *__restrict__ slot_tmp, int2 *__restrict__ slot_it,
+                                                 int32_t *__restrict__ slot_xyb, int32_t *__restrict__ ev_slot,
                                                  int32_t *__restrict__ long_list, int long_cap,
                                                  int32_t *__restrict__ status) {
     const int s = blockIdx.x * kBlock + threadIdx.x;
@@ -147,12 +152,12 @@ __global__ __launch_bounds__(kBlock) void k_order(int N, int64_t P, int W, int H
     const int p = (c & 4095) + W * (((c >> 12) & 4095) + H * (c >> 24));
     const int a = start[p];
     const int n = start[p + 1] - a;
-    if (n == 1) {
-        slot_it[s] = make_int2(e, ev_t[e]);
-    } else if (n <= kShortSeg) {
+    if (n <= kShortSeg) {
         int rank = 0;
         for (int k = 0; k < n; k++) rank += (slot_tmp[a + k] < e) ? 1 : 0;
         slot_it[a + rank] = make_int2(e, ev_t[e]);
+        slot_xyb[a + rank] = c;
+        ev_slot[e] = a + rank;
     } else if (s == a) {
         const int i = atomicAdd(&status[0], 1);
         if (i < long_cap) long_list[i] = p; else atomicOr(&status[1], 2);
@@ -162,7 +167,9 @@ __global__ __launch_bounds__(kBlock) void k_order(int N, int64_t P, int W, int H
 // K5: long segments (> kShortSeg events on one pixel).  Only the newest m = min(n, Q) events of a
 // pixel are ever visible to the search (FIFO depth Q, ev_graph.cu:201-211), so: radix-select the
 // m-th largest id, gather the m newest into LDS, rank-sort them into the tail of the segment.
-__global__ __launch_bounds__(kBlock) void k_order_long(int Q, const int32_t *__restrict__ ev_t,
+__global__ __launch_bounds__(kBlock) void k_order_long(int Q, const int32_t *__restrict__ ev_xyb,
+                                                      int32_t *__restrict__ slot_xyb, int32_t *__restrict__ ev_slot,
+                                                      const int32_t *__restrict__ ev_t,
                                                       const int32_t *__restrict__ start,
                                                       const int32_t *__restrict__ slot_tmp,
                                                       int2 *__restrict__ slot_it,
@@ -212,7 +219,12 @@ __global__ __launch_bounds__(kBlock) void k_order_long(int Q, const int32_t *__r
             if ((unsigned)v >= thr) sel[atomicAdd(&sh_nsel, 1)] = v;
             // older events are invisible to the search (beyond the FIFO depth) but remain graph nodes:
             // keep them, in any order, in the head of the segment (voxel pooling walks the segment)
-            else slot_it[a + atomicAdd(&sh_nrest, 1)] = make_int2(v, ev_t[v]);
+            else {
+                const int o = a + atomicAdd(&sh_nrest, 1);
+                slot_it[o] = make_int2(v, ev_t[v]);
+                slot_xyb[o] = ev_xyb[v];
+                ev_slot[v] = o;
+            }
         }
         __syncthreads();
         // sh_nsel == m (ids are unique)
@@ -221,6 +233,8 @@ __global__ __launch_bounds__(kBlock) void k_order_long(int Q, const int32_t *__r
             int rank = 0;
             for (int j = 0; j < m; j++) rank += (sel[j] < v) ? 1 : 0;
             slot_it[a + (n - m) + rank] = make_int2(v, ev_t[v]);
+            slot_xyb[a + (n - m) + rank] = ev_xyb[v];
+            ev_slot[v] = a + (n - m) + rank;
         }
         __syncthreads();
     }
@@ -253,21 +267,21 @@ __device__ __forceinline__ int group16_inclusive_scan(int v) {
     return v;
 }
 
-// kTile = true (2r+2 <= 16): the segment offsets of an event's (2r+1)^2 neighbourhood are fetched
-// row by row -- per instruction the 16 lanes of an event read the 2r+2 consecutive offsets of one
-// pixel row (1-2 cache lines, instead of one line per probed pixel on the vertical spiral legs) --
-// and parked in LDS; the spiral then runs out of LDS and only touches global memory for the
-// {id, t} pairs of non-empty pixels.  kTile = false: generic path, probes go to global memory.
-template <bool kTile>
-__global__ __launch_bounds__(kBlock) void k_search(int N, int W, int H, int K, int Q, int r, float delta_t,
-                                                  const int32_t *__restrict__ ev_xyb,
-                                                  const int32_t *__restrict__ ev_t,
+// Level-0 node numbering.  The graph is emitted in *slot space*: node n is CSR slot n, i.e. events
+// ordered by (sample, y, x) and by time inside a pixel.  Spatially adjacent destinations then sit next
+// to each other in every level-0 array, so the segment-offset rows, the {id,t} candidates and (in the
+// SplineConv) the source feature rows they touch are shared through L1/L2 instead of being re-fetched
+// per event, and voxel pooling streams its members.  Event-order views (edge_index, permutations) are
+// produced on demand by dagr_graph_edge_index / dagr_graph_node_order.
+//
+// Generic search (any radius): probes go to global memory, 16 lanes per destination, batches of 8 rounds.
+__global__ __launch_bounds__(kBlock) void k_search(const int32_t *__restrict__ m_ptr, int W, int H, int K, int Q, int r,
+                                                  float delta_t, const int32_t *__restrict__ slot_xyb,
                                                   const int32_t *__restrict__ start,
                                                   const int2 *__restrict__ slot_it,
                                                   int32_t *__restrict__ nbr_src, int16_t *__restrict__ nbr_code,
                                                   int32_t *__restrict__ deg, int32_t *__restrict__ status) {
-    __shared__ int16_t sp_tab[kTile ? 256 : kMaxSpiral];  // (sx + 64) | (sy + 64) << 8, spiral.h:1-15 order
-    __shared__ int tile[kTile ? (kBlock / 16) * 16 * 17 : 1];  // per event: segment offsets [row][col], row stride 17
+    __shared__ int16_t sp_tab[kMaxSpiral];  // (sx + 64) | (sy + 64) << 8, spiral.h:1-15 order
     __shared__ int blk_edges;
     const int side = 2 * r + 1;
     const int S = side * side;
@@ -278,123 +292,92 @@ __global__ __launch_bounds__(kBlock) void k_search(int N, int W, int H, int K, i
     }
     if (threadIdx.x == 0) blk_edges = 0;
     __syncthreads();
-
+    const int M = *m_ptr;
     const int l = threadIdx.x & 15;
-    const int grp = threadIdx.x >> 4;
-    const int e = (blockIdx.x * kBlock + threadIdx.x) >> 4;
+    const int n = (blockIdx.x * kBlock + threadIdx.x) >> 4;   // destination slot
     int total = 0;
-    if (e < N) {
-        const int c = ev_xyb[e];
-        const int t = ev_t[e];
-        const int64_t row = (int64_t)e * K;
+    if (n < M) {
+        const int2 me = slot_it[n];
+        const int e = me.x, t = me.y;
+        const int c = slot_xyb[n];
+        const int64_t row = (int64_t)n * K;
         total = 1;
         if (l == 0) {
-            nbr_src[row] = e;  // self loop first (ev_graph.cu:44-46)
+            nbr_src[row] = n;  // self loop first (ev_graph.cu:44-46)
             nbr_code[row] = (int16_t)(r * side + r);
         }
-        if (c >= 0) {
-            const int x = c & 4095, y = (c >> 12) & 4095, b = c >> 24;
-            const int plane = W * H * b;
-            int *my_tile = tile + (kTile ? grp * 16 * 17 : 0);
-            if (kTile) {
-                // lane l owns neighbourhood column x - r + l (clamped into the row, so that pixels
-                // outside the sensor read two equal offsets = empty); one instruction per row: the 16
-                // lanes of an event read 16 consecutive offsets (1-2 cache lines).
+        const int x = c & 4095, y = (c >> 12) & 4095, b = c >> 24;
+        const int plane = W * H * b;
+        constexpr int kRounds = 8;
+        for (int s0 = 0; s0 < S && total < K;) {
+            const int rounds = (s0 == 0) ? 1 : min(kRounds, (S - s0 + 15) >> 4);
+            int bnd[kRounds], vis[kRounds], ecode[kRounds];
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const int yn = y + i - r;
-                    int val = 0;
-                    if (i < side && yn >= 0 && yn < H) {
-                        // columns left of the sensor clamp to the first in-range pixel, columns right
-                        // of it to the row end: both give zero-length segments
-                        const int lo = max(x - r, 0), hi = min(x + r, W - 1) + 1;
-                        val = start[plane + yn * W + min(max(x - r + l, lo), hi)];
+            for (int m = 0; m < kRounds; m++) {
+                bnd[m] = 0; vis[m] = 0; ecode[m] = 0;
+                const int s = s0 + 16 * m + l;
+                if (m < rounds && s < S) {
+                    const int code = sp_tab[s];
+                    const int sx = (code & 255) - 64, sy = ((code >> 8) & 255) - 64;
+                    ecode[m] = (sx + r) * side + (sy + r);
+                    const int xn = x + sx, yn = y + sy;
+                    if (xn >= 0 && yn >= 0 && xn < W && yn < H) {  // out of FOV: skip this pixel only
+                        const int p = plane + yn * W + xn;
+                        const int a = start[p];
+                        bnd[m] = start[p + 1];
+                        vis[m] = min(bnd[m] - a, Q);                // FIFO depth
                     }
-                    if (i < side) my_tile[i * 17 + l] = val;
                 }
-                __builtin_amdgcn_wave_barrier();
             }
-            // Positions are consumed in batches of kRounds x 16 (first batch: 1 round = ring 0, ring 1
-            // and the start of ring 2, where dense scenes already fill their K slots).  Inside a batch
-            // every lane first collects the segment bounds of all its positions, then the newest
-            // {id, t} of every non-empty pixel, and only then evaluates them.
-            constexpr int kRounds = 8;
-            for (int s0 = 0; s0 < S && total < K;) {
-                const int rounds = (s0 == 0) ? 1 : min(kRounds, (S - s0 + 15) >> 4);
-                int bnd[kRounds], vis[kRounds], ecode[kRounds];
+            int2 it0[kRounds];
 #pragma unroll
-                for (int m = 0; m < kRounds; m++) {
-                    bnd[m] = 0; vis[m] = 0; ecode[m] = 0;
-                    const int s = s0 + 16 * m + l;
-                    if (m < rounds && s < S) {
-                        const int code = sp_tab[s];
-                        const int sx = (code & 255) - 64, sy = ((code >> 8) & 255) - 64;
-                        ecode[m] = (sx + r) * side + (sy + r);
-                        if (kTile) {
-                            const int cur = my_tile[(sy + r) * 17 + (sx + r)];
-                            bnd[m] = my_tile[(sy + r) * 17 + (sx + r) + 1];
-                            vis[m] = min(bnd[m] - cur, Q);                  // FIFO depth
-                        } else {
-                            const int xn = x + sx, yn = y + sy;
-                            if (xn >= 0 && yn >= 0 && xn < W && yn < H) {  // out of FOV: skip this pixel only
-                                const int p = plane + yn * W + xn;
-                                const int a = start[p];
-                                bnd[m] = start[p + 1];
-                                vis[m] = min(bnd[m] - a, Q);                // FIFO depth
-                            }
-                        }
+            for (int m = 0; m < kRounds; m++) {
+                it0[m] = make_int2(0x7fffffff, 0);
+                if (vis[m] > 0) it0[m] = slot_it[bnd[m] - 1];
+            }
+            // admissible sources per position, newest first:
+            //   skip ids >= e (newer or self, ev_graph.cu:64); skip dt > delta (continue, :69)
+            int v[kRounds];
+#pragma unroll
+            for (int m = 0; m < kRounds; m++) {
+                int cnt = 0;
+                if (vis[m] > 0) {
+                    cnt = (it0[m].x < e && !((float)(t - it0[m].y) > delta_t)) ? 1 : 0;
+                    for (int k = 1; k < vis[m] && cnt < K; k++) {
+                        const int2 it = slot_it[bnd[m] - 1 - k];
+                        if (it.x >= e) continue;
+                        if ((float)(t - it.y) > delta_t) continue;
+                        cnt++;
                     }
                 }
-                int2 it0[kRounds];
+                v[m] = cnt;
+            }
+            // sequential cut in spiral order: round by round, lane by lane
 #pragma unroll
-                for (int m = 0; m < kRounds; m++) {
-                    it0[m] = make_int2(0x7fffffff, 0);
-                    if (vis[m] > 0) it0[m] = slot_it[bnd[m] - 1];
-                }
-                // admissible sources per position, newest first:
-                //   skip ids >= e (newer or self, ev_graph.cu:64); skip dt > delta (continue, :69)
-                int v[kRounds];
-#pragma unroll
-                for (int m = 0; m < kRounds; m++) {
-                    int cnt = 0;
-                    if (vis[m] > 0) {
-                        cnt = (it0[m].x < e && !((float)(t - it0[m].y) > delta_t)) ? 1 : 0;
-                        for (int k = 1; k < vis[m] && cnt < K; k++) {
-                            const int2 it = slot_it[bnd[m] - 1 - k];
+            for (int m = 0; m < kRounds; m++) {
+                if (m < rounds) {   // uniform across the 16-lane group
+                    const int incl = group16_inclusive_scan(v[m]);
+                    int slot = total + incl - v[m];
+                    total += __shfl(incl, 15, 16);
+                    if (v[m] > 0 && slot < K) {
+                        for (int k = 0; k < vis[m] && slot < K; k++) {
+                            const int2 it = (k == 0) ? it0[m] : slot_it[bnd[m] - 1 - k];
                             if (it.x >= e) continue;
                             if ((float)(t - it.y) > delta_t) continue;
-                            cnt++;
-                        }
-                    }
-                    v[m] = cnt;
-                }
-                // sequential cut in spiral order: round by round, lane by lane
-#pragma unroll
-                for (int m = 0; m < kRounds; m++) {
-                    if (m < rounds) {   // uniform across the 16-lane group
-                        const int incl = group16_inclusive_scan(v[m]);
-                        int slot = total + incl - v[m];
-                        total += __shfl(incl, 15, 16);
-                        if (v[m] > 0 && slot < K) {
-                            for (int k = 0; k < vis[m] && slot < K; k++) {
-                                const int2 it = (k == 0) ? it0[m] : slot_it[bnd[m] - 1 - k];
-                                if (it.x >= e) continue;
-                                if ((float)(t - it.y) > delta_t) continue;
-                                nbr_src[row + slot] = it.x;
-                                nbr_code[row + slot] = (int16_t)ecode[m];
-                                slot++;
-                            }
+                            nbr_src[row + slot] = bnd[m] - 1 - k;   // source node = its CSR slot
+                            nbr_code[row + slot] = (int16_t)ecode[m];
+                            slot++;
                         }
                     }
                 }
-                s0 += 16 * rounds;
             }
-            if (total > K) total = K;
+            s0 += 16 * rounds;
         }
-        if (l == 0) deg[e] = total;
+        if (total > K) total = K;
+        if (l == 0) deg[n] = total;
     }
     // window edge count (status[2..3] as uint64)
-    if (l == 0 && e < N) atomicAdd(&blk_edges, total);
+    if (l == 0 && n < M) atomicAdd(&blk_edges, total);
     __syncthreads();
     if (threadIdx.x == 0 && blk_edges)
         atomicAdd(reinterpret_cast<unsigned long long *>(status + 2), (unsigned long long)blk_edges);
@@ -410,9 +393,9 @@ __global__ __launch_bounds__(kBlock) void k_search(int N, int W, int H, int K, i
 //     rounds with a multi-event pixel fall back to the exact prefix-sum walk.
 constexpr int kTileRounds = 15;  // ceil(15*15 / 16)
 
-__global__ __launch_bounds__(kBlock) void k_search_tiled(int N, int W, int H, int K, int Q, int r, float delta_t,
-                                                        const int32_t *__restrict__ ev_xyb,
-                                                        const int32_t *__restrict__ ev_t,
+__global__ __launch_bounds__(kBlock) void k_search_tiled(const int32_t *__restrict__ m_ptr, int W, int H, int K, int Q,
+                                                        int r, float delta_t,
+                                                        const int32_t *__restrict__ slot_xyb,
                                                         const int32_t *__restrict__ start,
                                                         const int2 *__restrict__ slot_it,
                                                         int32_t *__restrict__ nbr_src,
@@ -435,17 +418,28 @@ __global__ __launch_bounds__(kBlock) void k_search_tiled(int N, int W, int H, in
         pc[m] = (s < S) ? (((sy + r) * 17 + (sx + r)) | (((sx + r) * side + (sy + r)) << 16)) : -1;
     }
     long long edges_acc = 0;
-    const XcdSplit xs = xcd_split(N, kBlock / 16, grp);
-    for (int e = xs.first; e < xs.end; e += xs.stride) {
-        const int c = ev_xyb[e];
-        const int t = ev_t[e];
-        const int64_t row = (int64_t)e * K;
+    // every block sweeps a contiguous range of slots (= a run of pixels along image rows): consecutive
+    // destinations share most of their neighbourhood, so offsets and candidates come out of L1/L2
+    const int M = *m_ptr;
+    // XCD x = blockIdx % 8 owns the x-th eighth of the slots (one sample for B = 8), its blocks split it
+    // into contiguous strips: vertical neighbours of a strip live in the same XCD's L2
+    const int G = gridDim.x, nx = (G % 8 == 0) ? 8 : 1;
+    const int xcd = blockIdx.x % nx, lb = blockIdx.x / nx, bpx = G / nx;
+    const int chunk = (M + nx - 1) / nx;
+    const int per_block = (chunk + bpx - 1) / bpx;
+    const int n_begin = xcd * chunk + lb * per_block;
+    const int n_end = min(min(M, (xcd + 1) * chunk), n_begin + per_block);
+    for (int n = n_begin + grp; n < n_end; n += kBlock / 16) {
+        const int2 me = slot_it[n];
+        const int e = me.x, t = me.y;
+        const int c = slot_xyb[n];
+        const int64_t row = (int64_t)n * K;
         int total = 1;
         if (l == 0) {
-            nbr_src[row] = e;  // self loop first (ev_graph.cu:44-46)
+            nbr_src[row] = n;  // self loop first (ev_graph.cu:44-46)
             nbr_code[row] = (int16_t)(r * side + r);
         }
-        if (c >= 0) {
+        {
             const int x = c & 4095, y = (c >> 12) & 4095, b = c >> 24;
             const int plane = W * H * b;
             const int lo = max(x - r, 0), hi = min(x + r, W - 1) + 1;
@@ -490,7 +484,7 @@ __global__ __launch_bounds__(kBlock) void k_search_tiled(int N, int W, int H, in
                         const unsigned bits = (unsigned)(__ballot(ok0) >> gshift) & 0xffffu;
                         const int slot = total + __popc(bits & ((1u << l) - 1u));
                         if (ok0 && slot < K) {
-                            nbr_src[row + slot] = it0[j].x;
+                            nbr_src[row + slot] = bnd[j] - 1;   // source node = its CSR slot
                             nbr_code[row + slot] = (int16_t)ecode;
                         }
                         total += __popc(bits);
@@ -513,7 +507,7 @@ __global__ __launch_bounds__(kBlock) void k_search_tiled(int N, int W, int H, in
                                 const int2 it = (k == 0) ? it0[j] : slot_it[bnd[j] - 1 - k];
                                 if (it.x >= e) continue;
                                 if ((float)(t - it.y) > delta_t) continue;
-                                nbr_src[row + slot] = it.x;
+                                nbr_src[row + slot] = bnd[j] - 1 - k;
                                 nbr_code[row + slot] = (int16_t)ecode;
                                 slot++;
                             }
@@ -527,29 +521,71 @@ __global__ __launch_bounds__(kBlock) void k_search_tiled(int N, int W, int H, in
             if (total > K) total = K;
             __builtin_amdgcn_wave_barrier();  // tile reads of this event precede the next event's writes
         }
-        if (l == 0) { deg[e] = total; edges_acc += total; }
+        if (l == 0) { deg[n] = total; edges_acc += total; }
     }
     if (l == 0 && edges_acc) atomicAdd(reinterpret_cast<unsigned long long *>(status + 2), (unsigned long long)edges_acc);
 }
 
 // ---------------------------------------------------------------------------------------------
-// reference-shaped edge_index from the neighbour lists (graph/utils.py:22 order)
-__global__ __launch_bounds__(kBlock) void k_edge_index(int N, int K, const int32_t *__restrict__ nbr_src,
+// reference-shaped edge_index (event order, graph/utils.py:22) from the slot-space neighbour lists
+__global__ __launch_bounds__(kBlock) void k_deg_by_event(int N, const int32_t *__restrict__ ev_slot,
+                                                        const int32_t *__restrict__ deg,
+                                                        int32_t *__restrict__ rowptr) {
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e > N) return;
+    int d = 0;
+    if (e < N) { const int s = ev_slot[e]; d = s >= 0 ? deg[s] : 1; }
+    rowptr[e] = d;
+}
+
+__global__ __launch_bounds__(kBlock) void k_edge_index(int N, int K, const int32_t *__restrict__ ev_slot,
+                                                      const int2 *__restrict__ slot_it,
+                                                      const int32_t *__restrict__ nbr_src,
                                                       const int32_t *__restrict__ deg,
                                                       const int32_t *__restrict__ rowptr,
                                                       int64_t *__restrict__ edge_index, int64_t row_stride) {
     const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int e = (int)(gid / K);
     const int j = (int)(gid % K);
-    if (e >= N || j >= deg[e]) return;
+    if (e >= N) return;
+    const int s = ev_slot[e];
+    const int d = s >= 0 ? deg[s] : 1;
+    if (j >= d) return;
     const int64_t o = (int64_t)rowptr[e] + j;
     if (o >= row_stride) return;
-    edge_index[o] = nbr_src[(int64_t)e * K + j];
+    edge_index[o] = s >= 0 ? slot_it[nbr_src[(int64_t)s * K + j]].x : e;
     edge_index[row_stride + o] = e;
 }
 
-__global__ void k_rowptr_tail(const int32_t *deg, int32_t *rowptr, int64_t N) {
-    rowptr[N] = rowptr[N - 1] + deg[N - 1];
+__global__ __launch_bounds__(kBlock) void k_node_order(int N, const int2 *__restrict__ slot_it,
+                                                      const int32_t *__restrict__ ev_slot,
+                                                      const int32_t *__restrict__ m_ptr,
+                                                      int32_t *__restrict__ slot_event,
+                                                      int32_t *__restrict__ event_slot) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= N) return;
+    if (slot_event) slot_event[i] = i < *m_ptr ? slot_it[i].x : -1;
+    if (event_slot) event_slot[i] = ev_slot[i];
+}
+
+// level-0 inputs in node (slot) order: pos, sample index, and the [polarity | ... | pos_xy] feature row
+__global__ __launch_bounds__(kBlock) void k_gather_inputs(const int32_t *__restrict__ m_ptr, int N,
+                                                         const int2 *__restrict__ slot_it,
+                                                         const int32_t *__restrict__ slot_xyb,
+                                                         const float *__restrict__ pos,
+                                                         const float *__restrict__ feat,
+                                                         float *__restrict__ pos_s, int32_t *__restrict__ batch_s,
+                                                         float *__restrict__ x0, int ldx0, int col_pos) {
+    const int n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N || n >= *m_ptr) return;
+    const int e = slot_it[n].x;
+    const float px = pos[3 * (size_t)e], py = pos[3 * (size_t)e + 1], pt = pos[3 * (size_t)e + 2];
+    pos_s[3 * (size_t)n] = px; pos_s[3 * (size_t)n + 1] = py; pos_s[3 * (size_t)n + 2] = pt;
+    batch_s[n] = slot_xyb[n] >> 24;
+    float *row = x0 + (size_t)n * ldx0;
+    row[0] = feat[e];
+    row[col_pos] = px;
+    row[col_pos + 1] = py;
 }
 
 __global__ void k_format_events(const int16_t *__restrict__ xy, const int32_t *__restrict__ t,
@@ -575,6 +611,11 @@ void graph_ws_views(const dagr_graph_desc *desc, void *workspace, const int32_t 
     carve(*desc, (char *)workspace, &ws);
     *start = ws.start;
     *slot_it = ws.slot_it;
+}
+const int32_t *graph_ws_node_count(const dagr_graph_desc *desc, void *workspace) {
+    GraphWs ws;
+    carve(*desc, (char *)workspace, &ws);
+    return ws.start + ws.P;
 }
 }  // namespace dagr
 
@@ -641,30 +682,31 @@ int dagr_graph_build_window(const dagr_graph_desc *desc, void *workspace, const 
     DAGR_CHECK_LAUNCH();
     // start = exclusive_scan(cnt); cnt is re-zeroed in the same pass (invariant for the next window)
     DAGR_CHECK_HIP(exclusive_scan_i32(ws.cnt, ws.start, ws.P + 1, ws.scan_tmp, true, stream));
-    k_scatter<<<gN, kBlock, 0, stream>>>(n, W, H, ws.ev_xyb, ws.ev_rank, ws.start, ws.slot_tmp);
+    k_scatter<<<gN, kBlock, 0, stream>>>(n, W, H, ws.ev_xyb, ws.ev_rank, ws.start, ws.slot_tmp, ws.ev_slot);
     DAGR_CHECK_LAUNCH();
     // number of occupied CSR slots M = start[P] <= N (dropped events excluded); slots are a
     // prefix [0, M) so launching N threads with an in-kernel bound read would need M on the host.
     // Out-of-FOV events are an error condition; we order all N slots but guard on start[P].
     const int long_cap = (int)(desc->max_events / kShortSeg + 1);
     k_order<<<gN, kBlock, 0, stream>>>(n, ws.P, W, H, ws.ev_xyb, ws.ev_t, ws.start, ws.slot_tmp, ws.slot_it,
-                                       ws.long_list, long_cap, ws.status);
+                                       ws.slot_xyb, ws.ev_slot, ws.long_list, long_cap, ws.status);
     DAGR_CHECK_LAUNCH();
-    k_order_long<<<64, kBlock, 0, stream>>>(desc->queue_size, ws.ev_t, ws.start, ws.slot_tmp, ws.slot_it,
+    k_order_long<<<64, kBlock, 0, stream>>>(desc->queue_size, ws.ev_xyb, ws.slot_xyb, ws.ev_slot, ws.ev_t, ws.start,
+                                            ws.slot_tmp, ws.slot_it,
                                             ws.long_list, long_cap, ws.status);
     DAGR_CHECK_LAUNCH();
     const unsigned gS = (unsigned)ceil_div(N * 16, kBlock);
     if (2 * desc->radius + 2 <= 16) {
         static const unsigned resident = persistent_grid(k_search_tiled, kBlock, 0, 1 << 30);
         const unsigned gT = round_grid8(std::min<int64_t>(ceil_div(N * 16, kBlock), resident));
-        k_search_tiled<<<gT, kBlock, 0, stream>>>(n, W, H, desc->max_neighbors, desc->queue_size, desc->radius,
-                                                  (float)desc->delta_t_us, ws.ev_xyb, ws.ev_t, ws.start, ws.slot_it,
-                                                  nbr_src, nbr_code, deg, ws.status);
+        k_search_tiled<<<gT, kBlock, 0, stream>>>(ws.start + ws.P, W, H, desc->max_neighbors, desc->queue_size,
+                                                  desc->radius, (float)desc->delta_t_us, ws.slot_xyb, ws.start,
+                                                  ws.slot_it, nbr_src, nbr_code, deg, ws.status);
+    } else {
+        k_search<<<gS, kBlock, 0, stream>>>(ws.start + ws.P, W, H, desc->max_neighbors, desc->queue_size, desc->radius,
+                                            (float)desc->delta_t_us, ws.slot_xyb, ws.start, ws.slot_it, nbr_src,
+                                            nbr_code, deg, ws.status);
     }
-    else
-        k_search<false><<<gS, kBlock, 0, stream>>>(n, W, H, desc->max_neighbors, desc->queue_size, desc->radius,
-                                                   (float)desc->delta_t_us, ws.ev_xyb, ws.ev_t, ws.start, ws.slot_it,
-                                                   nbr_src, nbr_code, deg, ws.status);
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;
 }
@@ -697,27 +739,62 @@ int dagr_spiral_offsets(int32_t n, int32_t *dx_host, int32_t *dy_host) {
     return DAGR_OK;
 }
 
-int dagr_graph_edge_index(const int32_t *nbr_src, const int32_t *deg, int64_t N, int32_t K, int32_t *rowptr,
-                          int32_t *scan_scratch, int64_t *edge_index, int64_t row_stride, void *stream_) {
-    DAGR_CHECK_ARG(N >= 0 && K >= 1, "bad N/K");
-    DAGR_CHECK_ARG(rowptr && scan_scratch, "NULL pointer");
+int dagr_graph_edge_index(const dagr_graph_desc *desc, void *workspace, const int32_t *nbr_src, const int32_t *deg,
+                          int64_t N, int32_t *rowptr, int32_t *scan_scratch, int64_t *edge_index, int64_t row_stride,
+                          void *stream_) {
+    int rc = validate(desc);
+    if (rc != DAGR_OK) return rc;
+    DAGR_CHECK_ARG(workspace && N >= 0 && rowptr && scan_scratch, "bad arguments");
     hipStream_t stream = (hipStream_t)stream_;
     if (N == 0) {
         DAGR_CHECK_HIP(hipMemsetAsync(rowptr, 0, 4, stream));
         return DAGR_OK;
     }
     DAGR_CHECK_ARG(nbr_src && deg, "NULL pointer");
-    // rowptr[0..N] = exclusive scan of deg[0..N) with a trailing total: scan N+1 entries where the
-    // caller guarantees deg has room for one extra element? No -- scan N then patch the total.
-    DAGR_CHECK_HIP(exclusive_scan_i32(const_cast<int32_t *>(deg), rowptr, N, scan_scratch, false, stream));
-    // rowptr[N] = rowptr[N-1] + deg[N-1]
-    k_rowptr_tail<<<1, 1, 0, stream>>>(deg, rowptr, N);
+    GraphWs ws;
+    carve(*desc, (char *)workspace, &ws);
+    const int K = desc->max_neighbors;
+    // rowptr[0..N] = exclusive scan of the per-event in-degree (event order)
+    k_deg_by_event<<<(unsigned)ceil_div(N + 1, kBlock), kBlock, 0, stream>>>((int)N, ws.ev_slot, deg, rowptr);
     DAGR_CHECK_LAUNCH();
+    DAGR_CHECK_HIP(exclusive_scan_i32(rowptr, rowptr, N + 1, scan_scratch, false, stream));
     if (edge_index) {
-        k_edge_index<<<(unsigned)ceil_div(N * K, kBlock), kBlock, 0, stream>>>((int)N, K, nbr_src, deg, rowptr,
-                                                                              edge_index, row_stride);
+        k_edge_index<<<(unsigned)ceil_div(N * K, kBlock), kBlock, 0, stream>>>((int)N, K, ws.ev_slot, ws.slot_it,
+                                                                              nbr_src, deg, rowptr, edge_index,
+                                                                              row_stride);
         DAGR_CHECK_LAUNCH();
     }
+    return DAGR_OK;
+}
+
+int dagr_graph_node_order(const dagr_graph_desc *desc, void *workspace, int64_t N, int32_t *slot_event,
+                          int32_t *event_slot, void *stream) {
+    int rc = validate(desc);
+    if (rc != DAGR_OK) return rc;
+    DAGR_CHECK_ARG(workspace && N >= 0, "bad arguments");
+    if (N == 0) return DAGR_OK;
+    GraphWs ws;
+    carve(*desc, (char *)workspace, &ws);
+    k_node_order<<<(unsigned)ceil_div(N, kBlock), kBlock, 0, (hipStream_t)stream>>>((int)N, ws.slot_it, ws.ev_slot,
+                                                                                 ws.start + ws.P, slot_event,
+                                                                                 event_slot);
+    DAGR_CHECK_LAUNCH();
+    return DAGR_OK;
+}
+
+int dagr_graph_gather_inputs(const dagr_graph_desc *desc, void *workspace, const float *pos, const float *feat,
+                             int64_t N, float *pos_nodes, int32_t *batch_nodes, float *x0, int32_t ldx0,
+                             int32_t col_pos, void *stream) {
+    int rc = validate(desc);
+    if (rc != DAGR_OK) return rc;
+    DAGR_CHECK_ARG(workspace && N >= 0, "bad arguments");
+    if (N == 0) return DAGR_OK;
+    DAGR_CHECK_ARG(pos && feat && pos_nodes && batch_nodes && x0 && ldx0 >= col_pos + 2 && col_pos >= 1, "bad arguments");
+    GraphWs ws;
+    carve(*desc, (char *)workspace, &ws);
+    k_gather_inputs<<<(unsigned)ceil_div(N, kBlock), kBlock, 0, (hipStream_t)stream>>>(
+        ws.start + ws.P, (int)N, ws.slot_it, ws.slot_xyb, pos, feat, pos_nodes, batch_nodes, x0, ldx0, col_pos);
+    DAGR_CHECK_LAUNCH();
     return DAGR_OK;
 }
 

@@ -163,8 +163,8 @@ __global__ __launch_bounds__(kBlock) void k_pool_l0_cells(dagr_pool_desc d, int 
             const int base = W * (y + H * b);
             const int a = start[base + x0], bnd = start[base + x1 + 1];
             for (int s = a + g; s < bnd; s += 4) {
-                const int id = slot_it[s].x;
-                const float px = pos[3 * (size_t)id], py = pos[3 * (size_t)id + 1], pt = pos[3 * (size_t)id + 2];
+                const int id = slot_it[s].x;   // event id: only for consecutive_cluster's `perm`
+                const float px = pos[3 * (size_t)s], py = pos[3 * (size_t)s + 1], pt = pos[3 * (size_t)s + 2];
                 if (pt >= 1.0f) {
                     // QUIRK-1: t == 1.0 lands in the next sample's id range -> rare, atomics
                     const int rl = raw + d.gx * d.gy;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_l0_cells(dagr_pool_desc d, int 
                     for (int c = 0; c < kMaxChunks; c++) {
                         const int ch = c * 16 + l;
                         if (c < nchk && ch < C) {
-                            const float v = x[(size_t)id * ldx + ch];
+                            const float v = x[(size_t)s * ldx + ch];
                             if (d.aggr == 0)
                                 atomicMax(reinterpret_cast<int *>(ws.xacc + (size_t)rl * C + ch), enc_f(v));
                             else
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_l0_cells(dagr_pool_desc d, int 
                 for (int c = 0; c < kMaxChunks; c++) {
                     const int ch = c * 16 + l;
                     if (c < nchk && ch < C) {
-                        const float v = x[(size_t)id * ldx + ch];
+                        const float v = x[(size_t)s * ldx + ch];
                         mx[c] = fmaxf(mx[c], v);
                         sm[c] += (double)(long long)llrint((double)v * kFeatScale);
                     }
@@ -511,7 +511,8 @@ static int pool_tail(const dagr_pool_desc *d, PoolWs &ws, const int32_t *batch32
 
 int dagr_pool_l0(const dagr_pool_desc *desc, void *pool_ws, const dagr_graph_desc *gdesc, void *graph_ws,
                  const int32_t *xlo, const int32_t *ylo, const float *x, int32_t ldx, const float *pos,
-                 const void *batch, int32_t batch_is_int64, int64_t N, const int32_t *nbr_src, const int32_t *deg,
+                 const int32_t *batch_nodes, const void *batch, int32_t batch_is_int64, int64_t N,
+                 const int32_t *nbr_src, const int32_t *deg,
                  int32_t *cluster_scratch, float *x_out, int32_t ldo, int32_t xoff, float *pos_out,
                  int32_t *batch_out, int32_t *n_out, int32_t *rowptr_out, int32_t *col_out, int32_t *code_out,
                  int32_t *e_out, int32_t e_cap, void *stream_) {
@@ -528,7 +529,7 @@ int dagr_pool_l0(const dagr_pool_desc *desc, void *pool_ws, const dagr_graph_des
     const int32_t *b32 = batch_is_int64 ? nullptr : (const int32_t *)batch;
     const int64_t *b64 = batch_is_int64 ? (const int64_t *)batch : nullptr;
     if (N > 0) {
-        DAGR_CHECK_ARG(xlo && ylo && x && pos && batch && nbr_src && deg && cluster_scratch, "NULL input");
+        DAGR_CHECK_ARG(xlo && ylo && x && pos && batch_nodes && batch && nbr_src && deg && cluster_scratch, "NULL input");
         const int32_t *start; const int2 *slot_it;
         graph_ws_views(gdesc, graph_ws, &start, &slot_it);
         const int ncell = desc->gx * desc->gy * desc->batch_size;
@@ -541,8 +542,8 @@ int dagr_pool_l0(const dagr_pool_desc *desc, void *pool_ws, const dagr_graph_des
         *desc, ws, b32, b64, x_out, ldo, xoff, pos_out, batch_out, n_out);
     DAGR_CHECK_LAUNCH();
     if (N > 0) {
-        k_pool_l0_event_cluster<<<(unsigned)ceil_div(N, kBlock), kBlock, 0, stream>>>(*desc, (int)N, pos, b32, b64,
-                                                                                   cluster_scratch, ws.status);
+        k_pool_l0_event_cluster<<<(unsigned)ceil_div(N, kBlock), kBlock, 0, stream>>>(*desc, (int)N, pos, batch_nodes,
+                                                                                   nullptr, cluster_scratch, ws.status);
         DAGR_CHECK_LAUNCH();
         const int K = gdesc->max_neighbors;
         k_coarse_edges_ell<<<(unsigned)ceil_div(N * K, kBlock), kBlock, 0, stream>>>((int)N, K, nbr_src, deg,

@@ -7,6 +7,7 @@ host synchronisation: graph build -> fused level-0 convs -> voxel pooling -> (ta
 GEMM) per pooled conv -> dense head maps.  PyTorch supplies memory and the stream only.
 """
 import ctypes
+import types
 
 import numpy as np
 import torch
@@ -137,6 +138,7 @@ class WindowEngine:
         self._keep = []
         self._cnn_out = None
         self._img_stream = None
+        self._net_f = self._cnn_f = None
         self._prepare(bb, head)
         self.max_events = 0
         self._alloc_events(int(max_events))
@@ -277,6 +279,8 @@ class WindowEngine:
         self.hp0 = torch.zeros((n, 16 + self.feat_ch[1]), dtype=torch.float32, device=dev)  # [h2 | image feats]
         self.x0buf = torch.zeros((n, 1 + self.feat_ch[0] + 2), dtype=torch.float32, device=dev)
         self.cluster0 = torch.zeros((n,), dtype=torch.int32, device=dev)
+        self.pos_n = torch.zeros((n, 3), dtype=torch.float32, device=dev)     # node (slot) order
+        self.batch_n = torch.zeros((n,), dtype=torch.int32, device=dev)
 
     # ------------------------------------------------------------------------------- kernels
     def _conv_generic(self, lvl, pack, x, ldx, xskip, ldskip, out, ldo, dom, stream):
@@ -310,8 +314,38 @@ class WindowEngine:
                                                w, C, self.W, self.H, _lib.ptr(out), out.shape[1], coff,
                                                _lib.cur_stream(self.device)), "sample_features")
 
-    def _image_branch(self, image):
+    def _fold_image_branch(self):
+        """Inference copy of the image branch with every Conv2d+BatchNorm2d(eval) pair folded into one
+        conv (torch.nn.utils.fusion.fuse_conv_bn_eval): the BN passes over the 640x480 activations are
+        pure HBM traffic.  The stem conv1 stays unfolded: the reference taps its raw output
+        (feature_layers=["conv1", ...], net.py:47).  Parameters of the original modules are untouched."""
+        import copy
+        from torch.nn.utils.fusion import fuse_conv_bn_eval
         bb, head = self.model.backbone, self.model.head
+        net = copy.deepcopy(bb.net).eval()
+        cnn = copy.deepcopy(head.cnn_head).eval()
+
+        def fold_block(blk):
+            for ci, bi in (("conv1", "bn1"), ("conv2", "bn2"), ("conv3", "bn3")):
+                if hasattr(blk, ci):
+                    setattr(blk, ci, fuse_conv_bn_eval(getattr(blk, ci), getattr(blk, bi)))
+                    setattr(blk, bi, torch.nn.Identity())
+            if blk.downsample is not None:
+                blk.downsample = torch.nn.Sequential(fuse_conv_bn_eval(blk.downsample[0], blk.downsample[1]))
+        for name in ("layer1", "layer2", "layer3", "layer4"):
+            for blk in getattr(net.module, name):
+                fold_block(blk)
+        for m in cnn.modules():
+            if hasattr(m, "conv") and hasattr(m, "bn") and isinstance(m.bn, torch.nn.BatchNorm2d):
+                m.conv = fuse_conv_bn_eval(m.conv, m.bn)
+                m.bn = torch.nn.Identity()
+        self._net_f = net.to(memory_format=torch.channels_last)
+        self._cnn_f = cnn.to(memory_format=torch.channels_last)
+
+    def _image_branch(self, image):
+        if self._net_f is None:
+            self._fold_image_branch()
+        bb, head = types.SimpleNamespace(net=self._net_f), types.SimpleNamespace(cnn_head=self._cnn_f)
         feats, outs = bb.net(image.contiguous(memory_format=torch.channels_last))
         outs = outs[-self.num_scales:]
         resized = [torch.nn.functional.interpolate(f, o) for f, o in zip(outs, self.out_sizes)]
@@ -348,18 +382,18 @@ class WindowEngine:
         self._img_feats, self._cnn_out = feats, cnn_out
 
     def stage_l0_input(self, feat):
-        """x = cat(x, [image feats,] pos[:, :2]) (net.py:118,124-125)."""
+        """Level-0 inputs in node order: x = cat(x, [image feats,] pos[:, :2]) (net.py:118,124-125)."""
         N = self._N
-        f = feat.float().reshape(N, feat.shape[1] if feat.dim() > 1 else 1)
-        if not self.use_image:
-            self._x0 = torch.cat((f, self._pos[:, :2]), dim=1).contiguous()
-            return
+        f = feat.float().reshape(-1).contiguous()
         x0 = self.x0buf[:N]
         c = x0.shape[1]
-        x0[:, 0:1] = f
-        x0[:, c - 2:] = self._pos[:, :2]
-        b64 = 1 if self._batch.dtype == torch.int64 else 0
-        self._sample(None, N, self._pos, self._batch, b64, self._img_feats[0], x0, 1)
+        g = self.graph
+        _lib.check(self.L.dagr_graph_gather_inputs(ctypes.byref(g.desc), _lib.ptr(g.workspace), _lib.ptr(self._pos),
+                                                   _lib.ptr(f), N, _lib.ptr(self.pos_n), _lib.ptr(self.batch_n),
+                                                   _lib.ptr(x0), c, c - 2, _lib.cur_stream(self.device)),
+                   "graph_gather_inputs")
+        if self.use_image:
+            self._sample(None, N, self.pos_n, self.batch_n, 0, self._img_feats[0], x0, 1)
         self._x0 = x0
 
     def stage_l0_conv1(self):
@@ -373,7 +407,7 @@ class WindowEngine:
                                          P(nbr_code), P(deg), P(self._x0), c0, None, 0, P(self.tab0), P(w1), P(s1), 1,
                                          P(self.h1), 16, _lib.cur_stream(self.device)), "conv_l0")
 
-    def stage_l0_conv2(self):
+    def stage_l0_conv2(self, sample=True):
         """conv_block1.conv_block2: SplineConv(16->16)+BN + skip Linear+BN, ReLU (conv.py:47-56);
         with --use_image followed by sampling_skip(image_feat[1]) (net.py:129)."""
         L, P = self.L, _lib.ptr
@@ -384,9 +418,8 @@ class WindowEngine:
         _lib.check(L.dagr_spline_conv_l0(cin, cskip, self.ntaps0, self._N, self.graph.K, self.ncodes0, P(nbr_src),
                                          P(nbr_code), P(deg), P(self.h1), 16, P(self._x0), c0, P(self.tab0), P(w2),
                                          P(s2), 1, P(self.hp0), ldo, _lib.cur_stream(self.device)), "conv_l0")
-        if self.use_image:
-            b64 = 1 if self._batch.dtype == torch.int64 else 0
-            self._sample(None, self._N, self._pos, self._batch, b64, self._img_feats[1], self.hp0[:self._N], 16)
+        if self.use_image and sample:
+            self._sample(None, self._N, self.pos_n, self.batch_n, 0, self._img_feats[1], self.hp0[:self._N], 16)
 
     def stage_pool1(self):
         """pool1 (net.py:131) on the event graph."""
@@ -397,8 +430,9 @@ class WindowEngine:
         d = self.pool_desc[0]
         b64 = 1 if self._batch.dtype == torch.int64 else 0
         _lib.check(L.dagr_pool_l0(ctypes.byref(d), P(self.pool_ws[0]), ctypes.byref(g.desc), P(g.workspace),
-                                  P(self.xlo), P(self.ylo), P(self.hp0), self.hp0.shape[1], P(self._pos),
-                                  P(self._batch), b64, self._N, P(nbr_src), P(deg), P(self.cluster0), P(l1.x),
+                                  P(self.xlo), P(self.ylo), P(self.hp0), self.hp0.shape[1], P(self.pos_n),
+                                  P(self.batch_n), P(self._batch), b64, self._N, P(nbr_src), P(deg),
+                                  P(self.cluster0), P(l1.x),
                                   l1.x.shape[1], 0, P(l1.pos), P(l1.batch), P(l1.counts), P(l1.rowptr), P(l1.col),
                                   P(l1.code), ctypes.c_void_p(l1.counts.data_ptr() + 4), l1.e_cap,
                                   _lib.cur_stream(self.device)), "pool_l0")
@@ -475,9 +509,11 @@ class WindowEngine:
         self.stage_l0_conv2()
         if trace is not None:
             trace["nbr"] = tuple(t.clone() for t in self._nbr)
-            trace["layer1"] = self.hp0[:self._N, :16].clone()
+            _, ev_slot = self.graph.node_order(self._N)     # traces are reported in event order
+            ev_slot = ev_slot.long()
+            trace["layer1"] = self.hp0[:self._N, :16][ev_slot].clone()
             if self.use_image:
-                trace["x0"] = self._x0.clone()
+                trace["x0"] = self._x0[ev_slot].clone()
         self.stage_pool1()
         self.stage_tail(trace)
         outs = self.stage_head()

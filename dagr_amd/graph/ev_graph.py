@@ -21,7 +21,9 @@ class WindowGraphBuilder:
     """Thin owner of a ``dagr_graph_desc`` + device workspace; neighbour-list output.
 
     ``build(pos, batch)`` -> ``(nbr_src int32[N,K], nbr_code int16[N,K], deg int32[N])`` on the
-    current stream, no host synchronisation.
+    current stream, no host synchronisation.  The lists are in *node (slot) order*: node n is the n-th
+    event in (sample, y, x, time) order; ``node_order()`` returns the permutation and ``edge_index``
+    the reference-shaped, event-ordered ``int64[2,E]``.
     """
 
     def __init__(self, width, height, batch_size, max_num_neighbors, max_queue_size, radius, delta_t_us,
@@ -81,23 +83,32 @@ class WindowGraphBuilder:
                    "graph_status")
         return ne.value, fl.value
 
+    def node_order(self, N):
+        """(slot_event int32[N], event_slot int32[N]): event id of every node / node of every event."""
+        slot_event = torch.empty((N,), dtype=torch.int32, device=self.device)
+        event_slot = torch.empty((N,), dtype=torch.int32, device=self.device)
+        _lib.check(_lib.lib().dagr_graph_node_order(ctypes.byref(self.desc), _lib.ptr(self.workspace), N,
+                                                    _lib.ptr(slot_event), _lib.ptr(event_slot),
+                                                    _lib.cur_stream(self.device)), "graph_node_order")
+        return slot_event, event_slot
+
     def edge_index(self, nbr_src, deg):
-        """Reference-shaped ``int64[2,E]`` (synchronises to learn E) + rowptr int32[N+1]."""
+        """Reference-shaped ``int64[2,E]`` in event ids (synchronises to learn E) + rowptr int32[N+1]."""
         N = int(deg.shape[0])
         if N == 0:
             return torch.zeros((2, 0), dtype=torch.int64, device=self.device), \
                 torch.zeros((1,), dtype=torch.int32, device=self.device)
         L = _lib.lib()
-        K = self.K
         rowptr = torch.empty((N + 1,), dtype=torch.int32, device=self.device)
         scratch = torch.empty((L.dagr_scan_scratch_elems(N + 1),), dtype=torch.int32, device=self.device)
         stream = _lib.cur_stream(self.device)
-        _lib.check(L.dagr_graph_edge_index(_lib.ptr(nbr_src), _lib.ptr(deg), N, K, _lib.ptr(rowptr),
+        d, w = ctypes.byref(self.desc), _lib.ptr(self.workspace)
+        _lib.check(L.dagr_graph_edge_index(d, w, _lib.ptr(nbr_src), _lib.ptr(deg), N, _lib.ptr(rowptr),
                                            _lib.ptr(scratch), None, 0, stream), "graph_edge_index(rowptr)")
         E = int(rowptr[-1].item())
         edge_index = torch.empty((2, E), dtype=torch.int64, device=self.device)
         if E > 0:
-            _lib.check(L.dagr_graph_edge_index(_lib.ptr(nbr_src), _lib.ptr(deg), N, K, _lib.ptr(rowptr),
+            _lib.check(L.dagr_graph_edge_index(d, w, _lib.ptr(nbr_src), _lib.ptr(deg), N, _lib.ptr(rowptr),
                                                _lib.ptr(scratch), _lib.ptr(edge_index), E, stream),
                        "graph_edge_index")
         return edge_index, rowptr

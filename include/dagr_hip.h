@@ -83,11 +83,17 @@ size_t dagr_graph_workspace_bytes(const dagr_graph_desc *desc);
 /* must be called once on a fresh workspace (zeroes the per-pixel counters) */
 int dagr_graph_workspace_init(const dagr_graph_desc *desc, void *workspace, size_t workspace_bytes, void *stream);
 
-/* pos: pos_is_int32 == 0: normalised fp32 [N,3] exactly as format_data produces it (denormalised
+/* Node numbering: the graph comes out in *slot space* -- node n is the n-th event in (sample, y, x,
+ * time) order (the builder's CSR-by-pixel order), so that spatial neighbours are memory neighbours in
+ * every level-0 array.  nbr_src holds node numbers.  dagr_graph_node_order exports the permutation,
+ * dagr_graph_gather_inputs brings the per-event inputs into node order, dagr_graph_edge_index emits the
+ * reference-shaped, event-ordered int64 edge_index.
+ *
+ * pos: pos_is_int32 == 0: normalised fp32 [N,3] exactly as format_data produces it (denormalised
  *      on the fly, ev_tgn.py:11-16); pos_is_int32 == 1: int32 [N,3] = (x, y, t_us), the input
  *      contract of SlidingWindowGraph.forward (ev_graph.py:139).
  * batch: int32[N] or int64[N] (sample index, non-decreasing not required).
- * nbr_src[N,K] int32 : source event of slot j of destination n (slot 0 = n itself)
+ * nbr_src[N,K] int32 : source node of slot j of destination node n (slot 0 = n itself)
  * nbr_code[N,K] int16: (dx+r)*(2r+1) + (dy+r) with (dx,dy) = pixel offset source - destination
  * deg[N] int32       : number of valid slots (1..K)
  * Slots >= deg[n] are left untouched. */
@@ -103,13 +109,23 @@ int dagr_graph_status(const dagr_graph_desc *desc, void *workspace, int64_t *num
                       int32_t *flags /*host*/, void *stream);
 
 /* Reference-shaped output: edge_index int64[2,E] in the order of
- * `edges[:, edges[1] >= 0]` (graph/utils.py:22).  `row_stride` = allocated columns (>= E).
- * rowptr int32[N+1] receives the exclusive scan of deg (also useful as CSR-by-destination).
+ * `edges[:, edges[1] >= 0]` (graph/utils.py:22), i.e. event ids, destinations ascending.
+ * `row_stride` = allocated columns (>= E).  rowptr int32[N+1] receives the exclusive scan of the
+ * per-event in-degree.
  * Asynchronous; E = rowptr[N]. scratch: int32[dagr_scan_scratch_elems(N+1)]. */
 size_t dagr_scan_scratch_elems(int64_t n);
-int dagr_graph_edge_index(const int32_t *nbr_src, const int32_t *deg, int64_t N, int32_t K,
-                          int32_t *rowptr, int32_t *scan_scratch,
+int dagr_graph_edge_index(const dagr_graph_desc *desc, void *workspace, const int32_t *nbr_src, const int32_t *deg,
+                          int64_t N, int32_t *rowptr, int32_t *scan_scratch,
                           int64_t *edge_index, int64_t row_stride, void *stream);
+/* slot_event[n] = event id of node n, event_slot[e] = node of event e (either may be NULL) */
+int dagr_graph_node_order(const dagr_graph_desc *desc, void *workspace, int64_t N, int32_t *slot_event,
+                          int32_t *event_slot, void *stream);
+/* node-ordered level-0 inputs: pos_nodes[N,3], batch_nodes[N] (int32), and per node the feature row
+ * x0[n, 0] = feat[e], x0[n, col_pos..col_pos+1] = pos_xy[e]  (Net.forward's cat(x, pos[:, :2]), net.py:124-125;
+ * columns 1..col_pos-1 are left for the sampled image features) */
+int dagr_graph_gather_inputs(const dagr_graph_desc *desc, void *workspace, const float *pos, const float *feat,
+                             int64_t N, float *pos_nodes, int32_t *batch_nodes, float *x0, int32_t ldx0,
+                             int32_t col_pos, void *stream);
 
 /* ------------------------------------------------------------------------ *
  * SplineConv (degree-1 open B-spline, 5x5 kernel, sum aggregation)
@@ -182,8 +198,10 @@ int dagr_pool_workspace_init(const dagr_pool_desc *desc, void *workspace, size_t
  * division as grid_cluster).  x_out rows start at column xoff; outputs sized for
  * T = gx*gy*(B+1) clusters; rowptr_out has T+2 entries; e_cap = capacity of col_out/code_out. */
 int dagr_pool_l0(const dagr_pool_desc *desc, void *pool_ws, const dagr_graph_desc *gdesc, void *graph_ws,
-                 const int32_t *xlo, const int32_t *ylo, const float *x, int32_t ldx, const float *pos,
-                 const void *batch, int32_t batch_is_int64, int64_t N, const int32_t *nbr_src, const int32_t *deg,
+                 const int32_t *xlo, const int32_t *ylo, const float *x, int32_t ldx,
+                 const float *pos_nodes, const int32_t *batch_nodes /* node order */,
+                 const void *batch, int32_t batch_is_int64 /* event order */, int64_t N,
+                 const int32_t *nbr_src, const int32_t *deg,
                  int32_t *cluster_scratch /*[N]*/, float *x_out, int32_t ldo, int32_t xoff, float *pos_out,
                  int32_t *batch_out, int32_t *n_out, int32_t *rowptr_out, int32_t *col_out, int32_t *code_out,
                  int32_t *e_out, int32_t e_cap, void *stream);
@@ -214,6 +232,12 @@ int dagr_to_dense(const int32_t *n_ptr, int32_t n_max, const float *x, int32_t l
 int dagr_sample_features(const int32_t *n_ptr, int32_t n_max, const float *pos, const void *batch,
                          int32_t batch_is_int64, const float *feat_nhwc, int32_t B, int32_t h, int32_t w, int32_t C,
                          int32_t width, int32_t height, float *out, int32_t ldo, int32_t coff, void *stream);
+
+/* Profiling aid (not on the product path): streams a known number of bytes so that rocprofv3's
+ * FETCH_SIZE / WRITE_SIZE can be calibrated on this library's access patterns.
+ * mode 0: 4 B/lane reads of n_floats; 1: 16 B/lane reads; 2: n_gathers pseudo-random 64-byte rows
+ * read by 16-lane groups; 3: 4 B/lane writes of n_floats. */
+int dagr_debug_calibrate(int32_t mode, float *buf, size_t n_floats, size_t n_gathers, float *sink, void *stream);
 
 /* Host-side helper: first n offsets of the search spiral (spiral.h:1-15), the closed form the
  * search kernel uses.  dx/dy are HOST arrays.  Lets CPU-only tests pin the visiting order. */

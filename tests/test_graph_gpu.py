@@ -26,7 +26,19 @@ def _run_hip(case, use_float_pos=False):
         nbr_src, nbr_code, deg = g.build(pos, batch)
         ei, rowptr = g.edge_index(nbr_src, deg)
         ne, flags = g.status()
-        outs.append((ei.cpu().numpy(), nbr_src.cpu().numpy(), nbr_code.cpu().numpy(), deg.cpu().numpy(), ne, flags))
+        # neighbour lists are in node (slot) order: bring them to event order for the checks below
+        slot_event, event_slot = [v.cpu().numpy() for v in g.node_order(N)] if N else (np.zeros(0, int), np.zeros(0, int))
+        ok = event_slot >= 0
+        es = np.maximum(event_slot, 0)
+        deg_ev = np.where(ok, deg.cpu().numpy()[es], 1) if N else deg.cpu().numpy()
+        code_ev = nbr_code.cpu().numpy()[es] if N else nbr_code.cpu().numpy()
+        if N:
+            src_n = nbr_src.cpu().numpy()[es]
+            valid = (np.arange(src_n.shape[1])[None, :] < deg_ev[:, None]) & ok[:, None]
+            src_ev = np.where(valid, slot_event[np.where(valid, src_n, 0)], 0)
+        else:
+            src_ev = nbr_src.cpu().numpy()
+        outs.append((ei.cpu().numpy(), src_ev, code_ev, deg_ev, ne, flags))
     assert (outs[0][0] == outs[1][0]).all()
     return outs[1]
 

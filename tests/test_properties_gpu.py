@@ -40,6 +40,13 @@ def test_graph_invariants_full_size(big):
     nbr_src, nbr_code, deg = [v.cpu().numpy() for v in eng._nbr]
     ne, flags = eng.graph.status()
     assert flags == 0
+    # node (slot) order -> event order
+    slot_event, event_slot = [v.cpu().numpy() for v in eng.graph.node_order(len(deg))]
+    assert (np.sort(slot_event) == np.arange(len(deg))).all() and (slot_event[event_slot] == np.arange(len(deg))).all()
+    deg = deg[event_slot]
+    vmask = np.arange(16)[None, :] < deg[:, None]
+    nbr_src = np.where(vmask, slot_event[np.where(vmask, nbr_src[event_slot], 0)], 0)
+    nbr_code = nbr_code[event_slot]
     N, K, r = len(deg), 16, 7
     assert deg.min() >= 1 and deg.max() <= K and ne == deg.sum()
     assert (nbr_src[:, 0] == np.arange(N)).all()                       # self loop first
@@ -65,16 +72,17 @@ def test_windows_are_independent(big):
     from dagr_amd.graph.ev_graph import WindowGraphBuilder
     eng = big["model"].engine()
     eng.stage_graph(big["pos"], big["batch"])
-    nbr_src, _, deg = [v.clone() for v in eng._nbr]
+    ei_all, rowptr = eng.graph.edge_index(eng._nbr[0], eng._nbr[2])
+    ei_all, rowptr = ei_all.cpu(), rowptr.cpu().long()
     dev = big["pos"].device
     solo = WindowGraphBuilder(W, H, 1, 16, 128, 7, 10000, max_events=NPW, device=dev)
     for s in (0, 3, 7):
         sel = torch.nonzero(big["batch"] == s).flatten()
-        lo = int(sel[0])
+        lo, hi = int(sel[0]), int(sel[-1]) + 1
         s_src, _, s_deg = solo.build(big["pos"][sel].contiguous(), torch.zeros(len(sel), dtype=torch.int64, device=dev))
-        assert torch.equal(s_deg, deg[sel])
-        mask = torch.arange(16, device=dev)[None, :] < s_deg[:, None]
-        assert torch.equal(torch.where(mask, s_src + lo, 0), torch.where(mask, nbr_src[sel], 0))
+        ei_s, _ = solo.edge_index(s_src, s_deg)
+        part = ei_all[:, int(rowptr[lo]):int(rowptr[hi])]
+        assert torch.equal(ei_s.cpu() + lo, part)
 
 
 def test_idempotent_and_finite(big):
