@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--events-only", action="store_true",
                     help="BASELINE config 1 shape (no --use_image) instead of config 2 (ResNet-50 image branch)")
     ap.add_argument("--img-net", default="resnet50")
+    ap.add_argument("--engines", type=int, default=2,
+                    help="independent engine instances (own buffers + stream) that consecutive window batches "
+                         "alternate between; windows share no state, so batch i's tail overlaps batch i+1's level 0")
     ap.add_argument("--no-pipeline-image", dest="pipeline_image", action="store_false",
                     help="run the image branch in-line instead of one step ahead on a side stream")
     ap.add_argument("--cpu-windows", type=int, default=4)
@@ -155,6 +158,10 @@ def main():
     model = model.to(dev)
     model.cache_luts(width=W, height=H, radius=args.radius)
     eng = model.engine()
+    from dagr_amd.engine import WindowEngine
+    n_eng = max(1, a.engines)
+    engines = [eng] + [WindowEngine(model) for _ in range(n_eng - 1)]
+    streams = [torch.cuda.Stream(dev) for _ in range(n_eng)] if n_eng > 1 else [torch.cuda.current_stream(dev)]
 
     # synthetic inputs, resident in HBM before the timed region (distinct per rank and per slot)
     gen = syn.uniform_window if a.stream == "uniform" else syn.edges_window
@@ -176,28 +183,38 @@ def main():
     def step(i):
         s = i % len(slots)
         pos, feat, batch, image = slots[s]
-        if use_image and a.pipeline_image and not a.graph:
+        k = i % n_eng
+        e, st = engines[k], streams[k]
+        if a.graph:   # replay a captured hipGraph per (engine, input slot): fixed buffers and event count
+            key = (k, s)
+            if key not in graphs:
+                with torch.cuda.stream(st):
+                    e.forward_raw(pos, feat, batch, image=image)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=st):
+                    out = e.forward_raw(pos, feat, batch, image=image)
+                graphs[key] = (g, out)
+            g, out = graphs[key]
+            with torch.cuda.stream(st):
+                g.replay()
+            return out
+        if n_eng > 1:
+            with torch.cuda.stream(st):
+                return e.forward_raw(pos, feat, batch, image=image)
+        if use_image and a.pipeline_image:
             h = pending.pop(i, None) or eng.image_async(image)
             pending[i + 1] = eng.image_async(slots[(i + 1) % len(slots)][3])   # next batch's frames
             return eng.forward_raw(pos, feat, batch, image_handle=h)
-        if not a.graph:
-            return eng.forward_raw(pos, feat, batch, image=image)
-        if s not in graphs:   # capture once per input slot (fixed buffers and event count)
-            eng.forward_raw(pos, feat, batch, image=image)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                out = eng.forward_raw(pos, feat, batch, image=image)
-            graphs[s] = (g, out)
-        g, out = graphs[s]
-        g.replay()
-        return out
+        return eng.forward_raw(pos, feat, batch, image=image)
 
     ctx = torch.no_grad()
     ctx.__enter__()
     for i in range(a.warmup):
         step(i)
-    eng.check_status()
+    torch.cuda.synchronize()
+    for e in engines:
+        e.check_status()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -206,6 +223,8 @@ def main():
     outs = []
     for i in range(a.steps):
         outs.append(step(i))
+    for st in streams:
+        torch.cuda.current_stream(dev).wait_stream(st)
     if dist is not None:  # the only collective of the job: gather the run's detections (RCCL)
         mine = outs[-1].contiguous()
         gathered = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=dev)
@@ -262,8 +281,9 @@ def main():
             "config": {"workload": ("dagr-s + --use_image --img_net " + a.img_net if use_image else "dagr-s events-only")
                                    + f", {W}x{H} synthetic S-{a.stream}, B={B} windows/step x {NPW} events (50 ms "
                                    f"each), r={r}, K=16, events->graph->GNN(+image fusion)->decoded head outputs",
-                       "image_branch": ("one step ahead on a side stream" if (use_image and a.pipeline_image and not a.graph)
-                                        else ("in-line" if use_image else None)),
+                       "image_branch": (None if not use_image else "in-line" if (n_eng > 1 or a.graph or not a.pipeline_image)
+                                        else "one step ahead on a side stream"),
+                       "engines": n_eng,
                        "events_per_step_per_gpu": n_events_step, "edges_per_step": int(ne),
                        "level_nodes_edges": levels, "window_latency_ms": round(ms_per_step, 4)},
             "roofline": roofline, "stages": kernels,

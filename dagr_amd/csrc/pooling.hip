@@ -334,7 +334,9 @@ __device__ __forceinline__ void row_insert(int32_t *__restrict__ rows, int cd, i
     int32_t *row = rows + (size_t)cd * kRowSlots;
     unsigned h = ((unsigned)cs * 2654435761u) >> 26;  // 6 bits
     for (int probe = 0; probe < kRowSlots; probe++) {
-        const int cur = row[h];
+        // L2-coherent read (sc1): neighbouring nodes insert the same few sources over and over; a stale
+        // L1 line would send every one of them to the atomic
+        const int cur = __hip_atomic_load(&row[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur == cs) return;
         if (cur == -1) {
             const int old = atomicCAS(&row[h], -1, cs);
