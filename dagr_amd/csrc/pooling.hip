@@ -347,19 +347,51 @@ __device__ __forceinline__ void row_insert(int32_t *__restrict__ rows, int cd, i
     atomicOr(status, 2);  // more than 64 distinct sources
 }
 
-// level 0: fixed-stride neighbour lists; one thread per slot
+// level 0: fixed-stride neighbour lists.  Nodes are in pixel order, so a workgroup sweeping a contiguous
+// run of nodes sees the same few (source cluster -> destination cluster) pairs over and over: a small
+// LDS cache of recently inserted pairs filters them, each distinct pair of a wave is then inserted once
+// by one elected lane.  (Insertion is idempotent, so cache races only cost a redundant insert.)
 __global__ __launch_bounds__(kBlock) void k_coarse_edges_ell(int N, int K, const int32_t *__restrict__ nbr_src,
                                                             const int32_t *__restrict__ deg,
                                                             const int32_t *__restrict__ cluster_raw_in,
                                                             const int32_t *__restrict__ newid, int32_t *rows,
                                                             int32_t *status) {
-    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const int n = (int)(gid / K), j = (int)(gid % K);
-    if (n >= N || j >= deg[n]) return;
-    const int rd = cluster_raw_in[n];
-    const int rs = cluster_raw_in[nbr_src[(size_t)n * K + j]];
-    if (rd == rs || rd < 0 || rs < 0) return;
-    row_insert(rows, newid[rd], newid[rs], status);
+    __shared__ unsigned long long seen[256];
+    seen[threadIdx.x] = ~0ull;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int per_iter = kBlock / K;                         // nodes per block iteration (K divides 256 for K=16)
+    const int G = gridDim.x, nx = (G % 8 == 0) ? 8 : 1;
+    const int xcd = blockIdx.x % nx, lb = blockIdx.x / nx, bpx = G / nx;
+    const int chunk = (N + nx - 1) / nx;
+    const int per_block = (chunk + bpx - 1) / bpx;
+    const int n_begin = xcd * chunk + lb * per_block;
+    const int n_end = min(min(N, (xcd + 1) * chunk), n_begin + per_block);
+    const int sub = threadIdx.x / K, j = threadIdx.x % K;
+    for (int n0 = n_begin; n0 < n_end; n0 += per_iter) {
+        const int n = n0 + sub;
+        int rd = -1, rs = -1;
+        if (sub < per_iter && n < n_end && j < deg[n]) {
+            rd = cluster_raw_in[n];
+            rs = cluster_raw_in[nbr_src[(size_t)n * K + j]];
+        }
+        bool has = (rd != rs) && rd >= 0 && rs >= 0;
+        const unsigned long long key = ((unsigned long long)(unsigned)rd << 32) | (unsigned)rs;
+        const unsigned h = (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 56);
+        if (has && seen[h] == key) has = false;
+        unsigned long long pending = __ballot(has);
+        while (pending) {
+            const int leader = __ffsll((long long)pending) - 1;
+            const int prd = __shfl(rd, leader, 64), prs = __shfl(rs, leader, 64);
+            if (lane == leader) {
+                row_insert(rows, newid[prd], newid[prs], status);
+                seen[h] = key;
+            }
+            const bool same = has && rd == prd && rs == prs;
+            pending &= ~__ballot(same);
+            if (same) has = false;
+        }
+    }
 }
 
 // pooled levels: CSR; one thread per destination node
@@ -548,9 +580,10 @@ int dagr_pool_l0(const dagr_pool_desc *desc, void *pool_ws, const dagr_graph_des
                                                                                    nullptr, cluster_scratch, ws.status);
         DAGR_CHECK_LAUNCH();
         const int K = gdesc->max_neighbors;
-        k_coarse_edges_ell<<<(unsigned)ceil_div(N * K, kBlock), kBlock, 0, stream>>>((int)N, K, nbr_src, deg,
-                                                                                   cluster_scratch, ws.newid,
-                                                                                   ws.rows, ws.status);
+        DAGR_CHECK_ARG(K <= kBlock, "max_neighbors too large");
+        const unsigned gE = round_grid8(std::min<int64_t>(ceil_div(N, kBlock / K), 256 * 8));
+        k_coarse_edges_ell<<<gE, kBlock, 0, stream>>>((int)N, K, nbr_src, deg, cluster_scratch, ws.newid, ws.rows,
+                                                      ws.status);
         DAGR_CHECK_LAUNCH();
     }
     return pool_tail(desc, ws, b32, b64, x_out, ldo, xoff, pos_out, batch_out, n_out, rowptr_out, col_out, code_out,
