@@ -270,9 +270,18 @@ def main():
                    for k, v in stages.items()}
         dom = max(("l0_conv1", "l0_conv2"), key=lambda k: stages[k])  # single-launch stages
         achieved = ab[dom] / 1e9 / (stages[dom] / 1e3)
-        roofline = dict(kernel={"l0_conv1": "k_conv_l0<C0,0,NT>", "l0_conv2": "k_conv_l0<16,C0,NT>"}[dom],
-                        bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+        c0 = 19 if use_image else 3
+        nt = eng.ntaps0
+        kname = {"l0_conv1": (f"k_conv_l0<{c0}, 0, {nt}>" if use_image else f"k_conv_l0_narrow<{c0}, {nt}>"),
+                 "l0_conv2": f"k_conv_l0<16, {c0}, {nt}>"}[dom]
+        # HBM bytes per launch from the PMC passes of this same command (tools/pmc.sh -> profiles/r1_traffic.json);
+        # PMC counters cannot be read from inside this process
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "r1_traffic.json")
+        if use_image and NPW == 100000 and B == 8 and (W, H) == (640, 480) and os.path.exists(tj):
+            traffic = json.load(open(tj))["kernels"].get(kname, {}).get("traffic_bytes")
+        roofline = dict(kernel=kname, bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                         alg_bytes_per_launch=int(ab[dom]), launch_ms=round(stages[dom], 4))
         result = {
             "metric": "events_per_sec", "value": round(value, 1), "unit": "events/s", "n_gpus": world,
