@@ -414,6 +414,125 @@ __global__ __launch_bounds__(kBlock) void k_conv_l0_narrow(int N, int K, int nco
     }
 }
 
+// Mixed variant for CIN = 16 + CEX (CEX <= 4; the --use_image first conv: 1 polarity + 16 image channels + 2
+// position channels = 19).  A second 16-lane channel slot for 3 channels would double the work, so:
+// channels [0,16) run lane-per-channel exactly as k_conv_l0, channels [16, CIN) run tap-per-lane as in
+// k_conv_l0_narrow (lane k owns tap k of the window, lane NT the root rows).  Both partial results land
+// in the same 16 per-lane partial outputs before the transpose-reduce.  No skip branch (first conv).
+template <int CEX, int NT>
+__global__ __launch_bounds__(kBlock, 4) void k_conv_l0_mixed(int N, int K, int ncodes,
+                                                            const int32_t *__restrict__ nbr_src,
+                                                            const int16_t *__restrict__ nbr_code,
+                                                            const int32_t *__restrict__ deg,
+                                                            const float *__restrict__ x, int ldx,
+                                                            const float *__restrict__ tab,    // [ncodes][NTP]
+                                                            const float *__restrict__ wpack,  // [(NT+1)*CIN][16]
+                                                            const float *__restrict__ shift, int relu,
+                                                            float *__restrict__ out, int ldo) {
+    static_assert(NT <= 15 && CEX >= 1 && CEX <= 4, "tap-per-lane part needs NT+1 <= 16 lanes");
+    constexpr int CIN = 16 + CEX;
+    constexpr int NTP = (NT + 3) / 4 * 4;
+    constexpr int NROWS = (NT + 1) * CIN;
+    extern __shared__ __align__(16) float lds[];
+    float *w_s = lds;
+    float *tab_s = lds + NROWS * kL0RowStride;
+    for (int i = threadIdx.x; i < NROWS * kL0Out; i += kBlock)
+        w_s[(i >> 4) * kL0RowStride + (i & 15)] = wpack[i];
+    for (int i = threadIdx.x; i < ncodes * NTP; i += kBlock) tab_s[i] = tab[i];
+    __syncthreads();
+    const int l = threadIdx.x & 15;
+    const int groups_per_block = kBlock / 16;
+    const float my_shift = shift[l];
+    const XcdSplit xs = xcd_split(N, groups_per_block, threadIdx.x >> 4);
+    for (int n = xs.first; n < xs.end; n += xs.stride) {
+        const int d = deg[n];
+        const int64_t row = (int64_t)n * K;
+        float A[NTP], AX[CEX];
+#pragma unroll
+        for (int k = 0; k < NTP; k++) A[k] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < CEX; i++) AX[i] = 0.0f;
+        for (int j0 = 0; j0 < d; j0 += 8) {   // 8 source rows in flight per lane
+            int my_src = 0, my_code = 0;
+            if (l < 8 && j0 + l < d) { my_src = nbr_src[row + j0 + l]; my_code = nbr_code[row + j0 + l]; }
+            const int cnt = min(8, d - j0);
+            float v[8], vx[8][CEX];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int src = __shfl(my_src, j, 16);
+                const float *xsrc = x + (size_t)src * ldx;
+                v[j] = (j < cnt) ? xsrc[l] : 0.0f;
+#pragma unroll
+                for (int i = 0; i < CEX; i++) vx[j][i] = (j < cnt) ? xsrc[16 + i] : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if (j < cnt) {
+                    const int code = __shfl(my_code, j, 16);
+                    float t[NTP];
+#pragma unroll
+                    for (int q = 0; q < NTP / 4; q++) {
+                        const float4 tq = *reinterpret_cast<const float4 *>(tab_s + code * NTP + 4 * q);
+                        t[4 * q] = tq.x; t[4 * q + 1] = tq.y; t[4 * q + 2] = tq.z; t[4 * q + 3] = tq.w;
+                    }
+#pragma unroll
+                    for (int k = 0; k < NT; k++) A[k] = fmaf(t[k], v[j], A[k]);
+                    const float tk = tab_s[code * NTP + l];     // lane's own tap (pad columns are zero)
+#pragma unroll
+                    for (int i = 0; i < CEX; i++) AX[i] = fmaf(tk, vx[j][i], AX[i]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        const float *xn = x + (size_t)n * ldx;
+        if (l == NT) {
+#pragma unroll
+            for (int i = 0; i < CEX; i++) AX[i] = xn[16 + i];   // root rows of the extra channels
+        }
+        float p[16];
+#pragma unroll
+        for (int o = 0; o < 16; o++) p[o] = 0.0f;
+        auto fma_row = [&](float a, int r) {
+            const float4 *w4 = reinterpret_cast<const float4 *>(w_s + r * kL0RowStride);
+            const float4 w0 = w4[0], w1 = w4[1], w2 = w4[2], w3 = w4[3];
+            p[0] = fmaf(a, w0.x, p[0]); p[1] = fmaf(a, w0.y, p[1]); p[2] = fmaf(a, w0.z, p[2]); p[3] = fmaf(a, w0.w, p[3]);
+            p[4] = fmaf(a, w1.x, p[4]); p[5] = fmaf(a, w1.y, p[5]); p[6] = fmaf(a, w1.z, p[6]); p[7] = fmaf(a, w1.w, p[7]);
+            p[8] = fmaf(a, w2.x, p[8]); p[9] = fmaf(a, w2.y, p[9]); p[10] = fmaf(a, w2.z, p[10]); p[11] = fmaf(a, w2.w, p[11]);
+            p[12] = fmaf(a, w3.x, p[12]); p[13] = fmaf(a, w3.y, p[13]); p[14] = fmaf(a, w3.z, p[14]); p[15] = fmaf(a, w3.w, p[15]);
+        };
+#pragma unroll
+        for (int k = 0; k < NT; k++) fma_row(A[k], k * CIN + l);     // channels 0..15: lane = channel
+        fma_row(xn[l], NT * CIN + l);                                // their root rows
+        if (l <= NT) {                                               // channels 16..: lane = tap (NT = root)
+#pragma unroll
+            for (int i = 0; i < CEX; i++) fma_row(AX[i], l * CIN + 16 + i);
+        }
+        float q8[8], q4[4], q2[2], r;
+        {
+            const bool hi = (l & 8) != 0;
+#pragma unroll
+            for (int m = 0; m < 8; m++) q8[m] = (hi ? p[m + 8] : p[m]) + __shfl_xor(hi ? p[m] : p[m + 8], 8, 16);
+        }
+        {
+            const bool hi = (l & 4) != 0;
+#pragma unroll
+            for (int m = 0; m < 4; m++) q4[m] = (hi ? q8[m + 4] : q8[m]) + __shfl_xor(hi ? q8[m] : q8[m + 4], 4, 16);
+        }
+        {
+            const bool hi = (l & 2) != 0;
+#pragma unroll
+            for (int m = 0; m < 2; m++) q2[m] = (hi ? q4[m + 2] : q4[m]) + __shfl_xor(hi ? q4[m] : q4[m + 2], 2, 16);
+        }
+        {
+            const bool hi = (l & 1) != 0;
+            r = (hi ? q2[1] : q2[0]) + __shfl_xor(hi ? q2[0] : q2[1], 1, 16);
+        }
+        r += my_shift;
+        if (relu) r = fmaxf(r, 0.0f);
+        out[(size_t)n * ldo + l] = r;
+    }
+}
+
 // One thread per offset code: the window products bx[a]*by[b] at [a + tx*b], row stride ntp.
 __global__ void k_build_l0_table(int rx, int ry, float den_x, float den_y, int win_x, int tx, int win_y, int ty,
                                  int ntp, float *__restrict__ tab, int32_t *__restrict__ bad) {
@@ -498,6 +617,19 @@ int dagr_spline_conv_l0(int32_t cin, int32_t cskip, int32_t ntaps, int64_t N, in
     DAGR_L0_NARROW(3, 9)
     DAGR_L0_NARROW(3, 15)
 #undef DAGR_L0_NARROW
+#define DAGR_L0_MIXED(CEX, NTAPS)                                                                                  \
+    if (cin == 16 + CEX && cskip == 0 && ntaps == NTAPS) {                                                         \
+        DAGR_CHECK_HIP(hipFuncSetAttribute((const void *)k_conv_l0_mixed<CEX, NTAPS>,                              \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));            \
+        grid = round_grid8(persistent_grid(k_conv_l0_mixed<CEX, NTAPS>, kBlock, lds_bytes, useful));               \
+        k_conv_l0_mixed<CEX, NTAPS><<<grid, kBlock, lds_bytes, stream>>>((int)N, K, ncodes, nbr_src, nbr_code, deg, \
+                                                                         x, ldx, tab, wpack, shift, relu, out, ldo); \
+        DAGR_CHECK_LAUNCH();                                                                                       \
+        return DAGR_OK;                                                                                            \
+    }
+    DAGR_L0_MIXED(3, 9)
+    DAGR_L0_MIXED(3, 15)
+#undef DAGR_L0_MIXED
 #define DAGR_L0_CASE(CI, CS, NTAPS)                                                                                \
     if (cin == CI && cskip == CS && ntaps == NTAPS) {                                                              \
         DAGR_CHECK_HIP(hipFuncSetAttribute((const void *)k_conv_l0<CI, CS, NTAPS>,                                 \
