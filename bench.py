@@ -272,7 +272,7 @@ def main():
         achieved = ab[dom] / 1e9 / (stages[dom] / 1e3)
         c0 = 19 if use_image else 3
         nt = eng.ntaps0
-        kname = {"l0_conv1": (f"k_conv_l0<{c0}, 0, {nt}>" if use_image else f"k_conv_l0_narrow<{c0}, {nt}>"),
+        kname = {"l0_conv1": (f"k_conv_l0_mixed<{c0 - 16}, {nt}>" if use_image else f"k_conv_l0_narrow<{c0}, {nt}>"),
                  "l0_conv2": f"k_conv_l0<16, {c0}, {nt}>"}[dom]
         # HBM bytes per launch from the PMC passes of this same command (tools/pmc.sh -> profiles/r1_traffic.json);
         # PMC counters cannot be read from inside this process
