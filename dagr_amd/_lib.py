@@ -41,6 +41,11 @@ SIGNATURES = {
     "dagr_device_count": (ctypes.c_int, []),
     "dagr_format_events": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i32, c_i32, c_i32,
                                           c_void_p, c_void_p, c_void_p]),
+    "dagr_fill_edges": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_float, c_float, c_void_p,
+                                       c_i64, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_void_p]),
+    "dagr_insert_in_queue": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i32, c_i32, c_i32, c_i32,
+                                            c_void_p]),
+    "dagr_insert_in_queue_single": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32, c_void_p]),
     "dagr_graph_workspace_bytes": (c_size_t, [ctypes.POINTER(GraphDesc)]),
     "dagr_graph_workspace_init": (ctypes.c_int, [ctypes.POINTER(GraphDesc), c_void_p, c_size_t, c_void_p]),
     "dagr_graph_build_window": (ctypes.c_int, [ctypes.POINTER(GraphDesc), c_void_p, c_void_p, c_i32, c_void_p,

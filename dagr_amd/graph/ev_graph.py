@@ -4,17 +4,21 @@ Mirrors ``src/dagr/graph/ev_graph.py`` (``AsyncGraph`` :18-103, ``SlidingWindowG
 same constructor arguments, ``forward`` / ``reset`` / ``delete_nodes`` names and return shapes
 (``int64[2, E]`` in the order of ``edges[:, edges[1] >= 0]``, graph/utils.py:22).
 
-Difference by design: the reference keeps a ``B x Q x H x W`` FIFO volume and can append events to
-it call after call (``reset=False``); this round implements the *window* mode every evaluation
-script uses (``reset=True`` before each call: ``model/networks/dagr.py:74,90``,
-``model/layers/ev_tgn.py:45-49``), as one fused device pipeline (csrc/graph_build.hip).  Calling
-``forward`` twice without ``reset`` raises ``NotImplementedError`` instead of silently diverging.
+Two implementations sit behind these names:
+  * ``AsyncGraph`` / ``SlidingWindowGraph`` are the reference's state machines line for line (persistent
+    ``B x Q x H x W`` FIFO volume, timestamp log, growing index, ``delete_nodes``), on top of the 1:1
+    replacements of ``ev_graph_cuda`` (``graph/utils.py`` -> csrc/queue_compat.hip).  They cover
+    ``reset=False`` incremental use exactly like the reference.
+  * ``WindowGraphBuilder`` is the fast path for the ``reset=True`` windows every evaluation script uses
+    (``model/networks/dagr.py:74,90``, ``model/layers/ev_tgn.py:45-49``): one fused device pipeline
+    (csrc/graph_build.hip) without the FIFO volume; ``EV_TGN`` / the engine use it.
 """
 import ctypes
 
 import torch
 
 from .. import _lib
+from .utils import _insert_events_into_queue, _search_for_edges
 
 
 class WindowGraphBuilder:
@@ -115,12 +119,13 @@ class WindowGraphBuilder:
 
 
 class AsyncGraph:
-    """Mirror of ``ev_graph.py:18-103`` (window mode only, see module docstring)."""
+    """Mirror of ``ev_graph.py:18-103``."""
 
     def __init__(self, width=640, height=480, batch_size=1, max_num_neighbors=16, max_queue_size=512, radius=7,
                  delta_t_us=600000):
         self.radius = radius
         self.delta_t_us = delta_t_us
+        self.event_queue = None
         self.max_index = 0
         self.min_index = 0
         self.max_queue_size = max_queue_size
@@ -131,42 +136,53 @@ class AsyncGraph:
         self.device = None
         self.edges = torch.zeros((2, 0), dtype=torch.long)
         self.all_timestamps = torch.zeros((0,), dtype=torch.int32)
-        self._builder = None
-        self.last_neighbors = None  # (nbr_src, nbr_code, deg) of the last forward
+        self.new_indices = None
+        self.edge_buffer = None
 
-    def initialize(self, n_ev, device):
+    def initialize(self, n_ev, device):  # :45-50
         self.edges = torch.zeros((2, 0), dtype=torch.long, device=device)
         self.all_timestamps = torch.zeros((0,), dtype=torch.int32, device=device)
-        self._builder = WindowGraphBuilder(self.width, self.height, self.batch_size, self.max_num_neighbors,
-                                           self.max_queue_size, int(self.radius), int(self.delta_t_us),
-                                           max_events=max(n_ev, 1024), device=device)
+        self.new_indices = torch.arange(n_ev, dtype=torch.int32, device=device)
+        self.edge_buffer = torch.full((2, self.max_num_neighbors * n_ev), dtype=torch.int64, fill_value=-1,
+                                      device=device)
+        self.event_queue = torch.full((self.batch_size, self.max_queue_size, self.height, self.width), fill_value=-1,
+                                      device=device, dtype=torch.int32)
 
-    def reset(self):
+    def reset(self):  # :52-60
         self.edges = torch.zeros((2, 0), dtype=torch.long, device=self.device)
         self.all_timestamps = torch.zeros((0,), dtype=torch.int32, device=self.device)
         self.max_index = 0
         self.min_index = 0
+        if self.edge_buffer is not None:
+            self.edge_buffer.fill_(-1)
+        if self.event_queue is not None:
+            self.event_queue.fill_(-1)
 
-    def _forward(self, batch, pos, collect_edges=True):
+    def _forward(self, batch, pos, collect_edges=True):  # :63-103
         n_ev = len(batch)
-        if not batch.is_cuda:  # the reference asserts CUDA tensors (ev_graph.cu:9-11)
-            raise RuntimeError("batch must be a CUDA (HIP) tensor")
+        if not batch.is_cuda:  # the reference's CPU shim never triggers (ev_graph.py:7-8); its kernels assert CUDA
+            raise RuntimeError("batch must be a CUDA tensor")
         if self.device is None:
             self.device = batch.device
             self.initialize(n_ev, self.device)
-        if n_ev == 0:
+        if len(batch) == 0:
             return torch.zeros((2, 0), device=self.device, dtype=torch.int32)
         assert type(batch) is torch.Tensor and batch.dtype == torch.int32, [type(batch), batch.dtype]
-        if self.max_index != 0:
-            raise NotImplementedError(
-                "incremental graph updates (forward without reset()) are not implemented; "
-                "the window engine rebuilds the graph per reset=True call")
         pos = pos.int().contiguous()
+        batch = batch.contiguous()
         self.all_timestamps = torch.cat([self.all_timestamps, pos[:, 2]])
+        if n_ev > len(self.new_indices):
+            self.new_indices = torch.arange(0, n_ev, dtype=torch.int32, device=self.device)
+            self.edge_buffer = torch.full((2, self.max_num_neighbors * n_ev), dtype=torch.int64, fill_value=-1,
+                                          device=self.device)
+        indices = (self.max_index + self.new_indices[:n_ev]).contiguous()
         self.max_index += n_ev
-        nbr_src, nbr_code, deg = self._builder.build(pos, batch.contiguous())
-        self.last_neighbors = (nbr_src, nbr_code, deg)
-        edge_indices, _ = self._builder.edge_index(nbr_src, deg)
+        self.event_queue = _insert_events_into_queue(batch, pos, indices=indices, queue=self.event_queue)
+        self.edge_buffer.fill_(-1)
+        edge_indices = _search_for_edges(batch, pos, all_timestamps=self.all_timestamps.contiguous(), indices=indices,
+                                         queue=self.event_queue, max_num_neighbors=self.max_num_neighbors,
+                                         radius=self.radius, delta_t_us=self.delta_t_us, edges=self.edge_buffer,
+                                         min_index=self.min_index)
         if collect_edges:
             self.edges = torch.cat([self.edges, edge_indices], dim=-1)
         return edge_indices

@@ -57,6 +57,28 @@ int dagr_format_events(const int16_t *xy /*[N,2]*/, const int32_t *t /*[N]*/, co
                        float *pos_out /*[N,3]*/, float *feat_out /*[N]*/, void *stream);
 
 /* ------------------------------------------------------------------------ *
+ * 1:1 replacements of the reference's native module `ev_graph_cuda` (src/dagr/graph/ev_graph.cu:279-283),
+ * same arguments in the same order, on the caller's own state (FIFO volume int32[B,Q,H,W] with -1 =
+ * empty and q = 0 newest, timestamp log, -1-filled int64 edge buffer), so the Python classes of
+ * src/dagr/graph/ev_graph.py work unchanged on top of them -- including reset=False / min_index > 0.
+ *   dagr_fill_edges             <- fill_edges_cuda(batch, pos, all_timestamps, event_queue, indices,
+ *                                  max_num_neighbors, radius, delta_t_us, edges, min_index)   ev_graph.cu:82-128
+ *   dagr_insert_in_queue        <- insert_in_queue_cuda(indices, unique_coords, cumsum_counts, queue)   :241-276
+ *   dagr_insert_in_queue_single <- insert_in_queue_single_cuda(indices, events, queue)                  :215-238
+ * Shapes ride along as integers (N = len(batch), edges_cols = edges.size(1), queue dims).
+ * ------------------------------------------------------------------------ */
+int dagr_fill_edges(const int32_t *batch /*[N]*/, const int32_t *pos /*[N,3] x,y,t_us*/,
+                    const int32_t *all_timestamps, const int32_t *event_queue /*[B,Q,H,W]*/,
+                    const int32_t *indices /*[N]*/, int32_t max_num_neighbors, float radius, float delta_t_us,
+                    int64_t *edges /*[2,edges_cols], in/out*/, int64_t edges_cols, int32_t min_index,
+                    int64_t N, int32_t B, int32_t Q, int32_t H, int32_t W, void *stream);
+int dagr_insert_in_queue(const int32_t *indices /*[N] pixel-sorted*/, const int32_t *unique_coords /*[num_pixels]*/,
+                         const int32_t *cumsum_counts /*[num_pixels]*/, int64_t num_pixels, int32_t *queue,
+                         int32_t B, int32_t Q, int32_t H, int32_t W, void *stream);
+int dagr_insert_in_queue_single(const int32_t *indices /*[1]*/, const int32_t *event_xy /*>= [2]: x, y*/,
+                                int32_t *queue, int32_t B, int32_t Q, int32_t H, int32_t W, void *stream);
+
+/* ------------------------------------------------------------------------ *
  * Window graph builder (reset=True semantics)
  *   replaces, for one self-contained window, the sequence
  *     SlidingWindowGraph.reset()                       ev_graph.py:52-60
