@@ -1,0 +1,57 @@
+"""GPU test of the model-level drop-in API: Batch.from_data_list -> format_data -> DAGR.forward(data)
+(the body of scripts/run_test.py:52-62 / utils/testing.py:29-33) returns per-sample detection dicts that
+match the oracle's decoded outputs pushed through the same post-processing."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as om
+from dagr_amd.data import Batch, Data
+from dagr_amd.utils import synthetic as syn
+from dagr_amd.utils.buffers import format_data
+from dagr_amd.utils.testing_weights import randomize_
+
+pytestmark = pytest.mark.gpu
+
+
+def test_dagr_forward_on_data_batches():
+    from dagr_amd.model.networks.dagr import DAGR
+    from dagr_amd.model.networks.ema import ModelEMA
+    from dagr_amd.model.utils import postprocess_network_output
+    W, H, B = 320, 215, 2
+    torch.manual_seed(0)
+    args = om.default_args(batch_size=B)
+    model = randomize_(DAGR(args, height=H, width=W)).eval()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ema = ModelEMA(model.cuda())
+    ema.ema.load_state_dict(copy.deepcopy(model.state_dict()))          # run_test.py:57-58
+    ema.ema.cache_luts(radius=args.radius, height=H, width=W)           # run_test.py:59
+    samples, raw = [], []
+    for s in range(B):
+        x, y, t, p = syn.edges_window(4000, W, H, seed=50 + s)
+        raw.append((x, y, t, p))
+        samples.append(Data(x=torch.from_numpy(p.reshape(-1, 1)), pos=torch.from_numpy(np.stack([x, y], -1)),
+                            t=torch.from_numpy(t), width=W, height=H, time_window=1000000,
+                            bbox=torch.tensor([[10., 20., 30., 40., 1., 1., 0.]]), sequence=f"seq{s}"))
+    batch = Batch.from_data_list(samples, follow_batch=["bbox"]).cuda()
+    data = format_data(batch)                                            # utils/testing.py:32
+    assert data.pos.dtype == torch.float32 and data.pos.shape[1] == 3 and data.x.dtype == torch.float32
+    with torch.no_grad():
+        detections, targets = ema.ema(data)                              # utils/testing.py:33
+    assert len(detections) == B and len(targets) == B
+    assert targets[0]["boxes"].shape == (1, 4)
+    x = np.concatenate([r[0] for r in raw]); y = np.concatenate([r[1] for r in raw])
+    t = np.concatenate([r[2] for r in raw]); p = np.concatenate([r[3] for r in raw])
+    b = np.concatenate([np.full(len(r[0]), i, np.int64) for i, r in enumerate(raw)])
+    out_o, _ = om.forward_events(sd, args, H, W, x, y, t, p, b, B)
+    det_o = postprocess_network_output(out_o.clone(), 2, 0.001, 0.65, height=H, width=W)
+    for dh, do in zip(detections, det_o):
+        assert dh["boxes"].shape == do["boxes"].shape
+        if len(do["boxes"]):
+            order_h = torch.argsort(dh["scores"].cpu(), descending=True)
+            order_o = torch.argsort(do["scores"], descending=True)
+            assert torch.allclose(dh["scores"].cpu()[order_h], do["scores"][order_o], atol=1e-4)
+            assert torch.allclose(dh["boxes"].cpu()[order_h], do["boxes"][order_o], atol=1e-2, rtol=1e-4)
+            assert torch.equal(dh["labels"].cpu()[order_h], do["labels"][order_o])
