@@ -356,12 +356,14 @@ class WindowEngine:
         self._keep = []
         self._img_feats, self._cnn_out = self._image_branch(image)
 
-    def image_async(self, image):
+    def image_async(self, image, stream=None):
         """Start the image branch of a *future* window batch on a side stream and return a handle for
         ``forward_raw(..., image_handle=h)``.  Windows are independent, and a frame is available before
         the 50 ms of events that follow it, so the dense CNN of batch i+1 can share the GPU with the
         gather-bound event path of batch i."""
         cur = torch.cuda.current_stream(self.device)
+        if stream is not None:
+            self._img_stream = stream
         if self._img_stream is None:
             self._img_stream = torch.cuda.Stream(self.device)
         s = self._img_stream
