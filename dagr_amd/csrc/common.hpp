@@ -38,15 +38,34 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // Grid of a persistent (grid-stride) kernel: exactly the number of blocks that are co-resident, so
 // that every block gets the same share of the work (an over-sized grid runs in uneven waves).
+inline int device_cu_count() {
+    static int cus = [] {
+        int dev = 0, n = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        return n;
+    }();
+    return cus;
+}
 template <typename Kern>
 inline unsigned persistent_grid(Kern kernel, int block, size_t dyn_lds, int64_t max_useful_blocks) {
-    int per_cu = 0, dev = 0, cus = 256;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, dyn_lds) != hipSuccess || per_cu < 1)
-        per_cu = 1;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-        cus = prop.multiProcessorCount;
-    int64_t g = (int64_t)per_cu * cus;
+    // the occupancy query is cached per (kernel, dynamic LDS size): this runs on every launch.  Kernels of
+    // one signature share this instantiation, so the key includes the function address.
+    struct Entry { const void *fn; size_t lds; int per_cu; };
+    static thread_local Entry cache[32];
+    static thread_local int n_cached = 0;
+    const void *fn = reinterpret_cast<const void *>(kernel);
+    int cached_per_cu = 0;
+    for (int i = 0; i < n_cached; i++)
+        if (cache[i].fn == fn && cache[i].lds == dyn_lds) cached_per_cu = cache[i].per_cu;
+    if (cached_per_cu < 1) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, dyn_lds) != hipSuccess || per_cu < 1)
+            per_cu = 1;
+        cached_per_cu = per_cu;
+        if (n_cached < 32) cache[n_cached++] = Entry{fn, dyn_lds, per_cu};
+    }
+    int64_t g = (int64_t)cached_per_cu * device_cu_count();
     if (g > max_useful_blocks) g = max_useful_blocks;
     return (unsigned)(g < 1 ? 1 : g);
 }

@@ -606,8 +606,14 @@ int dagr_spline_conv_l0(int32_t cin, int32_t cskip, int32_t ntaps, int64_t N, in
     unsigned grid = 1;
 #define DAGR_L0_NARROW(CI, NTAPS)                                                                                  \
     if (cin == CI && cskip == 0 && ntaps == NTAPS) {                                                               \
-        DAGR_CHECK_HIP(hipFuncSetAttribute((const void *)k_conv_l0_narrow<CI, NTAPS>,                              \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));            \
+        {                                                                                                          \
+            static thread_local size_t set_for = 0;                                                                \
+            if (set_for != lds_bytes) {                                                                            \
+                DAGR_CHECK_HIP(hipFuncSetAttribute((const void *)k_conv_l0_narrow<CI, NTAPS>,                      \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));    \
+                set_for = lds_bytes;                                                                               \
+            }                                                                                                      \
+        }                                                                                                          \
         grid = round_grid8(persistent_grid(k_conv_l0_narrow<CI, NTAPS>, kBlock, lds_bytes, useful));                            \
         k_conv_l0_narrow<CI, NTAPS><<<grid, kBlock, lds_bytes, stream>>>((int)N, K, ncodes, nbr_src, nbr_code, deg, \
                                                                          x, ldx, tab, wpack, shift, relu, out, ldo); \
@@ -619,8 +625,14 @@ int dagr_spline_conv_l0(int32_t cin, int32_t cskip, int32_t ntaps, int64_t N, in
 #undef DAGR_L0_NARROW
 #define DAGR_L0_MIXED(CEX, NTAPS)                                                                                  \
     if (cin == 16 + CEX && cskip == 0 && ntaps == NTAPS) {                                                         \
-        DAGR_CHECK_HIP(hipFuncSetAttribute((const void *)k_conv_l0_mixed<CEX, NTAPS>,                              \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));            \
+        {                                                                                                          \
+            static thread_local size_t set_for = 0;                                                                \
+            if (set_for != lds_bytes) {                                                                            \
+                DAGR_CHECK_HIP(hipFuncSetAttribute((const void *)k_conv_l0_mixed<CEX, NTAPS>,                      \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));    \
+                set_for = lds_bytes;                                                                               \
+            }                                                                                                      \
+        }                                                                                                          \
         grid = round_grid8(persistent_grid(k_conv_l0_mixed<CEX, NTAPS>, kBlock, lds_bytes, useful));               \
         k_conv_l0_mixed<CEX, NTAPS><<<grid, kBlock, lds_bytes, stream>>>((int)N, K, ncodes, nbr_src, nbr_code, deg, \
                                                                          x, ldx, tab, wpack, shift, relu, out, ldo); \
@@ -632,8 +644,14 @@ int dagr_spline_conv_l0(int32_t cin, int32_t cskip, int32_t ntaps, int64_t N, in
 #undef DAGR_L0_MIXED
 #define DAGR_L0_CASE(CI, CS, NTAPS)                                                                                \
     if (cin == CI && cskip == CS && ntaps == NTAPS) {                                                              \
-        DAGR_CHECK_HIP(hipFuncSetAttribute((const void *)k_conv_l0<CI, CS, NTAPS>,                                 \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));            \
+        {                                                                                                          \
+            static thread_local size_t set_for = 0;                                                                \
+            if (set_for != lds_bytes) {                                                                            \
+                DAGR_CHECK_HIP(hipFuncSetAttribute((const void *)k_conv_l0<CI, CS, NTAPS>,                         \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));    \
+                set_for = lds_bytes;                                                                               \
+            }                                                                                                      \
+        }                                                                                                          \
         grid = round_grid8(persistent_grid(k_conv_l0<CI, CS, NTAPS>, kBlock, lds_bytes, useful));                               \
         k_conv_l0<CI, CS, NTAPS><<<grid, kBlock, lds_bytes, stream>>>((int)N, K, ncodes, nbr_src, nbr_code, deg, x, \
                                                                       ldx, xskip, ldskip, tab, wpack, shift, relu,  \
@@ -665,8 +683,14 @@ int dagr_spline_tap_aggregate(const int32_t *n_nodes_ptr, int32_t n_nodes_max, c
     DAGR_CHECK_ARG(cin >= 1 && lda >= 26 * cin + cskip, "lda too small");
     const size_t lds_bytes = (size_t)kAggWaves * 25 * cin * 4;
     DAGR_CHECK_ARG(lds_bytes <= 160 * 1024, "cin too large for the LDS accumulators");
-    DAGR_CHECK_HIP(hipFuncSetAttribute((const void *)k_tap_aggregate, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds_bytes));
+    {
+        static thread_local size_t set_max = 0;   // the attribute is a maximum: raise it only when needed
+        if (lds_bytes > set_max) {
+            DAGR_CHECK_HIP(hipFuncSetAttribute((const void *)k_tap_aggregate,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            set_max = lds_bytes;
+        }
+    }
     k_tap_aggregate<<<(unsigned)ceil_div(n_nodes_max, kAggWaves), kBlock, lds_bytes, (hipStream_t)stream>>>(
         n_nodes_ptr, n_nodes_max, rowptr, col, code, x, ldx, cin, xskip, ldskip, cskip, rx, ry, den_x, den_y, A, lda);
     DAGR_CHECK_LAUNCH();

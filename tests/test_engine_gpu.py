@@ -139,3 +139,31 @@ def test_use_image_resnet18_b2():
     image = torch.rand((B, 3, H, W), generator=torch.Generator().manual_seed(1)).cuda()
     with torch.no_grad():
         _compare(args, model, sd, W, H, B, *_events(syn.edges_window, 5000, B, W, H, seed=13), image=image)
+
+
+def test_dagr_l_widths_events_only():
+    """dagr-l (net_stem_width = yolo_stem_width = 1: 128-channel levels, N = 256 fused head GEMM)."""
+    W, H, B = 320, 215, 2
+    args, model, sd = _setup(W, H, B, seed=6, net_stem_width=1.0, yolo_stem_width=1.0)
+    _compare(args, model, sd, W, H, B, *_events(syn.edges_window, 5000, B, W, H, seed=17))
+
+
+def test_ncaltech_geometry_one_scale_100_classes():
+    """config/dagr-l-ncaltech.yaml shape: 240x180 (r = 3, square-ish tap window), num_scales = 1,
+    100 classes (N = 100 predictor GEMM), batch 1."""
+    W, H, B = 240, 180, 1
+    args, model, sd = _setup(W, H, B, seed=7, net_stem_width=1.0, yolo_stem_width=1.0, num_scales=1,
+                             dataset="ncaltech101")
+    _compare_one_scale(args, model, sd, W, H, B, *_events(syn.uniform_window, 6000, B, W, H, seed=19))
+
+
+def _compare_one_scale(args, model, sd, W, H, B, x, y, t, p, b, pos):
+    dev = torch.device("cuda:0")
+    eng = model.engine()
+    out_h = eng.forward_raw(torch.from_numpy(pos).to(dev), torch.from_numpy(p.astype(np.float32)).view(-1, 1).to(dev),
+                            torch.from_numpy(b).to(dev))
+    eng.check_status()
+    out_o, _ = om.forward_events(sd, args, H, W, x, y, t, p, b, B)
+    assert out_h.shape == out_o.shape == (B, 35, 105)
+    rel = ((out_h.cpu() - out_o).abs() / (1 + out_o.abs())).max().item()
+    assert rel < TOL, f"decoded outputs differ by {rel}"
