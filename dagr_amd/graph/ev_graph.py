@@ -192,41 +192,38 @@ class AsyncGraph:
 
 
 class SlidingWindowGraph(AsyncGraph):
-    """Mirror of ``ev_graph.py:106-166``."""
+    """``ev_graph.py:106-166``: ``AsyncGraph`` plus dropping the oldest nodes after every call."""
 
     def __init__(self, width=640, height=480, batch_size=1, max_num_neighbors=16, max_queue_size=1024, radius=7,
                  delta_t_us=600000):
-        AsyncGraph.__init__(self, width, height, batch_size, max_num_neighbors, max_queue_size, radius, delta_t_us)
+        super().__init__(width, height, batch_size, max_num_neighbors, max_queue_size, radius, delta_t_us)
 
     @property
     def init(self):
-        return len(self.all_timestamps) > 0
+        return self.all_timestamps.numel() > 0
 
     def delete_nodes(self, n_delete, delete_edges=True, return_edges=True):
+        """Forget the n oldest nodes: shift the index origin; edges touching them are removed (and returned)."""
         self.all_timestamps = self.all_timestamps[n_delete:]
         self.min_index += n_delete
-        deleted_edges = None
+        removed = None
         if delete_edges:
-            mask = (self.edges[0] < n_delete) | (self.edges[1] < n_delete)
-            deleted_edges = self.edges[:, mask].clone()
-            self.edges = self.edges[:, ~mask]
+            touches_old = (self.edges < n_delete).any(dim=0)
+            removed = self.edges[:, touches_old].clone()
+            self.edges = self.edges[:, ~touches_old]
         self.edges.add_(-n_delete)
-        if delete_edges and return_edges:
-            return deleted_edges
+        return removed if (delete_edges and return_edges) else None
 
     def forward(self, batch, pos, return_node_counts=False, return_total_edges=False, delete_nodes=True,
                 collect_edges=True):
-        n_delete = len(batch) if self.init else 0
-        edges = AsyncGraph._forward(self, batch, pos, collect_edges=collect_edges)
-        ret = [edges]
-        if return_total_edges:
-            total_edges = self.edges.clone()
-        if return_node_counts:
-            tot_nodes = len(self.all_timestamps)
+        n_old = len(batch) if self.init else 0
+        out = [self._forward(batch, pos, collect_edges=collect_edges)]
+        snapshot = self.edges.clone() if return_total_edges else None
+        n_total = len(self.all_timestamps)
         if delete_nodes:
-            ret.append(self.delete_nodes(n_delete))
+            out.append(self.delete_nodes(n_old))
         if return_total_edges:
-            ret.append(total_edges)
+            out.append(snapshot)
         if return_node_counts:
-            ret.append([n_delete, len(batch), tot_nodes])
-        return ret[0] if len(ret) == 1 else ret
+            out.append([n_old, len(batch), n_total])
+        return out[0] if len(out) == 1 else out

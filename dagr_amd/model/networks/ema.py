@@ -1,29 +1,29 @@
-"""Mirror of ``src/dagr/model/networks/ema.py:6-51`` (``ModelEMA``): evaluation loads the checkpoint's
-``ema`` state_dict into ``ModelEMA(model).ema`` (``scripts/run_test.py:54-58``).  ``update`` is kept
-for completeness; training itself is out of scope."""
+"""``ModelEMA`` with the reference's interface (``src/dagr/model/networks/ema.py:6-51``): evaluation loads the
+checkpoint's ``ema`` state_dict into ``ModelEMA(model).ema`` (``scripts/run_test.py:54-58``).  ``update`` is the
+standard exponential moving average over the floating-point state (training itself is out of scope)."""
+import copy
 import math
-from copy import deepcopy
 
 import torch
 
 
 class ModelEMA:
     def __init__(self, model, decay=0.9999, updates=0):
-        engine, model._engine = getattr(model, "_engine", None), None  # device plans are not deep-copied
-        self.ema = deepcopy(model).eval()
-        model._engine = engine
+        plan, model._engine = getattr(model, "_engine", None), None   # device-side plans are rebuilt, not copied
+        self.ema = copy.deepcopy(model).eval().requires_grad_(False)
+        model._engine = plan
         self.updates = updates
-        self.decay = lambda x: decay * (1 - math.exp(-x / 2000))
-        for p in self.ema.parameters():
-            p.requires_grad_(False)
+        self._decay = decay
 
+    def decay(self, step):
+        return self._decay * (1.0 - math.exp(-step / 2000.0))   # ramp: small decay during the first epochs
+
+    @torch.no_grad()
     def update(self, model):
-        with torch.no_grad():
-            self.updates += 1
-            d = self.decay(self.updates)
-            msd = model.state_dict()
-            for k, v in self.ema.state_dict().items():
-                if v.dtype.is_floating_point:
-                    v *= d
-                    v += (1.0 - d) * msd[k].detach()
+        self.updates += 1
+        d = self.decay(self.updates)
+        source = model.state_dict()
+        for name, avg in self.ema.state_dict().items():
+            if avg.dtype.is_floating_point:
+                avg.mul_(d).add_(source[name].detach(), alpha=1.0 - d)
         self.ema._engine = None

@@ -22,57 +22,50 @@ def compute_pooling_at_each_layer(pooling_dim_at_output, num_layers):  # net.py:
 
 
 class Net(torch.nn.Module):
+    """Parameter holder + derived constants of the backbone.  Sub-module names (``conv_block1``, ``pool1``,
+    ``layer2`` ... ``layer5``, ``net``) are the reference's, so checkpoints map one to one."""
+
+    LAYER_NAMES = ("conv_block1", "layer2", "layer3", "layer4", "layer5")
+
     def __init__(self, args, height, width):
         super().__init__()
-        channels = [1, int(args.base_width * 32), int(args.after_pool_width * 64), int(args.net_stem_width * 128),
-                    int(args.net_stem_width * 128), int(args.net_stem_width * 128)]
         self.height, self.width = height, width
-        self.out_channels_cnn = []
+        stem = int(args.net_stem_width * 128)
+        widths = [1, int(args.base_width * 32), int(args.after_pool_width * 64), stem, stem, stem]   # net.py:35-38
         self.use_image = bool(args.use_image)
+        self.num_scales = args.num_scales
+        self.num_classes = {"dsec": 2, "ncaltech101": 100}.get(args.dataset, 2)
+        self.out_channels_cnn = []
         if self.use_image:
             from .net_img import HookModule, make_img_net
             self.out_channels_cnn = [256, 256]
             self.net = HookModule(make_img_net(args.img_net), input_channels=3, height=height, width=width,
                                   feature_layers=["conv1", "layer1", "layer2", "layer3", "layer4"],
-                                  output_layers=["layer3", "layer4"], feature_channels=channels[1:],
+                                  output_layers=["layer3", "layer4"], feature_channels=widths[1:],
                                   output_channels=self.out_channels_cnn)
-        self.num_scales = args.num_scales
-        self.num_classes = dict(dsec=2, ncaltech101=100).get(args.dataset, 2)
         self.events_to_graph = EV_TGN(args)
 
-        output_channels = channels[1:]
-        self.out_channels = output_channels[-2:]
-        input_channels = channels[:-1]
-        if self.use_image:
-            input_channels = [input_channels[i] + self.net.feature_channels[i] for i in range(len(input_channels))]
-        self.input_channels = input_channels
-        self.output_channels = output_channels
+        self.output_channels = widths[1:]
+        self.out_channels = self.output_channels[-2:]
+        extra = self.net.feature_channels if self.use_image else [0] * 5
+        self.input_channels = [c + e for c, e in zip(widths[:-1], extra)]
 
+        # voxel sizes, head strides and cartesian maxima exactly as the reference derives them -- with torch
+        # fp32 ops, not python floats (SURVEY QUIRK-11)
         poolings = compute_pooling_at_each_layer(args.pooling_dim_at_output, num_layers=4)
-        max_vals_for_cartesian = 2 * poolings[:, :2].max(-1).values
-        self.strides = torch.ceil(poolings[-2:, 1] * height).numpy().astype("int32").tolist()
-        self.strides = self.strides[-self.num_scales:]
-
-        effective_radius = 2 * float(int(args.radius * width + 2) / width)
-        self.edge_attrs = Cartesian(norm=True, cat=False, max_value=effective_radius)
-        self.conv_block1 = Layer(2 + input_channels[0], output_channels[0], args=args)
-        cart1 = Cartesian(norm=True, cat=False, max_value=2 * effective_radius)
-        self.pool1 = Pooling(poolings[0], width=width, height=height, batch_size=args.batch_size, transform=cart1,
-                             aggr=args.pooling_aggr, keep_temporal_ordering=args.keep_temporal_ordering)
-        self.layer2 = Layer(input_channels[1] + 2, output_channels[1], args=args)
-        cart2 = Cartesian(norm=True, cat=False, max_value=max_vals_for_cartesian[1])
-        self.pool2 = Pooling(poolings[1], width=width, height=height, batch_size=args.batch_size, transform=cart2,
-                             aggr=args.pooling_aggr, keep_temporal_ordering=args.keep_temporal_ordering)
-        self.layer3 = Layer(input_channels[2] + 2, output_channels[2], args=args)
-        cart3 = Cartesian(norm=True, cat=False, max_value=max_vals_for_cartesian[2])
-        self.pool3 = Pooling(poolings[2], width=width, height=height, batch_size=args.batch_size, transform=cart3,
-                             aggr=args.pooling_aggr, keep_temporal_ordering=args.keep_temporal_ordering)
-        self.layer4 = Layer(input_channels[3] + 2, output_channels[3], args=args)
-        cart4 = Cartesian(norm=True, cat=False, max_value=max_vals_for_cartesian[3])
-        self.pool4 = Pooling(poolings[3], width=width, height=height, batch_size=args.batch_size, transform=cart4,
-                             aggr="mean", keep_temporal_ordering=args.keep_temporal_ordering)
-        self.layer5 = Layer(input_channels[4] + 2, output_channels[4], args=args)
+        cart_max = 2 * poolings[:, :2].max(-1).values
+        self.strides = torch.ceil(poolings[-2:, 1] * height).numpy().astype("int32").tolist()[-self.num_scales:]
+        r_eff = 2 * float(int(args.radius * width + 2) / width)
+        self.edge_attrs = Cartesian(norm=True, cat=False, max_value=r_eff)
+        pool_max = [2 * r_eff, cart_max[1], cart_max[2], cart_max[3]]                    # net.py:77,83,89,95
+        pool_aggr = [args.pooling_aggr] * 3 + ["mean"]                                    # net.py:96-97
+        for k, name in enumerate(self.LAYER_NAMES):
+            setattr(self, name, Layer(self.input_channels[k] + 2, self.output_channels[k], args=args))
+            if k < 4:
+                setattr(self, f"pool{k + 1}",
+                        Pooling(poolings[k], width=width, height=height, batch_size=args.batch_size,
+                                transform=Cartesian(norm=True, cat=False, max_value=pool_max[k]), aggr=pool_aggr[k],
+                                keep_temporal_ordering=args.keep_temporal_ordering))
 
     def get_output_sizes(self):  # net.py:103-106
-        poolings = [self.pool3.voxel_size[:2], self.pool4.voxel_size[:2]]
-        return [(1 / p + 1e-3).cpu().int().numpy().tolist()[::-1] for p in poolings]
+        return [(1 / p.voxel_size[:2] + 1e-3).cpu().int().numpy().tolist()[::-1] for p in (self.pool3, self.pool4)]

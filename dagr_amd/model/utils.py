@@ -1,6 +1,7 @@
-"""Mirror of the hot-path helpers in ``src/dagr/model/utils.py``: ``voxel_size_to_params`` :112-116,
-``postprocess_network_output`` :61-110 (+ ``batched_nms_coordinate_trick`` :25-33 with a torch NMS,
-torchvision being absent), ``convert_to_evaluation_format`` :35-44, ``init_subnetwork`` :9-23."""
+"""Hot-path helpers with the names of ``src/dagr/model/utils.py``: ``voxel_size_to_params`` :112-116,
+``postprocess_network_output`` :61-110 (batched on the device: csrc/nms.hip replaces the per-image
+``batched_nms_coordinate_trick`` / torchvision NMS loop), ``convert_to_evaluation_format`` :35-44,
+``init_subnetwork`` :9-23."""
 import numpy as np
 import torch
 
@@ -23,68 +24,39 @@ def init_subnetwork(net, state_dict, name="backbone.net.", freeze=False):
             param.requires_grad = False
 
 
-def nms(boxes, scores, iou_threshold):
-    """Greedy NMS with torchvision.ops.nms semantics (keep indices sorted by decreasing score;
-    suppress IoU > threshold).  Runs on whatever device the boxes are on; O(n^2) on <= 175 boxes/sample."""
-    n = boxes.shape[0]
-    if n == 0:
-        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
-    order = torch.argsort(scores, descending=True, stable=True)
-    b = boxes[order]
-    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
-    lt = torch.max(b[:, None, :2], b[None, :, :2])
-    rb = torch.min(b[:, None, 2:], b[None, :, 2:])
-    wh = (rb - lt).clamp(min=0)
-    inter = wh[..., 0] * wh[..., 1]
-    iou = inter / (area[:, None] + area[None, :] - inter)
-    over = (iou > iou_threshold).cpu()
-    keep = []
-    suppressed = torch.zeros(n, dtype=torch.bool)
-    for i in range(n):
-        if suppressed[i]:
-            continue
-        keep.append(i)
-        suppressed |= over[i]
-    return order[torch.as_tensor(keep, dtype=torch.int64, device=boxes.device)]
-
-
-def batched_nms_coordinate_trick(boxes, scores, idxs, iou_threshold, width, height):
-    if boxes.numel() == 0:
-        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
-    max_dim = max([width, height])
-    offsets = idxs * float(max_dim + 1)
-    return nms(boxes + offsets[:, None], scores, iou_threshold)
-
-
-def _empty(device):
-    return {"boxes": torch.zeros(0, 4, dtype=torch.float32, device=device),
-            "scores": torch.zeros(0, dtype=torch.float, device=device),
-            "labels": torch.zeros(0, dtype=torch.long, device=device)}
-
-
 def postprocess_network_output(prediction, num_classes, conf_thre=0.01, nms_thre=0.65, height=640, width=640,
                                filtering=True):
-    prediction[..., :2] -= prediction[..., 2:4] / 2  # cxcywh -> xywh
-    prediction[..., 2:4] += prediction[..., :2]
+    """Batched, device-side version of ``model/utils.py:61-110``: cxcywh -> xyxy, class max, the reference's
+    confidence mask (obj * cls * cls >= thr), class-offset greedy NMS for all images in ONE kernel launch
+    (``dagr_nms_batched``), then one small D2H copy of the survivor counts to cut the per-image result dicts
+    (the reference's return type is inherently variable-length).  ``prediction``: [B, A, 5 + C] on the GPU."""
+    import ctypes
+    from .. import _lib
+    if not prediction.is_cuda:
+        raise RuntimeError("postprocess_network_output expects the decoded head outputs on the GPU")
+    B, A = prediction.shape[:2]
+    xy, wh = prediction[..., :2], prediction[..., 2:4]
+    x1y1 = xy - wh / 2
+    boxes = torch.cat((x1y1, wh + x1y1), dim=-1).contiguous()                      # same op order as :62-63
+    class_conf, class_pred = torch.max(prediction[..., 5:5 + num_classes], dim=-1)
+    scores = (prediction[..., 4] * class_conf).contiguous()                        # image_pred[:, 4:5] *= class_conf
+    valid = (scores * class_conf >= conf_thre) if filtering else torch.ones_like(scores, dtype=torch.bool)
+    cls32 = class_pred.to(torch.int32).contiguous()
+    valid8 = valid.to(torch.uint8).contiguous()
+    dev = prediction.device
+    order = torch.empty((B, A), dtype=torch.int32, device=dev)
+    keep = torch.empty((B, A), dtype=torch.int32, device=dev)
+    n_keep = torch.empty((B,), dtype=torch.int32, device=dev)
+    thr = nms_thre if filtering else 2.0    # without filtering the reference keeps every row (only orders them)
+    _lib.check(_lib.lib().dagr_nms_batched(_lib.ptr(boxes), _lib.ptr(scores), _lib.ptr(cls32), _lib.ptr(valid8), B, A,
+                                           float(thr), float(max(width, height) + 1), _lib.ptr(order),
+                                           _lib.ptr(keep), _lib.ptr(n_keep), _lib.cur_stream(dev)), "nms_batched")
+    order = order.long()
+    kept = keep.bool()
     output = []
-    for image_pred in prediction:
-        if len(image_pred) == 0:
-            output.append(_empty(prediction.device))
-            continue
-        class_conf, class_pred = torch.max(image_pred[:, 5:5 + num_classes], 1, keepdim=True)
-        image_pred[:, 4:5] *= class_conf
-        conf_mask = (image_pred[:, 4] * class_conf.squeeze() >= conf_thre).squeeze()
-        detections = torch.cat((image_pred[:, :5], class_pred), 1)
-        if filtering:
-            detections = detections[conf_mask]
-        if len(detections) == 0:
-            output.append(_empty(prediction.device))
-            continue
-        keep = batched_nms_coordinate_trick(detections[:, :4], detections[:, 4], detections[:, 5], nms_thre,
-                                            width=width, height=height)
-        if filtering:
-            detections = detections[keep]
-        output.append({"boxes": detections[:, :4], "scores": detections[:, 4], "labels": detections[:, -1].long()})
+    for b in range(B):            # B result dicts; no per-anchor work on the host
+        sel = order[b][kept[b]]
+        output.append({"boxes": boxes[b, sel], "scores": scores[b, sel], "labels": class_pred[b, sel].long()})
     return output
 
 

@@ -255,6 +255,18 @@ int dagr_sample_features(const int32_t *n_ptr, int32_t n_max, const float *pos, 
                          int32_t batch_is_int64, const float *feat_nhwc, int32_t B, int32_t h, int32_t w, int32_t C,
                          int32_t width, int32_t height, float *out, int32_t ldo, int32_t coff, void *stream);
 
+/* ------------------------------------------------------------------------ *
+ * Detection post-processing -- model/utils.py:25-33,61-110 (batched_nms_coordinate_trick over
+ * torchvision.ops.nms, called per image from a Python loop)
+ *   boxes[B,A,4] (x1,y1,x2,y2), scores[B,A], cls[B,A] (class id; boxes are shifted by cls*class_offset
+ *   before the IoU test), valid[B,A] (uint8).  order_out[B,A]: anchor indices by descending score
+ *   (invalid last), keep_out[B,A]: 1 where order_out[i] survives greedy NMS (IoU > thr suppressed),
+ *   n_keep[B].  A <= 1024.
+ * ------------------------------------------------------------------------ */
+int dagr_nms_batched(const float *boxes, const float *scores, const int32_t *cls, const uint8_t *valid,
+                     int32_t B, int32_t A, float iou_threshold, float class_offset,
+                     int32_t *order_out, int32_t *keep_out, int32_t *n_keep, void *stream);
+
 /* Profiling aid (not on the product path): streams a known number of bytes so that rocprofv3's
  * FETCH_SIZE / WRITE_SIZE can be calibrated on this library's access patterns.
  * mode 0: 4 B/lane reads of n_floats; 1: 16 B/lane reads; 2: n_gathers pseudo-random 64-byte rows

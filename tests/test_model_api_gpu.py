@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 def test_dagr_forward_on_data_batches():
     from dagr_amd.model.networks.dagr import DAGR
     from dagr_amd.model.networks.ema import ModelEMA
-    from dagr_amd.model.utils import postprocess_network_output
+    from oracle.postprocess import postprocess_network_output
     W, H, B = 320, 215, 2
     torch.manual_seed(0)
     args = om.default_args(batch_size=B)
@@ -46,7 +46,7 @@ def test_dagr_forward_on_data_batches():
     t = np.concatenate([r[2] for r in raw]); p = np.concatenate([r[3] for r in raw])
     b = np.concatenate([np.full(len(r[0]), i, np.int64) for i, r in enumerate(raw)])
     out_o, _ = om.forward_events(sd, args, H, W, x, y, t, p, b, B)
-    det_o = postprocess_network_output(out_o.clone(), 2, 0.001, 0.65, height=H, width=W)
+    det_o = postprocess_network_output(out_o, 2, 0.001, 0.65, height=H, width=W)
     for dh, do in zip(detections, det_o):
         assert dh["boxes"].shape == do["boxes"].shape
         if len(do["boxes"]):
@@ -55,3 +55,24 @@ def test_dagr_forward_on_data_batches():
             assert torch.allclose(dh["scores"].cpu()[order_h], do["scores"][order_o], atol=1e-4)
             assert torch.allclose(dh["boxes"].cpu()[order_h], do["boxes"][order_o], atol=1e-2, rtol=1e-4)
             assert torch.equal(dh["labels"].cpu()[order_h], do["labels"][order_o])
+
+
+def test_batched_nms_matches_oracle_on_random_boxes():
+    """Device NMS vs the written-out greedy algorithm on crowded random boxes (many suppressions, 3 classes)."""
+    from oracle.postprocess import postprocess_network_output as pp_oracle
+    from dagr_amd.model.utils import postprocess_network_output as pp_hip
+    g = torch.Generator().manual_seed(0)
+    B, A, C = 4, 175, 3
+    pred = torch.zeros((B, A, 5 + C))
+    pred[..., :2] = torch.rand((B, A, 2), generator=g) * 200 + 50          # centres
+    pred[..., 2:4] = torch.rand((B, A, 2), generator=g) * 80 + 20          # sizes
+    pred[..., 4] = torch.rand((B, A), generator=g)
+    pred[..., 5:] = torch.rand((B, A, C), generator=g)
+    pred[1, :, 4] = 0.0                                                     # an image with no detections
+    do = pp_oracle(pred, C, 0.05, 0.5, height=215, width=320)
+    dh = pp_hip(pred.cuda(), C, 0.05, 0.5, height=215, width=320)
+    for a, b in zip(dh, do):
+        assert a["boxes"].shape == b["boxes"].shape
+        assert torch.allclose(a["scores"].cpu(), b["scores"], atol=1e-6)
+        assert torch.allclose(a["boxes"].cpu(), b["boxes"], atol=1e-4)
+        assert torch.equal(a["labels"].cpu(), b["labels"])
