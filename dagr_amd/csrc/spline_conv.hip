@@ -19,6 +19,8 @@
 //     and k_gemm_bias_act contracts it with the packed weight matrix.
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace dagr {
 namespace {
 
@@ -533,6 +535,140 @@ __global__ __launch_bounds__(kBlock, 4) void k_conv_l0_mixed(int N, int K, int n
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// MFMA variant of the level-0 SplineConv for 16 input channels (conv_block1.conv_block2: 16 -> 16 + skip).
+// PMC showed k_conv_l0 saturating the LDS pipe (broadcast table reads, weight rows, ds_bpermute) and VALU
+// issue while HBM traffic sat far below the roofline, so both contractions move to the matrix pipe
+// (v_mfma_f32_16x16x4_f32: exact fp32 FMA at the vector rate, but its operands are one float per lane):
+//   phase 1, per node:   D[tap][ch] = sum_edges T[edge][tap] * X[edge][ch]   (16 x 16 x deg: 4 MFMAs for K=16)
+//        A operand = the offset-table row of the edge (one LDS word), B operand = the gathered source row
+//        (16 lanes read 64 contiguous bytes per edge);
+//   phase 2, per 16 nodes: out[node][o] = sum_k A[node][k] * Wp[k][o],  k over (tap, ch) | root | skip
+//        A operand from an LDS staging tile (phase 1 results) resp. straight from global (root / skip rows).
+// One wave owns a tile of 16 consecutive nodes; 8 waves per workgroup share the packed weights and the
+// offset table in LDS (block = 512 threads, ~152 KB LDS, one workgroup per CU, persistent over an
+// XCD-contiguous node range).  Summation order differs from k_conv_l0 only by fp32 re-association.
+using f32x4_t = __attribute__((ext_vector_type(4))) float;
+constexpr int kMfmaWaves = 8;
+
+template <int CSKIP, int NT>
+__global__ __launch_bounds__(kMfmaWaves * 64) void k_conv_l0_mfma(
+    int N, int K, int ncodes, const int32_t *__restrict__ nbr_src, const int16_t *__restrict__ nbr_code,
+    const int32_t *__restrict__ deg, const float *__restrict__ x, int ldx, const float *__restrict__ xskip, int ldskip,
+    const float *__restrict__ tab, const float *__restrict__ wpack, const float *__restrict__ shift, int relu,
+    float *__restrict__ out, int ldo) {
+    constexpr int NTP = (NT + 3) / 4 * 4;
+    constexpr int KT = NT * 16;                    // tap rows
+    constexpr int KS = (CSKIP + 3) / 4 * 4;        // skip rows, zero padded
+    constexpr int KTOT = KT + 16 + KS;
+    constexpr int AS = KT + 1;                     // staging row stride (odd: conflict-free column reads)
+    extern __shared__ __align__(16) float lds[];
+    float *w_s = lds;                              // [KTOT][16]
+    float *tab_s = w_s + KTOT * 16;                // [ncodes][NTP]
+    float *a_all = tab_s + ncodes * NTP;           // [waves][16][AS]
+    for (int i = threadIdx.x; i < KTOT * 16; i += blockDim.x) {
+        const int r = i >> 4;
+        w_s[i] = (r < KT + 16 + CSKIP) ? wpack[i] : 0.0f;
+    }
+    for (int i = threadIdx.x; i < ncodes * NTP; i += blockDim.x) tab_s[i] = tab[i];
+    __syncthreads();
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = l & 15, q = l >> 4;
+    float *a_s = a_all + w * 16 * AS;
+    const float my_shift = shift[c];
+    // contiguous node range per block (XCD-contiguous), 16-node tiles dealt round-robin to the waves
+    const int G = gridDim.x, nx = (G % 8 == 0) ? 8 : 1;
+    const int xcd = blockIdx.x % nx, lb = blockIdx.x / nx, bpx = G / nx;
+    const int chunk = ((N + nx - 1) / nx + 15) / 16 * 16;
+    const int per_block = ((chunk + bpx - 1) / bpx + 15) / 16 * 16;
+    const int n_begin = xcd * chunk + lb * per_block;
+    const int n_end = min(min(N, (xcd + 1) * chunk), n_begin + per_block);
+    // Software pipeline: the neighbour lists of a tile (16 nodes x 16 slots) are read coalesced -- lane l
+    // holds slots l, l+64, l+128, l+192 of the tile -- one tile ahead of their use; all 64 source-row
+    // gathers of a tile are in flight before the first MFMA consumes one.  (K == 16 on this path.)
+    auto load_tile_idx = [&](int n0, int (&src)[4], int (&code)[4], int &dg) {
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int64_t f = (int64_t)n0 * 16 + l + 64 * m;
+            const bool ok = f < (int64_t)n_end * 16;
+            src[m] = ok ? nbr_src[f] : 0;
+            code[m] = ok ? (int)nbr_code[f] : 0;
+        }
+        dg = (l < 16 && n0 + l < n_end) ? deg[n0 + l] : 0;
+    };
+    int cur_src[4], cur_code[4], cur_deg;
+    int n0 = n_begin + 16 * w;
+    if (n0 < n_end) load_tile_idx(n0, cur_src, cur_code, cur_deg);
+    for (; n0 < n_end; n0 += 16 * kMfmaWaves) {
+        int nxt_src[4] = {0, 0, 0, 0}, nxt_code[4] = {0, 0, 0, 0}, nxt_deg = 0;
+        if (n0 + 16 * kMfmaWaves < n_end) load_tile_idx(n0 + 16 * kMfmaWaves, nxt_src, nxt_code, nxt_deg);
+        // ---- phase 1a: all gathers of the tile
+        float xv[16][4];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int d = __shfl(cur_deg, i, 64);
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const int e = 4 * kk + q;
+                const int src = __shfl(cur_src[i >> 2], (i & 3) * 16 + e, 64);
+                xv[i][kk] = (e < d) ? x[(size_t)src * ldx + c] : 0.0f;
+            }
+        }
+        // ---- phase 1b: D[tap][ch] = sum_edges T[edge][tap] * X[edge][ch], 4 MFMAs per node
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int d = __shfl(cur_deg, i, 64);
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                if (4 * kk < d) {   // wave-uniform
+                    const int e = 4 * kk + q;
+                    const int code = __shfl(cur_code[i >> 2], (i & 3) * 16 + e, 64);
+                    const float av = (e < d && c < NT) ? tab_s[code * NTP + c] : 0.0f;
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xv[i][kk], acc, 0, 0, 0);
+                }
+            }
+            float *dst = a_s + i * AS + (4 * q) * 16 + c;   // D[tap = 4q + r][ch = c]
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (4 * q + r < NT) dst[r * 16] = acc[r];
+        }
+#pragma unroll
+        for (int m = 0; m < 4; m++) { cur_src[m] = nxt_src[m]; cur_code[m] = nxt_code[m]; }
+        cur_deg = nxt_deg;
+        __builtin_amdgcn_wave_barrier();
+        // ---- phase 2: 16 nodes x KTOT x 16 outputs
+        f32x4_t o = {0.f, 0.f, 0.f, 0.f};
+        const float *arow = a_s + c * AS + q;               // A[node = c][k = kb + q]
+        const float *wrow = w_s + q * 16 + c;               // B[k = kb + q][o = c]
+#pragma unroll 4
+        for (int kb = 0; kb < KT; kb += 4) o = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[kb], wrow[kb * 16], o, 0, 0, 0);
+        const int nn = n0 + c;                               // this lane's node for the root / skip operands
+        const bool nn_ok = nn < n_end;
+#pragma unroll
+        for (int kb = 0; kb < 16; kb += 4) {
+            const float av = nn_ok ? x[(size_t)nn * ldx + kb + q] : 0.f;
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wrow[(KT + kb) * 16], o, 0, 0, 0);
+        }
+#pragma unroll
+        for (int kb = 0; kb < KS; kb += 4) {
+            const float av = (nn_ok && kb + q < CSKIP) ? xskip[(size_t)nn * ldskip + kb + q] : 0.f;
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wrow[(KT + 16 + kb) * 16], o, 0, 0, 0);
+        }
+        // o[r] = out[node = 4q + r][channel c]
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int n = n0 + 4 * q + r;
+            if (n < n_end) {
+                float v = o[r] + my_shift;
+                if (relu) v = fmaxf(v, 0.f);
+                out[(size_t)n * ldo + c] = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();   // staging tile is reused by the next tile of this wave
+    }
+}
+
 // One thread per offset code: the window products bx[a]*by[b] at [a + tx*b], row stride ntp.
 __global__ void k_build_l0_table(int rx, int ry, float den_x, float den_y, int win_x, int tx, int win_y, int ty,
                                  int ntp, float *__restrict__ tab, int32_t *__restrict__ bad) {
@@ -642,6 +778,33 @@ int dagr_spline_conv_l0(int32_t cin, int32_t cskip, int32_t ntaps, int64_t N, in
     DAGR_L0_MIXED(3, 9)
     DAGR_L0_MIXED(3, 15)
 #undef DAGR_L0_MIXED
+#define DAGR_L0_MFMA(CS, NTAPS)                                                                                    \
+    if (use_mfma && cin == 16 && cskip == CS && ntaps == NTAPS && K == 16) {                                       \
+        constexpr int kt = NTAPS * 16, ks = (CS + 3) / 4 * 4;                                                      \
+        const size_t mlds = ((size_t)(kt + 16 + ks) * 16 + (size_t)ncodes * ntp + (size_t)kMfmaWaves * 16 * (kt + 1)) * 4; \
+        if (mlds <= 160 * 1024) {                                                                                  \
+            static thread_local size_t set_for = 0;                                                                \
+            if (set_for != mlds) {                                                                                 \
+                DAGR_CHECK_HIP(hipFuncSetAttribute((const void *)k_conv_l0_mfma<CS, NTAPS>,                        \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));         \
+                set_for = mlds;                                                                                    \
+            }                                                                                                      \
+            const unsigned mg = round_grid8(std::min<int64_t>(ceil_div(N, 16 * kMfmaWaves), device_cu_count()));   \
+            k_conv_l0_mfma<CS, NTAPS><<<mg, kMfmaWaves * 64, mlds, stream>>>((int)N, K, ncodes, nbr_src, nbr_code, deg, \
+                                                                             x, ldx, xskip, ldskip, tab, wpack, shift, \
+                                                                             relu, out, ldo);                       \
+            DAGR_CHECK_LAUNCH();                                                                                   \
+            return DAGR_OK;                                                                                        \
+        }                                                                                                          \
+    }
+    // matrix-pipe variant (k_conv_l0_mfma): measured equal to the VALU kernel on an idle GPU (0.33 vs 0.35 ms)
+    // but it pins ~152 KB of LDS per CU; opt-in through DAGR_L0_MFMA=1 until it wins under overlap as well
+    static const bool use_mfma = [] { const char *e = std::getenv("DAGR_L0_MFMA"); return e && e[0] == '1'; }();
+    DAGR_L0_MFMA(3, 9)
+    DAGR_L0_MFMA(3, 15)
+    DAGR_L0_MFMA(19, 9)
+    DAGR_L0_MFMA(19, 15)
+#undef DAGR_L0_MFMA
 #define DAGR_L0_CASE(CI, CS, NTAPS)                                                                                \
     if (cin == CI && cskip == CS && ntaps == NTAPS) {                                                              \
         {                                                                                                          \
