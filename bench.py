@@ -282,7 +282,8 @@ def main():
         c0 = 19 if use_image else 3
         nt = eng.ntaps0
         kname = {"l0_conv1": (f"k_conv_l0_mixed<{c0 - 16}, {nt}>" if use_image else f"k_conv_l0_narrow<{c0}, {nt}>"),
-                 "l0_conv2": f"k_conv_l0<16, {c0}, {nt}>"}[dom]
+                 "l0_conv2": (f"k_conv_l0_mfma<{c0}, {nt}>" if os.environ.get("DAGR_L0_MFMA", "1") != "0"
+                              else f"k_conv_l0<16, {c0}, {nt}>")}[dom]
         # HBM bytes per launch from the PMC passes of this same command (tools/pmc.sh -> profiles/r1_traffic.json);
         # PMC counters cannot be read from inside this process
         traffic = None

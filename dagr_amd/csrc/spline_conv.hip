@@ -602,32 +602,32 @@ __global__ __launch_bounds__(kMfmaWaves * 64) void k_conv_l0_mfma(
     for (; n0 < n_end; n0 += 16 * kMfmaWaves) {
         int nxt_src[4] = {0, 0, 0, 0}, nxt_code[4] = {0, 0, 0, 0}, nxt_deg = 0;
         if (n0 + 16 * kMfmaWaves < n_end) load_tile_idx(n0 + 16 * kMfmaWaves, nxt_src, nxt_code, nxt_deg);
-        // ---- phase 1a: all gathers of the tile
-        float xv[16][4];
+        // ---- phase 1a: every operand of the tile's 64 MFMAs is requested up front: source rows (global
+        // gathers) and offset-table words (LDS)
+        float xv[16][4], tv[16][4];
+        int dd[16];
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            const int d = __shfl(cur_deg, i, 64);
+            dd[i] = __shfl(cur_deg, i, 64);
 #pragma unroll
             for (int kk = 0; kk < 4; kk++) {
                 const int e = 4 * kk + q;
-                const int src = __shfl(cur_src[i >> 2], (i & 3) * 16 + e, 64);
-                xv[i][kk] = (e < d) ? x[(size_t)src * ldx + c] : 0.0f;
+                const int from = (i & 3) * 16 + e;
+                const int src = __shfl(cur_src[i >> 2], from, 64);
+                const int code = __shfl(cur_code[i >> 2], from, 64);
+                const bool ok = e < dd[i];
+                xv[i][kk] = ok ? x[(size_t)src * ldx + c] : 0.0f;
+                tv[i][kk] = (ok && c < NT) ? tab_s[code * NTP + c] : 0.0f;
             }
         }
-        // ---- phase 1b: D[tap][ch] = sum_edges T[edge][tap] * X[edge][ch], 4 MFMAs per node
+        // ---- phase 1b: D[tap][ch] = sum_edges T[edge][tap] * X[edge][ch], <= 4 MFMAs per node
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            const int d = __shfl(cur_deg, i, 64);
             f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kk = 0; kk < 4; kk++) {
-                if (4 * kk < d) {   // wave-uniform
-                    const int e = 4 * kk + q;
-                    const int code = __shfl(cur_code[i >> 2], (i & 3) * 16 + e, 64);
-                    const float av = (e < d && c < NT) ? tab_s[code * NTP + c] : 0.0f;
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xv[i][kk], acc, 0, 0, 0);
-                }
-            }
+            for (int kk = 0; kk < 4; kk++)
+                if (4 * kk < dd[i])   // wave-uniform
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(tv[i][kk], xv[i][kk], acc, 0, 0, 0);
             float *dst = a_s + i * AS + (4 * q) * 16 + c;   // D[tap = 4q + r][ch = c]
 #pragma unroll
             for (int r = 0; r < 4; r++)
@@ -641,8 +641,15 @@ __global__ __launch_bounds__(kMfmaWaves * 64) void k_conv_l0_mfma(
         f32x4_t o = {0.f, 0.f, 0.f, 0.f};
         const float *arow = a_s + c * AS + q;               // A[node = c][k = kb + q]
         const float *wrow = w_s + q * 16 + c;               // B[k = kb + q][o = c]
-#pragma unroll 4
-        for (int kb = 0; kb < KT; kb += 4) o = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[kb], wrow[kb * 16], o, 0, 0, 0);
+        // operands of 12 k-steps are read before their MFMAs issue (LDS latency off the dependent chain)
+        static_assert(KT % 48 == 0, "tap rows come in blocks of 48");
+        for (int kb0 = 0; kb0 < KT; kb0 += 48) {
+            float av[12], wv[12];
+#pragma unroll
+            for (int u = 0; u < 12; u++) { av[u] = arow[kb0 + 4 * u]; wv[u] = wrow[(kb0 + 4 * u) * 16]; }
+#pragma unroll
+            for (int u = 0; u < 12; u++) o = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], wv[u], o, 0, 0, 0);
+        }
         const int nn = n0 + c;                               // this lane's node for the root / skip operands
         const bool nn_ok = nn < n_end;
 #pragma unroll
@@ -797,9 +804,9 @@ int dagr_spline_conv_l0(int32_t cin, int32_t cskip, int32_t ntaps, int64_t N, in
             return DAGR_OK;                                                                                        \
         }                                                                                                          \
     }
-    // matrix-pipe variant (k_conv_l0_mfma): measured equal to the VALU kernel on an idle GPU (0.33 vs 0.35 ms)
-    // but it pins ~152 KB of LDS per CU; opt-in through DAGR_L0_MFMA=1 until it wins under overlap as well
-    static const bool use_mfma = [] { const char *e = std::getenv("DAGR_L0_MFMA"); return e && e[0] == '1'; }();
+    // matrix-pipe variant (k_conv_l0_mfma): 0.30 vs 0.35 ms for the VALU kernel on an idle GPU, equal under
+    // two-engine overlap; DAGR_L0_MFMA=0 selects the VALU kernel (A/B and fallback)
+    static const bool use_mfma = [] { const char *e = std::getenv("DAGR_L0_MFMA"); return !(e && e[0] == '0'); }();
     DAGR_L0_MFMA(3, 9)
     DAGR_L0_MFMA(3, 15)
     DAGR_L0_MFMA(19, 9)
