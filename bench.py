@@ -288,8 +288,9 @@ def main():
         # PMC counters cannot be read from inside this process
         traffic = None
         tj = os.path.join(ROOT, "profiles", "r1_traffic.json")
-        if use_image and NPW == 100000 and B == 8 and (W, H) == (640, 480) and os.path.exists(tj):
-            traffic = json.load(open(tj))["kernels"].get(kname, {}).get("traffic_bytes")
+        if NPW == 100000 and B == 8 and (W, H) == (640, 480) and a.stream == "uniform" and os.path.exists(tj):
+            cfg = json.load(open(tj))["configs"]["use_image" if use_image else "events_only"]
+            traffic = cfg.get(kname, {}).get("traffic_bytes")
         roofline = dict(kernel=kname, bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                         alg_bytes_per_launch=int(ab[dom]), launch_ms=round(stages[dom], 4))
