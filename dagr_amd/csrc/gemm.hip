@@ -139,3 +139,215 @@ hipError_t launch_gemm_mfma(const int32_t *m_ptr, int m_max, const float *A, int
 }
 
 }  // namespace dagr
+
+// ---------------------------------------------------------------------------------------------
+// Fused pooled-level SplineConv: tap aggregation + contraction in one launch.
+// A workgroup owns 16 destination nodes.  Phase A: wave w aggregates node w's taps straight into the block's
+// LDS A-tile [16][K] (same arithmetic and order as k_tap_aggregate, spline_conv.hip): the [T, 26*Cin] matrix
+// never goes to HBM and 16 of the 32 launches per step disappear.  Phase B: the 16 x K x N contraction with
+// v_mfma_f32_16x16x4_f32, A operands read from the tile (row stride = 4 mod 32: conflict-free), weights read
+// straight from L2 (no reuse inside a block), 4 wave quads split K, fixed-order reduction.  Column blocks
+// of 64 are looped inside the same workgroup.
+namespace dagr {
+namespace {
+
+struct AxisF {
+    int k0, k1;
+    float b0, b1;
+};
+__device__ __forceinline__ AxisF spline_axis_f(int idx, int r, float den) {   // == spline_axis (spline_conv.hip)
+    const float pseudo = (float)(idx - r) / den + 0.5f;
+    const float v = pseudo * 4.0f;
+    const float fl = floorf(v);
+    const float frac = v - fl;
+    AxisF a;
+    const int f = (int)fl;
+    a.k0 = f % 5;
+    a.k1 = (f + 1) % 5;
+    a.b0 = ((1.0f - frac) - 0.0f) + (2.0f * frac) * 0.0f;
+    a.b1 = ((1.0f - frac) - 1.0f) + (2.0f * frac) * 1.0f;
+    return a;
+}
+
+__global__ __launch_bounds__(kGemmThreads) void k_conv_fused(
+    const int32_t *__restrict__ n_ptr, int n_max, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const int32_t *__restrict__ code, const float *__restrict__ x, int ldx, int cin, const float *__restrict__ xskip,
+    int ldskip, int cskip, int rx, int ry, float den_x, float den_y, const float *__restrict__ Wq,
+    const float *__restrict__ bias, float *__restrict__ C, int ldc, int N, int relu, int KP, int NC) {
+    extern __shared__ __align__(16) float fl[];
+    const int K = 26 * cin + cskip;
+    float *At = fl;                                  // [16][KP], columns K..KP-1 zero
+    float *red = fl + 16 * KP;                       // [KSPLIT][16][NB] split-K partials
+    const int m0 = blockIdx.x * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // rowptr has n_max + 1 entries: read it before the device-side bound is known (one latency, not two)
+    const int n_spec = min(m0 + wv, n_max - 1);
+    const int e0 = rowptr[n_spec], e1s = rowptr[n_spec + 1];
+    const int M = n_ptr ? min(*n_ptr, n_max) : n_max;
+    if (m0 >= M) return;
+    // ---- phase A: wave wv aggregates node m0 + wv (edge order and arithmetic of k_tap_aggregate)
+    {
+        const int n = m0 + wv;
+        float *row = At + wv * KP;
+        for (int i = lane; i < KP; i += 64) row[i] = 0.0f;
+        if (n < M) {
+            const int ne = e1s - e0;
+            const float *xn = x + (size_t)n * ldx;
+            for (int i = lane; i < cin; i += 64) row[25 * cin + i] = xn[i];
+            if (cskip > 0) {
+                const float *sn = xskip + (size_t)n * ldskip;
+                for (int i = lane; i < cskip; i += 64) row[26 * cin + i] = sn[i];
+            }
+            for (int base = 0; base < ne; base += 64) {
+                const int cnt = min(64, ne - base);
+                int my_src = 0, my_cd = 0;
+                if (lane < cnt) {
+                    my_src = col[e0 + base + lane];
+                    my_cd = code[e0 + base + lane];
+                }
+                for (int c0 = 0; c0 < cin; c0 += 64) {
+                    const int ch = c0 + lane;
+                    const bool ch_ok = ch < cin;
+                    constexpr int UA = 8;
+                    for (int j = 0; j < cnt; j += UA) {
+                        float v[UA];
+                        int cd[UA];
+#pragma unroll
+                        for (int u = 0; u < UA; u++) {   // UA gathers in flight
+                            const int jj = min(j + u, cnt - 1);
+                            const int src = __builtin_amdgcn_readlane(my_src, jj);
+                            cd[u] = __builtin_amdgcn_readlane(my_cd, jj);
+                            v[u] = ch_ok ? x[(size_t)src * ldx + ch] : 0.0f;
+                        }
+#pragma unroll
+                        for (int u = 0; u < UA; u++) {
+                            if (j + u < cnt && ch_ok) {
+                                const AxisF ax = spline_axis_f(cd[u] & 0xffff, rx, den_x);
+                                const AxisF ay = spline_axis_f(cd[u] >> 16, ry, den_y);
+                                const float b00 = ax.b0 * ay.b0, b10 = ax.b1 * ay.b0, b01 = ax.b0 * ay.b1,
+                                            b11 = ax.b1 * ay.b1;
+                                float *a00 = row + (ax.k0 + 5 * ay.k0) * cin + ch;
+                                float *a10 = row + (ax.k1 + 5 * ay.k0) * cin + ch;
+                                float *a01 = row + (ax.k0 + 5 * ay.k1) * cin + ch;
+                                float *a11 = row + (ax.k1 + 5 * ay.k1) * cin + ch;
+                                // the four taps of one edge are distinct (k0 != k1 on both axes): read all, then write
+                                const float o00 = *a00, o10 = *a10, o01 = *a01, o11 = *a11;
+                                *a00 = o00 + b00 * v[u];
+                                *a10 = o10 + b10 * v[u];
+                                *a01 = o01 + b01 * v[u];
+                                *a11 = o11 + b11 * v[u];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase B: [16 x K] . [K x N].  Wave (ks, w): K quarter ks, 16-column tile w of a 64-column block.
+    // No weight staging: every weight element is used by exactly one wave of the block, so the B operands
+    // come straight from L2 in the host-packed MFMA operand order Wq[col tile][k group of 16][lane][4]
+    // (element j of lane l = W[16 g + 4 j + (l >> 4)][16 c + (l & 15)]): one 1-KiB fully coalesced wave
+    // load feeds 4 MFMAs, U of them are in flight per wave, and the loop has no barrier.
+    // NC = column tiles per workgroup: 4 (one workgroup per 16 nodes, K split 4 ways) or, for levels with too few
+    // nodes to fill the chip, 1 (gridDim.y workgroups per 16 nodes, K split 16 ways).
+    const int ksplit = 16 / NC, NBc = 16 * NC;
+    const int ks = wv / NC, w = wv % NC;
+    const int kk = lane >> 4, nn = lane & 15;
+    const int G = (K + 15) / 16, Gq = (G + ksplit - 1) / ksplit;
+    const int gbeg = ks * Gq, gend = min(G, gbeg + Gq);
+    const float *a_rd = At + nn * KP + kk;
+    constexpr int U = 4;
+    const int n_first = (NC == 4) ? 0 : (int)blockIdx.y * NBc;
+    const int n_last = (NC == 4) ? N : min(N, n_first + NBc);
+    for (int n0 = n_first; n0 < n_last; n0 += NBc) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (n0 + w * 16 < N) {
+            const float4 *wq = reinterpret_cast<const float4 *>(Wq) + ((size_t)(n0 / 16 + w) * G) * 64 + lane;
+            float4 b[U], bn[U];
+            auto load_b = [&](float4 *dst, int g0) {
+#pragma unroll
+                for (int u = 0; u < U; u++) dst[u] = wq[(size_t)min(g0 + u, G - 1) * 64];
+            };
+            if (gbeg < gend) load_b(b, gbeg);
+            for (int g0 = gbeg; g0 < gend; g0 += U) {
+                const bool more = g0 + U < gend;
+                if (more) load_b(bn, g0 + U);
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    if (g0 + u < gend) {       // wave-uniform
+                        const float *ap = a_rd + 16 * (g0 + u);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[0], b[u].x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4], b[u].y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[8], b[u].z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[12], b[u].w, acc, 0, 0, 0);
+                    }
+                }
+                if (more) {
+#pragma unroll
+                    for (int u = 0; u < U; u++) b[u] = bn[u];
+                }
+            }
+        }
+        float *rd = red + ks * 16 * NBc;
+#pragma unroll
+        for (int q = 0; q < 4; q++) rd[(kk * 4 + q) * NBc + w * 16 + nn] = acc[q];
+        __syncthreads();
+        if (tid < 16 * NBc) {
+            const int idx = tid;
+            const int orow = m0 + idx / NBc, ocol = n0 + idx % NBc;
+            if (orow < M && ocol < N) {
+                float v = red[idx];
+                for (int s = 1; s < ksplit; s++) v += red[s * 16 * NBc + idx];   // fixed order
+                v += bias ? bias[ocol] : 0.f;
+                if (relu) v = fmaxf(v, 0.f);
+                C[(size_t)orow * ldc + ocol] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+}  // namespace dagr
+
+extern "C" int dagr_spline_conv_fused(const int32_t *n_nodes_ptr, int32_t n_nodes_max, const int32_t *rowptr,
+                                      const int32_t *col, const int32_t *code, const float *x, int32_t ldx, int32_t cin,
+                                      const float *xskip, int32_t ldskip, int32_t cskip, int32_t rx, int32_t ry,
+                                      float den_x, float den_y, const float *Wq, const float *bias, float *C,
+                                      int32_t ldc, int32_t N, int32_t relu, void *stream) {
+    using namespace dagr;
+    DAGR_CHECK_ARG(n_nodes_max >= 0 && cin >= 1 && N >= 1, "bad sizes");
+    if (n_nodes_max == 0) return DAGR_OK;
+    DAGR_CHECK_ARG(rowptr && col && code && x && Wq && C, "NULL pointer");
+    DAGR_CHECK_ARG(cskip == 0 || xskip, "xskip is NULL");
+    DAGR_CHECK_ARG(((uintptr_t)Wq % 16) == 0, "packed weights must be 16-byte aligned");
+    const int K = 26 * cin + cskip;
+    const int KP = (K + 31) / 32 * 32 + 4;        // >= K + 4 and = 4 (mod 32): bank = 4*row + k, conflict-free
+    const size_t lds_bytes = ((size_t)16 * KP + (size_t)KSPLIT * 16 * NB) * 4;
+    if (lds_bytes > 160 * 1024) {
+        set_error("dagr_spline_conv_fused: K too large for the LDS tile (use tap_aggregate + gemm)");
+        return DAGR_ERR_UNSUPPORTED;
+    }
+    static thread_local size_t set_max = 0;
+    if (lds_bytes > set_max) {
+        DAGR_CHECK_HIP(hipFuncSetAttribute((const void *)k_conv_fused, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds_bytes));
+        set_max = lds_bytes;
+    }
+    const int row_blocks = ceil_div(n_nodes_max, 16);
+    const int nc = (row_blocks * 2 <= device_cu_count()) ? 1 : 4;   // few nodes: spread the columns over workgroups
+    const dim3 grid((unsigned)row_blocks, nc == 1 ? (unsigned)ceil_div(N, 16) : 1u);
+    k_conv_fused<<<grid, kGemmThreads, lds_bytes, (hipStream_t)stream>>>(
+        n_nodes_ptr, n_nodes_max, rowptr, col, code, x, ldx, cin, xskip, ldskip, cskip, rx, ry, den_x, den_y, Wq, bias, C,
+        ldc, N, relu, KP, nc);
+    DAGR_CHECK_LAUNCH();
+    return DAGR_OK;
+}
+
+extern "C" size_t dagr_spline_conv_fused_lds_bytes(int32_t cin, int32_t cskip) {
+    using namespace dagr;
+    const int K = 26 * cin + cskip;
+    const int KP = (K + 31) / 32 * 32 + 4;
+    return ((size_t)16 * KP + (size_t)KSPLIT * 16 * NB) * 4;
+}

@@ -37,6 +37,12 @@ class _ConvPack:
         if self.ldw != self.N:
             Wm = torch.cat([Wm, torch.zeros((self.K, self.ldw - self.N), dtype=Wm.dtype, device=Wm.device)], 1)
         self.cin, self.cskip, self.Wm, self.bias, self.relu = cin, cskip, Wm.contiguous(), bias.contiguous(), relu
+        # MFMA operand order for dagr_spline_conv_fused: Wq[c][g][l][j] = W[16g + 4j + (l>>4)][16c + (l&15)]
+        K16, N16 = (self.K + 15) // 16 * 16, (self.N + 15) // 16 * 16
+        Wp = torch.zeros((K16, N16), dtype=Wm.dtype, device=Wm.device)
+        Wp[: self.K, : self.N] = Wm[:, : self.N]
+        # [g, j, kk, c, nn] -> [c, g, kk, nn, j]  (lane l = 16 kk + nn)
+        self.Wq = Wp.view(K16 // 16, 4, 4, N16 // 16, 16).permute(3, 0, 2, 4, 1).contiguous()
 
 
 def _pack_generic(convs, norms, skip=None, relu=True, device="cuda"):
@@ -168,6 +174,8 @@ class WindowEngine:
         self._cnn_out = None
         self._img_stream = None
         self._net_f = self._cnn_f = None
+        import os
+        self.fuse_convs = os.environ.get("DAGR_FUSE_CONVS", "1") != "0"
         self._prepare(bb, head)
         self.max_events = 0
         self._alloc_events(int(max_events))
@@ -315,6 +323,13 @@ class WindowEngine:
     def _conv_generic(self, lvl, pack, x, ldx, xskip, ldskip, out, ldo, dom, stream):
         L = self.L
         P = _lib.ptr
+        if self.fuse_convs and L.dagr_spline_conv_fused_lds_bytes(pack.cin, pack.cskip) <= 160 * 1024:
+            # tap aggregation + contraction in one launch (A tile lives in LDS)
+            _lib.check(L.dagr_spline_conv_fused(P(lvl.counts), lvl.T, P(lvl.rowptr), P(lvl.col), P(lvl.code), x, ldx,
+                                                pack.cin, xskip, ldskip, pack.cskip, dom["rx"], dom["ry"], dom["den_x"],
+                                                dom["den_y"], P(pack.Wq), P(pack.bias), out, ldo, pack.N,
+                                                1 if pack.relu else 0, stream), "spline_conv_fused")
+            return
         lda = (pack.K + 3) // 4 * 4    # 16-byte aligned rows for the MFMA GEMM's float4 loads
         _lib.check(L.dagr_spline_tap_aggregate(P(lvl.counts), lvl.T, P(lvl.rowptr), P(lvl.col), P(lvl.code),
                                                x, ldx, pack.cin, xskip, ldskip, pack.cskip, dom["rx"], dom["ry"],

@@ -187,6 +187,17 @@ int dagr_spline_tap_aggregate(const int32_t *n_nodes_ptr, int32_t n_nodes_max, c
                               int32_t cin, const float *xskip, int32_t ldskip, int32_t cskip,
                               int32_t rx, int32_t ry, float den_x, float den_y,
                               float *A, int32_t lda, void *stream);
+/* fused steps 1+2 for K = 26*cin + cskip small enough to keep 16 aggregated rows in LDS
+ * (dagr_spline_conv_fused_lds_bytes(cin, cskip) <= 160 KiB): no A matrix in HBM, one launch.
+ * Wq = the [K, N] matrix of dagr_gemm_bias_act re-packed on the host into MFMA operand order:
+ *   Wq[c][g][l][j] = W[16 g + 4 j + (l >> 4)][16 c + (l & 15)],  c < ceil(N/16), g < ceil(K/16), l < 64, j < 4,
+ * zero outside [K, N]; 16-byte aligned. */
+size_t dagr_spline_conv_fused_lds_bytes(int32_t cin, int32_t cskip);
+int dagr_spline_conv_fused(const int32_t *n_nodes_ptr, int32_t n_nodes_max, const int32_t *rowptr,
+                           const int32_t *col, const int32_t *code, const float *x, int32_t ldx, int32_t cin,
+                           const float *xskip, int32_t ldskip, int32_t cskip, int32_t rx, int32_t ry,
+                           float den_x, float den_y, const float *Wq, const float *bias, float *C, int32_t ldc,
+                           int32_t N, int32_t relu, void *stream);
 /* generic step 2: C[M,N] = act(A[M,K] . Wm[K,N] + bias[N]); M = min(*m_ptr, m_max) */
 int dagr_gemm_bias_act(const int32_t *m_ptr, int32_t m_max, const float *A, int32_t lda,
                        const float *Wm, int32_t ldw, const float *bias, float *C, int32_t ldc,
