@@ -145,7 +145,7 @@ hipError_t launch_gemm_mfma(const int32_t *m_ptr, int m_max, const float *A, int
 // A workgroup owns 16 destination nodes.  Phase A: wave w aggregates node w's taps straight into the block's
 // LDS A-tile [16][K] (same arithmetic and order as k_tap_aggregate, spline_conv.hip): the [T, 26*Cin] matrix
 // never goes to HBM and 16 of the 32 launches per step disappear.  Phase B: the 16 x K x N contraction with
-// v_mfma_f32_16x16x4_f32, A operands read from the tile (row stride = 4 mod 32: conflict-free), weights read
+// v_mfma_f32_16x16x4_f32, A operands read from the tile (row stride = 2 mod 32: conflict-free), weights read
 // straight from L2 (no reuse inside a block), 4 wave quads split K, fixed-order reduction.  Column blocks
 // of 64 are looped inside the same workgroup.
 namespace dagr {
@@ -179,7 +179,9 @@ __global__ __launch_bounds__(kGemmThreads) void k_conv_fused(
     float *At = fl;                                  // [16][KP], columns K..KP-1 zero
     float *red = fl + 16 * KP;                       // [KSPLIT][16][NB] split-K partials
     const int m0 = blockIdx.x * 16;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: loop bounds below stay in SGPRs
+    constexpr int U = 4;
     // rowptr has n_max + 1 entries: read it before the device-side bound is known (one latency, not two)
     const int n_spec = min(m0 + wv, n_max - 1);
     const int e0 = rowptr[n_spec], e1s = rowptr[n_spec + 1];
@@ -256,39 +258,56 @@ __global__ __launch_bounds__(kGemmThreads) void k_conv_fused(
     const int kk = lane >> 4, nn = lane & 15;
     const int G = (K + 15) / 16, Gq = (G + ksplit - 1) / ksplit;
     const int gbeg = ks * Gq, gend = min(G, gbeg + Gq);
+    const int nfull = max(0, gend - gbeg) / U;              // wave-uniform (wv is scalar)
     const float *a_rd = At + nn * KP + kk;
-    constexpr int U = 4;
     const int n_first = (NC == 4) ? 0 : (int)blockIdx.y * NBc;
     const int n_last = (NC == 4) ? N : min(N, n_first + NBc);
     for (int n0 = n_first; n0 < n_last; n0 += NBc) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         if (n0 + w * 16 < N) {
             const float4 *wq = reinterpret_cast<const float4 *>(Wq) + ((size_t)(n0 / 16 + w) * G) * 64 + lane;
-            float4 b[U], bn[U];
-            auto load_b = [&](float4 *dst, int g0) {
+            auto load_b = [&](float4(&dst)[U], int g0) {
 #pragma unroll
-                for (int u = 0; u < U; u++) dst[u] = wq[(size_t)min(g0 + u, G - 1) * 64];
+                for (int u = 0; u < U; u++) dst[u] = wq[(size_t)(g0 + u) * 64];
             };
-            if (gbeg < gend) load_b(b, gbeg);
-            for (int g0 = gbeg; g0 < gend; g0 += U) {
-                const bool more = g0 + U < gend;
-                if (more) load_b(bn, g0 + U);
+            // U groups = 16 k-steps: all A operands are read from the tile first, then the MFMAs run back to back
+            auto mac = [&](const float4(&b)[U], int g0) {
+                float a[U][4];
+                const float *ap = a_rd + 16 * g0;
+#pragma unroll
+                for (int u = 0; u < U; u++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) a[u][j] = ap[16 * u + 4 * j];
 #pragma unroll
                 for (int u = 0; u < U; u++) {
-                    if (g0 + u < gend) {       // wave-uniform
-                        const float *ap = a_rd + 16 * (g0 + u);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[0], b[u].x, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4], b[u].y, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[8], b[u].z, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[12], b[u].w, acc, 0, 0, 0);
-                    }
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][0], b[u].x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][1], b[u].y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][2], b[u].z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][3], b[u].w, acc1, 0, 0, 0);
                 }
-                if (more) {
-#pragma unroll
-                    for (int u = 0; u < U; u++) b[u] = bn[u];
+            };
+            float4 b0[U], b1[U];
+            int g = gbeg;
+            if (nfull > 0) load_b(b0, g);
+            for (int it = 0; it < nfull; it += 2) {     // ping-pong: no register copies between batches
+                if (it + 1 < nfull) load_b(b1, g + U);
+                mac(b0, g);
+                if (it + 1 < nfull) {
+                    if (it + 2 < nfull) load_b(b0, g + 2 * U);
+                    mac(b1, g + U);
                 }
+                g += 2 * U;
+            }
+            for (g = gbeg + nfull * U; g < gend; g++) {   // < U left-over groups
+                const float4 bt = wq[(size_t)g * 64];
+                const float *ap = a_rd + 16 * g;
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[0], bt.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4], bt.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[8], bt.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[12], bt.w, acc1, 0, 0, 0);
             }
         }
+        const f32x4 acc = {acc0[0] + acc1[0], acc0[1] + acc1[1], acc0[2] + acc1[2], acc0[3] + acc1[3]};
         float *rd = red + ks * 16 * NBc;
 #pragma unroll
         for (int q = 0; q < 4; q++) rd[(kk * 4 + q) * NBc + w * 16 + nn] = acc[q];
@@ -323,7 +342,7 @@ extern "C" int dagr_spline_conv_fused(const int32_t *n_nodes_ptr, int32_t n_node
     DAGR_CHECK_ARG(cskip == 0 || xskip, "xskip is NULL");
     DAGR_CHECK_ARG(((uintptr_t)Wq % 16) == 0, "packed weights must be 16-byte aligned");
     const int K = 26 * cin + cskip;
-    const int KP = (K + 31) / 32 * 32 + 4;        // >= K + 4 and = 4 (mod 32): bank = 4*row + k, conflict-free
+    const int KP = (K + 1 + 31) / 32 * 32 + 2;    // >= K + 3 and = 2 (mod 32): bank = 2*row + k, conflict-free per half-wave
     const size_t lds_bytes = ((size_t)16 * KP + (size_t)KSPLIT * 16 * NB) * 4;
     if (lds_bytes > 160 * 1024) {
         set_error("dagr_spline_conv_fused: K too large for the LDS tile (use tap_aggregate + gemm)");
@@ -348,6 +367,6 @@ extern "C" int dagr_spline_conv_fused(const int32_t *n_nodes_ptr, int32_t n_node
 extern "C" size_t dagr_spline_conv_fused_lds_bytes(int32_t cin, int32_t cskip) {
     using namespace dagr;
     const int K = 26 * cin + cskip;
-    const int KP = (K + 31) / 32 * 32 + 4;
+    const int KP = (K + 1 + 31) / 32 * 32 + 2;
     return ((size_t)16 * KP + (size_t)KSPLIT * 16 * NB) * 4;
 }

@@ -54,7 +54,7 @@ def test_fused_and_unfused_match_float64(T, cin, cskip, N, max_deg, relu):
     L = _lib.lib()
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(T * 131 + cin)
-    r, den = 7, (3.5, 2.75)
+    r, den = 7, (14.0, 17.5)      # den >= 2 r keeps the pseudo-coordinate inside [0, 1] (cartesian(), oracle/ops.py:17)
     deg = rng.integers(0, max_deg + 1, size=T)
     rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
     E = int(rowptr[-1])
@@ -119,5 +119,5 @@ def test_fused_rejects_oversized_k():
     z = torch.zeros(64, dtype=torch.int32, device=dev)
     f = torch.zeros(4096, dtype=torch.float32, device=dev)
     rc = L.dagr_spline_conv_fused(None, 1, _lib.ptr(z), _lib.ptr(z), _lib.ptr(z), _lib.ptr(f), 130, 130, None, 0, 0, 7, 7,
-                                  3.5, 3.5, _lib.ptr(f), None, _lib.ptr(f), 64, 64, 1, _lib.cur_stream(dev))
+                                  14.0, 14.0, _lib.ptr(f), None, _lib.ptr(f), 64, 64, 1, _lib.cur_stream(dev))
     assert rc != 0 and b"too large" in L.dagr_last_error()
