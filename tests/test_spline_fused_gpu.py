@@ -45,6 +45,7 @@ CASES = [  # T, cin, cskip, N, max_deg, relu
     (300, 16, 0, 21, 5, True),        # narrow, odd N (column-split mode)
     (5000, 82, 0, 64, 8, True),       # cin > 64 (two channel chunks), K = 2132
     (16, 3, 5, 7, 0, True),           # no edges at all
+    (200, 64, 0, 200, 6, False),      # N > 128: four column blocks
 ]
 
 
