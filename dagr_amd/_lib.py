@@ -72,7 +72,7 @@ SIGNATURES = {
     "dagr_pool_workspace_init": (ctypes.c_int, [ctypes.POINTER(PoolDesc), c_void_p, c_size_t, c_void_p]),
     "dagr_pool_l0": (ctypes.c_int, [ctypes.POINTER(PoolDesc), c_void_p, ctypes.POINTER(GraphDesc), c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_i32, c_i64,
-                                    c_void_p,
+                                    c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_void_p]),
     "dagr_pool_csr": (ctypes.c_int, [ctypes.POINTER(PoolDesc), c_void_p, c_void_p, c_i32, c_void_p, c_i32, c_void_p,

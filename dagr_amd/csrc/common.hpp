@@ -132,5 +132,6 @@ hipError_t launch_gemm_mfma(const int32_t *m_ptr, int m_max, const float *A, int
                             const float *bias, float *C, int ldc, int K, int N, int relu, hipStream_t stream);
 const int32_t *graph_ws_node_count(const dagr_graph_desc *desc, void *workspace);
 void graph_ws_views(const dagr_graph_desc *desc, void *workspace, const int32_t **start, const int2 **slot_it);
+const int32_t *graph_ws_slot_xyb(const dagr_graph_desc *desc, void *workspace);
 
 }  // namespace dagr

@@ -746,6 +746,11 @@ void graph_ws_views(const dagr_graph_desc *desc, void *workspace, const int32_t 
     *start = ws.start;
     *slot_it = ws.slot_it;
 }
+const int32_t *graph_ws_slot_xyb(const dagr_graph_desc *desc, void *workspace) {
+    GraphWs ws;
+    carve(*desc, (char *)workspace, &ws);
+    return ws.slot_xyb;
+}
 const int32_t *graph_ws_node_count(const dagr_graph_desc *desc, void *workspace) {
     GraphWs ws;
     carve(*desc, (char *)workspace, &ws);

@@ -20,12 +20,15 @@
 //     (atomicCAS), then one wave per cluster sorts its row; rows -> CSR; each edge gets the integer
 //     LUT coordinate the next SplineConv needs, computed with the reference's float formula
 //     (T.Cartesian then spline_conv.py:41-42).
+#include <climits>
+
 #include "common.hpp"
 
 namespace dagr {
 namespace {
 
 constexpr int kRowSlots = 64;           // coarse in-degree bound per cluster (flagged if exceeded)
+constexpr int kLeakCap = 8192;          // in-edges of t == 1.0 nodes handled apart (beyond: generic path)
 constexpr int kMaxChunks = 9;           // up to 144 feature channels at level 0
 constexpr double kPosScale = 1099511627776.0;  // 2^40
 constexpr double kFeatScale = 4294967296.0;    // 2^32
@@ -40,7 +43,9 @@ struct PoolWs {
     long long *xacc;     // [T][C]: ordered-int max (low 32 bits) or fixed-point sum
     int32_t *rows;       // [T][64] source-cluster sets, -1 = empty
     int32_t *rowcnt;     // [T+1]
-    int32_t *status;     // [4]: 0 flags
+    int32_t *status;     // [4]: 0 flags (sticky); 1 = bitmap path not applicable to this window, 2 = #leak_edges (cleared by rearm)
+    int32_t *nbmask;     // [T] level 0: 5x5 bitmap of neighbouring source cells, zero between calls
+    int2 *leak_edges;    // [kLeakCap] level 0: (dst raw, src raw) of the in-edges of t == 1.0 nodes; count = status[2]
 };
 
 __host__ __device__ inline size_t pool_carve(const dagr_pool_desc &d, char *base, PoolWs *ws) {
@@ -62,6 +67,8 @@ __host__ __device__ inline size_t pool_carve(const dagr_pool_desc &d, char *base
     w.rows = (int32_t *)take(T * (size_t)kRowSlots * 4);
     w.rowcnt = (int32_t *)take((T + 9) * 4);
     w.status = (int32_t *)take(16);
+    w.nbmask = (int32_t *)take((T + 9) * 4);
+    w.leak_edges = (int2 *)take((size_t)kLeakCap * 8);
     if (ws) *ws = w;
     return off;
 }
@@ -135,41 +142,115 @@ __global__ __launch_bounds__(kBlock) void k_pool_accumulate(dagr_pool_desc d, co
 }
 
 // ---------------------------------------------------------------------------------------------
-// level 0: one wave per source voxel (cx, cy, b); 4 events in flight (16 lanes = 16 channels each)
+// level 0: one wave per source voxel (cx, cy, b).  The voxel's members are the slot runs of its pixel rows
+// (CSR-by-pixel): the row bounds are fetched by one lane per row in a single round, prefix-summed, and the
+// members are then walked as one flat list, 8 in flight (4 lane groups x 2, 16 lanes = 16 channels / 16
+// neighbour slots each) -- walking row by row instead costs two dependent HBM latencies per pixel row.
+template <int MC>   // accumulator chunks of 16 channels held in registers
 __global__ __launch_bounds__(kBlock) void k_pool_l0_cells(dagr_pool_desc d, int W, int H,
                                                          const int32_t *__restrict__ xlo,  // [gx+1] pixel bounds
                                                          const int32_t *__restrict__ ylo,  // [gy+1]
                                                          const int32_t *__restrict__ start,
                                                          const int2 *__restrict__ slot_it,
                                                          const float *__restrict__ x, int ldx,
-                                                         const float *__restrict__ pos, PoolWs ws) {
-    const int lane = threadIdx.x & 63, l = lane & 15, g = lane >> 4;
-    const int cell = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+                                                         const float *__restrict__ pos, PoolWs ws,
+                                                         // coarse-edge fast path (NULL = off): neighbour offset codes
+                                                         const int16_t *__restrict__ nbr_code,
+                                                         const int32_t *__restrict__ nbr_src,
+                                                         const int32_t *__restrict__ deg,
+                                                         const int32_t *__restrict__ slot_xyb, int K, int r) {
+    __shared__ int s_a[kBlock / 64][64], s_off[kBlock / 64][65];
+    const int lane = threadIdx.x & 63, l = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+    const int cell = blockIdx.x * (kBlock / 64) + wv;
     const int ncell = d.gx * d.gy * d.batch_size;
     if (cell >= ncell) return;
     const int cx = cell % d.gx, cy = (cell / d.gx) % d.gy, b = cell / (d.gx * d.gy);
     const int x0 = xlo[cx], x1 = xlo[cx + 1] - 1, y0 = ylo[cy], y1 = ylo[cy + 1] - 1;
     const int C = d.channels;
     const int nchk = (C + 15) >> 4;
-    float mx[kMaxChunks];
-    double sm[kMaxChunks];
+    float mx[MC];
+    double sm[MC];
 #pragma unroll
-    for (int c = 0; c < kMaxChunks; c++) { mx[c] = -INFINITY; sm[c] = 0.0; }
+    for (int c = 0; c < MC; c++) { mx[c] = -INFINITY; sm[c] = 0.0; }
     long long ps0 = 0, ps1 = 0, ps2 = 0;
     int cnt = 0, pmax = -1;
     const int raw = cx + d.gx * (cy + d.gy * b);
-    if (x1 >= x0) {
-        for (int y = y0; y <= y1; y++) {
-            const int base = W * (y + H * b);
-            const int a = start[base + x0], bnd = start[base + x1 + 1];
-            for (int s = a + g; s < bnd; s += 4) {
+    // Coarse edges without a hash set: a source lies within r pixels of its destination, r <= 2 cells (checked by
+    // the caller), so the source cells of this voxel's in-edges form a 5x5 bitmap around it.  Lower pixel bounds
+    // of the cells cx-1 .. cx+2 (and rows): the source's cell = cx-2 + #(bounds <= its pixel).
+    int nbm = 0;
+    int bx[4], by[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int qx = cx - 1 + i, qy = cy - 1 + i;
+        bx[i] = qx <= 0 ? INT_MIN : (qx >= d.gx ? INT_MAX : xlo[qx]);
+        by[i] = qy <= 0 ? INT_MIN : (qy >= d.gy ? INT_MAX : ylo[qy]);
+    }
+    const int side = 2 * r + 1;
+    const int side_magic = (65536 + side - 1) / side;   // code / side == (code * magic) >> 16 for code * side < 65536
+    const int cells = d.gx * d.gy;
+    const int ny = (x1 >= x0) ? y1 - y0 + 1 : 0;
+    for (int yb = 0; yb < ny; yb += 64) {
+        // row bounds of up to 64 pixel rows, one lane each; exclusive scan of the run lengths
+        int a = 0, len = 0;
+        if (yb + lane < ny) {
+            const int base = W * (y0 + yb + lane + H * b);
+            a = start[base + x0];
+            len = start[base + x1 + 1] - a;
+        }
+        int incl = len;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        const int total = __shfl(incl, 63, 64);
+        __builtin_amdgcn_wave_barrier();   // previous chunk's readers are done
+        s_a[wv][lane] = a;
+        s_off[wv][lane] = incl - len;
+        if (lane == 63) s_off[wv][64] = total;
+        __builtin_amdgcn_wave_barrier();
+        for (int i0 = 0; i0 < total; i0 += 8) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int i = i0 + 4 * h + g;
+                if (i >= total) continue;
+                // row of member i: the last j with off[j] <= i (empty rows share their successor's offset)
+                int j = 0;
+#pragma unroll
+                for (int st = 32; st >= 1; st >>= 1)
+                    if (s_off[wv][j + st] <= i) j += st;
+                const int s = s_a[wv][j] + (i - s_off[wv][j]);
+                const int y = y0 + yb + j;
                 const int id = slot_it[s].x;   // event id: only for consecutive_cluster's `perm`
                 const float px = pos[3 * (size_t)s], py = pos[3 * (size_t)s + 1], pt = pos[3 * (size_t)s + 2];
-                if (pt >= 1.0f) {
+                const bool leak = pt >= 1.0f;
+                if (nbr_code && l < deg[s]) {
+                    const int code = nbr_code[(size_t)s * K + l];
+                    const int ox = (code * side_magic) >> 16, oy = code - ox * side;
+                    const int xs = (slot_xyb[s] & 4095) + ox - r, ys = y + oy - r;
+                    const int dcx = (xs >= bx[0]) + (xs >= bx[1]) + (xs >= bx[2]) + (xs >= bx[3]);   // 0..4, 2 = own cell
+                    const int dcy = (ys >= by[0]) + (ys >= by[1]) + (ys >= by[2]) + (ys >= by[3]);
+                    if (!leak) {
+                        nbm |= 1 << (dcy * 5 + dcx);
+                    } else {
+                        // QUIRK-1: a t == 1.0 node belongs to cluster raw + gx*gy, so its in-edges are not this
+                        // voxel's; its sources may be t == 1.0 nodes themselves.  Few per window: listed apart.
+                        const int src = nbr_src[(size_t)s * K + l];
+                        const int rs = raw + (dcx - 2) + d.gx * (dcy - 2) + (pos[3 * (size_t)src + 2] >= 1.0f ? cells : 0);
+                        const int rdst = raw + cells;
+                        if (rs != rdst) {
+                            const int at = atomicAdd(&ws.status[2], 1);
+                            if (at < kLeakCap) ws.leak_edges[at] = make_int2(rdst, rs);
+                            else ws.status[1] = 1;   // pathological window: generic path
+                        }
+                    }
+                }
+                if (leak) {
                     // QUIRK-1: t == 1.0 lands in the next sample's id range -> rare, atomics
-                    const int rl = raw + d.gx * d.gy;
+                    const int rl = raw + cells;
 #pragma unroll
-                    for (int c = 0; c < kMaxChunks; c++) {
+                    for (int c = 0; c < MC; c++) {
                         const int ch = c * 16 + l;
                         if (c < nchk && ch < C) {
                             const float v = x[(size_t)s * ldx + ch];
@@ -194,7 +275,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_l0_cells(dagr_pool_desc d, int 
                     continue;
                 }
 #pragma unroll
-                for (int c = 0; c < kMaxChunks; c++) {
+                for (int c = 0; c < MC; c++) {
                     const int ch = c * 16 + l;
                     if (c < nchk && ch < C) {
                         const float v = x[(size_t)s * ldx + ch];
@@ -214,7 +295,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_l0_cells(dagr_pool_desc d, int 
 #pragma unroll
     for (int off = 16; off < 64; off <<= 1) {
 #pragma unroll
-        for (int c = 0; c < kMaxChunks; c++) {
+        for (int c = 0; c < MC; c++) {
             if (c < nchk) {
                 mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], off, 64));
                 sm[c] += __shfl_xor(sm[c], off, 64);
@@ -226,11 +307,17 @@ __global__ __launch_bounds__(kBlock) void k_pool_l0_cells(dagr_pool_desc d, int 
         cnt += __shfl_xor(cnt, off, 64);
         pmax = max(pmax, __shfl_xor(pmax, off, 64));
     }
+    if (nbr_code) {
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) nbm |= __shfl_xor(nbm, off, 64);
+        nbm &= ~(1 << 12);   // own cell
+        if (lane == 0 && nbm) ws.nbmask[raw] = nbm;
+    }
     if (cnt > 0 && g == 0) {
         // this wave is the only non-atomic writer of slot `raw`; leak events of sample b-1 may hit it
         // concurrently with atomics, so merge with atomics as well (exactly-once per channel).
 #pragma unroll
-        for (int c = 0; c < kMaxChunks; c++) {
+        for (int c = 0; c < MC; c++) {
             const int ch = c * 16 + l;
             if (c < nchk && ch < C) {
                 if (d.aggr == 0)
@@ -257,9 +344,9 @@ __global__ __launch_bounds__(kBlock) void k_pool_l0_event_cluster(dagr_pool_desc
                                                                  const int32_t *__restrict__ batch32,
                                                                  const int64_t *__restrict__ batch64,
                                                                  int32_t *__restrict__ cluster_raw_out,
-                                                                 int32_t *__restrict__ status) {
+                                                                 int32_t *__restrict__ status, int only_if_leak) {
     const int n = blockIdx.x * kBlock + threadIdx.x;
-    if (n >= N) return;
+    if (n >= N || (only_if_leak && status[1] == 0)) return;
     bool ok;
     const int b = batch32 ? batch32[n] : (int)batch64[n];
     const int raw = cluster_raw(pos[3 * (size_t)n], pos[3 * (size_t)n + 1], pos[3 * (size_t)n + 2], b, d, ok);
@@ -326,6 +413,8 @@ __global__ __launch_bounds__(kBlock) void k_pool_rearm(int T, PoolWs ws) {
     if (raw >= T) return;
     ws.cnt[raw] = 0;
     ws.perm[raw] = -1;
+    ws.nbmask[raw] = 0;
+    if (raw == 0) { ws.status[1] = 0; ws.status[2] = 0; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -347,6 +436,52 @@ __device__ __forceinline__ void row_insert(int32_t *__restrict__ rows, int cd, i
     atomicOr(status, 2);  // more than 64 distinct sources
 }
 
+// level 0 fast path: the 5x5 source-cell bitmaps of k_pool_l0_cells -> slot sets (one thread per cell).
+// In-edges of t == 1.0 nodes (their cluster ids leave the pixel grid, QUIRK-1) come from k_rows_from_leaks.
+__global__ __launch_bounds__(kBlock) void k_rows_from_masks(dagr_pool_desc d, PoolWs ws) {
+    const int raw = blockIdx.x * kBlock + threadIdx.x;
+    const int ncell = d.gx * d.gy * d.batch_size;
+    if (raw >= ncell || ws.status[1] != 0) return;
+    int m = ws.nbmask[raw];
+    if (m == 0) return;
+    int32_t *row = ws.rows + (size_t)ws.newid[raw] * kRowSlots;
+    int i = 0;
+    while (m) {
+        const int bit = __ffs(m) - 1;
+        m &= m - 1;
+        const int dcx = bit % 5 - 2, dcy = bit / 5 - 2;
+        row[i++] = ws.newid[raw + dcx + d.gx * dcy];
+    }
+}
+
+// ... plus the listed in-edges of t == 1.0 nodes (a handful to a few hundred per window): one thread per listed
+// edge.  The first occurrence of a (dst, src) pair owns the insertion, so concurrent threads always hold
+// distinct values: scan the row for the value (the bitmap kernel may have stored it), else claim the first
+// empty slot with a CAS and move on if another thread took it.
+__global__ __launch_bounds__(kBlock) void k_rows_from_leaks(PoolWs ws) {
+    __shared__ int2 lst[kLeakCap];   // 64 KiB: the part of the list this workgroup has to look back over
+    if (ws.status[1] != 0) return;
+    const int n = min(ws.status[2], kLeakCap);
+    const int i0 = blockIdx.x * kBlock;
+    if (i0 >= n) return;
+    const int need = min(n, i0 + kBlock);
+    for (int j = threadIdx.x; j < need; j += kBlock) lst[j] = ws.leak_edges[j];
+    __syncthreads();
+    const int i = i0 + threadIdx.x;
+    if (i >= n) return;
+    const int2 e = lst[i];
+    for (int j = 0; j < i; j++)
+        if (lst[j].x == e.x && lst[j].y == e.y) return;
+    const int cs = ws.newid[e.y];
+    int32_t *row = ws.rows + (size_t)ws.newid[e.x] * kRowSlots;
+    for (int k = 0; k < kRowSlots; k++) {
+        int cur = __hip_atomic_load(&row[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == -1) cur = atomicCAS(&row[k], -1, cs);
+        if (cur == -1 || cur == cs) return;
+    }
+    atomicOr(&ws.status[0], 2);
+}
+
 // level 0: fixed-stride neighbour lists.  Nodes are in pixel order, so a workgroup sweeping a contiguous
 // run of nodes sees the same few (source cluster -> destination cluster) pairs over and over: a small
 // LDS cache of recently inserted pairs filters them, each distinct pair of a wave is then inserted once
@@ -355,7 +490,8 @@ __global__ __launch_bounds__(kBlock) void k_coarse_edges_ell(int N, int K, const
                                                             const int32_t *__restrict__ deg,
                                                             const int32_t *__restrict__ cluster_raw_in,
                                                             const int32_t *__restrict__ newid, int32_t *rows,
-                                                            int32_t *status) {
+                                                            int32_t *status, int only_if_leak) {
+    if (only_if_leak && status[1] == 0) return;   // the bitmap path covers this window
     __shared__ unsigned long long seen[256];
     seen[threadIdx.x] = ~0ull;
     __syncthreads();
@@ -511,6 +647,7 @@ int dagr_pool_workspace_init(const dagr_pool_desc *desc, void *workspace, size_t
     DAGR_CHECK_HIP(hipMemsetAsync(ws.rows, 0xff, T * (size_t)kRowSlots * 4, stream));
     DAGR_CHECK_HIP(hipMemsetAsync(ws.rowcnt, 0, (T + 9) * 4, stream));
     DAGR_CHECK_HIP(hipMemsetAsync(ws.status, 0, 16, stream));
+    DAGR_CHECK_HIP(hipMemsetAsync(ws.nbmask, 0, (T + 9) * 4, stream));
     // feature accumulators: ordered-int minimum for max, 0 for mean
     {
         const size_t n = T * (size_t)desc->channels;
@@ -546,7 +683,7 @@ static int pool_tail(const dagr_pool_desc *d, PoolWs &ws, const int32_t *batch32
 int dagr_pool_l0(const dagr_pool_desc *desc, void *pool_ws, const dagr_graph_desc *gdesc, void *graph_ws,
                  const int32_t *xlo, const int32_t *ylo, const float *x, int32_t ldx, const float *pos,
                  const int32_t *batch_nodes, const void *batch, int32_t batch_is_int64, int64_t N,
-                 const int32_t *nbr_src, const int32_t *deg,
+                 const int32_t *nbr_src, const int16_t *nbr_code, const int32_t *deg,
                  int32_t *cluster_scratch, float *x_out, int32_t ldo, int32_t xoff, float *pos_out,
                  int32_t *batch_out, int32_t *n_out, int32_t *rowptr_out, int32_t *col_out, int32_t *code_out,
                  int32_t *e_out, int32_t e_cap, void *stream_) {
@@ -562,13 +699,27 @@ int dagr_pool_l0(const dagr_pool_desc *desc, void *pool_ws, const dagr_graph_des
     const int T = desc->gx * desc->gy * (desc->batch_size + 1);
     const int32_t *b32 = batch_is_int64 ? nullptr : (const int32_t *)batch;
     const int64_t *b64 = batch_is_int64 ? (const int64_t *)batch : nullptr;
+    // coarse edges from per-cell bitmaps when a source can be at most two cells away from its destination
+    // (cells are floor or ceil of W*vx pixels wide) and the neighbour lists carry their offset codes
+    const int K = gdesc->max_neighbors;
+    const int cell_w = (int)floorf(desc->vx * (float)gdesc->width), cell_h = (int)floorf(desc->vy * (float)gdesc->height);
+    const bool fast_edges = nbr_code != nullptr && K <= 16 && gdesc->radius <= 2 * std::min(cell_w, cell_h) &&
+                            gdesc->width <= 4096;
     if (N > 0) {
         DAGR_CHECK_ARG(xlo && ylo && x && pos && batch_nodes && batch && nbr_src && deg && cluster_scratch, "NULL input");
         const int32_t *start; const int2 *slot_it;
         graph_ws_views(gdesc, graph_ws, &start, &slot_it);
         const int ncell = desc->gx * desc->gy * desc->batch_size;
-        k_pool_l0_cells<<<(unsigned)ceil_div(ncell, kBlock / 64), kBlock, 0, stream>>>(
-            *desc, gdesc->width, gdesc->height, xlo, ylo, start, slot_it, x, ldx, pos, ws);
+        const int nchk = (desc->channels + 15) / 16;
+#define DAGR_POOL_L0(MC)                                                                                              \
+    k_pool_l0_cells<MC><<<(unsigned)ceil_div(ncell, kBlock / 64), kBlock, 0, stream>>>(                               \
+        *desc, gdesc->width, gdesc->height, xlo, ylo, start, slot_it, x, ldx, pos, ws, fast_edges ? nbr_code : nullptr, \
+        nbr_src, deg, graph_ws_slot_xyb(gdesc, graph_ws), K, gdesc->radius)
+        if (nchk <= 1) DAGR_POOL_L0(1);
+        else if (nchk <= 2) DAGR_POOL_L0(2);
+        else if (nchk <= 5) DAGR_POOL_L0(5);
+        else DAGR_POOL_L0(kMaxChunks);
+#undef DAGR_POOL_L0
         DAGR_CHECK_LAUNCH();
     }
     DAGR_CHECK_HIP(exclusive_scan_i32(ws.occupied, ws.newid, T + 1, ws.scan_tmp, true, stream));
@@ -576,15 +727,23 @@ int dagr_pool_l0(const dagr_pool_desc *desc, void *pool_ws, const dagr_graph_des
         *desc, ws, b32, b64, x_out, ldo, xoff, pos_out, batch_out, n_out);
     DAGR_CHECK_LAUNCH();
     if (N > 0) {
-        k_pool_l0_event_cluster<<<(unsigned)ceil_div(N, kBlock), kBlock, 0, stream>>>(*desc, (int)N, pos, batch_nodes,
-                                                                                   nullptr, cluster_scratch, ws.status);
+        // generic path: always when the bitmaps are off, else only for windows that overflow the t == 1.0 edge list
+        // (device-side flag, no host sync: the kernels return at once otherwise)
+        k_pool_l0_event_cluster<<<(unsigned)ceil_div(N, kBlock), kBlock, 0, stream>>>(
+            *desc, (int)N, pos, batch_nodes, nullptr, cluster_scratch, ws.status, fast_edges ? 1 : 0);
         DAGR_CHECK_LAUNCH();
-        const int K = gdesc->max_neighbors;
         DAGR_CHECK_ARG(K <= kBlock, "max_neighbors too large");
         const unsigned gE = round_grid8(std::min<int64_t>(ceil_div(N, kBlock / K), 256 * 8));
         k_coarse_edges_ell<<<gE, kBlock, 0, stream>>>((int)N, K, nbr_src, deg, cluster_scratch, ws.newid, ws.rows,
-                                                      ws.status);
+                                                      ws.status, fast_edges ? 1 : 0);
         DAGR_CHECK_LAUNCH();
+        if (fast_edges) {
+            const int ncell = desc->gx * desc->gy * desc->batch_size;
+            k_rows_from_masks<<<(unsigned)ceil_div(ncell, kBlock), kBlock, 0, stream>>>(*desc, ws);
+            DAGR_CHECK_LAUNCH();
+            k_rows_from_leaks<<<(unsigned)ceil_div(kLeakCap, kBlock), kBlock, 0, stream>>>(ws);
+            DAGR_CHECK_LAUNCH();
+        }
     }
     return pool_tail(desc, ws, b32, b64, x_out, ldo, xoff, pos_out, batch_out, n_out, rowptr_out, col_out, code_out,
                      e_out, e_cap, stream);

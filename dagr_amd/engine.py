@@ -176,6 +176,7 @@ class WindowEngine:
         self._net_f = self._cnn_f = None
         import os
         self.fuse_convs = os.environ.get("DAGR_FUSE_CONVS", "1") != "0"
+        self.fast_coarse_edges = os.environ.get("DAGR_FAST_COARSE_EDGES", "1") != "0"
         self._prepare(bb, head)
         self.max_events = 0
         self._alloc_events(int(max_events))
@@ -482,8 +483,8 @@ class WindowEngine:
         b64 = 1 if self._batch.dtype == torch.int64 else 0
         _lib.check(L.dagr_pool_l0(ctypes.byref(d), P(self.pool_ws[0]), ctypes.byref(g.desc), P(g.workspace),
                                   P(self.xlo), P(self.ylo), P(self.hp0), self.hp0.shape[1], P(self.pos_n),
-                                  P(self.batch_n), P(self._batch), b64, self._N, P(nbr_src), P(deg),
-                                  P(self.cluster0), P(l1.x),
+                                  P(self.batch_n), P(self._batch), b64, self._N, P(nbr_src),
+                                  P(nbr_code) if self.fast_coarse_edges else None, P(deg), P(self.cluster0), P(l1.x),
                                   l1.x.shape[1], 0, P(l1.pos), P(l1.batch), P(l1.counts), P(l1.rowptr), P(l1.col),
                                   P(l1.code), ctypes.c_void_p(l1.counts.data_ptr() + 4), l1.e_cap,
                                   _lib.cur_stream(self.device)), "pool_l0")

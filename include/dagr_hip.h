@@ -229,12 +229,16 @@ int dagr_pool_workspace_init(const dagr_pool_desc *desc, void *workspace, size_t
 /* level 0: pools the events of the window whose graph was just built on (gdesc, graph_ws).
  * xlo[gx+1] / ylo[gy+1]: first pixel column/row of each voxel (device int32; from the same fp32
  * division as grid_cluster).  x_out rows start at column xoff; outputs sized for
- * T = gx*gy*(B+1) clusters; rowptr_out has T+2 entries; e_cap = capacity of col_out/code_out. */
+ * T = gx*gy*(B+1) clusters; rowptr_out has T+2 entries; e_cap = capacity of col_out/code_out.
+ * nbr_code (the offset codes dagr_graph_build_window wrote next to nbr_src) enables the coarse-edge fast
+ * path: with radius <= 2 voxels the source voxels of a voxel's in-edges are a 5x5 bitmap collected while it
+ * is pooled; windows containing t == 1.0 events (whose cluster ids leave the pixel grid) and NULL fall back
+ * to the generic per-edge set insertion.  Same result either way. */
 int dagr_pool_l0(const dagr_pool_desc *desc, void *pool_ws, const dagr_graph_desc *gdesc, void *graph_ws,
                  const int32_t *xlo, const int32_t *ylo, const float *x, int32_t ldx,
                  const float *pos_nodes, const int32_t *batch_nodes /* node order */,
                  const void *batch, int32_t batch_is_int64 /* event order */, int64_t N,
-                 const int32_t *nbr_src, const int32_t *deg,
+                 const int32_t *nbr_src, const int16_t *nbr_code /* may be NULL */, const int32_t *deg,
                  int32_t *cluster_scratch /*[N]*/, float *x_out, int32_t ldo, int32_t xoff, float *pos_out,
                  int32_t *batch_out, int32_t *n_out, int32_t *rowptr_out, int32_t *col_out, int32_t *code_out,
                  int32_t *e_out, int32_t e_cap, void *stream);

@@ -167,3 +167,35 @@ def _compare_one_scale(args, model, sd, W, H, B, x, y, t, p, b, pos):
     assert out_h.shape == out_o.shape == (B, 35, 105)
     rel = ((out_h.cpu() - out_o).abs() / (1 + out_o.abs())).max().item()
     assert rel < TOL, f"decoded outputs differ by {rel}"
+
+
+def test_coarse_edge_bitmap_and_generic_paths_agree():
+    """pool1's coarse edges: the per-voxel 5x5 bitmap path and the generic per-edge set insertion give the same
+    CSR: on a window without t == 1.0 events, on one whose last events sit at t == 1.0 as the dataset makes them
+    (QUIRK-1: their in-edges go through the side list), and on one where every event does (device-side fallback)."""
+    W, H, B = 320, 215, 2
+    args, model, sd = _setup(W, H, B, seed=4)
+    dev = torch.device("cuda:0")
+    eng = model.engine()
+    x, y, t, p, b, _ = _events(syn.edges_window, 9000, B, W, H, seed=11)
+    last = np.flatnonzero(np.diff(np.concatenate([b, [B]])) != 0)      # last event of every sample
+    for with_leak in (0, 1, 2):
+        tt = np.minimum(t, 999999)
+        if with_leak == 1:
+            tt[last] = 1000000                                            # pos[:, 2] == 1.0 (QUIRK-1)
+        elif with_leak == 2:
+            tt[:] = 1000000                                               # every node: overflows the side list
+        pp = syn.format_data_np(x, y, tt, W, H)
+        assert (pp[:, 2].max() >= 1.0) == (with_leak > 0)
+        snaps = []
+        for fast in (True, False):
+            eng.fast_coarse_edges = fast
+            tr = {}
+            eng.forward_raw(torch.from_numpy(pp).to(dev), torch.from_numpy(p.astype(np.float32)).view(-1, 1).to(dev),
+                            torch.from_numpy(b).to(dev), trace=tr)
+            eng.check_status()
+            snaps.append(tr["pool1"])
+        eng.fast_coarse_edges = True
+        for key in ("rowptr", "col", "code"):
+            assert torch.equal(snaps[0][key], snaps[1][key]), f"pool1 {key} differs (leak={with_leak})"
+        assert snaps[0]["col"].numel() > 1000
