@@ -578,63 +578,97 @@ __global__ __launch_bounds__(kBlock) void k_search_rows(const int32_t *__restric
     const int per_block = (chunk + bpx - 1) / bpx;
     const int n_begin = xcd * chunk + lb * per_block;
     const int n_end = min(min(M, (xcd + 1) * chunk), n_begin + per_block);
-    for (int n = n_begin + grp; n < n_end; n += G) {
-        const int2 me = slot_it[n];
-        const int e = me.x, t = me.y;
-        const int c = slot_xyb[n];
+    // Software pipeline over this lane group's destinations: the dependent chain {id,t | x,y,b} -> row bounds ->
+    // candidates is three HBM latencies; the first two are issued one and two destinations ahead.
+    auto load_node = [&](int n, int2 &me, int &c) {
+        const int nn = min(n, M - 1);
+        me = slot_it[nn];
+        c = slot_xyb[nn];
+    };
+    auto load_rows = [&](int c, int &lo, int &len) {
         const int x = c & 4095, y = (c >> 12) & 4095, b = (c >> 24) & 127;
-        const int64_t row = (int64_t)n * K;
-        // 1. row ranges
-        int lo = 0, len = 0;
-        {
-            const int yn = y + l - r;
-            if (l < side && yn >= 0 && yn < H) {
-                const int base = W * (yn + H * b);
-                lo = start[base + max(x - r, 0)];
-                len = start[base + min(x + r, W - 1) + 1] - lo;
-            }
+        const int yn = y + l - r;
+        lo = 0;
+        len = 0;
+        if (l < side && yn >= 0 && yn < H) {
+            const int base = W * (yn + H * b);
+            lo = start[base + max(x - r, 0)];
+            len = start[base + min(x + r, W - 1) + 1] - lo;
         }
+    };
+    int2 me, me1;
+    int c, c1, lo, len;
+    if (n_begin + grp < n_end) {
+        load_node(n_begin + grp, me, c);
+        load_node(n_begin + grp + G, me1, c1);
+        load_rows(c, lo, len);
+    }
+    for (int n = n_begin + grp; n < n_end; n += G) {
+        // next destinations' loads (results are used one iteration later)
+        int2 me2;
+        int c2, lo1, len1;
+        load_node(n + 2 * G, me2, c2);
+        load_rows(c1, lo1, len1);
+        const int e = me.x, t = me.y;
+        const int x = c & 4095;
+        const int64_t row = (int64_t)n * K;
+        // 1. row ranges: 15 lanes hold the 15 row ranges, a 16-lane scan concatenates them
         const int incl = group16_inclusive_scan(len);
         const int C = __shfl(incl, 15, 16);
+        const int lo_cur = lo, len_cur = len;
+        me = me1; c = c1; me1 = me2; c1 = c2; lo = lo1; len = len1;   // rotate the pipeline
         if (C > kRowCap) {   // defer to the position-centric kernel
             if (l == 0) node_list[atomicAdd(node_list_count, 1)] = n;
             continue;
         }
-        row_lo[grp][l] = lo;
-        row_base[grp][l] = incl - len;
+        row_lo[grp][l] = lo_cur;
+        row_base[grp][l] = incl - len_cur;
         if (l == 15) row_base[grp][16] = C;
         __builtin_amdgcn_wave_barrier();
-        // 2. candidates, 16 at a time
+        // 2. candidates, 16 per round, 4 rounds of loads in flight
         int V = 0;
-        for (int c0 = 0; c0 < C; c0 += 16) {
-            const int ci = c0 + l;
-            bool valid = false;
-            int key = 0, s = 0;
-            if (ci < C) {
-                int rr = 0;
-                if (row_base[grp][rr + 8] <= ci) rr += 8;
-                if (row_base[grp][rr + 4] <= ci) rr += 4;
-                if (row_base[grp][rr + 2] <= ci) rr += 2;
-                if (row_base[grp][rr + 1] <= ci) rr += 1;
-                const int rel = ci - row_base[grp][rr];
-                s = row_lo[grp][rr] + rel;
-                const int2 it = slot_it[s];
-                const int cx = slot_xyb[s];
-                // visible in the FIFO; older than the destination (ev_graph.cu:64); dt <= delta (:69)
-                valid = (cx < 0) && it.x < e && !((float)(t - it.y) > delta_t);
-                const int dx = (cx & 4095) - x;
-                const int rank = sp_rank[rr * 16 + (dx + r)];
-                // spiral rank first, then newest first inside the pixel (larger slot = newer)
-                key = (rank << 20) | (0xFFFFF - rel);
-                // low 8 bits of v_src's partner are not needed: the offset code follows from rank
+        for (int c0 = 0; c0 < C; c0 += 64) {
+            int2 it[4];
+            int cxv[4], sv[4], relv[4], rrv[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int ci = c0 + 16 * q + l;
+                it[q] = make_int2(0, 0);
+                cxv[q] = 0; sv[q] = 0; relv[q] = 0; rrv[q] = 0;
+                if (ci < C) {
+                    int rr = 0;
+                    if (row_base[grp][rr + 8] <= ci) rr += 8;
+                    if (row_base[grp][rr + 4] <= ci) rr += 4;
+                    if (row_base[grp][rr + 2] <= ci) rr += 2;
+                    if (row_base[grp][rr + 1] <= ci) rr += 1;
+                    relv[q] = ci - row_base[grp][rr];
+                    rrv[q] = rr;
+                    sv[q] = row_lo[grp][rr] + relv[q];
+                    it[q] = slot_it[sv[q]];
+                    cxv[q] = slot_xyb[sv[q]];
+                }
             }
-            const unsigned bits = (unsigned)(__ballot(valid) >> gshift) & 0xffffu;
-            if (valid) {
-                const int p = V + __popc(bits & lt_mask);
-                v_key[grp][p] = key;
-                v_src[grp][p] = s;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int ci = c0 + 16 * q + l;
+                bool valid = false;
+                int key = 0;
+                if (ci < C) {
+                    // visible in the FIFO; older than the destination (ev_graph.cu:64); dt <= delta (:69)
+                    valid = (cxv[q] < 0) && it[q].x < e && !((float)(t - it[q].y) > delta_t);
+                    const int dx = (cxv[q] & 4095) - x;
+                    const int rank = sp_rank[rrv[q] * 16 + (dx + r)];
+                    // spiral rank first, then newest first inside the pixel (larger slot = newer)
+                    key = (rank << 20) | (0xFFFFF - relv[q]);
+                }
+                const unsigned bits = (unsigned)(__ballot(valid) >> gshift) & 0xffffu;
+                if (valid) {
+                    const int pidx = V + __popc(bits & lt_mask);
+                    v_key[grp][pidx] = key;
+                    v_src[grp][pidx] = sv[q];
+                }
+                V += __popc(bits);
             }
-            V += __popc(bits);
         }
         __builtin_amdgcn_wave_barrier();
         // 3. the K-1 smallest keys, in key order

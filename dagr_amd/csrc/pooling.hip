@@ -454,32 +454,37 @@ __global__ __launch_bounds__(kBlock) void k_rows_from_masks(dagr_pool_desc d, Po
     }
 }
 
-// ... plus the listed in-edges of t == 1.0 nodes (a handful to a few hundred per window): one thread per listed
-// edge.  The first occurrence of a (dst, src) pair owns the insertion, so concurrent threads always hold
-// distinct values: scan the row for the value (the bitmap kernel may have stored it), else claim the first
-// empty slot with a CAS and move on if another thread took it.
+// ... plus the listed in-edges of t == 1.0 nodes (a handful to a few hundred per window): one wave per listed
+// edge.  The first occurrence of a (dst, src) pair owns the insertion, so concurrent waves always hold
+// distinct values: the wave reads the whole slot row at once, returns if the value is there (the bitmap kernel
+// may have stored it), else claims the first empty slot with a CAS and re-reads if another wave took it.
 __global__ __launch_bounds__(kBlock) void k_rows_from_leaks(PoolWs ws) {
-    __shared__ int2 lst[kLeakCap];   // 64 KiB: the part of the list this workgroup has to look back over
     if (ws.status[1] != 0) return;
     const int n = min(ws.status[2], kLeakCap);
-    const int i0 = blockIdx.x * kBlock;
-    if (i0 >= n) return;
-    const int need = min(n, i0 + kBlock);
-    for (int j = threadIdx.x; j < need; j += kBlock) lst[j] = ws.leak_edges[j];
-    __syncthreads();
-    const int i = i0 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     if (i >= n) return;
-    const int2 e = lst[i];
-    for (int j = 0; j < i; j++)
-        if (lst[j].x == e.x && lst[j].y == e.y) return;
+    const int2 e = ws.leak_edges[i];
+    bool dup = false;
+    for (int j = lane; j < i; j += 64) {
+        const int2 o = ws.leak_edges[j];
+        dup |= (o.x == e.x && o.y == e.y);
+    }
+    if (__ballot(dup)) return;
     const int cs = ws.newid[e.y];
     int32_t *row = ws.rows + (size_t)ws.newid[e.x] * kRowSlots;
-    for (int k = 0; k < kRowSlots; k++) {
-        int cur = __hip_atomic_load(&row[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cur == -1) cur = atomicCAS(&row[k], -1, cs);
-        if (cur == -1 || cur == cs) return;
+    for (int attempt = 0; attempt < kRowSlots; attempt++) {
+        const int cur = __hip_atomic_load(&row[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__ballot(cur == cs)) return;
+        const unsigned long long empty = __ballot(cur == -1);
+        if (!empty) break;
+        const int slot = __ffsll((long long)empty) - 1;
+        int old = 0;
+        if (lane == 0) old = atomicCAS(&row[slot], -1, cs);
+        old = __shfl(old, 0, 64);
+        if (old == -1 || old == cs) return;
     }
-    atomicOr(&ws.status[0], 2);
+    if (lane == 0) atomicOr(&ws.status[0], 2);
 }
 
 // level 0: fixed-stride neighbour lists.  Nodes are in pixel order, so a workgroup sweeping a contiguous
@@ -741,7 +746,7 @@ int dagr_pool_l0(const dagr_pool_desc *desc, void *pool_ws, const dagr_graph_des
             const int ncell = desc->gx * desc->gy * desc->batch_size;
             k_rows_from_masks<<<(unsigned)ceil_div(ncell, kBlock), kBlock, 0, stream>>>(*desc, ws);
             DAGR_CHECK_LAUNCH();
-            k_rows_from_leaks<<<(unsigned)ceil_div(kLeakCap, kBlock), kBlock, 0, stream>>>(ws);
+            k_rows_from_leaks<<<(unsigned)ceil_div(kLeakCap, kBlock / 64), kBlock, 0, stream>>>(ws);
             DAGR_CHECK_LAUNCH();
         }
     }
