@@ -279,8 +279,8 @@ __global__ __launch_bounds__(kBlock) void k_pool_l0_cells(dagr_pool_desc d, int 
                     const int ch = c * 16 + l;
                     if (c < nchk && ch < C) {
                         const float v = x[(size_t)s * ldx + ch];
-                        mx[c] = fmaxf(mx[c], v);
-                        sm[c] += (double)(long long)llrint((double)v * kFeatScale);
+                        if (d.aggr == 0) mx[c] = fmaxf(mx[c], v);
+                        else sm[c] += (double)(long long)llrint((double)v * kFeatScale);
                     }
                 }
                 ps0 += (long long)llrint((double)px * kPosScale);
@@ -297,8 +297,8 @@ __global__ __launch_bounds__(kBlock) void k_pool_l0_cells(dagr_pool_desc d, int 
 #pragma unroll
         for (int c = 0; c < MC; c++) {
             if (c < nchk) {
-                mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], off, 64));
-                sm[c] += __shfl_xor(sm[c], off, 64);
+                if (d.aggr == 0) mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], off, 64));
+                else sm[c] += __shfl_xor(sm[c], off, 64);
             }
         }
         ps0 += __shfl_xor(ps0, off, 64);

@@ -344,15 +344,30 @@ __global__ __launch_bounds__(kBlock) void k_conv_l0_narrow(int N, int K, int nco
     const int groups_per_block = kBlock / 16;
     const float my_shift = shift[l];
     const XcdSplit xs = xcd_split(N, groups_per_block, threadIdx.x >> 4);
+    // The chain deg/neighbour row -> source rows -> output is three HBM latencies per node and this kernel is
+    // latency-bound: the next node's degree and neighbour row are fetched one iteration ahead (the row is
+    // K entries long whatever the degree, so it is read without waiting for the degree).
+    int d_nx = 0, src_nx = 0, code_nx = 0;
+    auto prefetch = [&](int n) {
+        if (n < xs.end) {
+            d_nx = deg[n];
+            if (l < K) { src_nx = nbr_src[(int64_t)n * K + l]; code_nx = nbr_code[(int64_t)n * K + l]; }
+        }
+    };
+    prefetch(xs.first);
     for (int n = xs.first; n < xs.end; n += xs.stride) {
-        const int d = deg[n];
+        const int d = d_nx, src0 = src_nx, code0 = code_nx;
+        prefetch(n + xs.stride);
         const int64_t row = (int64_t)n * K;
         float A[CIN];
 #pragma unroll
         for (int i = 0; i < CIN; i++) A[i] = 0.0f;
         for (int j0 = 0; j0 < d; j0 += 16) {
-            int my_src = 0, my_code = 0;
-            if (j0 + l < d) { my_src = nbr_src[row + j0 + l]; my_code = nbr_code[row + j0 + l]; }
+            int my_src = src0, my_code = code0;
+            if (j0 > 0) {
+                my_src = my_code = 0;
+                if (j0 + l < d) { my_src = nbr_src[row + j0 + l]; my_code = nbr_code[row + j0 + l]; }
+            }
             const int cnt = min(16, d - j0);
             float v[16][CIN];
 #pragma unroll
@@ -446,8 +461,18 @@ __global__ __launch_bounds__(kBlock, 4) void k_conv_l0_mixed(int N, int K, int n
     const int groups_per_block = kBlock / 16;
     const float my_shift = shift[l];
     const XcdSplit xs = xcd_split(N, groups_per_block, threadIdx.x >> 4);
+    // next node's degree and neighbour row one iteration ahead (see k_conv_l0_narrow)
+    int d_nx = 0, src_nx = 0, code_nx = 0;
+    auto prefetch = [&](int n) {
+        if (n < xs.end) {
+            d_nx = deg[n];
+            if (l < K) { src_nx = nbr_src[(int64_t)n * K + l]; code_nx = nbr_code[(int64_t)n * K + l]; }
+        }
+    };
+    prefetch(xs.first);
     for (int n = xs.first; n < xs.end; n += xs.stride) {
-        const int d = deg[n];
+        const int d = d_nx, src0 = src_nx, code0 = code_nx;   // entries 0..15 of the row, one per lane
+        prefetch(n + xs.stride);
         const int64_t row = (int64_t)n * K;
         float A[NTP], AX[CEX];
 #pragma unroll
@@ -455,8 +480,14 @@ __global__ __launch_bounds__(kBlock, 4) void k_conv_l0_mixed(int N, int K, int n
 #pragma unroll
         for (int i = 0; i < CEX; i++) AX[i] = 0.0f;
         for (int j0 = 0; j0 < d; j0 += 8) {   // 8 source rows in flight per lane
-            int my_src = 0, my_code = 0;
-            if (l < 8 && j0 + l < d) { my_src = nbr_src[row + j0 + l]; my_code = nbr_code[row + j0 + l]; }
+            int my_src, my_code;
+            if (j0 < 16) {   // wave-uniform: lanes 0..7 take entries j0..j0+7 of the prefetched row
+                my_src = __shfl(src0, (j0 + l) & 15, 16);
+                my_code = __shfl(code0, (j0 + l) & 15, 16);
+            } else {
+                my_src = my_code = 0;
+                if (l < 8 && j0 + l < d) { my_src = nbr_src[row + j0 + l]; my_code = nbr_code[row + j0 + l]; }
+            }
             const int cnt = min(8, d - j0);
             float v[8], vx[8][CEX];
 #pragma unroll
