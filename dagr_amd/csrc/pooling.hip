@@ -146,7 +146,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_accumulate(dagr_pool_desc d, co
 // (CSR-by-pixel): the row bounds are fetched by one lane per row in a single round, prefix-summed, and the
 // members are then walked as one flat list, 8 in flight (4 lane groups x 2, 16 lanes = 16 channels / 16
 // neighbour slots each) -- walking row by row instead costs two dependent HBM latencies per pixel row.
-template <int MC>   // accumulator chunks of 16 channels held in registers
+template <int MC, int AGGR>   // accumulator chunks of 16 channels held in registers; 0 = max, 1 = mean
 __global__ __launch_bounds__(kBlock) void k_pool_l0_cells(dagr_pool_desc d, int W, int H,
                                                          const int32_t *__restrict__ xlo,  // [gx+1] pixel bounds
                                                          const int32_t *__restrict__ ylo,  // [gy+1]
@@ -168,10 +168,13 @@ __global__ __launch_bounds__(kBlock) void k_pool_l0_cells(dagr_pool_desc d, int 
     const int x0 = xlo[cx], x1 = xlo[cx + 1] - 1, y0 = ylo[cy], y1 = ylo[cy + 1] - 1;
     const int C = d.channels;
     const int nchk = (C + 15) >> 4;
-    float mx[MC];
-    double sm[MC];
+    float mx[AGGR == 0 ? MC : 1];
+    double sm[AGGR == 0 ? 1 : MC];
 #pragma unroll
-    for (int c = 0; c < MC; c++) { mx[c] = -INFINITY; sm[c] = 0.0; }
+    for (int c = 0; c < MC; c++) {
+        if (AGGR == 0) mx[c] = -INFINITY;
+        else sm[c] = 0.0;
+    }
     long long ps0 = 0, ps1 = 0, ps2 = 0;
     int cnt = 0, pmax = -1;
     const int raw = cx + d.gx * (cy + d.gy * b);
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_l0_cells(dagr_pool_desc d, int 
                         const int ch = c * 16 + l;
                         if (c < nchk && ch < C) {
                             const float v = x[(size_t)s * ldx + ch];
-                            if (d.aggr == 0)
+                            if (AGGR == 0)
                                 atomicMax(reinterpret_cast<int *>(ws.xacc + (size_t)rl * C + ch), enc_f(v));
                             else
                                 atomicAdd(reinterpret_cast<unsigned long long *>(ws.xacc + (size_t)rl * C + ch),
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_l0_cells(dagr_pool_desc d, int 
                     const int ch = c * 16 + l;
                     if (c < nchk && ch < C) {
                         const float v = x[(size_t)s * ldx + ch];
-                        if (d.aggr == 0) mx[c] = fmaxf(mx[c], v);
+                        if (AGGR == 0) mx[c] = fmaxf(mx[c], v);
                         else sm[c] += (double)(long long)llrint((double)v * kFeatScale);
                     }
                 }
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_l0_cells(dagr_pool_desc d, int 
 #pragma unroll
         for (int c = 0; c < MC; c++) {
             if (c < nchk) {
-                if (d.aggr == 0) mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], off, 64));
+                if (AGGR == 0) mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], off, 64));
                 else sm[c] += __shfl_xor(sm[c], off, 64);
             }
         }
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_l0_cells(dagr_pool_desc d, int 
         for (int c = 0; c < MC; c++) {
             const int ch = c * 16 + l;
             if (c < nchk && ch < C) {
-                if (d.aggr == 0)
+                if (AGGR == 0)
                     atomicMax(reinterpret_cast<int *>(ws.xacc + (size_t)raw * C + ch), enc_f(mx[c]));
                 else
                     atomicAdd(reinterpret_cast<unsigned long long *>(ws.xacc + (size_t)raw * C + ch),
@@ -716,15 +719,21 @@ int dagr_pool_l0(const dagr_pool_desc *desc, void *pool_ws, const dagr_graph_des
         graph_ws_views(gdesc, graph_ws, &start, &slot_it);
         const int ncell = desc->gx * desc->gy * desc->batch_size;
         const int nchk = (desc->channels + 15) / 16;
-#define DAGR_POOL_L0(MC)                                                                                              \
-    k_pool_l0_cells<MC><<<(unsigned)ceil_div(ncell, kBlock / 64), kBlock, 0, stream>>>(                               \
+#define DAGR_POOL_L0_A(MC, AG)                                                                                        \
+    k_pool_l0_cells<MC, AG><<<(unsigned)ceil_div(ncell, kBlock / 64), kBlock, 0, stream>>>(                           \
         *desc, gdesc->width, gdesc->height, xlo, ylo, start, slot_it, x, ldx, pos, ws, fast_edges ? nbr_code : nullptr, \
         nbr_src, deg, graph_ws_slot_xyb(gdesc, graph_ws), K, gdesc->radius)
+#define DAGR_POOL_L0(MC)                                                                                              \
+    do {                                                                                                              \
+        if (desc->aggr == 0) DAGR_POOL_L0_A(MC, 0);                                                                   \
+        else DAGR_POOL_L0_A(MC, 1);                                                                                   \
+    } while (0)
         if (nchk <= 1) DAGR_POOL_L0(1);
         else if (nchk <= 2) DAGR_POOL_L0(2);
         else if (nchk <= 5) DAGR_POOL_L0(5);
         else DAGR_POOL_L0(kMaxChunks);
 #undef DAGR_POOL_L0
+#undef DAGR_POOL_L0_A
         DAGR_CHECK_LAUNCH();
     }
     DAGR_CHECK_HIP(exclusive_scan_i32(ws.occupied, ws.newid, T + 1, ws.scan_tmp, true, stream));

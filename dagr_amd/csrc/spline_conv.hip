@@ -634,21 +634,40 @@ __global__ __launch_bounds__(kMfmaWaves * 64) void k_conv_l0_mfma(
         int nxt_src[4] = {0, 0, 0, 0}, nxt_code[4] = {0, 0, 0, 0}, nxt_deg = 0;
         if (n0 + 16 * kMfmaWaves < n_end) load_tile_idx(n0 + 16 * kMfmaWaves, nxt_src, nxt_code, nxt_deg);
         // ---- phase 1a: every operand of the tile's 64 MFMAs is requested up front: source rows (global
-        // gathers) and offset-table words (LDS)
+        // gathers) and offset-table words (LDS).  The coalesced-loaded neighbour lists are re-laid through the
+        // (still free) staging tile instead of 144 ds_bpermutes: lane (c, q) then reads its 4 consecutive
+        // edges 4q..4q+3 of node i as one 16-byte word (MFMA k index <-> edge is any bijection).
+        // (kept as float bit patterns: same type as the tile's later contents, so the compiler orders them)
+        float *idx_s = a_s;                                 // [256] src | [256] code | [16] deg
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            idx_s[l + 64 * m] = __int_as_float(cur_src[m]);
+            idx_s[256 + l + 64 * m] = __int_as_float(cur_code[m]);
+        }
+        if (l < 16) idx_s[512 + l] = __int_as_float(cur_deg);
+        __builtin_amdgcn_wave_barrier();
+        // root / skip operands of phase 2: requested now, consumed after the tap contraction
+        const int nn = n0 + c;                               // this lane's node for the root / skip operands
+        const bool nn_ok = nn < n_end;
+        float xroot[4], xsk[KS / 4 > 0 ? KS / 4 : 1];
+#pragma unroll
+        for (int kb = 0; kb < 16; kb += 4) xroot[kb / 4] = nn_ok ? x[(size_t)nn * ldx + kb + q] : 0.f;
+#pragma unroll
+        for (int kb = 0; kb < KS; kb += 4)
+            xsk[kb / 4] = (nn_ok && kb + q < CSKIP) ? xskip[(size_t)nn * ldskip + kb + q] : 0.f;
         float xv[16][4], tv[16][4];
         int dd[16];
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            dd[i] = __shfl(cur_deg, i, 64);
+            dd[i] = __float_as_int(idx_s[512 + i]);
+            const float *sp = idx_s + i * 16 + 4 * q, *cp = idx_s + 256 + i * 16 + 4 * q;
+            const int srcs[4] = {__float_as_int(sp[0]), __float_as_int(sp[1]), __float_as_int(sp[2]), __float_as_int(sp[3])};
+            const int codes[4] = {__float_as_int(cp[0]), __float_as_int(cp[1]), __float_as_int(cp[2]), __float_as_int(cp[3])};
 #pragma unroll
             for (int kk = 0; kk < 4; kk++) {
-                const int e = 4 * kk + q;
-                const int from = (i & 3) * 16 + e;
-                const int src = __shfl(cur_src[i >> 2], from, 64);
-                const int code = __shfl(cur_code[i >> 2], from, 64);
-                const bool ok = e < dd[i];
-                xv[i][kk] = ok ? x[(size_t)src * ldx + c] : 0.0f;
-                tv[i][kk] = (ok && c < NT) ? tab_s[code * NTP + c] : 0.0f;
+                const bool ok = 4 * q + kk < dd[i];
+                xv[i][kk] = ok ? x[(size_t)srcs[kk] * ldx + c] : 0.0f;
+                tv[i][kk] = (ok && c < NT) ? tab_s[codes[kk] * NTP + c] : 0.0f;
             }
         }
         // ---- phase 1b: D[tap][ch] = sum_edges T[edge][tap] * X[edge][ch], <= 4 MFMAs per node
@@ -657,7 +676,7 @@ __global__ __launch_bounds__(kMfmaWaves * 64) void k_conv_l0_mfma(
             f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kk = 0; kk < 4; kk++)
-                if (4 * kk < dd[i])   // wave-uniform
+                if (kk < dd[i])   // wave-uniform: step kk holds edges kk, 4 + kk, 8 + kk, 12 + kk
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(tv[i][kk], xv[i][kk], acc, 0, 0, 0);
             float *dst = a_s + i * AS + (4 * q) * 16 + c;   // D[tap = 4q + r][ch = c]
 #pragma unroll
@@ -681,18 +700,12 @@ __global__ __launch_bounds__(kMfmaWaves * 64) void k_conv_l0_mfma(
 #pragma unroll
             for (int u = 0; u < 12; u++) o = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], wv[u], o, 0, 0, 0);
         }
-        const int nn = n0 + c;                               // this lane's node for the root / skip operands
-        const bool nn_ok = nn < n_end;
 #pragma unroll
-        for (int kb = 0; kb < 16; kb += 4) {
-            const float av = nn_ok ? x[(size_t)nn * ldx + kb + q] : 0.f;
-            o = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wrow[(KT + kb) * 16], o, 0, 0, 0);
-        }
+        for (int kb = 0; kb < 16; kb += 4)
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(xroot[kb / 4], wrow[(KT + kb) * 16], o, 0, 0, 0);
 #pragma unroll
-        for (int kb = 0; kb < KS; kb += 4) {
-            const float av = (nn_ok && kb + q < CSKIP) ? xskip[(size_t)nn * ldskip + kb + q] : 0.f;
-            o = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wrow[(KT + 16 + kb) * 16], o, 0, 0, 0);
-        }
+        for (int kb = 0; kb < KS; kb += 4)
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(xsk[kb / 4], wrow[(KT + 16 + kb) * 16], o, 0, 0, 0);
         // o[r] = out[node = 4q + r][channel c]
 #pragma unroll
         for (int r = 0; r < 4; r++) {
