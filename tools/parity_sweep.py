@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""One-off randomized parity sweep on the GPU box: engine vs CPU oracle (tests/test_engine_gpu.py:_compare) over
+sensor sizes, batch sizes, stream types and seeds beyond the fixed cases of the test-suite.
+usage: python tools/parity_sweep.py [n_cases] [first_seed]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+import test_engine_gpu as T
+from dagr_amd.utils import synthetic as syn
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+rng = np.random.default_rng(seed0)
+geoms = [(320, 215), (640, 480), (240, 180), (346, 260)]
+t0 = time.time()
+for k in range(n_cases):
+    W, H = geoms[int(rng.integers(0, len(geoms)))]
+    B = int(rng.integers(1, 4))
+    gen = syn.uniform_window if rng.integers(0, 2) else syn.edges_window
+    n = int(rng.integers(1500, 9000))
+    seed = seed0 + k
+    kind = int(rng.integers(0, 10))      # 0-1: image fusion (resnet18), 2: dagr-l widths, else dagr-s events-only
+    over = {}
+    image = None
+    if kind <= 1:
+        over = dict(use_image=True, img_net="resnet18")
+    elif kind == 2:
+        over = dict(net_stem_width=1.0, yolo_stem_width=1.0)
+    if rng.integers(0, 4) == 0:
+        n = int(rng.integers(15000, 40000))      # dense: > 128 candidates per neighbourhood, FIFO pressure
+    args, model, sd = T._setup(W, H, B, seed=seed, **over)
+    if kind <= 1:
+        import torch
+        image = torch.rand((B, 3, H, W), generator=torch.Generator().manual_seed(seed)).cuda()
+    import torch
+    with torch.no_grad():
+        T._compare(args, model, sd, W, H, B, *T._events(gen, n, B, W, H, seed=seed * 7 + 1), image=image)
+    print(f"case {k}: {W}x{H} B={B} {gen.__name__} n={n}/sample kind={kind} seed={seed}: ok ({time.time() - t0:.0f} s)",
+          flush=True)
+    del model
+print("sweep ok")
