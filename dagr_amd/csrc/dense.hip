@@ -59,3 +59,43 @@ extern "C" int dagr_to_dense(const int32_t *n_ptr, int32_t n_max, const float *x
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// y = relu(y + z), in place: the residual join of the image branch's ResNet blocks (net_img.py) as one pass
+// over the two activation maps instead of torch's add (new tensor) + in-place clamp.
+namespace dagr {
+namespace {
+__global__ __launch_bounds__(kBlock) void k_add_relu(float *__restrict__ y, const float *__restrict__ z, int64_t n4,
+                                                    int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
+        float4 a = reinterpret_cast<float4 *>(y)[i];
+        const float4 b = reinterpret_cast<const float4 *>(z)[i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        a.x = a.x < 0.f ? 0.f : a.x;   // NaN stays NaN, as torch.relu
+        a.y = a.y < 0.f ? 0.f : a.y;
+        a.z = a.z < 0.f ? 0.f : a.z;
+        a.w = a.w < 0.f ? 0.f : a.w;
+        reinterpret_cast<float4 *>(y)[i] = a;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {   // tail
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        const float v = y[i] + z[i];
+        y[i] = v < 0.f ? 0.f : v;
+    }
+}
+}  // namespace
+}  // namespace dagr
+
+extern "C" int dagr_add_relu(float *y, const float *z, int64_t n, void *stream) {
+    using namespace dagr;
+    DAGR_CHECK_ARG(n >= 0, "bad size");
+    if (n == 0) return DAGR_OK;
+    DAGR_CHECK_ARG(y && z, "NULL pointer");
+    DAGR_CHECK_ARG(((uintptr_t)y % 16) == 0 && ((uintptr_t)z % 16) == 0, "buffers must be 16-byte aligned");
+    const int64_t n4 = n >> 2;
+    const int64_t blocks = ceil_div(n4 > 0 ? n4 : 1, (int64_t)kBlock * 4);
+    k_add_relu<<<(unsigned)std::min<int64_t>(blocks, 256 * 16), kBlock, 0, (hipStream_t)stream>>>(y, z, n4, n);
+    DAGR_CHECK_LAUNCH();
+    return DAGR_OK;
+}

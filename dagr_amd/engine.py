@@ -99,10 +99,11 @@ class _Conv1x1Gemm(torch.nn.Module):
     hipBLASLt's fp32 GEMM is ~25 % faster than MIOpen's implicit-GEMM kernels on these shapes
     (tools/conv1x1_bench.py).  Output stays channels-last (a permuted view of the NHWC result)."""
 
-    def __init__(self, conv):
+    def __init__(self, conv, relu=False):
         super().__init__()
         cout, cin = conv.weight.shape[:2]
         self.stride = conv.stride[0]
+        self.relu = relu       # ReLU in the GEMM epilogue (hipBLASLt) instead of a separate pass
         self.register_buffer("wt", conv.weight.detach().reshape(cout, cin).t().contiguous())
         self.register_buffer("b", conv.bias.detach().clone() if conv.bias is not None else torch.zeros(cout, device=conv.weight.device))
 
@@ -110,7 +111,8 @@ class _Conv1x1Gemm(torch.nn.Module):
         if self.stride != 1:
             x = x[:, :, ::self.stride, ::self.stride]
         B, C, H, W = x.shape
-        y = torch.addmm(self.b, x.permute(0, 2, 3, 1).reshape(-1, C), self.wt)
+        a = x.permute(0, 2, 3, 1).reshape(-1, C)
+        y = torch._addmm_activation(self.b, a, self.wt) if self.relu else torch.addmm(self.b, a, self.wt)
         return y.view(B, H, W, -1).permute(0, 3, 1, 2)
 
 
@@ -121,6 +123,33 @@ def _gemmify_1x1(module):
             setattr(module, name, _Conv1x1Gemm(child))
         else:
             _gemmify_1x1(child)
+
+
+def _add_relu_(y, z):
+    """y = relu(y + z) in place, one pass (dagr_add_relu) when both maps share one dense layout."""
+    if y.is_cuda and y.dtype == torch.float32 and z.dtype == torch.float32 and y.shape == z.shape \
+            and y.stride() == z.stride() and y.data_ptr() % 16 == 0 and z.data_ptr() % 16 == 0 \
+            and (y.is_contiguous() or y.is_contiguous(memory_format=torch.channels_last)):
+        _lib.check(_lib.lib().dagr_add_relu(_lib.ptr(y), _lib.ptr(z), y.numel(), _lib.cur_stream(y.device)), "add_relu")
+        return y
+    return torch.relu_(y.add_(z))
+
+
+def _bottleneck_forward(blk, x):
+    """Bottleneck.forward (net_img.py:43-48) of the folded inference copy: conv1's ReLU rides in its GEMM
+    epilogue, the residual join is one pass."""
+    identity = x if blk.downsample is None else blk.downsample(x)
+    out = blk.conv1(x)
+    if not getattr(blk.conv1, "relu", False):
+        out = blk.relu(out)
+    out = blk.relu(blk.conv2(out))
+    return _add_relu_(blk.conv3(out), identity)
+
+
+def _basicblock_forward(blk, x):
+    identity = x if blk.downsample is None else blk.downsample(x)
+    out = blk.relu(blk.conv1(x))
+    return _add_relu_(blk.conv2(out), identity)
 
 
 class _Level:
@@ -177,6 +206,7 @@ class WindowEngine:
         import os
         self.fuse_convs = os.environ.get("DAGR_FUSE_CONVS", "1") != "0"
         self.fast_coarse_edges = os.environ.get("DAGR_FAST_COARSE_EDGES", "1") != "0"
+        self.fuse_image_epilogues = os.environ.get("DAGR_IMG_EPILOGUES", "1") != "0"
         self._prepare(bb, head)
         self.max_events = 0
         self._alloc_events(int(max_events))
@@ -388,6 +418,13 @@ class WindowEngine:
         cnn = cnn.to(memory_format=torch.channels_last)
         for blkname in ("layer1", "layer2", "layer3", "layer4"):
             _gemmify_1x1(getattr(net.module, blkname))
+            for blk in getattr(net.module, blkname):
+                if hasattr(blk, "conv3"):
+                    if isinstance(blk.conv1, _Conv1x1Gemm) and self.fuse_image_epilogues:
+                        blk.conv1.relu = True
+                    blk.forward = types.MethodType(_bottleneck_forward, blk)
+                else:
+                    blk.forward = types.MethodType(_basicblock_forward, blk)
         _gemmify_1x1(net.feature_dconv)
         _gemmify_1x1(net.output_dconv)
         self._net_f, self._cnn_f = net, cnn

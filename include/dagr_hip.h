@@ -261,6 +261,11 @@ int dagr_to_dense(const int32_t *n_ptr, int32_t n_max, const float *x, int32_t l
                   const float *pos, const int32_t *batch, float vx, float vy, int32_t batch_size,
                   int32_t Hc, int32_t Wc, int32_t *winner_scratch, float *dense, int32_t *status, void *stream);
 
+/* y = relu(y + z) in place over n floats (16-byte aligned buffers of identical layout): the residual join of the
+ * image branch's ResNet blocks (reference: torchvision Bottleneck/BasicBlock.forward, used by
+ * src/dagr/model/networks/net_img.py:42-86) in one pass instead of add + clamp. */
+int dagr_add_relu(float *y, const float *z, int64_t n, void *stream);
+
 /* ------------------------------------------------------------------------ *
  * sample_features (--use_image) -- model/networks/net.py:15-17,193-221
  *   out[n, coff:coff+C] = trilinear grid_sample (align_corners=True) of feat at node n's position;

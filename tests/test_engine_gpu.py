@@ -199,3 +199,26 @@ def test_coarse_edge_bitmap_and_generic_paths_agree():
         for key in ("rowptr", "col", "code"):
             assert torch.equal(snaps[0][key], snaps[1][key]), f"pool1 {key} differs (leak={with_leak})"
         assert snaps[0]["col"].numel() > 1000
+
+
+@pytest.mark.parametrize("img_net", ["resnet18", "resnet50"])
+def test_image_branch_inference_copy_matches_the_modules(img_net):
+    """The engine's inference copy of the image branch (BN folded, channels-last, 1x1 convs as GEMMs with the ReLU in
+    the epilogue, one-pass residual joins) against the plain eval-mode modules it was derived from."""
+    W, H, B = 320, 215, 2
+    args, model, sd = _setup(W, H, B, seed=8, use_image=True, img_net=img_net)
+    eng = model.engine()
+    image = torch.rand((B, 3, H, W), generator=torch.Generator().manual_seed(5)).cuda()
+    with torch.no_grad():
+        feats, cnn_out = eng._image_branch(image)
+        feats_ref, outs_ref = model.backbone.net(image)
+        outs_ref = outs_ref[-eng.num_scales:]
+        resized = [torch.nn.functional.interpolate(f, o) for f, o in zip(outs_ref, eng.out_sizes)]
+        cnn_ref = model.head.cnn_head(resized)
+    for a, b in zip(feats, feats_ref):
+        scale = max(1.0, float(b.abs().max()))
+        assert float((a - b).abs().max()) <= 2e-4 * scale
+    for k in cnn_ref:
+        for a, b in zip(cnn_out[k], cnn_ref[k]):
+            scale = max(1.0, float(b.abs().max()))
+            assert float((a - b).abs().max()) <= 2e-4 * scale
