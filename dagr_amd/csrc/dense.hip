@@ -99,3 +99,60 @@ extern "C" int dagr_add_relu(float *y, const float *z, int64_t n, void *stream) 
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// ResNet stem tail in one pass: y = maxpool3x3/s2/p1( relu( x * scale[c] + shift[c] ) ) over a channels-last map
+// (torchvision ResNet.forward: bn1 -> relu -> maxpool after the raw conv1 output the reference taps,
+// net_img.py:80-84).  One thread per (output pixel, 4 channels); eval-mode BatchNorm as the affine pair
+// scale = weight / sqrt(var + eps), shift = bias - mean * scale.
+namespace dagr {
+namespace {
+__global__ __launch_bounds__(kBlock) void k_bn_relu_maxpool(const float *__restrict__ x, int B, int H, int W, int C,
+                                                           const float *__restrict__ scale,
+                                                           const float *__restrict__ shift, float *__restrict__ y,
+                                                           int OH, int OW) {
+    const int C4 = C >> 2;
+    const int64_t total = (int64_t)B * OH * OW * C4;
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= total) return;
+    const int c4 = (int)(gid % C4);
+    int64_t r = gid / C4;
+    const int ow = (int)(r % OW); r /= OW;
+    const int oh = (int)(r % OH);
+    const int b = (int)(r / OH);
+    const float4 sc = reinterpret_cast<const float4 *>(scale)[c4], sh = reinterpret_cast<const float4 *>(shift)[c4];
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);   // relu output >= 0 and every window holds a valid pixel
+#pragma unroll
+    for (int dy = 0; dy < 3; dy++) {
+        const int ih = 2 * oh - 1 + dy;
+        if (ih < 0 || ih >= H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++) {
+            const int iw = 2 * ow - 1 + dx;
+            if (iw < 0 || iw >= W) continue;
+            const float4 v = reinterpret_cast<const float4 *>(x + (((size_t)b * H + ih) * W + iw) * C)[c4];
+            m.x = fmaxf(m.x, v.x * sc.x + sh.x);
+            m.y = fmaxf(m.y, v.y * sc.y + sh.y);
+            m.z = fmaxf(m.z, v.z * sc.z + sh.z);
+            m.w = fmaxf(m.w, v.w * sc.w + sh.w);
+        }
+    }
+    reinterpret_cast<float4 *>(y + (((size_t)b * OH + oh) * OW + ow) * C)[c4] = m;
+}
+}  // namespace
+}  // namespace dagr
+
+extern "C" int dagr_bn_relu_maxpool(const float *x_nhwc, int32_t B, int32_t H, int32_t W, int32_t C, const float *scale,
+                                    const float *shift, float *y_nhwc, void *stream) {
+    using namespace dagr;
+    DAGR_CHECK_ARG(B >= 1 && H >= 1 && W >= 1 && C >= 4 && C % 4 == 0, "bad sizes (C must be a multiple of 4)");
+    DAGR_CHECK_ARG(x_nhwc && scale && shift && y_nhwc, "NULL pointer");
+    DAGR_CHECK_ARG(((uintptr_t)x_nhwc % 16) == 0 && ((uintptr_t)y_nhwc % 16) == 0 && ((uintptr_t)scale % 16) == 0 &&
+                       ((uintptr_t)shift % 16) == 0, "buffers must be 16-byte aligned");
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    const int64_t total = (int64_t)B * OH * OW * (C / 4);
+    k_bn_relu_maxpool<<<(unsigned)ceil_div(total, (int64_t)kBlock), kBlock, 0, (hipStream_t)stream>>>(
+        x_nhwc, B, H, W, C, scale, shift, y_nhwc, OH, OW);
+    DAGR_CHECK_LAUNCH();
+    return DAGR_OK;
+}

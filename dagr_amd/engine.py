@@ -146,6 +146,30 @@ def _bottleneck_forward(blk, x):
     return _add_relu_(blk.conv3(out), identity)
 
 
+def _resnet_features_forward(net, x):
+    """ResNet.forward_features (net_img.py:80-88) of the inference copy: bn1 -> relu -> maxpool after the raw conv1
+    output (which the reference taps) in one pass over the largest activation map of the network."""
+    c1 = net.conv1(x)
+    mp = net.maxpool
+    ok = (c1.is_cuda and c1.dtype == torch.float32 and c1.is_contiguous(memory_format=torch.channels_last)
+          and c1.shape[1] % 4 == 0 and mp.kernel_size == 3 and mp.stride == 2 and mp.padding == 1
+          and mp.dilation == 1 and not mp.ceil_mode and hasattr(net, "_stem_affine"))
+    if ok:
+        B, C, H, W = c1.shape
+        scale, shift = net._stem_affine
+        y = torch.empty((B, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=c1.dtype, device=c1.device,
+                        memory_format=torch.channels_last)
+        _lib.check(_lib.lib().dagr_bn_relu_maxpool(_lib.ptr(c1), B, H, W, C, _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(y),
+                                                   _lib.cur_stream(c1.device)), "bn_relu_maxpool")
+    else:
+        y = net.maxpool(net.relu(net.bn1(c1)))
+    l1 = net.layer1(y)
+    l2 = net.layer2(l1)
+    l3 = net.layer3(l2)
+    l4 = net.layer4(l3)
+    return dict(conv1=c1, layer1=l1, layer2=l2, layer3=l3, layer4=l4)
+
+
 def _basicblock_forward(blk, x):
     identity = x if blk.downsample is None else blk.downsample(x)
     out = blk.relu(blk.conv1(x))
@@ -425,6 +449,12 @@ class WindowEngine:
                     blk.forward = types.MethodType(_bottleneck_forward, blk)
                 else:
                     blk.forward = types.MethodType(_basicblock_forward, blk)
+        if self.fuse_image_epilogues:
+            bn = net.module.bn1
+            scale = (bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)).contiguous()
+            shift = (bn.bias.detach().float() - bn.running_mean.detach().float() * scale).contiguous()
+            net.module._stem_affine = (scale, shift)
+            net.module.forward_features = types.MethodType(_resnet_features_forward, net.module)
         _gemmify_1x1(net.feature_dconv)
         _gemmify_1x1(net.output_dconv)
         self._net_f, self._cnn_f = net, cnn
