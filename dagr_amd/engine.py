@@ -135,14 +135,36 @@ def _add_relu_(y, z):
     return torch.relu_(y.add_(z))
 
 
+def _bias_relu_(y, bias):
+    """y = relu(y + bias[c]) in place, one pass (dagr_bias_relu) on a channels-last map."""
+    C = y.shape[1]
+    if y.is_cuda and y.dtype == torch.float32 and C % 4 == 0 and y.is_contiguous(memory_format=torch.channels_last) \
+            and y.data_ptr() % 16 == 0 and bias.data_ptr() % 16 == 0:
+        _lib.check(_lib.lib().dagr_bias_relu(_lib.ptr(y), _lib.ptr(bias), y.numel(), C, _lib.cur_stream(y.device)),
+                   "bias_relu")
+        return y
+    return torch.relu_(y.add_(bias.view(1, -1, 1, 1)))
+
+
+def _conv_bias_relu(blk, name, x):
+    """relu(conv(x) + bias): spatial convs of the inference copy run bias-free (MIOpen would add the bias in a pass of
+    its own) and get bias + ReLU in one pass; the 1x1 GEMMs keep their epilogue."""
+    conv = getattr(blk, name)
+    b = getattr(blk, "_" + name + "_bias", None)
+    out = conv(x)
+    if b is not None:
+        return _bias_relu_(out, b)
+    if getattr(conv, "relu", False):
+        return out
+    return blk.relu(out)
+
+
 def _bottleneck_forward(blk, x):
     """Bottleneck.forward (net_img.py:43-48) of the folded inference copy: conv1's ReLU rides in its GEMM
     epilogue, the residual join is one pass."""
     identity = x if blk.downsample is None else blk.downsample(x)
-    out = blk.conv1(x)
-    if not getattr(blk.conv1, "relu", False):
-        out = blk.relu(out)
-    out = blk.relu(blk.conv2(out))
+    out = _conv_bias_relu(blk, "conv1", x)
+    out = _conv_bias_relu(blk, "conv2", out)
     return _add_relu_(blk.conv3(out), identity)
 
 
@@ -172,7 +194,7 @@ def _resnet_features_forward(net, x):
 
 def _basicblock_forward(blk, x):
     identity = x if blk.downsample is None else blk.downsample(x)
-    out = blk.relu(blk.conv1(x))
+    out = _conv_bias_relu(blk, "conv1", x)
     return _add_relu_(blk.conv2(out), identity)
 
 
@@ -443,12 +465,17 @@ class WindowEngine:
         for blkname in ("layer1", "layer2", "layer3", "layer4"):
             _gemmify_1x1(getattr(net.module, blkname))
             for blk in getattr(net.module, blkname):
-                if hasattr(blk, "conv3"):
-                    if isinstance(blk.conv1, _Conv1x1Gemm) and self.fuse_image_epilogues:
-                        blk.conv1.relu = True
-                    blk.forward = types.MethodType(_bottleneck_forward, blk)
-                else:
-                    blk.forward = types.MethodType(_basicblock_forward, blk)
+                relu_convs = ("conv1", "conv2") if hasattr(blk, "conv3") else ("conv1",)
+                if self.fuse_image_epilogues:
+                    for cname in relu_convs:
+                        conv = getattr(blk, cname)
+                        if isinstance(conv, _Conv1x1Gemm):
+                            conv.relu = True                      # ReLU in the hipBLASLt epilogue
+                        elif isinstance(conv, torch.nn.Conv2d) and conv.bias is not None:
+                            setattr(blk, "_" + cname + "_bias", conv.bias.detach().clone().contiguous())
+                            conv.bias = None                      # bias + ReLU in one pass after the conv
+                blk.forward = types.MethodType(_bottleneck_forward if hasattr(blk, "conv3") else _basicblock_forward,
+                                               blk)
         if self.fuse_image_epilogues:
             bn = net.module.bn1
             scale = (bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)).contiguous()

@@ -265,6 +265,9 @@ int dagr_to_dense(const int32_t *n_ptr, int32_t n_max, const float *x, int32_t l
  * image branch's ResNet blocks (reference: torchvision Bottleneck/BasicBlock.forward, used by
  * src/dagr/model/networks/net_img.py:42-86) in one pass instead of add + clamp. */
 int dagr_add_relu(float *y, const float *z, int64_t n, void *stream);
+/* y = relu(y + bias[c]) in place over a channels-last map of n floats, C channels (C % 4 == 0): bias + ReLU after a
+ * bias-free convolution in one pass (torchvision block forward: bnX folded into convX, then relu). */
+int dagr_bias_relu(float *y_nhwc, const float *bias, int64_t n, int32_t C, void *stream);
 /* ResNet stem tail in one pass over channels-last maps: y[B, OH, OW, C] = maxpool 3x3 / stride 2 / pad 1 of
  * relu(x[B, H, W, C] * scale[c] + shift[c]), OH = (H-1)/2 + 1 (torchvision ResNet.forward bn1 -> relu -> maxpool,
  * net_img.py:80-84; eval-mode BatchNorm as an affine pair).  C % 4 == 0, 16-byte aligned buffers. */
