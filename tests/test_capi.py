@@ -46,3 +46,27 @@ def test_spiral_helper_matches_oracle():
     assert _lib.lib().dagr_spiral_offsets(n, dx.ctypes.data, dy.ctypes.data) == 0
     ox, oy = og.spiral_offsets(n)
     assert (dx == ox).all() and (dy == oy).all()
+
+
+def test_argument_validation_of_the_conv_and_elementwise_entry_points():
+    """These calls are rejected on the host before any device work, so they run without a GPU."""
+    L = _lib.lib()
+    # fused pooled-level conv: the 16-node LDS tile bounds K = 26*cin + cskip
+    assert 0 < L.dagr_spline_conv_fused_lds_bytes(64, 64) <= 160 * 1024
+    assert 0 < L.dagr_spline_conv_fused_lds_bytes(82, 0) <= 160 * 1024
+    assert L.dagr_spline_conv_fused_lds_bytes(130, 0) > 160 * 1024
+    one = ctypes.c_void_p(16)     # non-NULL, 16-byte aligned, never dereferenced
+    rc = L.dagr_spline_conv_fused(None, 1, one, one, one, one, 130, 130, None, 0, 0, 7, 7, 14.0, 14.0, one, None, one,
+                                  64, 64, 1, None)
+    assert rc != 0 and b"too large" in L.dagr_last_error()
+    assert L.dagr_spline_conv_fused(None, 1, None, one, one, one, 64, 64, None, 0, 0, 7, 7, 14.0, 14.0, one, None, one,
+                                    64, 64, 1, None) != 0
+    assert b"NULL" in L.dagr_last_error()
+    # image-branch elementwise kernels
+    assert L.dagr_add_relu(None, one, 8, None) != 0 and b"NULL" in L.dagr_last_error()
+    assert L.dagr_add_relu(ctypes.c_void_p(20), one, 8, None) != 0 and b"aligned" in L.dagr_last_error()
+    assert L.dagr_add_relu(one, one, 0, None) == 0
+    assert L.dagr_bias_relu(one, one, 30, 6, None) != 0 and b"multiple of 4" in L.dagr_last_error()
+    assert L.dagr_bias_relu(one, one, 30, 8, None) != 0          # C does not divide n
+    assert L.dagr_bn_relu_maxpool(one, 1, 8, 8, 6, one, one, one, None) != 0
+    assert b"multiple of 4" in L.dagr_last_error()
