@@ -10,11 +10,21 @@ Parity pin status
 * graph build (integer): pinned against the reference's own ``ev_graph.cu``
   compiled from ``/root/reference`` (``oracle/Makefile`` -> ``oracle/_ref``) and
   run on an MI355X; outputs committed under ``tests/golden/graph_ref_*.npz``.
-* SplineConv / pooling / head (fp32): the arithmetic lives in un-vendored,
+* the reference's own plain-torch functions on the path -- ``_sample_features``, ``to_dense``,
+  ``consecutive_cluster``, ``round_to_pixel``, ``compute_pooling_at_each_layer``,
+  ``voxel_size_to_params``, ``init_grid_and_stride`` + ``decode_outputs``,
+  ``postprocess_network_output``, ``format_data``, ``denormalize_pos``, and (with the third-party
+  calls inside them served by the restatements below) ``MySplineConv.init_lut`` / ``message_lut``,
+  ``Pooling.forward`` and the ``AsyncGraph`` / ``SlidingWindowGraph`` host state machine: pinned.
+  ``tests/make_golden_refpy.py`` imports ``/root/reference/src`` with the absent packages stubbed,
+  runs that code on CPU and commits ``tests/golden/ref_py_functions.npz``;
+  ``tests/test_oracle_refpy.py`` checks the restatements (and the host mirror's twins) against it.
+* third-party SplineConv / scatter / cluster arithmetic (fp32): it lives in un-vendored,
   un-pinned third-party packages (torch_spline_conv, torch_scatter,
   torch_cluster, torch_sparse, torch_geometric -- ``install_env.sh:3-11``) that
   are absent here, and the reference has no tests or golden vectors for this
-  path: **parity unpinned** for those ops.  They restate the published
+  path: **parity unpinned** for those primitives (``spline_basis``, ``spline_weighting``,
+  ``grid_cluster``, ``scatter_max/mean``, ``T.Cartesian``, ``ToSparseTensor`` ordering).  They restate the published
   algorithms and are anchored on the reference's in-repo
   call sites and restatements cited in each docstring.
 """

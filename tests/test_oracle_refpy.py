@@ -1,0 +1,153 @@
+"""Pins the oracle's restatements (and the host mirror's twins) of the reference's own plain-torch functions to
+outputs of those functions themselves: tests/golden/ref_py_functions.npz was produced by
+tests/make_golden_refpy.py, which imports /root/reference/src with the absent third-party packages stubbed and
+calls the reference code on CPU.  Exact equality unless stated."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as om
+from oracle import ops as oo
+from oracle import postprocess as opost
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_py_functions.npz"))
+
+
+def T(name):
+    return torch.from_numpy(G[name])
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_sample_features(k):
+    W, H = [int(v) for v in G[f"samp{k}_WH"]]
+    pos = torch.stack([T(f"samp{k}_x") / W, T(f"samp{k}_y") / H, torch.zeros(len(G[f"samp{k}_x"]))], 1)
+    got = om.sample_features(pos, T(f"samp{k}_b"), T(f"samp{k}_feat"), W, H)
+    # pos * W re-creates the pixel coordinate up to one fp32 rounding of x / W * W
+    assert (got - T(f"samp{k}_out")).abs().max().item() <= 2e-5 * max(1.0, float(T(f"samp{k}_out").abs().max()))
+
+
+def test_pooling_sizes_and_lut_params():
+    from dagr_amd.model.networks import net as mirror_net
+    from dagr_amd.model import utils as mirror_utils
+    for k, spec in enumerate(["5x7", "4x5"]):
+        assert torch.equal(om.compute_pooling_at_each_layer(spec, 4), T(f"pool_sizes{k}"))
+        assert torch.equal(mirror_net.compute_pooling_at_each_layer(spec, 4), T(f"pool_sizes{k}"))
+    ps = T("pool_sizes0")
+    for i in range(4):
+        cart_max = float(2 * ps[i][0])
+        want = G["voxel_params"][i]
+        got = om.voxel_size_to_params(types.SimpleNamespace(voxel_size=ps[i], cart_max=cart_max), 215, 320)
+        assert list(got) == [int(want[0]), int(want[1]), want[2]]
+        layer = types.SimpleNamespace(voxel_size=ps[i], transform=types.SimpleNamespace(max=cart_max))
+        got = mirror_utils.voxel_size_to_params(layer, 215, 320)
+        assert list(got) == [int(want[0]), int(want[1]), want[2]]
+
+
+def test_consecutive_cluster_and_round_to_pixel():
+    u, inv, perm, cnt = oo.consecutive_cluster(T("cc_src"))
+    assert torch.equal(u, T("cc_unique")) and torch.equal(inv, T("cc_inv"))
+    assert torch.equal(perm, T("cc_perm")) and torch.equal(cnt, T("cc_counts"))
+    assert torch.equal(oo.round_to_pixel(T("rtp_in").clone(), T("rtp_whinv")), T("rtp_out"))
+
+
+def test_to_dense():
+    got = oo.to_dense(T("dense_x"), T("dense_pos"), T("dense_pooling"), T("dense_batch"), 2)
+    assert torch.equal(got, T("dense_out"))
+
+
+def test_head_decode():
+    """decode_outputs + init_grid_and_stride as restated at the end of oracle.model.head_forward."""
+    hw, strides = [tuple(int(v) for v in r) for r in G["dec_hw"]], [int(s) for s in G["dec_strides"]]
+    grids, strs = [], []
+    for (hs, ws), stride in zip(hw, strides):
+        yv, xv = torch.meshgrid(torch.arange(hs), torch.arange(ws), indexing="ij")
+        grids.append(torch.stack((xv, yv), 2).view(1, -1, 2))
+        strs.append(torch.full((1, hs * ws, 1), stride))
+    grid, stride = torch.cat(grids, 1).float(), torch.cat(strs, 1).float()
+    assert torch.equal(grid, T("dec_grid")) and torch.equal(stride, T("dec_stride"))
+    out = T("dec_raw").clone()
+    out[..., :2] = (out[..., :2] + grid) * stride
+    out[..., 2:4] = torch.exp(out[..., 2:4]) * stride
+    assert torch.equal(out, T("dec_out"))
+    # the very lines of the oracle, so that an edit there cannot drift away from this check unnoticed
+    import inspect
+    src = inspect.getsource(om.head_forward)
+    assert "outputs[..., :2] = (outputs[..., :2] + grid_cache) * stride_cache" in src
+    assert "outputs[..., 2:4] = torch.exp(outputs[..., 2:4]) * stride_cache" in src
+
+
+def test_postprocess_network_output():
+    res = opost.postprocess_network_output(T("post_pred"), 3, conf_thre=0.2, nms_thre=0.5, height=215, width=320)
+    for i, r in enumerate(res):
+        assert torch.equal(r["boxes"], T(f"post{i}_boxes"))
+        assert torch.equal(r["scores"], T(f"post{i}_scores"))
+        assert torch.equal(r["labels"], T(f"post{i}_labels"))
+    assert sum(len(r["boxes"]) for r in res) > 10
+
+
+def test_format_data_and_denormalize_pos():
+    from dagr_amd.utils import buffers as mirror_buf
+    from dagr_amd.utils import synthetic as syn
+    d = types.SimpleNamespace(width=torch.tensor([320]), height=torch.tensor([215]), time_window=torch.tensor([1000000]),
+                              pos=T("fmt_pos"), t=T("fmt_t"), x=T("fmt_x"))
+    d = mirror_buf.format_data(d)       # CPU tensors: the torch branch of the mirror
+    assert torch.equal(d.pos, T("fmt_out_pos")) and torch.equal(d.x, T("fmt_out_x")) and d.t is None
+    pos_np = syn.format_data_np(G["fmt_pos"][:, 0], G["fmt_pos"][:, 1], G["fmt_t"], 320, 215)
+    assert np.array_equal(pos_np, G["fmt_out_pos"])
+    # ev_tgn.py:11-16 -- the integer pixel / microsecond coordinates the graph builder works on
+    den = torch.tensor([320, 215, 1000000])
+    got = (den.view(1, -1) * d.pos + 1e-3).int()
+    assert torch.equal(got, T("denorm_out"))
+    assert torch.equal(got[:, :2], T("fmt_pos").int()) and torch.equal(got[:, 2], T("fmt_t"))
+
+
+def test_lut_construction_and_lookup():
+    """MySplineConv.init_lut + message_lut (spline_conv.py:16-47), run with the oracle's spline_basis in place of
+    torch_spline_conv's: the reference's table, remapping matrix and messages vs the oracle's SplineConvParams."""
+    Himg, Wimg, rx, ry, Mx, My = G["lut_params"]
+    p = oo.SplineConvParams(T("lut_weight"), root_weight=None)
+    p.init_lut(int(Himg), int(Wimg), int(rx), float(Mx), int(ry), float(My))
+    assert torch.equal(p.remap, T("lut_remap"))
+    assert torch.equal(p.full_lut(), T("lut_table"))
+    dx, dy = p.lut_index(T("lut_edge_attr"))
+    assert int(dx.min()) >= 0 and int(dx.max()) <= 2 * int(rx) and int(dy.max()) <= 2 * int(ry)
+    assert torch.equal(p.message(T("lut_xj"), T("lut_edge_attr")), T("lut_msg"))
+
+
+@pytest.mark.parametrize("k,aggr", [(0, "max"), (1, "mean")])
+def test_pooling_forward_glue(k, aggr):
+    """Pooling.forward (pooling.py:51-97) executed from the reference with grid_cluster / scatter_max / pool_pos served
+    by the oracle's primitives: cluster relabelling, coarse-edge filtering + unique, batch[perm], round_to_pixel."""
+    pp = oo.PoolingParams(T(f"pool{k}_size"), 320, 215, 2, cart_max=1.0, aggr=aggr)
+    x, pos, batch, ei, _ = oo.pooling(pp, T(f"pool{k}_x"), T(f"pool{k}_pos"), T(f"pool{k}_batch"), T(f"pool{k}_ei"))
+    assert torch.equal(x, T(f"pool{k}_out_x")) and torch.equal(pos, T(f"pool{k}_out_pos"))
+    assert torch.equal(batch, T(f"pool{k}_out_batch")) and torch.equal(ei, T(f"pool{k}_out_ei"))
+    assert ei.shape[1] > 500 and x.shape[0] > 50
+
+
+def test_sliding_window_graph_host_state_machine():
+    """AsyncGraph / SlidingWindowGraph (graph/ev_graph.py:18-166) and graph/utils.py, run from the reference over five
+    consecutive windows (400, 1, 350, 0, 300 events: batched insert, single-event insert, empty window) with
+    ev_graph_cuda served by the C emulation: new edges, deleted edges, running edge list and node counts."""
+    from oracle import graph as og
+    Wg, Hg, Bg, Kg, Qg, rg, dtg = [int(v) for v in G["swg_params"]]
+    swg = og.SlidingWindowGraph(width=Wg, height=Hg, batch_size=Bg, max_num_neighbors=Kg, max_queue_size=Qg, radius=rg,
+                                delta_t_us=dtg)
+    n_edges = 0
+    for w in range(5):
+        ret = swg.forward(G[f"swg{w}_batch"], G[f"swg{w}_pos"], return_node_counts=True, return_total_edges=True,
+                          delete_nodes=True, collect_edges=True)
+        edges, deleted, total, counts = ret
+        assert np.array_equal(edges, G[f"swg{w}_edges"]), f"window {w}: new edges"
+        want_del = G[f"swg{w}_deleted"]
+        if deleted is None:
+            assert want_del.shape[1] == 0
+        else:
+            assert np.array_equal(deleted, want_del), f"window {w}: deleted edges"
+        assert np.array_equal(total, G[f"swg{w}_total"]), f"window {w}: running edge list"
+        assert list(counts) == [int(v) for v in G[f"swg{w}_counts"]]
+        n_edges += edges.shape[1]
+    assert n_edges > 2000
