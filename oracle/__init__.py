@@ -19,6 +19,14 @@ Parity pin status
   ``tests/make_golden_refpy.py`` imports ``/root/reference/src`` with the absent packages stubbed,
   runs that code on CPU and commits ``tests/golden/ref_py_functions.npz``;
   ``tests/test_oracle_refpy.py`` checks the restatements (and the host mirror's twins) against it.
+* the whole path end to end -- the reference's own ``Net`` / ``Layer`` / ``ConvBlock`` / ``MySplineConv`` (LUT path)
+  / ``Pooling`` / ``EV_TGN`` + ``SlidingWindowGraph`` / ``GNNHead`` / ``CNNHead`` / ``HookModule`` /
+  ``DAGR.cache_luts`` code, executed unmodified on CPU over functional stand-ins of the absent packages that are
+  built on this oracle's primitives (``tests/refpy_fakes.py``, ``tests/make_golden_refpy_model.py``): pinned.
+  ``oracle.model.forward_events`` reproduces its decoded outputs to 1e-6 for dagr-s, dagr-l, a 240x180 sensor and
+  the ResNet-18 image-fusion configuration (``tests/golden/ref_py_model.npz``,
+  ``tests/test_oracle_refpy.py::test_whole_model_wiring_matches_the_reference_code``), i.e. the wiring of the
+  oracle is the reference's, independently of the reading that produced ``oracle/model.py``.
 * third-party SplineConv / scatter / cluster arithmetic (fp32): it lives in un-vendored,
   un-pinned third-party packages (torch_spline_conv, torch_scatter,
   torch_cluster, torch_sparse, torch_geometric -- ``install_env.sh:3-11``) that

@@ -1,0 +1,74 @@
+#!/usr/bin/env python
+"""Golden outputs of the reference's OWN model code, executed on CPU.
+
+tests/refpy_fakes.py puts functional stand-ins for the absent third-party packages (PyG, torch_scatter,
+torch_cluster, torch_spline_conv, yolox, ev_graph_cuda) into sys.modules, built on the oracle's restatements of
+those primitives.  With them the reference's Net / Layer / ConvBlock / MySplineConv (LUT path) / Pooling /
+EV_TGN + SlidingWindowGraph / GNNHead / DAGR.cache_luts run unmodified from /root/reference/src.  This script loads
+reference-layout weights (the host mirror's randomised state_dict, strict=True), pushes synthetic windows through
+``YOLOX.forward(model, data)`` in eval mode and stores events + decoded outputs in
+tests/golden/ref_py_model.npz.  tests/test_oracle_refpy.py::test_whole_model_* then requires
+oracle.model.forward_events -- the function every GPU parity test compares the HIP path with -- to reproduce
+them: the oracle's wiring of the whole path is thereby pinned to the reference's code, independently of the
+reading of it that produced oracle/model.py.
+Run: python tests/make_golden_refpy_model.py   (build container only)."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+CASES = [  # name, W, H, B, events/sample, stream, seed, model overrides
+    ("s_b2", 320, 215, 2, 2500, "uniform", 11, {}),
+    ("s_b1_edges", 240, 180, 1, 3000, "edges", 12, {}),
+    ("l_b2", 320, 215, 2, 1500, "edges", 13, dict(net_stem_width=1.0, yolo_stem_width=1.0)),
+    ("s_img18_b2", 320, 215, 2, 2000, "edges", 14, dict(use_image=True, img_net="resnet18")),
+]
+
+
+def main():
+    import refpy_fakes
+    refpy_fakes.install()
+    sys.path.insert(0, "/root/reference/src")
+    import dagr.model.networks.dagr as rdagr
+    from oracle import model as om
+    from dagr_amd.model.networks.dagr import DAGR as MirrorDAGR
+    from dagr_amd.utils import synthetic as syn
+    from dagr_amd.utils.testing_weights import randomize_
+    out = {}
+    for name, W, H, B, n, stream, seed, over in CASES:
+        args = om.default_args(batch_size=B, **over)
+        torch.manual_seed(seed)
+        mirror = randomize_(MirrorDAGR(args, height=H, width=W), seed=seed).eval()
+        sd = mirror.state_dict()
+        ref = rdagr.DAGR(argparse.Namespace(**vars(args)), height=H, width=W)
+        ref.load_state_dict(sd, strict=True)      # the mirror's state_dict layout IS the reference's
+        ref.eval()
+        ref.cache_luts(width=W, height=H, radius=args.radius)
+        gen = syn.uniform_window if stream == "uniform" else syn.edges_window
+        x, y, t, p, b = syn.batch_windows(gen, n, B, W, H, seed=seed * 3 + 1)
+        data = refpy_fakes.Data(x=torch.from_numpy(p.astype(np.float32)).view(-1, 1),
+                                pos=torch.from_numpy(syn.format_data_np(x, y, t, W, H)), batch=torch.from_numpy(b),
+                                width=torch.tensor([W] * B), height=torch.tensor([H] * B),
+                                time_window=torch.tensor([1000000] * B), num_graphs=B, reset=True)
+        if getattr(args, "use_image", False):     # format_data'd frames (uint8 / 255, utils/buffers.py:37-38)
+            img = torch.randint(0, 256, (B, 3, H, W), generator=torch.Generator().manual_seed(seed)).float() / 255.0
+            data.image = img                      # re-drawn from the seed by the test, not stored
+        ref.head.output_sizes = ref.backbone.get_output_sizes()
+        with torch.no_grad():
+            outputs = rdagr.YOLOX.forward(ref, data)
+        print(name, "outputs", tuple(outputs.shape), "edges", int(data.edge_index.shape[1]) if hasattr(data, "edge_index") else "-")
+        out.update({f"{name}_x": x, f"{name}_y": y, f"{name}_t": t, f"{name}_p": p, f"{name}_b": b,
+                    f"{name}_out": outputs.numpy()})
+    path = os.path.join(ROOT, "tests", "golden", "ref_py_model.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()
