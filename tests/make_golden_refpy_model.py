@@ -65,6 +65,22 @@ def main():
         print(name, "outputs", tuple(outputs.shape), "edges", int(data.edge_index.shape[1]) if hasattr(data, "edge_index") else "-")
         out.update({f"{name}_x": x, f"{name}_y": y, f"{name}_t": t, f"{name}_p": p, f"{name}_b": b,
                     f"{name}_out": outputs.numpy()})
+    # ---- EV_TGN over consecutive calls: reset=True, reset=False (nodes attach to the running graph), reset=True
+    import dagr.model.layers.ev_tgn as rtgn
+    W, H, B = 64, 48, 2
+    tgn = rtgn.EV_TGN(argparse.Namespace(radius=0.05, max_neighbors=16))
+    for k, (reset, n, seed) in enumerate([(True, 500, 31), (False, 300, 32), (True, 400, 33)]):
+        x, y, t, p, b = syn.batch_windows(syn.uniform_window, n, B, W, H, seed=seed)
+        ev = refpy_fakes.Data(x=torch.from_numpy(p.astype(np.float32)).view(-1, 1),
+                              pos=torch.from_numpy(syn.format_data_np(x, y, t, W, H)), batch=torch.from_numpy(b),
+                              width=torch.tensor([W] * B), height=torch.tensor([H] * B),
+                              time_window=torch.tensor([1000000] * B), num_graphs=B)
+        ev = tgn.forward(ev, reset=reset)
+        out.update({f"tgn{k}_x": x, f"tgn{k}_y": y, f"tgn{k}_t": t, f"tgn{k}_b": b, f"tgn{k}_reset": np.array(reset),
+                    f"tgn{k}_edges": ev.edge_index.numpy()})
+        print("EV_TGN call", k, "reset", reset, "edges", tuple(ev.edge_index.shape))
+    out["tgn_params"] = np.array([W, H, B])
+
     path = os.path.join(ROOT, "tests", "golden", "ref_py_model.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")
