@@ -81,6 +81,27 @@ def main():
         print("EV_TGN call", k, "reset", reset, "edges", tuple(ev.edge_index.shape))
     out["tgn_params"] = np.array([W, H, B])
 
+    # ---- the reference's in-repo restatements of two third-party primitives (asynchronous/): T.Cartesian and the
+    # 2-D voxel index of grid_cluster -- anchors for the oracle's restatements of those
+    refpy_fakes._module("asy_tools")
+    refpy_fakes._module("torch_geometric.nn.norm")
+    import importlib
+    rcart = importlib.import_module("dagr.asynchronous.cartesian")
+    rmp = importlib.import_module("dagr.asynchronous.max_pool")
+    gq = torch.Generator().manual_seed(77)
+    pos = torch.rand((400, 3), generator=gq)
+    ei = torch.randint(0, 400, (2, 1500), generator=gq)
+    out.update(cart_pos=pos.numpy(), cart_ei=ei.numpy(),
+               cart_out=getattr(rcart, "__edge_attr")(pos, ei, True, 0.0625).numpy())
+    ps = om.compute_pooling_at_each_layer("5x7", 4)
+    for i in range(4):
+        module = argparse.Namespace(voxel_size=torch.cat([ps[i], torch.Tensor([1])]))
+        p2 = torch.stack([torch.randint(0, 320, (600,), generator=gq).float() / 320,
+                          torch.randint(0, 215, (600,), generator=gq).float() / 215], 1)
+        out[f"vox{i}_pos"] = p2.numpy()
+        out[f"vox{i}_idx"] = getattr(rmp, "__get_global_cluster_index")(module, p2).numpy()
+    out["vox_sizes"] = ps.numpy()
+
     path = os.path.join(ROOT, "tests", "golden", "ref_py_model.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

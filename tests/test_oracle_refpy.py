@@ -212,3 +212,18 @@ def test_ev_tgn_reset_and_incremental_calls():
             g.reset()
         e = g.forward(np.ascontiguousarray(b.astype(np.int32)), pos, delete_nodes=False, collect_edges=reset)
         assert np.array_equal(e.astype(np.int64), GM[f"tgn{k}_edges"]), f"call {k} (reset={reset})"
+
+
+def test_in_repo_restatements_of_third_party_primitives():
+    """The reference restates two of the absent third-party primitives itself (asynchronous/cartesian.py:6-15 for
+    T.Cartesian, asynchronous/max_pool.py:245-252 for the 2-D voxel index of grid_cluster): the oracle's restatements
+    agree with those on the model's pooling sizes."""
+    pos, ei = torch.from_numpy(GM["cart_pos"]), torch.from_numpy(GM["cart_ei"])
+    assert torch.equal(oo.cartesian(pos, ei, 0.0625), torch.from_numpy(GM["cart_out"]))
+    ps = torch.from_numpy(GM["vox_sizes"])
+    for i in range(4):
+        p2 = torch.from_numpy(GM[f"vox{i}_pos"])
+        pp = oo.PoolingParams(ps[i], 320, 215, 1, cart_max=1.0)
+        pos4 = torch.cat([p2, torch.zeros(len(p2), 2)], 1)          # t = 0, sample 0
+        got = oo.grid_cluster(pos4, pp.voxel_size, pp.start, pp.end)
+        assert torch.equal(got, torch.from_numpy(GM[f"vox{i}_idx"]))
