@@ -92,6 +92,7 @@ SIGNATURES = {
                                               c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p]),
     "dagr_add_relu": (ctypes.c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
     "dagr_bias_relu": (ctypes.c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p]),
+    "dagr_bias_silu": (ctypes.c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p]),
     "dagr_bn_relu_maxpool": (ctypes.c_int, [c_void_p, c_i32, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dagr_gemm_bias_act": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_i32, c_void_p, c_i32, c_void_p, c_void_p,
                                           c_i32, c_i32, c_i32, c_i32, c_void_p]),

@@ -179,6 +179,39 @@ __global__ __launch_bounds__(kBlock) void k_bias_relu(float *__restrict__ y, con
 }  // namespace
 }  // namespace dagr
 
+namespace dagr {
+namespace {
+// y = silu(y + bias[c]) in place (yolox BaseConv: conv -> folded BN -> SiLU), v / (1 + exp(-v)) as ATen's silu kernel
+__global__ __launch_bounds__(kBlock) void k_bias_silu(float *__restrict__ y, const float *__restrict__ bias, int64_t n4,
+                                                     int C4) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
+        float4 a = reinterpret_cast<float4 *>(y)[i];
+        const float4 b = reinterpret_cast<const float4 *>(bias)[i % C4];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        a.x = a.x / (1.0f + expf(-a.x));
+        a.y = a.y / (1.0f + expf(-a.y));
+        a.z = a.z / (1.0f + expf(-a.z));
+        a.w = a.w / (1.0f + expf(-a.w));
+        reinterpret_cast<float4 *>(y)[i] = a;
+    }
+}
+}  // namespace
+}  // namespace dagr
+
+extern "C" int dagr_bias_silu(float *y_nhwc, const float *bias, int64_t n, int32_t C, void *stream) {
+    using namespace dagr;
+    DAGR_CHECK_ARG(n >= 0 && C >= 4 && C % 4 == 0 && n % C == 0, "bad sizes (C must be a multiple of 4 and divide n)");
+    if (n == 0) return DAGR_OK;
+    DAGR_CHECK_ARG(y_nhwc && bias, "NULL pointer");
+    DAGR_CHECK_ARG(((uintptr_t)y_nhwc % 16) == 0 && ((uintptr_t)bias % 16) == 0, "buffers must be 16-byte aligned");
+    const int64_t n4 = n >> 2;
+    const int64_t blocks = ceil_div(n4, (int64_t)kBlock * 4);
+    k_bias_silu<<<(unsigned)std::min<int64_t>(blocks, 256 * 16), kBlock, 0, (hipStream_t)stream>>>(y_nhwc, bias, n4, C / 4);
+    DAGR_CHECK_LAUNCH();
+    return DAGR_OK;
+}
+
 extern "C" int dagr_bias_relu(float *y_nhwc, const float *bias, int64_t n, int32_t C, void *stream) {
     using namespace dagr;
     DAGR_CHECK_ARG(n >= 0 && C >= 4 && C % 4 == 0 && n % C == 0, "bad sizes (C must be a multiple of 4 and divide n)");

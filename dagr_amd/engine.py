@@ -146,6 +146,19 @@ def _bias_relu_(y, bias):
     return torch.relu_(y.add_(bias.view(1, -1, 1, 1)))
 
 
+def _baseconv_forward(m, x):
+    """yolox BaseConv.forward of the inference copy: bias-free conv, then folded-BN bias + SiLU in one pass."""
+    y = m.conv(x)
+    b = m._bias
+    C = y.shape[1]
+    if y.is_cuda and y.dtype == torch.float32 and C % 4 == 0 and y.is_contiguous(memory_format=torch.channels_last) \
+            and y.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0:
+        _lib.check(_lib.lib().dagr_bias_silu(_lib.ptr(y), _lib.ptr(b), y.numel(), C, _lib.cur_stream(y.device)),
+                   "bias_silu")
+        return y
+    return torch.nn.functional.silu(y.add_(b.view(1, -1, 1, 1)), inplace=True)
+
+
 def _conv_bias_relu(blk, name, x):
     """relu(conv(x) + bias): spatial convs of the inference copy run bias-free (MIOpen would add the bias in a pass of
     its own) and get bias + ReLU in one pass; the 1x1 GEMMs keep their epilogue."""
@@ -460,6 +473,11 @@ class WindowEngine:
             if hasattr(m, "conv") and hasattr(m, "bn") and isinstance(m.bn, torch.nn.BatchNorm2d):
                 m.conv = fuse_conv_bn_eval(m.conv, m.bn)
                 m.bn = torch.nn.Identity()
+                if self.fuse_image_epilogues and isinstance(getattr(m, "act", None), torch.nn.SiLU) \
+                        and m.conv.bias is not None:
+                    m._bias = m.conv.bias.detach().clone().contiguous()
+                    m.conv.bias = None
+                    m.forward = types.MethodType(_baseconv_forward, m)
         net = net.to(memory_format=torch.channels_last)
         cnn = cnn.to(memory_format=torch.channels_last)
         for blkname in ("layer1", "layer2", "layer3", "layer4"):

@@ -268,6 +268,8 @@ int dagr_add_relu(float *y, const float *z, int64_t n, void *stream);
 /* y = relu(y + bias[c]) in place over a channels-last map of n floats, C channels (C % 4 == 0): bias + ReLU after a
  * bias-free convolution in one pass (torchvision block forward: bnX folded into convX, then relu). */
 int dagr_bias_relu(float *y_nhwc, const float *bias, int64_t n, int32_t C, void *stream);
+/* same with SiLU (v / (1 + exp(-v))): yolox BaseConv (conv -> BN -> SiLU) of the CNN head (dagr.py:106-122). */
+int dagr_bias_silu(float *y_nhwc, const float *bias, int64_t n, int32_t C, void *stream);
 /* ResNet stem tail in one pass over channels-last maps: y[B, OH, OW, C] = maxpool 3x3 / stride 2 / pad 1 of
  * relu(x[B, H, W, C] * scale[c] + shift[c]), OH = (H-1)/2 + 1 (torchvision ResNet.forward bn1 -> relu -> maxpool,
  * net_img.py:80-84; eval-mode BatchNorm as an affine pair).  C % 4 == 0, 16-byte aligned buffers. */
