@@ -68,5 +68,7 @@ def test_argument_validation_of_the_conv_and_elementwise_entry_points():
     assert L.dagr_add_relu(one, one, 0, None) == 0
     assert L.dagr_bias_relu(one, one, 30, 6, None) != 0 and b"multiple of 4" in L.dagr_last_error()
     assert L.dagr_bias_relu(one, one, 30, 8, None) != 0          # C does not divide n
+    assert L.dagr_bias_silu(one, one, 32, 6, None) != 0 and b"multiple of 4" in L.dagr_last_error()
+    assert L.dagr_bias_silu(one, one, 0, 8, None) == 0
     assert L.dagr_bn_relu_maxpool(one, 1, 8, 8, 6, one, one, one, None) != 0
     assert b"multiple of 4" in L.dagr_last_error()
