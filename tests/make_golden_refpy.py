@@ -266,6 +266,23 @@ def main():
                     f"swg{w}_total": total_w.clone(), f"swg{w}_counts": torch.tensor(counts_w)})
     out["swg_params"] = torch.tensor([Wg, Hg, Bg, Kg, Qg, rg, dtg])
 
+    # ---- ModelEMA (networks/ema.py:6-51): three updates of a toy module
+    import dagr.model.networks.ema as rema
+
+    def toy(seed):
+        torch.manual_seed(seed)
+        m = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.BatchNorm1d(3))
+        with torch.no_grad():
+            m[1].running_mean.normal_()
+            m[1].running_var.uniform_(0.5, 1.5)
+        return m
+    ema = rema.ModelEMA(toy(0))
+    for s in (1, 2, 3):
+        ema.update(toy(s))
+    for k, v in ema.ema.state_dict().items():
+        out["ema_" + k] = v.clone()
+    out["ema_updates"] = torch.tensor(ema.updates)
+
     path = os.path.join(ROOT, "tests", "golden", "ref_py_functions.npz")
     np.savez_compressed(path, **{k: (v.numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in out.items()})
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")

@@ -153,6 +153,30 @@ def test_sliding_window_graph_host_state_machine():
     assert n_edges > 2000
 
 
+def test_model_ema_mirror():
+    """networks/ema.py:6-51 run from the reference (three updates of a toy module) vs the host mirror's ModelEMA."""
+    from dagr_amd.model.networks.ema import ModelEMA
+
+    def toy(seed):
+        torch.manual_seed(seed)
+        m = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.BatchNorm1d(3))
+        with torch.no_grad():
+            m[1].running_mean.normal_()
+            m[1].running_var.uniform_(0.5, 1.5)
+        return m
+    ema = ModelEMA(toy(0))
+    for s in (1, 2, 3):
+        ema.update(toy(s))
+    assert ema.updates == int(G["ema_updates"])
+    for k, v in ema.ema.state_dict().items():
+        want = T("ema_" + k)
+        if v.dtype.is_floating_point:
+            assert (v - want).abs().max().item() <= 1e-6 * (1 + want.abs().max().item()), k
+        else:
+            assert torch.equal(v, want), k
+    assert all(not p.requires_grad for p in ema.ema.parameters()) and not ema.ema.training
+
+
 GM = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_py_model.npz"))
 MODEL_CASES = [  # must mirror tests/make_golden_refpy_model.py:CASES
     ("s_b2", 320, 215, 2, 11, {}),
