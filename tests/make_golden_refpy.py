@@ -283,6 +283,19 @@ def main():
         out["ema_" + k] = v.clone()
     out["ema_updates"] = torch.tensor(ema.updates)
 
+    # ---- utils/args.py FLAGS() on the shipped model configs (what `args` the model constructors see)
+    import json
+    import dagr.utils.args as rargs
+    flags = {}
+    argv0 = list(sys.argv)
+    for name in ("dagr-n", "dagr-s", "dagr-m", "dagr-l"):
+        sys.argv = ["x", "--config", f"/root/reference/config/{name}-dsec.yaml", "--dataset_directory", "/d",
+                    "--output_directory", "/o", "--batch_size", "8"]
+        ns = rargs.FLAGS()
+        flags[name] = {k: (str(v) if not isinstance(v, (int, float, bool, str)) else v) for k, v in vars(ns).items()}
+    sys.argv = argv0
+    out["flags_json"] = np.frombuffer(json.dumps(flags, sort_keys=True).encode(), dtype=np.uint8)
+
     path = os.path.join(ROOT, "tests", "golden", "ref_py_functions.npz")
     np.savez_compressed(path, **{k: (v.numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in out.items()})
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")

@@ -177,6 +177,23 @@ def test_model_ema_mirror():
     assert all(not p.requires_grad for p in ema.ema.parameters()) and not ema.ema.training
 
 
+def test_model_args_match_the_reference_flags_on_its_configs():
+    """utils/args.py FLAGS() run from the reference on config/dagr-{n,s,m,l}-dsec.yaml (with --batch_size 8) vs the
+    mirror's model_args(): every field the model constructors read has the same value."""
+    import json
+    from dagr_amd.utils.args import model_args
+    flags = json.loads(bytes(G["flags_json"]).decode())
+    read_by_model = ["radius", "max_neighbors", "edge_attr_dim", "aggr", "kernel_size", "activation", "pooling_aggr",
+                     "base_width", "after_pool_width", "net_stem_width", "yolo_stem_width", "num_scales",
+                     "pooling_dim_at_output", "use_image", "img_net", "no_events", "pretrain_cnn",
+                     "keep_temporal_ordering", "batch_size", "dataset", "time_window_us"]
+    for name, ref in flags.items():
+        mine = vars(model_args(name, batch_size=8))
+        for k in read_by_model:
+            assert k in ref and k in mine, (name, k)
+            assert mine[k] == ref[k], (name, k, mine[k], ref[k])
+
+
 GM = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_py_model.npz"))
 MODEL_CASES = [  # must mirror tests/make_golden_refpy_model.py:CASES
     ("s_b2", 320, 215, 2, 11, {}),
