@@ -7,6 +7,7 @@ host synchronisation: graph build -> fused level-0 convs -> voxel pooling -> (ta
 GEMM) per pooled conv -> dense head maps.  PyTorch supplies memory and the stream only.
 """
 import ctypes
+import os
 import types
 
 import numpy as np
@@ -262,7 +263,6 @@ class WindowEngine:
         self._cnn_out = None
         self._img_stream = None
         self._net_f = self._cnn_f = None
-        import os
         self.fuse_convs = os.environ.get("DAGR_FUSE_CONVS", "1") != "0"
         self.fast_coarse_edges = os.environ.get("DAGR_FAST_COARSE_EDGES", "1") != "0"
         self.fuse_image_epilogues = os.environ.get("DAGR_IMG_EPILOGUES", "1") != "0"
