@@ -49,11 +49,11 @@ def parse():
 
 
 def make_model(W, H, B, use_image=False, img_net="resnet50"):
-    from oracle.model import default_args  # argument defaults only (config/dagr-s-dsec.yaml values)
+    from dagr_amd.utils.args import model_args   # config/dagr-s-dsec.yaml values (pinned to the reference's FLAGS())
     from dagr_amd.model.networks.dagr import DAGR
     from dagr_amd.utils.testing_weights import randomize_
     torch.manual_seed(0)
-    args = default_args(batch_size=B, use_image=use_image, img_net=img_net)
+    args = model_args("dagr-s", batch_size=B, use_image=use_image, img_net=img_net)
     model = randomize_(DAGR(args, height=H, width=W)).eval()
     return args, model
 

@@ -613,6 +613,31 @@ __global__ __launch_bounds__(kBlock) void k_rows_emit(dagr_pool_desc d, int T, c
     code[o] = (ix & 0xffff) | (iy << 16);
 }
 
+// LUT coordinates of an existing CSR level for a consumer whose table was built for ANOTHER domain
+// (DAGR.cache_luts, dagr.py:52-62: with num_scales = 1 head "1" consumes out4 but keeps the pool3 table):
+// the edge attribute is this level's T.Cartesian value, the index is message_lut's with the consumer's
+// attr_remapping_matrix (spline_conv.py:41-42).  One wave per destination row.
+__global__ __launch_bounds__(kBlock) void k_recode(const int32_t *__restrict__ n_ptr, int n_max,
+                                                  const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                  const float *__restrict__ pos, float two_max, float r00, float r02,
+                                                  float r11, float r12, int rx, int ry, int32_t *__restrict__ code,
+                                                  int e_cap, int32_t *status) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int nc = min(*n_ptr, n_max);
+    if (c >= nc) return;
+    const int e0 = rowptr[c], e1 = min(rowptr[c + 1], e_cap);
+    for (int o = e0 + lane; o < e1; o += 64) {
+        const int v = col[o];
+        const float ax = (pos[3 * v] - pos[3 * c]) / two_max + 0.5f;
+        const float ay = (pos[3 * v + 1] - pos[3 * c + 1]) / two_max + 0.5f;
+        const int ix = (int)((ax * r00 + r02) + 1e-3f);
+        const int iy = (int)((ay * r11 + r12) + 1e-3f);
+        if (ix < 0 || ix > 2 * rx || iy < 0 || iy > 2 * ry) atomicOr(status, 8);
+        code[o] = (ix & 0xffff) | (iy << 16);
+    }
+}
+
 }  // namespace
 }  // namespace dagr
 
@@ -804,6 +829,19 @@ int dagr_pool_status(const dagr_pool_desc *desc, void *pool_ws, int32_t *flags_h
     pool_carve(*desc, (char *)pool_ws, &ws);
     DAGR_CHECK_HIP(hipMemcpyAsync(flags_host, ws.status, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
     DAGR_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return DAGR_OK;
+}
+
+int dagr_pool_recode(const int32_t *n_ptr, int32_t n_max, const int32_t *rowptr, const int32_t *col, const float *pos,
+                     float two_max, float r00, float r02, float r11, float r12, int32_t rx, int32_t ry,
+                     int32_t *code_out, int32_t e_cap, int32_t *status, void *stream) {
+    DAGR_CHECK_ARG(n_max >= 0 && e_cap >= 0, "bad sizes");
+    if (n_max == 0) return DAGR_OK;
+    DAGR_CHECK_ARG(n_ptr && rowptr && col && pos && code_out && status, "NULL pointer");
+    DAGR_CHECK_ARG(two_max > 0 && rx >= 0 && ry >= 0, "bad domain");
+    k_recode<<<(unsigned)ceil_div(n_max, kBlock / 64), kBlock, 0, (hipStream_t)stream>>>(
+        n_ptr, n_max, rowptr, col, pos, two_max, r00, r02, r11, r12, rx, ry, code_out, e_cap, status);
+    DAGR_CHECK_LAUNCH();
     return DAGR_OK;
 }
 

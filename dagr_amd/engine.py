@@ -22,6 +22,11 @@ def _f32(v):
     return float(torch.as_tensor(v, dtype=torch.float32))
 
 
+def _same_domain(a, b):
+    return (a["rx"], a["ry"], a["den_x"], a["den_y"]) == (b["rx"], b["ry"], b["den_x"], b["den_y"]) \
+        and torch.equal(a["remap"], b["remap"])
+
+
 def _bn_affine(bn):
     m = bn.module
     scale = (m.weight / torch.sqrt(m.running_var + m.eps)).detach().float()
@@ -344,7 +349,7 @@ class WindowEngine:
         self.xlo = torch.searchsorted(cellx, torch.arange(d.gx + 1)).to(torch.int32).to(dev)
         self.ylo = torch.searchsorted(celly, torch.arange(d.gy + 1)).to(torch.int32).to(dev)
         # ---- head
-        self.head_packs = []
+        self.head_packs, self.head_dom = [], []
         first_level = 5 - self.num_scales   # levels feeding scale 1..num_scales (3,4 or 4)
         self.head_levels = list(range(first_level, 5))
         for s in range(1, self.num_scales + 1):
@@ -355,6 +360,14 @@ class WindowEngine:
             cls = _pack_generic([g("cls_pred")], [None], relu=False, device=dev)
             ro = _pack_generic([g("reg_pred"), g("obj_pred")], [None, None], relu=False, device=dev)
             self.head_packs.append((stem, cr, cls, ro))
+            # DAGR.cache_luts ties the table to the head's name ("1" -> pool3, "2" -> pool4), whatever level it
+            # consumes (dagr.py:52-72): the convs of head s are evaluated on THEIR domain
+            hd = g("stem").conv.lut_domain
+            for n in ("cls_conv", "reg_conv"):
+                assert _same_domain(getattr(head, n + str(s)).conv.lut_domain, hd)
+            for n in ("cls_pred", "reg_pred", "obj_pred"):
+                assert _same_domain(getattr(head, n + str(s)).lut_domain, hd)
+            self.head_dom.append(hd)
         self.n_reg = head.stem1.conv.out_channels
         osz = bb.get_output_sizes()[-self.num_scales:]
         self.out_sizes = osz                                   # [[H,W], ...]
@@ -379,6 +392,12 @@ class WindowEngine:
                 winner=torch.zeros((self.B * Hc * Wc,), dtype=torch.int32, device=dev),
                 dense=torch.zeros((self.B, 5 + self.num_classes, Hc, Wc), dtype=torch.float32, device=dev)))
         self.status = torch.zeros((4,), dtype=torch.int32, device=dev)
+        # a head whose table domain is not its input level's (num_scales = 1: head "1" on out4 with the pool3
+        # table) gets its own LUT coordinates (dagr_pool_recode)
+        self.head_code = []
+        for i, lvl in enumerate(self.head_levels):
+            same = _same_domain(self.head_dom[i], self.dom[lvl])
+            self.head_code.append(None if same else torch.zeros_like(self.levels[lvl - 1].code))
         # grid / stride cache of decode_outputs (model/utils.py:119-134)
         grids, strides = [], []
         for (hs, ws_), stride in zip(self.out_sizes, self.strides):
@@ -410,18 +429,19 @@ class WindowEngine:
         self.batch_n = torch.zeros((n,), dtype=torch.int32, device=dev)
 
     # ------------------------------------------------------------------------------- kernels
-    def _conv_generic(self, lvl, pack, x, ldx, xskip, ldskip, out, ldo, dom, stream):
+    def _conv_generic(self, lvl, pack, x, ldx, xskip, ldskip, out, ldo, dom, stream, code=None):
         L = self.L
         P = _lib.ptr
+        code = lvl.code if code is None else code
         if self.fuse_convs and L.dagr_spline_conv_fused_lds_bytes(pack.cin, pack.cskip) <= 160 * 1024:
             # tap aggregation + contraction in one launch (A tile lives in LDS)
-            _lib.check(L.dagr_spline_conv_fused(P(lvl.counts), lvl.T, P(lvl.rowptr), P(lvl.col), P(lvl.code), x, ldx,
+            _lib.check(L.dagr_spline_conv_fused(P(lvl.counts), lvl.T, P(lvl.rowptr), P(lvl.col), P(code), x, ldx,
                                                 pack.cin, xskip, ldskip, pack.cskip, dom["rx"], dom["ry"], dom["den_x"],
                                                 dom["den_y"], P(pack.Wq), P(pack.bias), out, ldo, pack.N,
                                                 1 if pack.relu else 0, stream), "spline_conv_fused")
             return
         lda = (pack.K + 3) // 4 * 4    # 16-byte aligned rows for the MFMA GEMM's float4 loads
-        _lib.check(L.dagr_spline_tap_aggregate(P(lvl.counts), lvl.T, P(lvl.rowptr), P(lvl.col), P(lvl.code),
+        _lib.check(L.dagr_spline_tap_aggregate(P(lvl.counts), lvl.T, P(lvl.rowptr), P(lvl.col), P(code),
                                                x, ldx, pack.cin, xskip, ldskip, pack.cskip, dom["rx"], dom["ry"],
                                                dom["den_x"], dom["den_y"], P(self.A), lda, stream), "tap_aggregate")
         _lib.check(L.dagr_gemm_bias_act(P(lvl.counts), lvl.T, P(self.A), lda, P(pack.Wm), pack.ldw, P(pack.bias),
@@ -636,17 +656,25 @@ class WindowEngine:
             lvl = self.levels[lvln - 1]
             stem, cr, cls, ro = self.head_packs[i]
             hb = self.head_buf[i]
-            dom = self.dom[lvln]
+            dom = self.head_dom[i]
+            code = self.head_code[i]
+            if code is not None:
+                rm = dom["remap"]
+                _lib.check(L.dagr_pool_recode(P(lvl.counts), lvl.T, P(lvl.rowptr), P(lvl.col), P(lvl.pos),
+                                              self.pool_desc[lvln - 1].two_max, float(rm[0, 0]), float(rm[0, 2]),
+                                              float(rm[1, 1]), float(rm[1, 2]), dom["rx"], dom["ry"], P(code),
+                                              lvl.e_cap, ctypes.c_void_p(self.status.data_ptr() + 4), stream),
+                           "pool_recode")
             nr = self.n_reg
-            self._conv_generic(lvl, stem, P(lvl.hp), lvl.hp.shape[1], None, 0, P(hb["stem"]), nr, dom, stream)
-            self._conv_generic(lvl, cr, P(hb["stem"]), nr, None, 0, P(hb["cr"]), 2 * nr, dom, stream)
+            self._conv_generic(lvl, stem, P(lvl.hp), lvl.hp.shape[1], None, 0, P(hb["stem"]), nr, dom, stream, code)
+            self._conv_generic(lvl, cr, P(hb["stem"]), nr, None, 0, P(hb["cr"]), 2 * nr, dom, stream, code)
             pred = hb["pred"]
             npred = pred.shape[1]
             # pred columns: [reg(4) | obj(1) | cls(num_classes)] = order of collect_outputs (dagr.py:300-302)
             self._conv_generic(lvl, ro, ctypes.c_void_p(hb["cr"].data_ptr() + 4 * nr), 2 * nr, None, 0, P(pred), npred,
-                               dom, stream)
+                               dom, stream, code)
             self._conv_generic(lvl, cls, P(hb["cr"]), 2 * nr, None, 0, ctypes.c_void_p(pred.data_ptr() + 4 * 5), npred,
-                               dom, stream)
+                               dom, stream, code)
             Hc, Wc = self.out_sizes[i]
             vox = self.head_vox[i]
             _lib.check(L.dagr_to_dense(P(lvl.counts), lvl.T, P(pred), npred, npred, P(lvl.pos), P(lvl.batch),
@@ -716,8 +744,11 @@ class WindowEngine:
                                                _lib.cur_stream(self.device)), "pool_status")
             if f.value:
                 raise RuntimeError(f"pool{k + 1} flagged {f.value:#x}")
-        if int(self.status[0].item()):
+        st = self.status.tolist()
+        if st[0]:
             raise RuntimeError("to_dense: node outside the output map")
+        if st[1]:
+            raise RuntimeError("head: LUT coordinate outside the head's table (dagr_pool_recode)")
 
     def forward_data(self, data):
         """``DAGR.forward`` input contract: ``data`` after ``format_data`` (pos fp32[N,3] normalised,

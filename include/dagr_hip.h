@@ -248,6 +248,14 @@ int dagr_pool_csr(const dagr_pool_desc *desc, void *pool_ws, const int32_t *n_pt
                   int32_t *cluster_scratch /*[n_max]*/, float *x_out, int32_t ldo, int32_t xoff, float *pos_out,
                   int32_t *batch_out, int32_t *n_out, int32_t *rowptr_out, int32_t *col_out, int32_t *code_out,
                   int32_t *e_out, int32_t e_cap, void *stream);
+/* LUT coordinates of an existing pooled level (CSR + pos as written by dagr_pool_*) for a consumer whose table
+ * covers ANOTHER domain: DAGR.cache_luts (dagr.py:52-62) gives head "1" the pool3 table even when num_scales = 1
+ * makes it consume out4.  code_out[e] = ix | iy<<16 with ix = trunc(attr_x*r00 + r02 + 1e-3) (message_lut,
+ * spline_conv.py:41-42), attr = (pos[src]-pos[dst])/two_max + 0.5 of THIS level's Cartesian transform.
+ * status (device int32): bit3 set when a coordinate leaves [0,2rx] x [0,2ry]. */
+int dagr_pool_recode(const int32_t *n_ptr, int32_t n_max, const int32_t *rowptr, const int32_t *col, const float *pos,
+                     float two_max, float r00, float r02, float r11, float r12, int32_t rx, int32_t ry,
+                     int32_t *code_out, int32_t e_cap, int32_t *status, void *stream);
 /* flags bit0: node outside the voxel grid; bit1: > 64 distinct sources for one cluster;
  * bit2: edge capacity exceeded; bit3: LUT coordinate out of range.  Synchronises `stream`. */
 int dagr_pool_status(const dagr_pool_desc *desc, void *pool_ws, int32_t *flags_host, void *stream);

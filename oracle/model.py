@@ -82,7 +82,8 @@ def voxel_size_to_params(pool, height, width):  # model/utils.py:112-116
 
 def level_lut_params(args, nc):
     """(rx, ry, M) for graph levels 0..4 as ``DAGR.cache_luts`` assigns them (dagr.py:37-72).
-    Level 0: the event graph; level k>=1: after pool k.  Head scale 1 uses level 3, scale 2 level 4."""
+    Level 0: the event graph; level k>=1: after pool k.  Head "1" uses level 3's, head "2" level 4's -- whatever
+    level they consume (see head_forward)."""
     M0 = 2 * float(int(args.radius * nc.width + 2) / nc.width)
     r0 = int(args.radius * nc.width + 1)
     levels = [(r0, r0, M0)]
@@ -238,9 +239,13 @@ def head_forward(sd, args, nc, outs, batch_size, use_lut=True, cnn_out=None, tra
     luts = level_lut_params(args, nc) if use_lut else None
     hybrid = []
     raw = []
-    first_level = 5 - len(outs)  # num_scales=2 -> levels 3,4 ; num_scales=1 -> level 4
     for k, g in enumerate(outs):
-        lvl = first_level + k
+        # DAGR.cache_luts (dagr.py:52-72) ties the LUT to the head's NAME, not to the level it consumes: stem1 /
+        # cls_conv1 / reg_conv1 / *_pred1 always get the pool3 domain, *2 the pool4 domain.  With num_scales = 1
+        # (config/dagr-l-ncaltech.yaml) head "1" consumes out4, whose edge attributes were normalised by pool4's
+        # Cartesian maximum, and looks them up in the pool3 table: message_lut's index becomes a
+        # half-resolution one (trunc(dx_pix * M3/M4 + rx3 + 1e-3)).
+        lvl = 3 + k
         lut = None if not use_lut else (luts[lvl][0], luts[lvl][1], luts[lvl][2], H, W)
         cls_o, reg_o, obj_o = head_process_feature(sd, k + 1, g, lut, batch_size)
         if cnn_out is not None:  # dagr.py:219-222,230-234

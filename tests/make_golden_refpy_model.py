@@ -28,6 +28,10 @@ CASES = [  # name, W, H, B, events/sample, stream, seed, model overrides
     ("s_b1_edges", 240, 180, 1, 3000, "edges", 12, {}),
     ("l_b2", 320, 215, 2, 1500, "edges", 13, dict(net_stem_width=1.0, yolo_stem_width=1.0)),
     ("s_img18_b2", 320, 215, 2, 2000, "edges", 14, dict(use_image=True, img_net="resnet18")),
+    # config/dagr-l-ncaltech.yaml: one head scale -- head "1" then consumes out4 but keeps the pool3 LUT that
+    # DAGR.cache_luts gives it (dagr.py:52-62): the message_lut index is a half-resolution look-up
+    ("l_ncaltech_b2", 240, 180, 2, 2500, "edges", 15, dict(net_stem_width=1.0, yolo_stem_width=1.0, num_scales=1,
+                                                          dataset="ncaltech101")),
 ]
 
 

@@ -222,3 +222,48 @@ def test_image_branch_inference_copy_matches_the_modules(img_net):
         for a, b in zip(cnn_out[k], cnn_ref[k]):
             scale = max(1.0, float(b.abs().max()))
             assert float((a - b).abs().max()) <= 2e-4 * scale
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The configurations the numbers are quoted on (VERDICT r1 "weak" #1): stage-by-stage against the oracle at full
+# size.  The CPU oracle needs ~4 s per 100 k events (C graph builder + torch-CPU convs), so these take a minute each.
+def _bench_image(B, H, W, seed):
+    # the very generator bench.py draws its resident frames from (slot 0, rank 0)
+    return torch.rand((B, 3, H, W), generator=torch.Generator().manual_seed(seed)).cuda()
+
+
+def test_bench_workload_dagr_s_resnet50_vga_b8_100k():
+    """bench.py's default step (BASELINE config 2 on the synthetic 640x480 stream): dagr-s + --use_image --img_net
+    resnet50, B = 8 windows x 100 k S-uniform events, seeds 1234.. (bench.py slot 0)."""
+    W, H, B = 640, 480, 8
+    args, model, sd = _setup(W, H, B, seed=0, use_image=True, img_net="resnet50")
+    with torch.no_grad():
+        _compare(args, model, sd, W, H, B, *_events(syn.uniform_window, 100000, B, W, H, seed=1234),
+                 image=_bench_image(B, H, W, 77))
+
+
+def test_bench_workload_events_only_vga_b8_100k():
+    """bench.py --events-only / the `events_only` leg of the default line (BASELINE config 1 shape at B = 8)."""
+    W, H, B = 640, 480, 8
+    args, model, sd = _setup(W, H, B, seed=0)
+    _compare(args, model, sd, W, H, B, *_events(syn.uniform_window, 100000, B, W, H, seed=1234))
+
+
+def test_s_dsec_geometry_resnet50_b8_50k_edges():
+    """SURVEY 8(d) S-dsec: the geometry the reference runs DSEC at (320x215, r = 4), N = 50 k per window, B = 8,
+    S-edges (saturates K = 16, stresses the FIFO depth), dagr-s + resnet50 (BASELINE config 2)."""
+    W, H, B = 320, 215, 8
+    args, model, sd = _setup(W, H, B, seed=9, use_image=True, img_net="resnet50")
+    with torch.no_grad():
+        _compare(args, model, sd, W, H, B, *_events(syn.edges_window, 50000, B, W, H, seed=2234),
+                 image=_bench_image(B, H, W, 78))
+
+
+def test_dagr_l_resnet50_b8():
+    """BASELINE config 4: dagr-l (128-channel levels) + --use_image --img_net resnet50, batch 8, DSEC geometry."""
+    W, H, B = 320, 215, 8
+    args, model, sd = _setup(W, H, B, seed=10, use_image=True, img_net="resnet50", net_stem_width=1.0,
+                             yolo_stem_width=1.0)
+    with torch.no_grad():
+        _compare(args, model, sd, W, H, B, *_events(syn.edges_window, 30000, B, W, H, seed=3234),
+                 image=_bench_image(B, H, W, 79))

@@ -4,6 +4,7 @@ import pytest
 import torch
 
 from oracle import graph as og
+from dagr_amd.utils import synthetic as syn
 from tests.graph_cases import small_cases, medium_cases
 
 pytestmark = pytest.mark.gpu
@@ -90,3 +91,27 @@ def test_out_of_range_event_is_flagged():
     case["x"] = case["x"].copy(); case["x"][0] = case["W"] + 3
     ei, nbr_src, nbr_code, deg, ne, flags = _run_hip(case)
     assert flags & 1
+
+
+def test_format_events_bit_exact_vs_reference_golden():
+    """a1 `format_data` (utils/buffers.py:33-44): `dagr_format_events` on the dataset's raw dtypes against the outputs
+    of the reference's own function (tests/golden/ref_py_functions.npz: fmt_*), bit for bit; plus a 640x480 window
+    against the fp32 true division written out in numpy."""
+    import os
+    import types
+    from dagr_amd.utils.buffers import format_data
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_py_functions.npz"))
+    d = types.SimpleNamespace(width=torch.tensor([320]), height=torch.tensor([215]), time_window=torch.tensor([1000000]),
+                              pos=torch.from_numpy(G["fmt_pos"]).cuda(), t=torch.from_numpy(G["fmt_t"]).cuda(),
+                              x=torch.from_numpy(G["fmt_x"]).cuda())
+    assert d.pos.dtype == torch.int16 and d.t.dtype == torch.int32 and d.x.dtype == torch.int8   # -> the HIP kernel
+    d = format_data(d)
+    assert d.t is None
+    assert np.array_equal(d.pos.cpu().numpy(), G["fmt_out_pos"]) and np.array_equal(d.x.cpu().numpy(), G["fmt_out_x"])
+    x, y, t, p = syn.uniform_window(100000, 640, 480, seed=3)
+    d = types.SimpleNamespace(width=torch.tensor([640]), height=torch.tensor([480]), time_window=torch.tensor([1000000]),
+                              pos=torch.from_numpy(np.stack([x, y], -1)).cuda(), t=torch.from_numpy(t).cuda(),
+                              x=torch.from_numpy(p.reshape(-1, 1)).cuda())
+    d = format_data(d)
+    assert np.array_equal(d.pos.cpu().numpy(), syn.format_data_np(x, y, t, 640, 480))
+    assert np.array_equal(d.x.cpu().numpy(), p.astype(np.float32).reshape(-1, 1))

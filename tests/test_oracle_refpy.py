@@ -200,6 +200,8 @@ MODEL_CASES = [  # must mirror tests/make_golden_refpy_model.py:CASES
     ("s_b1_edges", 240, 180, 1, 12, {}),
     ("l_b2", 320, 215, 2, 13, dict(net_stem_width=1.0, yolo_stem_width=1.0)),
     ("s_img18_b2", 320, 215, 2, 14, dict(use_image=True, img_net="resnet18")),
+    ("l_ncaltech_b2", 240, 180, 2, 15, dict(net_stem_width=1.0, yolo_stem_width=1.0, num_scales=1,
+                                            dataset="ncaltech101")),
 ]
 
 
