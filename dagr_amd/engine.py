@@ -253,6 +253,7 @@ class WindowEngine:
         self.num_classes = bb.num_classes
         self.num_scales = int(args.num_scales)
         self.use_image = bool(args.use_image)
+        self.no_events = bool(getattr(args, "no_events", False))
         # channels of the image features concatenated before Layer k (net.py:47-50): [16,64,s,s,s]
         self.feat_ch = list(bb.net.feature_channels) if self.use_image else [0] * 5
         if self.use_image:   # channels-last image branch: its feature maps are then read as [B,h,w,C] rows
@@ -695,6 +696,12 @@ class WindowEngine:
                 raise RuntimeError("model was built with --use_image: an image batch is required")
             else:
                 self.stage_image(image)
+        if self.no_events:
+            # GNNHead.forward eval, dagr.py:283-284: the image branch's own outputs (dagr.py:207-212); the reference
+            # still runs the event path and throws its maps away -- here it is skipped
+            c = self._cnn_out
+            return self._decode_maps([torch.cat([c["reg_output"][k], c["obj_output"][k], c["cls_output"][k]], 1)
+                                      for k in range(self.num_scales)])
         self.stage_graph(pos.contiguous(), batch.contiguous())
         self.stage_l0_input(feat)
         self.stage_l0_conv1()
@@ -722,6 +729,9 @@ class WindowEngine:
                 fused.append(o + torch.cat([c["reg_output"][k], c["obj_output"][k], c["cls_output"][k]], 1))
             dense_maps = fused
             self._fused_dense = fused
+        return self._decode_maps(dense_maps)
+
+    def _decode_maps(self, dense_maps):
         hybrid = [torch.cat([o[:, :4], o[:, 4:].sigmoid()], 1) for o in dense_maps]
         outputs = torch.cat([o.flatten(start_dim=2) for o in hybrid], dim=2).permute(0, 2, 1).contiguous()
         outputs[..., :2] = (outputs[..., :2] + self.grid_cache) * self.stride_cache
@@ -755,4 +765,13 @@ class WindowEngine:
         x fp32[N,1], batch)."""
         batch = data.batch if getattr(data, "batch", None) is not None else \
             torch.zeros(data.pos.shape[0], dtype=torch.int64, device=data.pos.device)
+        ng = getattr(data, "num_graphs", None)
+        if ng is not None and int(ng) > self.B:
+            raise RuntimeError(f"batch of {int(ng)} windows, but the model was built with batch_size = {self.B}")
+        for name, want in (("width", self.W), ("height", self.H), ("time_window", self.time_window)):
+            v = getattr(data, name, None)
+            if v is not None and not (torch.is_tensor(v) and v.is_cuda):   # no device read-back on the hot path
+                v = int(v[0]) if hasattr(v, "__len__") else int(v)
+                if v != want:
+                    raise RuntimeError(f"data.{name} = {v}, but the model was built for {want}")
         return self.forward_raw(data.pos.float(), data.x.float(), batch, image=getattr(data, "image", None))

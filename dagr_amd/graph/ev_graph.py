@@ -5,10 +5,10 @@ same constructor arguments, ``forward`` / ``reset`` / ``delete_nodes`` names and
 (``int64[2, E]`` in the order of ``edges[:, edges[1] >= 0]``, graph/utils.py:22).
 
 Two implementations sit behind these names:
-  * ``AsyncGraph`` / ``SlidingWindowGraph`` are the reference's state machines line for line (persistent
-    ``B x Q x H x W`` FIFO volume, timestamp log, growing index, ``delete_nodes``), on top of the 1:1
-    replacements of ``ev_graph_cuda`` (``graph/utils.py`` -> csrc/queue_compat.hip).  They cover
-    ``reset=False`` incremental use exactly like the reference.
+  * ``AsyncGraph`` / ``SlidingWindowGraph`` keep the reference's interface and semantics (persistent
+    ``B x Q x H x W`` FIFO volume, ever-growing node ids, ``delete_nodes``) for ``reset=False`` incremental use;
+    their state is one ``EventQueueState`` object over the 1:1 replacements of ``ev_graph_cuda``
+    (``graph/utils.py`` -> csrc/queue_compat.hip).
   * ``WindowGraphBuilder`` is the fast path for the ``reset=True`` windows every evaluation script uses
     (``model/networks/dagr.py:74,90``, ``model/layers/ev_tgn.py:45-49``): one fused device pipeline
     (csrc/graph_build.hip) without the FIFO volume; ``EV_TGN`` / the engine use it.
@@ -18,7 +18,7 @@ import ctypes
 import torch
 
 from .. import _lib
-from .utils import _insert_events_into_queue, _search_for_edges
+from .utils import push_events, connect_events
 
 
 class WindowGraphBuilder:
@@ -118,81 +118,145 @@ class WindowGraphBuilder:
         return edge_index, rowptr
 
 
+class EventQueueState:
+    """Device-resident state of a running event graph: the per-pixel FIFO volume ``int32[B,Q,H,W]`` (-1 = empty, slot 0
+    newest), the log of node timestamps and the id window ``[origin, next_id)`` of the nodes still alive.  Owns the calls
+    into ``libdagr_hip``'s queue entry points (``graph/utils.py``).
+
+    Unlike a tensor that is re-concatenated per call, the timestamp log and the list of collected edges live in
+    capacity-doubling buffers with a fill mark, so a long ``reset=False`` stream costs amortised O(1) copies per
+    event; ``timestamps`` / ``edges`` are views of the live part."""
+
+    def __init__(self, shape, neighbors, radius, delta_t_us):
+        self.shape = tuple(int(v) for v in shape)          # (B, Q, H, W)
+        self.neighbors, self.radius, self.delta_t_us = int(neighbors), radius, delta_t_us
+        self.device = None
+        self.volume = None
+        self.origin = 0                                   # id of the oldest node still alive
+        self.next_id = 0                                  # id the next inserted event receives
+        self._ts, self._ts_lo, self._ts_hi = None, 0, 0   # log buffer; live part = [_ts_lo, _ts_hi)
+        self._edges, self._n_edges = None, 0
+        self._ids = None                                  # arange scratch
+        self._scratch = None                              # -1-filled int64[2, K*n] the search kernel writes into
+
+    # -- storage ---------------------------------------------------------------------------------------------------
+    def attach(self, device):
+        if self.device is None:
+            self.device = device
+            self.volume = torch.full(self.shape, -1, dtype=torch.int32, device=device)
+            self._ts = torch.empty((1024,), dtype=torch.int32, device=device)
+            self._edges = torch.empty((2, 1024), dtype=torch.int64, device=device)
+
+    def clear(self):
+        self.origin = self.next_id = 0
+        self._ts_lo = self._ts_hi = self._n_edges = 0
+        if self.volume is not None:
+            self.volume.fill_(-1)
+
+    @property
+    def timestamps(self):
+        if self._ts is None:
+            return torch.zeros((0,), dtype=torch.int32)
+        return self._ts[self._ts_lo:self._ts_hi]
+
+    @property
+    def edges(self):
+        if self._edges is None:
+            return torch.zeros((2, 0), dtype=torch.long)
+        return self._edges[:, :self._n_edges]
+
+    def _log_timestamps(self, t):
+        n = t.numel()
+        if self._ts_hi + n > self._ts.numel():            # compact the dead prefix away, then grow if still needed
+            live = self._ts[self._ts_lo:self._ts_hi].clone()
+            if live.numel() + n > self._ts.numel():
+                self._ts = torch.empty((2 * (live.numel() + n),), dtype=torch.int32, device=self.device)
+            self._ts[:live.numel()] = live
+            self._ts_lo, self._ts_hi = 0, live.numel()
+        self._ts[self._ts_hi:self._ts_hi + n] = t
+        self._ts_hi += n
+
+    def _collect(self, e):
+        n = e.shape[1]
+        if self._n_edges + n > self._edges.shape[1]:
+            grown = torch.empty((2, 2 * (self._n_edges + n)), dtype=torch.int64, device=self.device)
+            grown[:, :self._n_edges] = self._edges[:, :self._n_edges]
+            self._edges = grown
+        self._edges[:, self._n_edges:self._n_edges + n] = e
+        self._n_edges += n
+
+    # -- one call: insert the events, connect them ---------------------------------------------------------------------
+    def append(self, batch, pos, collect):
+        """Push ``n`` events (ids ``next_id ..``) into the FIFO volume, then search their neighbourhoods.
+        Returns ``int64[2, E]`` with source / destination ids relative to ``origin``-free numbering as the native
+        module writes them (global ids)."""
+        n = int(batch.shape[0])
+        if self._ids is None or self._ids.numel() < n:
+            self._ids = torch.arange(n, dtype=torch.int32, device=self.device)
+            self._scratch = torch.empty((2, self.neighbors * n), dtype=torch.int64, device=self.device)
+        ids = (self._ids[:n] + self.next_id).contiguous()
+        self.next_id += n
+        self._log_timestamps(pos[:, 2])
+        push_events(self.volume, batch, pos, ids)
+        self._scratch.fill_(-1)
+        found = connect_events(self.volume, batch, pos, self.timestamps.contiguous(), ids, self.neighbors, self.radius,
+                               self.delta_t_us, self._scratch, self.origin)
+        if collect:
+            self._collect(found)
+        return found
+
+    def forget_oldest(self, n, drop_edges):
+        """The ``n`` oldest nodes leave the graph: ids are renumbered from the new origin.  Collected edges that touch
+        a forgotten node are cut out (and returned) when ``drop_edges``."""
+        self._ts_lo = min(self._ts_lo + n, self._ts_hi)
+        self.origin += n
+        cut = None
+        live = self.edges
+        if drop_edges:
+            dead = live.min(dim=0).values < n if live.shape[1] else torch.zeros((0,), dtype=torch.bool, device=live.device)
+            cut = live[:, dead].clone()
+            kept = live[:, ~dead]
+            self._n_edges = kept.shape[1]
+            self._edges[:, :self._n_edges] = kept
+        self.edges.sub_(n)
+        return cut
+
+
 class AsyncGraph:
-    """Mirror of ``ev_graph.py:18-103``."""
+    """Same constructor / ``forward`` / ``reset`` as ``ev_graph.py:18-103``; the state lives in ``EventQueueState``."""
 
     def __init__(self, width=640, height=480, batch_size=1, max_num_neighbors=16, max_queue_size=512, radius=7,
                  delta_t_us=600000):
-        self.radius = radius
-        self.delta_t_us = delta_t_us
-        self.event_queue = None
-        self.max_index = 0
-        self.min_index = 0
-        self.max_queue_size = max_queue_size
-        self.max_num_neighbors = max_num_neighbors
-        self.width = width
-        self.height = height
-        self.batch_size = batch_size
-        self.device = None
-        self.edges = torch.zeros((2, 0), dtype=torch.long)
-        self.all_timestamps = torch.zeros((0,), dtype=torch.int32)
-        self.new_indices = None
-        self.edge_buffer = None
+        self.width, self.height, self.batch_size = width, height, batch_size
+        self.max_num_neighbors, self.max_queue_size = max_num_neighbors, max_queue_size
+        self.radius, self.delta_t_us = radius, delta_t_us
+        self.state = EventQueueState((batch_size, max_queue_size, height, width), max_num_neighbors, radius, delta_t_us)
 
-    def initialize(self, n_ev, device):  # :45-50
-        self.edges = torch.zeros((2, 0), dtype=torch.long, device=device)
-        self.all_timestamps = torch.zeros((0,), dtype=torch.int32, device=device)
-        self.new_indices = torch.arange(n_ev, dtype=torch.int32, device=device)
-        self.edge_buffer = torch.full((2, self.max_num_neighbors * n_ev), dtype=torch.int64, fill_value=-1,
-                                      device=device)
-        self.event_queue = torch.full((self.batch_size, self.max_queue_size, self.height, self.width), fill_value=-1,
-                                      device=device, dtype=torch.int32)
+    # the reference's attribute names, as read-only views of the state
+    device = property(lambda self: self.state.device)
+    event_queue = property(lambda self: self.state.volume)
+    all_timestamps = property(lambda self: self.state.timestamps)
+    edges = property(lambda self: self.state.edges)
+    min_index = property(lambda self: self.state.origin)
+    max_index = property(lambda self: self.state.next_id)
 
-    def reset(self):  # :52-60
-        self.edges = torch.zeros((2, 0), dtype=torch.long, device=self.device)
-        self.all_timestamps = torch.zeros((0,), dtype=torch.int32, device=self.device)
-        self.max_index = 0
-        self.min_index = 0
-        if self.edge_buffer is not None:
-            self.edge_buffer.fill_(-1)
-        if self.event_queue is not None:
-            self.event_queue.fill_(-1)
-
-    def _forward(self, batch, pos, collect_edges=True):  # :63-103
-        n_ev = len(batch)
-        if not batch.is_cuda:  # the reference's CPU shim never triggers (ev_graph.py:7-8); its kernels assert CUDA
-            raise RuntimeError("batch must be a CUDA tensor")
-        if self.device is None:
-            self.device = batch.device
-            self.initialize(n_ev, self.device)
-        if len(batch) == 0:
-            return torch.zeros((2, 0), device=self.device, dtype=torch.int32)
-        assert type(batch) is torch.Tensor and batch.dtype == torch.int32, [type(batch), batch.dtype]
-        pos = pos.int().contiguous()
-        batch = batch.contiguous()
-        self.all_timestamps = torch.cat([self.all_timestamps, pos[:, 2]])
-        if n_ev > len(self.new_indices):
-            self.new_indices = torch.arange(0, n_ev, dtype=torch.int32, device=self.device)
-            self.edge_buffer = torch.full((2, self.max_num_neighbors * n_ev), dtype=torch.int64, fill_value=-1,
-                                          device=self.device)
-        indices = (self.max_index + self.new_indices[:n_ev]).contiguous()
-        self.max_index += n_ev
-        self.event_queue = _insert_events_into_queue(batch, pos, indices=indices, queue=self.event_queue)
-        self.edge_buffer.fill_(-1)
-        edge_indices = _search_for_edges(batch, pos, all_timestamps=self.all_timestamps.contiguous(), indices=indices,
-                                         queue=self.event_queue, max_num_neighbors=self.max_num_neighbors,
-                                         radius=self.radius, delta_t_us=self.delta_t_us, edges=self.edge_buffer,
-                                         min_index=self.min_index)
-        if collect_edges:
-            self.edges = torch.cat([self.edges, edge_indices], dim=-1)
-        return edge_indices
+    def reset(self):
+        self.state.clear()
 
     def forward(self, batch, pos, collect_edges=True):
-        return self._forward(batch, pos, collect_edges=collect_edges)
+        if not batch.is_cuda:   # the native kernels assert CUDA tensors (ev_graph.cu:9); there is no CPU path
+            raise RuntimeError("batch must be a CUDA tensor")
+        self.state.attach(batch.device)
+        if batch.numel() == 0:
+            return torch.zeros((2, 0), device=batch.device, dtype=torch.int32)
+        if batch.dtype != torch.int32:
+            raise AssertionError([type(batch), batch.dtype])
+        return self.state.append(batch.contiguous(), pos.int().contiguous(), collect_edges)
 
 
 class SlidingWindowGraph(AsyncGraph):
-    """``ev_graph.py:106-166``: ``AsyncGraph`` plus dropping the oldest nodes after every call."""
+    """``ev_graph.py:106-166``: after every call the window slides -- as many of the oldest nodes leave as new ones
+    arrived (unless ``delete_nodes=False``)."""
 
     def __init__(self, width=640, height=480, batch_size=1, max_num_neighbors=16, max_queue_size=1024, radius=7,
                  delta_t_us=600000):
@@ -200,30 +264,22 @@ class SlidingWindowGraph(AsyncGraph):
 
     @property
     def init(self):
-        return self.all_timestamps.numel() > 0
+        return self.state.timestamps.numel() > 0
 
     def delete_nodes(self, n_delete, delete_edges=True, return_edges=True):
-        """Forget the n oldest nodes: shift the index origin; edges touching them are removed (and returned)."""
-        self.all_timestamps = self.all_timestamps[n_delete:]
-        self.min_index += n_delete
-        removed = None
-        if delete_edges:
-            touches_old = (self.edges < n_delete).any(dim=0)
-            removed = self.edges[:, touches_old].clone()
-            self.edges = self.edges[:, ~touches_old]
-        self.edges.add_(-n_delete)
-        return removed if (delete_edges and return_edges) else None
+        cut = self.state.forget_oldest(int(n_delete), delete_edges)
+        return cut if (delete_edges and return_edges) else None
 
     def forward(self, batch, pos, return_node_counts=False, return_total_edges=False, delete_nodes=True,
                 collect_edges=True):
-        n_old = len(batch) if self.init else 0
-        out = [self._forward(batch, pos, collect_edges=collect_edges)]
-        snapshot = self.edges.clone() if return_total_edges else None
-        n_total = len(self.all_timestamps)
+        leaving = int(batch.shape[0]) if self.init else 0
+        result = [AsyncGraph.forward(self, batch, pos, collect_edges=collect_edges)]
+        everything = self.edges.clone() if return_total_edges else None
+        alive = int(self.state.timestamps.numel())
         if delete_nodes:
-            out.append(self.delete_nodes(n_old))
+            result.append(self.delete_nodes(leaving))
         if return_total_edges:
-            out.append(snapshot)
+            result.append(everything)
         if return_node_counts:
-            out.append([n_old, len(batch), n_total])
-        return out[0] if len(out) == 1 else out
+            result.append([leaving, int(batch.shape[0]), alive])
+        return result if len(result) > 1 else result[0]

@@ -63,6 +63,7 @@ class DAGR(torch.nn.Module):
         super().__init__()
         self.conf_threshold = 0.001
         self.nms_threshold = 0.65
+        self.check_device_status = True    # set False to skip the per-call status read-back
         self.height = height
         self.width = width
         self.args = args
@@ -71,6 +72,11 @@ class DAGR(torch.nn.Module):
                             in_channels_cnn=self.backbone.out_channels_cnn, strides=self.backbone.strides,
                             pretrain_cnn=args.pretrain_cnn, args=args)
         self._engine = None
+        self._engine_stamp = None
+        if bool(args.no_events) and not bool(args.use_image):
+            raise ValueError("--no_events returns the image branch's detections (dagr.py:283-284): it needs --use_image")
+        if bool(getattr(args, "keep_temporal_ordering", False)):
+            raise NotImplementedError("--keep_temporal_ordering (pooling.py:69-72) is not implemented by the HIP pooling")
         if "img_net_checkpoint" in vars(args):
             from ..utils import init_subnetwork
             state_dict = torch.load(args.img_net_checkpoint)
@@ -98,10 +104,28 @@ class DAGR(torch.nn.Module):
                     getattr(h, name + s).init_lut(height=height, width=width, Mx=M, rx=rx, ry=ry)
         self._engine = None  # parameters / domains changed: rebuild the device-side plan lazily
 
+    def _weights_stamp(self):
+        """Cheap fingerprint of everything the engine snapshots (packed, BN-folded weights; the folded copy of the
+        image branch): in-place edits bump ``_version``, ``.to()`` / ``load_state_dict`` on sub-modules
+        (``init_subnetwork``) change storage or version."""
+        ver, first = 0, None
+        for t in list(self.parameters()) + list(self.buffers()):
+            ver += t._version
+            if first is None:
+                first = (t.data_ptr(), str(t.device))
+        return ver, first
+
+    def invalidate_engine(self):
+        """Drop the device-side plan; the next forward re-packs the weights."""
+        self._engine = None
+
     def engine(self):
-        if self._engine is None:
+        stamp = self._weights_stamp()
+        if self._engine is None or self._engine_stamp != stamp:
             from ...engine import WindowEngine
+            self._engine = None
             self._engine = WindowEngine(self)
+            self._engine_stamp = self._weights_stamp()
         return self._engine
 
     def load_state_dict(self, *a, **kw):
@@ -115,10 +139,16 @@ class DAGR(torch.nn.Module):
             raise NotImplementedError("training (losses, backward) is outside this round's scope")
         if not reset:
             raise NotImplementedError("incremental (reset=False) inference is not implemented")
-        outputs = self.engine().forward_data(x)
+        eng = self.engine()
+        outputs = eng.forward_data(x)
         detections = postprocess_network_output(outputs, self.backbone.num_classes, self.conf_threshold,
                                                 self.nms_threshold, filtering=filtering, height=self.height,
                                                 width=self.width)
+        if self.check_device_status:
+            # sticky device-side flags (events outside the sensor / batch range, pooled-level capacity overflows,
+            # to_dense cells outside the map): a window that tripped one was computed on a truncated graph.  The
+            # stream was just drained by postprocess, so this is a handful of 4-byte reads.
+            eng.check_status()
         ret = [detections]
         if return_targets and hasattr(x, "bbox"):
             ret.append(convert_to_evaluation_format(x))

@@ -28,9 +28,7 @@ def postprocess_network_output(prediction, num_classes, conf_thre=0.01, nms_thre
                                filtering=True):
     """Batched, device-side version of ``model/utils.py:61-110``: cxcywh -> xyxy, class max, the reference's
     confidence mask (obj * cls * cls >= thr), class-offset greedy NMS for all images in ONE kernel launch
-    (``dagr_nms_batched``), then one small D2H copy of the survivor counts to cut the per-image result dicts
-    (the reference's return type is inherently variable-length).  ``prediction``: [B, A, 5 + C] on the GPU."""
-    import ctypes
+    (``dagr_nms_batched``).  ``prediction``: [B, A, 5 + C] on the GPU."""
     from .. import _lib
     if not prediction.is_cuda:
         raise RuntimeError("postprocess_network_output expects the decoded head outputs on the GPU")
@@ -40,24 +38,29 @@ def postprocess_network_output(prediction, num_classes, conf_thre=0.01, nms_thre
     boxes = torch.cat((x1y1, wh + x1y1), dim=-1).contiguous()                      # same op order as :62-63
     class_conf, class_pred = torch.max(prediction[..., 5:5 + num_classes], dim=-1)
     scores = (prediction[..., 4] * class_conf).contiguous()                        # image_pred[:, 4:5] *= class_conf
-    valid = (scores * class_conf >= conf_thre) if filtering else torch.ones_like(scores, dtype=torch.bool)
+    if not filtering:
+        # :87-88,101-102: neither the confidence mask nor the NMS indices are applied -- every anchor comes back,
+        # in anchor order
+        return [{"boxes": boxes[b], "scores": scores[b], "labels": class_pred[b].long()} for b in range(B)]
+    valid = scores * class_conf >= conf_thre
     cls32 = class_pred.to(torch.int32).contiguous()
     valid8 = valid.to(torch.uint8).contiguous()
     dev = prediction.device
     order = torch.empty((B, A), dtype=torch.int32, device=dev)
     keep = torch.empty((B, A), dtype=torch.int32, device=dev)
     n_keep = torch.empty((B,), dtype=torch.int32, device=dev)
-    thr = nms_thre if filtering else 2.0    # without filtering the reference keeps every row (only orders them)
     _lib.check(_lib.lib().dagr_nms_batched(_lib.ptr(boxes), _lib.ptr(scores), _lib.ptr(cls32), _lib.ptr(valid8), B, A,
-                                           float(thr), float(max(width, height) + 1), _lib.ptr(order),
+                                           float(nms_thre), float(max(width, height) + 1), _lib.ptr(order),
                                            _lib.ptr(keep), _lib.ptr(n_keep), _lib.cur_stream(dev)), "nms_batched")
-    order = order.long()
-    kept = keep.bool()
-    output = []
-    for b in range(B):            # B result dicts; no per-anchor work on the host
-        sel = order[b][kept[b]]
-        output.append({"boxes": boxes[b, sel], "scores": scores[b, sel], "labels": class_pred[b, sel].long()})
-    return output
+    # survivors to the front of every row (score order kept), then ONE D2H copy (the B survivor counts) cuts the
+    # per-image dicts: the reference's return type is variable-length, so one synchronisation is inherent
+    front = torch.argsort(keep == 0, dim=1, stable=True)
+    sel = order.long().gather(1, front)
+    bsel = boxes.gather(1, sel.unsqueeze(-1).expand(B, A, 4))
+    ssel = scores.gather(1, sel)
+    lsel = class_pred.gather(1, sel)
+    counts = n_keep.tolist()
+    return [{"boxes": bsel[b, :n], "scores": ssel[b, :n], "labels": lsel[b, :n].long()} for b, n in enumerate(counts)]
 
 
 def convert_to_evaluation_format(data):

@@ -76,3 +76,84 @@ def test_batched_nms_matches_oracle_on_random_boxes():
         assert torch.allclose(a["scores"].cpu(), b["scores"], atol=1e-6)
         assert torch.allclose(a["boxes"].cpu(), b["boxes"], atol=1e-4)
         assert torch.equal(a["labels"].cpu(), b["labels"])
+
+
+def _tiny_batch(W, H, B, with_image=False, seed=60):
+    samples = []
+    for s in range(B):
+        x, y, t, p = syn.edges_window(2000, W, H, seed=seed + s)
+        d = Data(x=torch.from_numpy(p.reshape(-1, 1)), pos=torch.from_numpy(np.stack([x, y], -1)),
+                 t=torch.from_numpy(t), width=W, height=H, time_window=1000000)
+        if with_image:
+            d.image = torch.randint(0, 256, (1, 3, H, W), generator=torch.Generator().manual_seed(seed + s),
+                                    dtype=torch.uint8)
+        samples.append(d)
+    return format_data(Batch.from_data_list(samples).cuda())
+
+
+def test_filtering_false_returns_every_anchor_in_anchor_order():
+    """model/utils.py:87-88,101-102: without filtering neither the confidence mask nor the NMS indices are applied."""
+    from dagr_amd.model.networks.dagr import DAGR
+    W, H, B = 320, 215, 2
+    torch.manual_seed(0)
+    model = randomize_(DAGR(om.default_args(batch_size=B), height=H, width=W)).eval().cuda()
+    data = _tiny_batch(W, H, B)
+    with torch.no_grad():
+        raw = model.engine().forward_data(data).clone()
+        det, = model(data, filtering=False)
+    assert len(det) == B
+    for b in range(B):
+        assert det[b]["boxes"].shape == (175, 4) and det[b]["scores"].shape == (175,)
+        cc, cp = raw[b, :, 5:].max(-1)
+        assert torch.equal(det[b]["labels"], cp)
+        assert torch.allclose(det[b]["scores"], raw[b, :, 4] * cc)
+        assert torch.allclose(det[b]["boxes"][:, :2], raw[b, :, :2] - raw[b, :, 2:4] / 2)
+
+
+def test_no_events_returns_the_image_branch_outputs():
+    """GNNHead.forward eval with --no_events (dagr.py:283-284): the CNN head's own maps, decoded."""
+    from dagr_amd.model.networks.dagr import DAGR
+    W, H, B = 320, 215, 2
+    torch.manual_seed(0)
+    args = om.default_args(batch_size=B, use_image=True, img_net="resnet18", no_events=True)
+    model = randomize_(DAGR(args, height=H, width=W)).eval().cuda()
+    data = _tiny_batch(W, H, B, with_image=True)
+    with torch.no_grad():
+        eng = model.engine()
+        out = eng.forward_data(data)
+        feats, outs = model.backbone.net(data.image)
+        resized = [torch.nn.functional.interpolate(f, o) for f, o in zip(outs[-2:], eng.out_sizes)]
+        c = model.head.cnn_head(resized)
+        maps = [torch.cat([c["reg_output"][k], c["obj_output"][k].sigmoid(), c["cls_output"][k].sigmoid()], 1)
+                for k in range(2)]
+        want = torch.cat([m.flatten(start_dim=2) for m in maps], dim=2).permute(0, 2, 1).contiguous()
+        want[..., :2] = (want[..., :2] + eng.grid_cache) * eng.stride_cache
+        want[..., 2:4] = torch.exp(want[..., 2:4]) * eng.stride_cache
+    rel = ((out - want).abs() / (1 + want.abs())).max().item()
+    assert rel < 2e-4, rel
+    with pytest.raises(ValueError):
+        DAGR(om.default_args(batch_size=B, no_events=True), height=H, width=W)
+
+
+def test_engine_follows_weight_edits_and_rejects_oversized_batches():
+    """The engine snapshots packed weights: in-place parameter edits / sub-module load_state_dict must re-pack."""
+    from dagr_amd.model.networks.dagr import DAGR
+    W, H, B = 320, 215, 2
+    torch.manual_seed(0)
+    model = randomize_(DAGR(om.default_args(batch_size=B), height=H, width=W)).eval().cuda()
+    data = _tiny_batch(W, H, B)
+    with torch.no_grad():
+        o1 = model.engine().forward_data(data).clone()
+        e1 = model.engine()
+        assert model.engine() is e1                       # nothing changed: same plan
+        model.head.obj_pred1.bias.add_(1.0)               # in-place edit
+        o2 = model.engine().forward_data(data).clone()
+        assert model.engine() is not e1
+        sub = {k: v.clone() for k, v in model.backbone.layer5.state_dict().items()}
+        sub["conv_block1.conv.weight"] *= 0.5
+        model.backbone.layer5.load_state_dict(sub)        # what init_subnetwork does
+        o3 = model.engine().forward_data(data).clone()
+    assert not torch.equal(o1, o2) and not torch.equal(o2, o3)
+    three = _tiny_batch(W, H, 3)
+    with pytest.raises(RuntimeError):
+        model.engine().forward_data(three)
