@@ -1,12 +1,18 @@
 #!/usr/bin/env python
-"""bench.py -- events/sec of the DAGR event-graph hot path on MI355X.
+"""bench.py -- events/sec and per-window latency of the DAGR event-graph hot path on MI355X.
 
-One "step" = one pass of the hot path (format_data'd events -> graph build -> SplineConv stack +
-voxel pooling -> decoded detection-head outputs [B,175,5+C]) over one batch of B synthetic 50 ms
-event windows already resident in HBM.  `python bench.py --gpus N --steps K --warmup W`; for N > 1
-the driver launches it under torch.distributed.run (one rank per GPU); windows are independent so
-ranks share nothing on the data path (weak scaling) and RCCL is used once, to all-gather the
-detections of the run.  Prints ONE JSON line on rank 0.
+One "step" = one pass of the hot path (format_data'd events -> graph build -> SplineConv stack + voxel pooling ->
+decoded detection-head outputs [B,175,5+C] -> device-side confidence mask + NMS) over one batch of B synthetic 50 ms
+event windows already resident in HBM.  `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches
+it under torch.distributed.run (one rank per GPU); windows are independent so ranks share nothing on the data path
+(weak scaling) and RCCL is used once, to gather the run's detections (variable length).  Prints ONE JSON line on rank 0:
+
+  value / ms_per_step   BASELINE config 2 on the synthetic 640x480 stream (dagr-s + resnet50 image branch), K steps
+  events_only           the same K steps on the events-only model (config 1 shape): the hand-written path alone
+  latency_ms            per-window latency (HIP events, one window batch at a time, 20 warm-up + 100 timed windows):
+                        median / p95 for B in {1, 8}, N in {25k..400k} events per window, S-uniform and S-edges
+  roofline / stages     dominant kernel of the event path and per-stage timings (HIP events on the kernels' stream)
+  cpu_baseline          the CPU oracle (a port of the reference's op sequence) on the host cores, median of 10 windows
 """
 import argparse
 import json
@@ -20,7 +26,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6290.0  # same guide: 6.29 TB/s measured float4 copy -- what `floor_us` is priced at
 
 
 def parse():
@@ -34,17 +41,19 @@ def parse():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--stream", choices=["uniform", "edges"], default="uniform")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the per-window latency sweep")
+    ap.add_argument("--no-events-only-leg", action="store_true", help="skip the events-only sub-measurement")
     ap.add_argument("--events-only", action="store_true",
-                    help="BASELINE config 1 shape (no --use_image) instead of config 2 (ResNet-50 image branch)")
+                    help="make the events-only model (BASELINE config 1 shape) the headline instead of config 2")
     ap.add_argument("--img-net", default="resnet50")
     ap.add_argument("--engines", type=int, default=3,
                     help="independent engine instances (own buffers + stream) that consecutive window batches "
                          "rotate through; windows share no state, so batch i's latency-bound tail overlaps the level 0 "
-                         "of batches i+1, i+2 (measured events-only: 1 -> 458 M, 2 -> 557 M, 3 -> 596 M, 4 -> 544 M ev/s)")
-    ap.add_argument("--pipeline-image", dest="pipeline_image", action="store_true",
-                    help="run the image branch one step ahead on a shared side stream instead of in-line per engine "
-                         "(measured slower: 8.9 vs 8.2 ms/step with 2 engines)")
-    ap.add_argument("--cpu-windows", type=int, default=4)
+                         "of batches i+1, i+2")
+    ap.add_argument("--cpu-windows", type=int, default=10)
+    ap.add_argument("--latency-windows", type=int, default=100)
+    ap.add_argument("--latency-warmup", type=int, default=20)
+    ap.add_argument("--latency-n", type=str, default="25000,50000,100000,200000,400000")
     return ap.parse_args()
 
 
@@ -89,6 +98,20 @@ def algorithmic_bytes(N, E, r, levels, use_image=False):
     return out
 
 
+def compulsory_bytes(N, K, use_image):
+    """Bytes a level-0 conv launch cannot avoid moving once (what `floor_us` prices): its input rows, the fixed-stride
+    neighbour lists as this library stores them (K x (int32 src + int16 code) + int32 degree), its output rows; the
+    per-edge gathers the 8(d) formula charges are served by L2 because level 0 is laid out in pixel-slot order."""
+    c0 = 19 if use_image else 3
+    nbr = K * 6 + 4
+    return {"l0_conv1": N * (4 * c0 + nbr + 64), "l0_conv2": N * (64 + 4 * c0 + nbr + 64)}
+
+
+def _sync():
+    if torch.cuda.is_available():   # (the CPU/gloo dry-run of the control flow in tests/ has no device to wait for)
+        torch.cuda.synchronize()
+
+
 def time_gpu(fn, iters, warm=3):
     for _ in range(warm):
         fn()
@@ -104,19 +127,20 @@ def time_gpu(fn, iters, warm=3):
 
 
 def cpu_baseline(model_cpu, model_sd, W, H, n_events, n_windows, stream, use_image, img_net):
-    """The oracle (op-for-op CPU restatement, `port`) on a bounded sample: B=1 windows of the same
-    synthetic stream.  Graph build: single-threaded C; conv/pool (and, with the image branch, the same
-    torch ResNet/CNN-head modules) on all host threads."""
+    """The oracle (op-for-op CPU restatement, `port`) on a bounded sample: B=1 windows of the same synthetic stream,
+    median per-window time over `n_windows`.  Graph build: single-threaded C; conv/pool (and, with the image branch, the
+    same torch ResNet/CNN-head modules) on all host threads."""
     from oracle import model as om
     from dagr_amd.utils import synthetic as syn
     gen = syn.uniform_window if stream == "uniform" else syn.edges_window
     a = om.default_args(batch_size=1, use_image=use_image, img_net=img_net)
     nc = om.NetConstants(a, H, W)
-    tot_ev, t0 = 0, time.perf_counter()
+    times = []
     with torch.no_grad():
         for w in range(n_windows):
             x, y, t, p = gen(n_events, W, H, seed=1234 + w)
             b = np.zeros(len(x), np.int64)
+            t0 = time.perf_counter()
             image_feat = cnn_out = None
             if use_image:
                 img = torch.rand((1, 3, H, W), generator=torch.Generator().manual_seed(w))
@@ -125,12 +149,204 @@ def cpu_baseline(model_cpu, model_sd, W, H, n_events, n_windows, stream, use_ima
                 cnn_out = model_cpu.head.cnn_head(resized)
                 image_feat = feats
             om.forward_events(model_sd, a, H, W, x, y, t, p, b, 1, image_feat=image_feat, cnn_out=cnn_out)
-            tot_ev += len(x)
-    dt = time.perf_counter() - t0
+            times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
     what = f"dagr-s + {img_net} image branch" if use_image else "events-only dagr-s"
-    return dict(value=tot_ev / dt, unit="events/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{n_windows} windows x {n_events} events, {W}x{H}, B=1, {what}, "
-                       f"oracle/model.py (torch-CPU fp32 + C graph builder), {dt:.1f} s")
+    return dict(value=n_events / med, unit="events/s", cores=torch.get_num_threads(), kind="port",
+                window_ms_median=round(1e3 * med, 1), window_ms_p95=round(1e3 * float(np.percentile(times, 95)), 1),
+                sample=f"median of {n_windows} windows x {n_events} events, {W}x{H}, B=1, {what}, oracle/model.py "
+                       f"(torch-CPU fp32 + C graph builder), {sum(times):.1f} s of CPU work")
+
+
+class Rig:
+    """One model on the device + its engines / streams + resident synthetic slots."""
+
+    def __init__(self, W, H, B, use_image, img_net, n_eng, dev):
+        from dagr_amd.engine import WindowEngine
+        self.W, self.H, self.B, self.use_image, self.dev = W, H, B, use_image, dev
+        self.args, model = make_model(W, H, B, use_image=use_image, img_net=img_net)
+        self.sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        self.model = model.to(dev)
+        self.model.cache_luts(width=W, height=H, radius=self.args.radius)
+        eng = self.model.engine()
+        self.engines = [eng] + [WindowEngine(self.model) for _ in range(n_eng - 1)]
+        self.streams = [torch.cuda.Stream(dev) for _ in range(n_eng)] if n_eng > 1 else [torch.cuda.current_stream(dev)]
+        self.num_classes = self.model.backbone.num_classes
+
+    def make_slots(self, gen, npw, n_slots, seed):
+        from dagr_amd.utils import synthetic as syn
+        slots = []
+        for s in range(n_slots):
+            x, y, t, p, b = syn.batch_windows(gen, npw, self.B, self.W, self.H, seed=seed + 10 * s)
+            pos = torch.from_numpy(syn.format_data_np(x, y, t, self.W, self.H)).to(self.dev)
+            feat = torch.from_numpy(p.astype(np.float32)).view(-1, 1).to(self.dev)
+            batch = torch.from_numpy(b).to(self.dev)
+            image = None
+            if self.use_image:  # format_data'd frames (uint8/255, utils/buffers.py:37-38), resident like the events
+                image = torch.rand((self.B, 3, self.H, self.W),
+                                   generator=torch.Generator().manual_seed(77 + s + seed - 1234)).to(self.dev)
+            slots.append((pos, feat, batch, image))
+        return slots
+
+    def step(self, i, slots):
+        """forward + device-side post-processing of window batch i on engine i % n; returns (det[B,A,6], n_keep[B])."""
+        from dagr_amd.model.utils import postprocess_device
+        pos, feat, batch, image = slots[i % len(slots)]
+        k = i % len(self.engines)
+        e, st = self.engines[k], self.streams[k]
+        with torch.cuda.stream(st):
+            out = e.forward_raw(pos, feat, batch, image=image)
+            return postprocess_device(out, self.num_classes, self.model.conf_threshold, self.model.nms_threshold,
+                                      self.H, self.W)
+
+    def drain(self):
+        cur = torch.cuda.current_stream(self.dev)
+        for st in self.streams:
+            cur.wait_stream(st)
+
+
+def detections_rows(results, rank, B):
+    """Variable-length detection rows (window id, x1, y1, x2, y2, score, label) of a run, cut on the device."""
+    det = torch.stack([d for d, _ in results])            # [K, B, A, 6]
+    n = torch.stack([k for _, k in results])               # [K, B]
+    K, _, A, _ = det.shape
+    wid = (torch.arange(K, device=det.device).view(K, 1) * B + torch.arange(B, device=det.device).view(1, B)
+           + rank * K * B).float()
+    rows = torch.cat([wid.view(K, B, 1, 1).expand(K, B, A, 1), det], -1)
+    mask = torch.arange(A, device=det.device).view(1, 1, A) < n.view(K, B, 1)
+    return rows[mask]
+
+
+def timed_run(rig, slots, steps, warmup, dist, world, rank):
+    """W untimed warm-up steps, then exactly `steps` steps between barrier + synchronize brackets; MAX over ranks."""
+    from dagr_amd import parallel
+    dev = rig.dev
+    for i in range(warmup):
+        rig.step(i, slots)
+    _sync()
+    for e in rig.engines:
+        e.check_status()
+    _sync()
+    if dist is not None:
+        dist.barrier()
+    _sync()
+    t0 = time.perf_counter()
+    results = [rig.step(i, slots) for i in range(steps)]
+    rig.drain()
+    _sync()
+    t_compute = time.perf_counter() - t0
+    rows = detections_rows(results, rank, rig.B)           # the run's detections of this rank
+    allrows = parallel.gather_detections(rows) if dist is not None else rows   # the job's only collective (RCCL)
+    _sync()
+    t_gather = time.perf_counter() - t0 - t_compute
+    if dist is not None:
+        dist.barrier()
+    _sync()
+    elapsed = time.perf_counter() - t0
+    per_rank = None
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        mine = torch.tensor([t_compute, t_gather], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [[float(v) for v in t.tolist()] for t in every]
+    rig.engines[0].check_status()
+    return dict(elapsed=elapsed, t_compute=t_compute, t_gather=t_gather, per_rank=per_rank,
+                n_detections=int(allrows.shape[0]))
+
+
+def stage_timings(rig, slots, n_events_step):
+    """Per-stage / per-kernel timing of one engine on the stream the kernels run on (HIP events) + roofline inputs."""
+    eng = rig.engines[0]
+    use_image = rig.use_image
+    pos, feat, batch, image = slots[0]
+    eng.forward_raw(pos, feat, batch, image=image)
+    ne, _ = eng.graph.status()
+    levels = [tuple(int(v) for v in lvl.counts.tolist()) for lvl in eng.levels]
+    r = eng.graph.params["radius"]
+    ab = algorithmic_bytes(n_events_step, ne, r, levels, use_image)
+    iters = 20
+    stages = {}
+    if use_image:
+        stages["image_branch"] = time_gpu(lambda: eng.stage_image(image), 5, warm=1)
+    stages["graph"] = time_gpu(lambda: eng.stage_graph(pos, batch), iters)
+    eng.stage_l0_input(feat)
+    stages["l0_input"] = time_gpu(lambda: eng.stage_l0_input(feat), iters)
+    stages["l0_conv1"] = time_gpu(eng.stage_l0_conv1, iters)
+    stages["l0_conv2"] = time_gpu(lambda: eng.stage_l0_conv2(sample=False), iters)
+    if use_image:
+        stages["l0_sample1"] = time_gpu(lambda: (eng.stage_l0_conv2(sample=True)), iters) - stages["l0_conv2"]
+    stages["pool1"] = time_gpu(eng.stage_pool1, iters)
+    stages["tail"] = time_gpu(eng.stage_tail, iters)
+    stages["head"] = time_gpu(lambda: eng._decode(eng.stage_head()), iters)
+    kernels = {k: dict(ms=round(v, 4), alg_MB=round(ab[k] / 1e6, 2) if k in ab else None,
+                       alg_GBs=round(ab[k] / 1e9 / (v / 1e3), 1) if k in ab else None)
+               for k, v in stages.items()}
+    dom = max(("l0_conv1", "l0_conv2"), key=lambda k: stages[k])  # single-launch stages
+    achieved = ab[dom] / 1e9 / (stages[dom] / 1e3)
+    kname = eng.l0_kernel_names()[dom]
+    # HBM bytes per launch: PMC counters cannot be read from inside this process; the number is the one the
+    # rocprofv3 --pmc passes of this same command produced (tools/pmc.sh -> profiles/r*_traffic.json, committed)
+    traffic, src = None, None
+    for tj in ("r2_traffic.json", "r1_traffic.json"):
+        path = os.path.join(ROOT, "profiles", tj)
+        if n_events_step == 800000 and (rig.W, rig.H) == (640, 480) and os.path.exists(path):
+            cfg = json.load(open(path))["configs"]["use_image" if use_image else "events_only"]
+            if kname in cfg:
+                traffic, src = cfg[kname].get("traffic_bytes"), "profiles/" + tj
+                break
+    floor = compulsory_bytes(n_events_step, eng.graph.K, use_image)[dom]
+    floor_us = floor / (HBM_ACHIEVABLE_GBS * 1e3)
+    roofline = dict(kernel=kname, bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=src,
+                    frac_traffic=(round(traffic / 1e9 / (stages[dom] / 1e3) / HBM_PEAK_GBS, 4) if traffic else None),
+                    compulsory_bytes=int(floor), floor_us=round(floor_us, 1),
+                    x_over_floor=round(stages[dom] * 1e3 / floor_us, 1),
+                    alg_bytes_per_launch=int(ab[dom]), launch_ms=round(stages[dom], 4))
+    return dict(roofline=roofline, stages=kernels, edges_per_step=int(ne), levels=levels, radius=r,
+                batch_latency_ms=round(sum(stages.values()), 4))
+
+
+def latency_sweep(W, H, use_image, img_net, dev, Ns, n_warm, n_timed):
+    """Per-window latency: one window batch at a time through ONE engine; the device is idle when a window starts
+    (synchronize), HIP events bracket forward + post-processing on the engine's stream."""
+    from dagr_amd.utils import synthetic as syn
+    from dagr_amd.model.utils import postprocess_device
+    out = {}
+    for B in (1, 8):
+        rig = Rig(W, H, B, use_image, img_net, 1, dev)
+        eng = rig.engines[0]
+        for sname, gen in (("uniform", syn.uniform_window), ("edges", syn.edges_window)):
+            for N in Ns:
+                slots = rig.make_slots(gen, N, 2, seed=4234)
+
+                def window(i):
+                    pos, feat, batch, image = slots[i % 2]
+                    o = eng.forward_raw(pos, feat, batch, image=image)
+                    return postprocess_device(o, rig.num_classes, 0.001, 0.65, H, W)
+                for i in range(n_warm):
+                    window(i)
+                torch.cuda.synchronize()
+                evs = []
+                for i in range(n_timed):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    torch.cuda.synchronize()
+                    e0.record()
+                    window(i)
+                    e1.record()
+                    evs.append((e0, e1))
+                torch.cuda.synchronize()
+                eng.check_status()
+                ms = np.array([a.elapsed_time(b) for a, b in evs])
+                out.setdefault(sname, {}).setdefault(f"B{B}", {})[str(N)] = dict(
+                    p50=round(float(np.median(ms)), 4), p95=round(float(np.percentile(ms, 95)), 4),
+                    events_per_s=round(B * N / (float(np.median(ms)) / 1e3), 1))
+                del slots
+        del rig, eng
+        torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -150,154 +366,79 @@ def main():
 
     W, H, B, NPW = a.width, a.height, a.batch, a.events_per_window
     use_image = not a.events_only
-    args, model = make_model(W, H, B, use_image=use_image, img_net=a.img_net)
-    sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    model_cpu = None
-    if use_image and world == 1 and not a.no_cpu_baseline:
-        import copy
-        model_cpu = copy.deepcopy(model).eval()
-    model = model.to(dev)
-    model.cache_luts(width=W, height=H, radius=args.radius)
-    eng = model.engine()
-    from dagr_amd.engine import WindowEngine
     n_eng = max(1, a.engines)
-    engines = [eng] + [WindowEngine(model) for _ in range(n_eng - 1)]
-    # one stream per engine; with --pipeline-image the image branch runs one batch ahead on a shared stream
-    streams = [torch.cuda.Stream(dev) for _ in range(n_eng)] if n_eng > 1 else [torch.cuda.current_stream(dev)]
-    img_stream = torch.cuda.Stream(dev) if use_image else None
-
-    # synthetic inputs, resident in HBM before the timed region (distinct per rank and per slot)
     gen = syn.uniform_window if a.stream == "uniform" else syn.edges_window
-    slots = []
-    for s in range(4):
-        x, y, t, p, b = syn.batch_windows(gen, NPW, B, W, H, seed=1234 + 1000 * rank + 10 * s)
-        pos = torch.from_numpy(syn.format_data_np(x, y, t, W, H)).to(dev)
-        feat = torch.from_numpy(p.astype(np.float32)).view(-1, 1).to(dev)
-        batch = torch.from_numpy(b).to(dev)
-        image = None
-        if use_image:  # format_data'd frames (uint8/255, utils/buffers.py:37-38), resident like the events
-            image = torch.rand((B, 3, H, W), generator=torch.Generator().manual_seed(77 + s + 10 * rank)).to(dev)
-        slots.append((pos, feat, batch, image))
     n_events_step = B * NPW
-
-    pending = {}   # step index -> image-branch handle started one step ahead on the side stream
-
-    def step(i):
-        s = i % len(slots)
-        pos, feat, batch, image = slots[s]
-        k = i % n_eng
-        e, st = engines[k], streams[k]
-        if n_eng > 1:
-            if use_image and a.pipeline_image:
-                h = pending.pop(i, None) or e.image_async(image, stream=img_stream)
-                nxt = engines[(i + 1) % n_eng]
-                pending[i + 1] = nxt.image_async(slots[(i + 1) % len(slots)][3], stream=img_stream)
-                with torch.cuda.stream(st):
-                    return e.forward_raw(pos, feat, batch, image_handle=h)
-            with torch.cuda.stream(st):
-                return e.forward_raw(pos, feat, batch, image=image)
-        if use_image and a.pipeline_image:
-            h = pending.pop(i, None) or eng.image_async(image)
-            pending[i + 1] = eng.image_async(slots[(i + 1) % len(slots)][3])   # next batch's frames
-            return eng.forward_raw(pos, feat, batch, image_handle=h)
-        return eng.forward_raw(pos, feat, batch, image=image)
-
     ctx = torch.no_grad()
     ctx.__enter__()
-    for i in range(a.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    for e in engines:
-        e.check_status()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    outs = []
-    for i in range(a.steps):
-        outs.append(step(i))
-    for st in streams + ([img_stream] if img_stream is not None else []):
-        torch.cuda.current_stream(dev).wait_stream(st)
-    if dist is not None:  # the only collective of the job: gather the run's detections (RCCL)
-        mine = outs[-1].contiguous()
-        gathered = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=dev)
-        dist.all_gather_into_tensor(gathered, mine)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    eng.check_status()
+
+    # ---- headline: the configuration BASELINE.json quotes the metric on
+    rig = Rig(W, H, B, use_image, a.img_net, n_eng, dev)
+    slots = rig.make_slots(gen, NPW, 4, seed=1234 + 1000 * rank)
+    run = timed_run(rig, slots, a.steps, a.warmup, dist, world, rank)
+
+    # ---- the hand-written path alone: same steps on the events-only model
+    ev_leg = ev_rig = ev_slots = None
+    if use_image and not a.no_events_only_leg:
+        ev_rig = Rig(W, H, B, False, a.img_net, n_eng, dev)
+        ev_slots = ev_rig.make_slots(gen, NPW, 4, seed=1234 + 1000 * rank)
+        ev_leg = timed_run(ev_rig, ev_slots, a.steps, a.warmup, dist, world, rank)
 
     result = None
     if rank == 0:
-        ms_per_step = 1e3 * elapsed / a.steps
-        value = world * n_events_step * a.steps / elapsed
-        # ---- per-stage / per-kernel timing on the stream the kernels run on (HIP events)
-        pos, feat, batch, image = slots[0]
-        eng.forward_raw(pos, feat, batch, image=image)
-        ne, _ = eng.graph.status()
-        levels = [tuple(int(v) for v in lvl.counts.tolist()) for lvl in eng.levels]
-        r = eng.graph.params["radius"]
-        ab = algorithmic_bytes(n_events_step, ne, r, levels, use_image)
-        iters = 20
-        stages = {}
-        if use_image:
-            stages["image_branch"] = time_gpu(lambda: eng.stage_image(image), 5, warm=1)
-        stages["graph"] = time_gpu(lambda: eng.stage_graph(pos, batch), iters)
-        eng.stage_l0_input(feat)
-        stages["l0_input"] = time_gpu(lambda: eng.stage_l0_input(feat), iters)
-        stages["l0_conv1"] = time_gpu(eng.stage_l0_conv1, iters)
-        stages["l0_conv2"] = time_gpu(lambda: eng.stage_l0_conv2(sample=False), iters)
-        if use_image:
-            stages["l0_sample1"] = time_gpu(lambda: (eng.stage_l0_conv2(sample=True)), iters) - stages["l0_conv2"]
-        stages["pool1"] = time_gpu(eng.stage_pool1, iters)
-        stages["tail"] = time_gpu(eng.stage_tail, iters)
-        stages["head"] = time_gpu(lambda: eng._decode(eng.stage_head()), iters)
-        kernels = {k: dict(ms=round(v, 4), alg_MB=round(ab[k] / 1e6, 2) if k in ab else None,
-                           alg_GBs=round(ab[k] / 1e9 / (v / 1e3), 1) if k in ab else None)
-                   for k, v in stages.items()}
-        dom = max(("l0_conv1", "l0_conv2"), key=lambda k: stages[k])  # single-launch stages
-        achieved = ab[dom] / 1e9 / (stages[dom] / 1e3)
-        c0 = 19 if use_image else 3
-        nt = eng.ntaps0
-        kname = {"l0_conv1": (f"k_conv_l0_mixed<{c0 - 16}, {nt}>" if use_image else f"k_conv_l0_narrow<{c0}, {nt}>"),
-                 "l0_conv2": (f"k_conv_l0_mfma<{c0}, {nt}>" if os.environ.get("DAGR_L0_MFMA", "1") != "0"
-                              else f"k_conv_l0<16, {c0}, {nt}>")}[dom]
-        # HBM bytes per launch from the PMC passes of this same command (tools/pmc.sh -> profiles/r1_traffic.json);
-        # PMC counters cannot be read from inside this process
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "r1_traffic.json")
-        if NPW == 100000 and B == 8 and (W, H) == (640, 480) and a.stream == "uniform" and os.path.exists(tj):
-            cfg = json.load(open(tj))["configs"]["use_image" if use_image else "events_only"]
-            traffic = cfg.get(kname, {}).get("traffic_bytes")
-        roofline = dict(kernel=kname, bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
-                        alg_bytes_per_launch=int(ab[dom]), launch_ms=round(stages[dom], 4))
+        ms_per_step = 1e3 * run["elapsed"] / a.steps
+        value = world * n_events_step * a.steps / run["elapsed"]
+        st = stage_timings(rig, slots, n_events_step)
         result = {
             "metric": "events_per_sec", "value": round(value, 1), "unit": "events/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("dagr-s + --use_image --img_net " + a.img_net if use_image else "dagr-s events-only")
                                    + f", {W}x{H} synthetic S-{a.stream}, B={B} windows/step x {NPW} events (50 ms "
-                                   f"each), r={r}, K=16, events->graph->GNN(+image fusion)->decoded head outputs",
-                       "image_branch": (None if not use_image else "in-line" if not a.pipeline_image
-                                        else "one step ahead on a side stream"),
-                       "engines": n_eng,
-                       "events_per_step_per_gpu": n_events_step, "edges_per_step": int(ne),
-                       "level_nodes_edges": levels,
-                       # one batch through one engine, stages run back to back (sum of the stage timings below)
-                       "batch_latency_ms": round(sum(stages.values()), 4)},
-            "roofline": roofline, "stages": kernels,
+                                   f"each), r={st['radius']}, K=16, events->graph->GNN(+image fusion)->decoded head "
+                                   "outputs->confidence mask + NMS (device)",
+                       "image_branch": ("in-line" if use_image else None), "engines": n_eng,
+                       "events_per_step_per_gpu": n_events_step, "edges_per_step": st["edges_per_step"],
+                       "level_nodes_edges": st["levels"],
+                       # one batch through one engine, stages run back to back (sum of the isolated stage timings
+                       # below; the measured per-window latency is `latency_ms`)
+                       "stage_sum_ms": st["batch_latency_ms"]},
+            "gather": {"detections": run["n_detections"], "gather_ms_rank0": round(1e3 * run["t_gather"], 3),
+                       "compute_ms_rank0": round(1e3 * run["t_compute"], 3)},
+            "roofline": st["roofline"], "stages": st["stages"],
         }
-        if world == 1 and not a.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(model_cpu, sd_cpu, W, H, NPW, a.cpu_windows, a.stream, use_image,
-                                                  a.img_net)
+        if run["per_rank"] is not None:
+            result["per_rank"] = [dict(events_per_s=round(n_events_step * a.steps / c, 1), gather_ms=round(1e3 * g, 3))
+                                  for c, g in run["per_rank"]]
+        if ev_leg is not None:
+            est = stage_timings(ev_rig, ev_slots, n_events_step)
+            result["events_only"] = {
+                "value": round(world * n_events_step * a.steps / ev_leg["elapsed"], 1), "unit": "events/s",
+                "ms_per_step": round(1e3 * ev_leg["elapsed"] / a.steps, 4), "steps": a.steps, "engines": n_eng,
+                "workload": f"dagr-s events-only, {W}x{H} S-{a.stream}, B={B} x {NPW} events",
+                "roofline": est["roofline"], "stages": est["stages"], "stage_sum_ms": est["batch_latency_ms"]}
+    want_cpu = rank == 0 and world == 1 and not a.no_cpu_baseline
+    sd_cpu = rig.sd_cpu
+    model_cpu = None
+    if want_cpu and use_image:
+        _, model_cpu = make_model(W, H, 1, use_image=True, img_net=a.img_net)
+        model_cpu.load_state_dict(sd_cpu)
+    del slots, ev_slots, rig, ev_rig
+    torch.cuda.empty_cache()
+
+    if rank == 0 and world == 1 and not a.no_latency:
+        Ns = [int(v) for v in a.latency_n.split(",") if v]
+        lat = {"protocol": f"one window batch at a time on one engine, device idle at window start, HIP events around "
+                           f"forward + post-processing; {a.latency_warmup} warm-up + {a.latency_windows} timed windows"}
+        lat["events_only"] = latency_sweep(W, H, False, a.img_net, dev, Ns, a.latency_warmup, a.latency_windows)
+        if use_image:
+            lat["image_" + a.img_net] = latency_sweep(W, H, True, a.img_net, dev, Ns, a.latency_warmup,
+                                                      a.latency_windows)
+        result["latency_ms"] = lat
+    if want_cpu:
+        result["cpu_baseline"] = cpu_baseline(model_cpu, sd_cpu, W, H, NPW, a.cpu_windows, a.stream, use_image,
+                                              a.img_net)
+    if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

@@ -83,6 +83,115 @@ __global__ __launch_bounds__(kBlock) void k_nms(const float *__restrict__ boxes,
     __syncthreads();
     if (threadIdx.x == 0) n_keep[b] = s_count;
 }
+
+// Whole post-processing of one window batch in one launch (model/utils.py:61-110, filtering=True): decoded head
+// rows [cx, cy, w, h, obj, cls...] -> xyxy (x1 = cx - w/2, x2 = w + x1: the reference's in-place op order), class
+// max / argmax, score = obj * class_conf, confidence mask (score * class_conf >= thr), class-offset greedy NMS, and
+// the survivors written front-compacted in descending-score order as rows (x1, y1, x2, y2, score, label).
+__global__ __launch_bounds__(kBlock) void k_postprocess(const float *__restrict__ pred, int A, int Apad, int ncls,
+                                                       float conf_thr, float nms_thr, float class_offset,
+                                                       float *__restrict__ det, int32_t *__restrict__ n_keep) {
+    __shared__ float s_key[kMaxAnchors];
+    __shared__ int s_idx[kMaxAnchors];
+    __shared__ float4 s_raw[kMaxAnchors];     // un-offset boxes, anchor order
+    __shared__ float s_score[kMaxAnchors];
+    __shared__ int s_cls[kMaxAnchors];
+    __shared__ float4 s_box[kMaxAnchors];     // class-offset boxes, score order
+    __shared__ int s_keep[kMaxAnchors];
+    __shared__ int s_scan[4];
+    const int b = blockIdx.x;
+    const int ld = 5 + ncls;
+    const float *p = pred + (size_t)b * A * ld;
+    for (int i = threadIdx.x; i < Apad; i += kBlock) {
+        bool ok = false;
+        float sc = -INFINITY;
+        if (i < A) {
+            const float *r = p + (size_t)i * ld;
+            const float x1 = r[0] - r[2] / 2.0f, y1 = r[1] - r[3] / 2.0f;
+            s_raw[i] = make_float4(x1, y1, r[2] + x1, r[3] + y1);
+            float cc = r[5];
+            int cp = 0;
+            for (int c = 1; c < ncls; c++)
+                if (r[5 + c] > cc) { cc = r[5 + c]; cp = c; }
+            sc = r[4] * cc;
+            s_score[i] = sc;
+            s_cls[i] = cp;
+            ok = sc * cc >= conf_thr;
+        }
+        s_key[i] = ok ? sc : -INFINITY;
+        s_idx[i] = i < A ? i : 0x7fffffff;
+    }
+    __syncthreads();
+    for (int k = 2; k <= Apad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < Apad; i += kBlock) {
+                const int q = i ^ j;
+                if (q > i) {
+                    const float ka = s_key[i], kb = s_key[q];
+                    const int ia = s_idx[i], ib = s_idx[q];
+                    const bool a_first = (ka > kb) || (ka == kb && ia < ib);
+                    const bool up = (i & k) == 0;
+                    if (up ? !a_first : a_first) {
+                        s_key[i] = kb; s_key[q] = ka; s_idx[i] = ib; s_idx[q] = ia;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < A; i += kBlock) {
+        const bool ok = s_key[i] > -INFINITY;
+        float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) {
+            const int a = s_idx[i];
+            const float off = (float)s_cls[a] * class_offset;
+            const float4 r = s_raw[a];
+            bb = make_float4(r.x + off, r.y + off, r.z + off, r.w + off);
+        }
+        s_box[i] = bb;
+        s_keep[i] = ok ? 1 : 0;
+    }
+    __syncthreads();
+    for (int i = 0; i < A; i++) {
+        if (s_keep[i]) {
+            const float4 bi = s_box[i];
+            const float area_i = (bi.z - bi.x) * (bi.w - bi.y);
+            for (int j = i + 1 + threadIdx.x; j < A; j += kBlock) {
+                if (!s_keep[j]) continue;
+                const float4 bj = s_box[j];
+                const float w = fmaxf(fminf(bi.z, bj.z) - fmaxf(bi.x, bj.x), 0.f);
+                const float h = fmaxf(fminf(bi.w, bj.w) - fmaxf(bi.y, bj.y), 0.f);
+                const float inter = w * h;
+                const float area_j = (bj.z - bj.x) * (bj.w - bj.y);
+                if (inter / (area_i + area_j - inter) > nms_thr) s_keep[j] = 0;
+            }
+        }
+        __syncthreads();
+    }
+    // front-compaction: thread t owns the 4 consecutive sorted positions 4t .. 4t+3
+    int mine[4], cnt = 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int i = 4 * threadIdx.x + u;
+        mine[u] = (i < A) ? s_keep[i] : 0;
+        cnt += mine[u];
+    }
+    int total;
+    int base = block_exclusive_scan(cnt, s_scan, total);
+    float *d = det + (size_t)b * A * 6;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int i = 4 * threadIdx.x + u;
+        if (i < A && mine[u]) {
+            const int a = s_idx[i];
+            const float4 r = s_raw[a];
+            float *row = d + (size_t)base * 6;
+            row[0] = r.x; row[1] = r.y; row[2] = r.z; row[3] = r.w; row[4] = s_score[a]; row[5] = (float)s_cls[a];
+            base++;
+        }
+    }
+    if (threadIdx.x == 0) n_keep[b] = total;
+}
 }  // namespace
 }  // namespace dagr
 
@@ -98,6 +207,23 @@ extern "C" int dagr_nms_batched(const float *boxes, const float *scores, const i
     while (Apad < A) Apad <<= 1;
     k_nms<<<B, kBlock, 0, (hipStream_t)stream>>>(boxes, scores, cls, valid, A, Apad, iou_threshold, class_offset,
                                                  order_out, keep_out, n_keep);
+    DAGR_CHECK_LAUNCH();
+    return DAGR_OK;
+}
+
+extern "C" int dagr_postprocess(const float *pred, int32_t B, int32_t A, int32_t num_classes, float conf_threshold,
+                                float iou_threshold, float class_offset, float *det, int32_t *n_keep, void *stream) {
+    DAGR_CHECK_ARG(B >= 0 && A >= 0 && A <= kMaxAnchors && num_classes >= 1, "A must be <= 1024, num_classes >= 1");
+    if (B == 0) return DAGR_OK;
+    DAGR_CHECK_ARG(pred && det && n_keep, "NULL pointer");
+    if (A == 0) {
+        DAGR_CHECK_HIP(hipMemsetAsync(n_keep, 0, (size_t)B * 4, (hipStream_t)stream));
+        return DAGR_OK;
+    }
+    int Apad = 1;
+    while (Apad < A) Apad <<= 1;
+    k_postprocess<<<B, kBlock, 0, (hipStream_t)stream>>>(pred, A, Apad, num_classes, conf_threshold, iou_threshold,
+                                                         class_offset, det, n_keep);
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;
 }

@@ -743,6 +743,15 @@ class WindowEngine:
         return dict(x=x[:n].clone(), pos=lvl.pos[:n].clone(), batch=lvl.batch[:n].clone(),
                     rowptr=lvl.rowptr[:n + 1].clone(), col=lvl.col[:e].clone(), code=lvl.code[:e].clone())
 
+    def l0_kernel_names(self):
+        """Kernel (as rocprofv3 prints it) behind each level-0 conv stage, for bench.py's roofline line."""
+        c0 = 3 + self.feat_ch[0]
+        nt = self.ntaps0
+        mfma = os.environ.get("DAGR_L0_MFMA", "1") != "0"
+        first = f"k_conv_l0_mixed<{c0 - 16}, {nt}>" if self.use_image else f"k_conv_l0_narrow<{c0}, {nt}>"
+        return {"l0_conv1": first,
+                "l0_conv2": f"k_conv_l0_mfma<{c0}, {nt}>" if mfma else f"k_conv_l0<16, {c0}, {nt}>"}
+
     def check_status(self):
         """Raise if any kernel flagged an inconsistency (synchronises)."""
         ne, fl = self.graph.status()

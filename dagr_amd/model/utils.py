@@ -27,40 +27,40 @@ def init_subnetwork(net, state_dict, name="backbone.net.", freeze=False):
 def postprocess_network_output(prediction, num_classes, conf_thre=0.01, nms_thre=0.65, height=640, width=640,
                                filtering=True):
     """Batched, device-side version of ``model/utils.py:61-110``: cxcywh -> xyxy, class max, the reference's
-    confidence mask (obj * cls * cls >= thr), class-offset greedy NMS for all images in ONE kernel launch
-    (``dagr_nms_batched``).  ``prediction``: [B, A, 5 + C] on the GPU."""
-    from .. import _lib
+    confidence mask (obj * cls * cls >= thr) and class-offset greedy NMS for all images in ONE kernel launch
+    (``dagr_postprocess``, csrc/nms.hip).  ``prediction``: [B, A, 5 + C] on the GPU."""
     if not prediction.is_cuda:
         raise RuntimeError("postprocess_network_output expects the decoded head outputs on the GPU")
-    B, A = prediction.shape[:2]
-    xy, wh = prediction[..., :2], prediction[..., 2:4]
-    x1y1 = xy - wh / 2
-    boxes = torch.cat((x1y1, wh + x1y1), dim=-1).contiguous()                      # same op order as :62-63
-    class_conf, class_pred = torch.max(prediction[..., 5:5 + num_classes], dim=-1)
-    scores = (prediction[..., 4] * class_conf).contiguous()                        # image_pred[:, 4:5] *= class_conf
     if not filtering:
         # :87-88,101-102: neither the confidence mask nor the NMS indices are applied -- every anchor comes back,
         # in anchor order
+        B = prediction.shape[0]
+        xy, wh = prediction[..., :2], prediction[..., 2:4]
+        x1y1 = xy - wh / 2
+        boxes = torch.cat((x1y1, wh + x1y1), dim=-1)                                   # same op order as :62-63
+        class_conf, class_pred = torch.max(prediction[..., 5:5 + num_classes], dim=-1)
+        scores = prediction[..., 4] * class_conf                                       # image_pred[:, 4:5] *= class_conf
         return [{"boxes": boxes[b], "scores": scores[b], "labels": class_pred[b].long()} for b in range(B)]
-    valid = scores * class_conf >= conf_thre
-    cls32 = class_pred.to(torch.int32).contiguous()
-    valid8 = valid.to(torch.uint8).contiguous()
-    dev = prediction.device
-    order = torch.empty((B, A), dtype=torch.int32, device=dev)
-    keep = torch.empty((B, A), dtype=torch.int32, device=dev)
-    n_keep = torch.empty((B,), dtype=torch.int32, device=dev)
-    _lib.check(_lib.lib().dagr_nms_batched(_lib.ptr(boxes), _lib.ptr(scores), _lib.ptr(cls32), _lib.ptr(valid8), B, A,
-                                           float(nms_thre), float(max(width, height) + 1), _lib.ptr(order),
-                                           _lib.ptr(keep), _lib.ptr(n_keep), _lib.cur_stream(dev)), "nms_batched")
-    # survivors to the front of every row (score order kept), then ONE D2H copy (the B survivor counts) cuts the
-    # per-image dicts: the reference's return type is variable-length, so one synchronisation is inherent
-    front = torch.argsort(keep == 0, dim=1, stable=True)
-    sel = order.long().gather(1, front)
-    bsel = boxes.gather(1, sel.unsqueeze(-1).expand(B, A, 4))
-    ssel = scores.gather(1, sel)
-    lsel = class_pred.gather(1, sel)
+    det, n_keep = postprocess_device(prediction, num_classes, conf_thre, nms_thre, height, width)
+    # ONE D2H copy (the B survivor counts) cuts the per-image dicts: the reference's return type is variable-length,
+    # so one synchronisation is inherent
     counts = n_keep.tolist()
-    return [{"boxes": bsel[b, :n], "scores": ssel[b, :n], "labels": lsel[b, :n].long()} for b, n in enumerate(counts)]
+    return [{"boxes": det[b, :n, :4], "scores": det[b, :n, 4], "labels": det[b, :n, 5].long()}
+            for b, n in enumerate(counts)]
+
+
+def postprocess_device(prediction, num_classes, conf_thre=0.01, nms_thre=0.65, height=640, width=640):
+    """One launch, no synchronisation (``dagr_postprocess``): returns ``det[B, A, 6]`` whose first ``n_keep[b]`` rows
+    per image are the surviving detections (x1, y1, x2, y2, score, label) by descending score, and ``n_keep[B]``."""
+    from .. import _lib
+    B, A, C = prediction.shape
+    pred = prediction.contiguous()
+    det = torch.empty((B, A, 6), dtype=torch.float32, device=pred.device)
+    n_keep = torch.empty((B,), dtype=torch.int32, device=pred.device)
+    _lib.check(_lib.lib().dagr_postprocess(_lib.ptr(pred), B, A, int(num_classes), float(conf_thre), float(nms_thre),
+                                           float(max(width, height) + 1), _lib.ptr(det), _lib.ptr(n_keep),
+                                           _lib.cur_stream(pred.device)), "postprocess")
+    return det, n_keep
 
 
 def convert_to_evaluation_format(data):

@@ -305,6 +305,14 @@ int dagr_nms_batched(const float *boxes, const float *scores, const int32_t *cls
                      int32_t B, int32_t A, float iou_threshold, float class_offset,
                      int32_t *order_out, int32_t *keep_out, int32_t *n_keep, void *stream);
 
+/* The whole of postprocess_network_output (model/utils.py:61-110, filtering=True) for a window batch in ONE launch:
+ * pred[B,A,5+C] = decoded head outputs (cx, cy, w, h, obj, cls...) -> cxcywh->xyxy in the reference's op order,
+ * class max / argmax, score = obj*class_conf, mask (score*class_conf >= conf_threshold), class-offset greedy NMS.
+ * det[B,A,6]: the survivors of image b are rows 0..n_keep[b]-1 = (x1, y1, x2, y2, score, label) in descending score
+ * (ties: ascending anchor); rows beyond are unspecified.  A <= 1024. */
+int dagr_postprocess(const float *pred, int32_t B, int32_t A, int32_t num_classes, float conf_threshold,
+                     float iou_threshold, float class_offset, float *det, int32_t *n_keep, void *stream);
+
 /* Profiling aid (not on the product path): streams a known number of bytes so that rocprofv3's
  * FETCH_SIZE / WRITE_SIZE can be calibrated on this library's access patterns.
  * mode 0: 4 B/lane reads of n_floats; 1: 16 B/lane reads; 2: n_gathers pseudo-random 64-byte rows
