@@ -221,8 +221,12 @@ def timed_run(rig, slots, steps, warmup, dist, world, rank):
     """W untimed warm-up steps, then exactly `steps` steps between barrier + synchronize brackets; MAX over ranks."""
     from dagr_amd import parallel
     dev = rig.dev
-    for i in range(warmup):
-        rig.step(i, slots)
+    warm = [rig.step(i, slots) for i in range(warmup)]
+    if warm:   # the detection cut + gather once outside the timed region (allocator / lazy-init costs of its torch ops)
+        rows = detections_rows(warm, rank, rig.B)
+        if dist is not None:
+            parallel.gather_detections(rows)
+    del warm
     _sync()
     for e in rig.engines:
         e.check_status()

@@ -57,7 +57,10 @@ SIGNATURES = {
                                              c_void_p, c_void_p, c_i64, c_void_p]),
     "dagr_graph_node_order": (ctypes.c_int, [ctypes.POINTER(GraphDesc), c_void_p, c_i64, c_void_p, c_void_p, c_void_p]),
     "dagr_graph_gather_inputs": (ctypes.c_int, [ctypes.POINTER(GraphDesc), c_void_p, c_void_p, c_void_p, c_i64,
-                                                c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_void_p]),
+                                                c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p]),
+    "dagr_spline_conv_l0_tiles": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_float,
+                                                 c_float, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_i32,
+                                                 c_void_p, c_i32, c_void_p, c_void_p, c_i32, c_void_p, c_i32, c_void_p]),
     "dagr_spiral_offsets": (ctypes.c_int, [c_i32, c_void_p, c_void_p]),
     "dagr_spline_tap_window": (ctypes.c_int, [c_i32, c_float, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
     "dagr_spline_l0_table": (ctypes.c_int, [c_i32, c_i32, c_float, c_float, c_i32, c_i32, c_i32, c_i32, c_void_p,

@@ -71,6 +71,27 @@ inline unsigned persistent_grid(Kern kernel, int block, size_t dyn_lds, int64_t 
 }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// ---- degree-1 open B-spline basis at an integer LUT coordinate (spline_conv.py:27-34 builds the
+// pseudo-coordinate; torch_spline_conv basis: v = pseudo*(5-1), frac = v-floor(v),
+// factor(k_mod) = 1 - frac - k_mod + 2*frac*k_mod, tap = (floor(v)+k_mod) % 5, x fastest).
+struct Axis {
+    int k0, k1;     // kernel taps
+    float b0, b1;   // their weights
+};
+__host__ __device__ inline Axis spline_axis(int idx, int r, float den) {
+    const float pseudo = (float)(idx - r) / den + 0.5f;
+    const float v = pseudo * 4.0f;
+    const float fl = floorf(v);
+    const float frac = v - fl;
+    Axis a;
+    const int f = (int)fl;
+    a.k0 = f % 5;
+    a.k1 = (f + 1) % 5;
+    a.b0 = ((1.0f - frac) - 0.0f) + (2.0f * frac) * 0.0f;
+    a.b1 = ((1.0f - frac) - 1.0f) + (2.0f * frac) * 1.0f;
+    return a;
+}
+
 // ---- device-side wave / block primitives (wave = 64 lanes) -------------------------------
 __device__ __forceinline__ int wave_inclusive_scan(int v) {
     const int lane = threadIdx.x & 63;

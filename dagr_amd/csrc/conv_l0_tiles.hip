@@ -1,0 +1,276 @@
+// conv_l0_tiles.hip -- level-0 SplineConv (event graph) as 16-node wave tiles, gfx950, fp32.
+//
+// Reference op: MySplineConv.forward/_forward/message_lut (src/dagr/model/layers/spline_conv.py:39-78) fused with
+// BatchNorm(eval)+ReLU (model/layers/conv.py:23-28) and the skip Linear+BN of ConvBlockWithSkip (conv.py:47-56);
+// same re-association as spline_conv.hip:   A[n][tap][ch] = sum_edges basis[edge][tap] * x[src][ch]   (phase 1)
+//                                           out[n][:]      = [A[n] | x[n] | xskip[n]] . Wpack + shift   (phase 2)
+//
+// What limited the previous level-0 kernels was LDS bandwidth (per-edge offset-table rows and per-node weight rows as
+// ds_read_b128, PMC: profiles/r1_final_image_pmc_sq.csv) and, in the MFMA variant, the staging of phase-1 results through
+// LDS to turn "one node per 16-lane group" into the MFMA A-operand layout.  This kernel is laid out so that neither
+// exists:
+//   * one wave owns a tile of 16 consecutive nodes (node = CSR slot, so a tile is a run of events of neighbouring
+//     pixels); lane (c = l & 15, q = l >> 4) works for NODE c on channel quad q: it walks the node's neighbour list
+//     itself (<= 16 entries) and keeps A[tap][4q..4q+3] in registers -- TX*TY*4 accumulators (60 for the 3x5 tap window
+//     of a 640x480 sensor).  A source row is 64 bytes read as four 16-byte pieces by the node's four lanes.
+//   * those registers already ARE the A operand of v_mfma_f32_16x16x4_f32 (A[i = l & 15][k = l >> 4]: row = node,
+//     k-slice = this lane's channel quad): phase 2 is TX*TY*4 (+ root/extras/skip) MFMAs straight from registers; the
+//     B operands (packed weights, re-laid at kernel start into [k-step][lane] order) are one conflict-free
+//     ds_read_b32 each.  No staging tile, no per-edge LDS table: the per-axis basis weights (2r+1 rows of 4 / 8 floats)
+//     sit in LDS and are combined in registers.
+//   * channels beyond the 16 "main" ones (the first conv of the --use_image model has 19 inputs, the events-only one 3)
+//     are "extras": lane q < CE keeps A[tap] for channel CM + q and feeds one extra k-step per tap.
+// Exact fp32 throughout (the f32 MFMA is a k-ordered fmaf chain); only the summation order differs from the oracle.
+#include "common.hpp"
+
+namespace dagr {
+namespace {
+
+using f32x4_t = __attribute__((ext_vector_type(4))) float;
+
+template <int CM, int CE, int CS, int TX, int TY>
+struct L0Steps {
+    static constexpr int NT = TX * TY;
+    static constexpr int CIN = CM + CE;
+    static constexpr int SKF = CS >= 16 ? 1 : 0;                  // skip columns 0..15 as a float4 per lane
+    static constexpr int SKE = CS - 16 * SKF;                     // remaining skip columns (one k-step, lane q < SKE)
+    static constexpr int kMain = CM ? NT * 4 : 0;                 // step s = tap*4 + r : row tap*CIN + 4q + r
+    static constexpr int kExtra = CE ? NT : 0;                    // step tap          : row tap*CIN + CM + q (q < CE)
+    static constexpr int kRootM = CM ? 4 : 0;                     // step r            : row NT*CIN + 4q + r
+    static constexpr int kRootE = CE ? 1 : 0;                     //                     row NT*CIN + CM + q
+    static constexpr int kSkipF = SKF ? 4 : 0;                    // step r            : row (NT+1)*CIN + 4q + r
+    static constexpr int kSkipE = SKE ? 1 : 0;                    //                     row (NT+1)*CIN + 16*SKF + q
+    static constexpr int N = kMain + kExtra + kRootM + kRootE + kSkipF + kSkipE;
+    static_assert(CM == 0 || CM == 16, "main channel block is 0 or 16 wide");
+    static_assert(CE >= 0 && CE <= 4 && SKE >= 0 && SKE <= 4, "extras / skip remainder ride on the 4 lanes of a node");
+    // packed-weight row behind k-step s for lane quad q, or -1 (zero operand)
+    __host__ __device__ static int row(int s, int q) {
+        if (s < kMain) return (s >> 2) * CIN + 4 * q + (s & 3);
+        s -= kMain;
+        if (s < kExtra) return q < CE ? s * CIN + CM + q : -1;
+        s -= kExtra;
+        if (s < kRootM) return NT * CIN + 4 * q + s;
+        s -= kRootM;
+        if (s < kRootE) return q < CE ? NT * CIN + CM + q : -1;
+        s -= kRootE;
+        if (s < kSkipF) return (NT + 1) * CIN + 4 * q + s;
+        s -= kSkipF;
+        return q < SKE ? (NT + 1) * CIN + 16 * SKF + q : -1;
+    }
+};
+
+constexpr int kTileWaves = 4;   // waves per workgroup (each owns its tiles; they share the weight image in LDS)
+
+template <int CM, int CE, int CS, int TX, int TY>
+__global__ __launch_bounds__(kTileWaves * 64, 3) void k_conv_l0_tiles(
+    int N, int rx, int ry, float den_x, float den_y, int win_x, int win_y, const int32_t *__restrict__ nbr_src,
+    const int16_t *__restrict__ nbr_code, const int32_t *__restrict__ deg, const float *__restrict__ x, int ldx,
+    const float *__restrict__ xskip, int ldskip, const float *__restrict__ wpack, const float *__restrict__ shift,
+    int relu, float *__restrict__ out, int ldo) {
+    using S = L0Steps<CM, CE, CS, TX, TY>;
+    constexpr int NT = S::NT;
+    extern __shared__ __align__(16) float lds[];
+    float *w_l = lds;                            // [S::N][64]  B operands in [k-step][lane] order
+    float *ax_l = w_l + S::N * 64;               // [2rx+1][4]  per-axis basis weights of the TX-wide tap window
+    float *ay_l = ax_l + (2 * rx + 1) * 4;       // [2ry+1][8]
+    for (int i = threadIdx.x; i < S::N * 64; i += blockDim.x) {
+        const int s = i >> 6, lq = (i >> 4) & 3, c = i & 15;
+        const int r = S::row(s, lq);
+        w_l[i] = r >= 0 ? wpack[r * 16 + c] : 0.0f;
+    }
+    for (int i = threadIdx.x; i < (2 * rx + 1) * 4; i += blockDim.x) {
+        const Axis a = spline_axis(i >> 2, rx, den_x);
+        const int t = (i & 3) + win_x;           // tap of the 5-tap kernel this column stands for
+        ax_l[i] = (i & 3) < TX ? ((t == a.k0 ? a.b0 : 0.0f) + (t == a.k1 ? a.b1 : 0.0f)) : 0.0f;
+    }
+    for (int i = threadIdx.x; i < (2 * ry + 1) * 8; i += blockDim.x) {
+        const Axis a = spline_axis(i >> 3, ry, den_y);
+        const int t = (i & 7) + win_y;
+        ay_l[i] = (i & 7) < TY ? ((t == a.k0 ? a.b0 : 0.0f) + (t == a.k1 ? a.b1 : 0.0f)) : 0.0f;
+    }
+    __syncthreads();
+
+    const int l = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = l & 15, q = l >> 4;
+    const float my_shift = shift[c];
+    const float inv_sy = 1.0f / (float)(2 * ry + 1);
+    const int sy = 2 * ry + 1;
+    // XCD-contiguous node ranges per workgroup, 16-node tiles dealt round-robin to its waves
+    const int G = gridDim.x, nx = (G % 8 == 0) ? 8 : 1;
+    const int xcd = blockIdx.x % nx, lb = blockIdx.x / nx, bpx = G / nx;
+    const int chunk = ((N + nx - 1) / nx + 15) / 16 * 16;
+    const int per_block = ((chunk + bpx - 1) / bpx + 15) / 16 * 16;
+    const int n_begin = xcd * chunk + lb * per_block;
+    const int n_end = min(min(N, (xcd + 1) * chunk), n_begin + per_block);
+
+    for (int n0 = n_begin + 16 * wv; n0 < n_end; n0 += 16 * kTileWaves) {
+        const int n = n0 + c;
+        const bool valid = n < n_end;
+        const int nn = valid ? n : n0;                  // a row that exists, for the predicated-off lanes
+        const int d = valid ? deg[n] : 0;
+        int dmax = d;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) dmax = max(dmax, __shfl_xor(dmax, off, 16));
+        // root / skip operands of phase 2: requested now, consumed at the end
+        float4 xr = make_float4(0.f, 0.f, 0.f, 0.f), xs = make_float4(0.f, 0.f, 0.f, 0.f);
+        float xre = 0.f, xse = 0.f;
+        if (CM) xr = *reinterpret_cast<const float4 *>(x + (size_t)nn * ldx + 4 * q);
+        if (CE) xre = (q < CE) ? x[(size_t)nn * ldx + CM + q] : 0.f;
+        if (S::SKF) xs = *reinterpret_cast<const float4 *>(xskip + (size_t)nn * ldskip + 4 * q);
+        if (S::SKE) xse = (q < S::SKE) ? xskip[(size_t)nn * ldskip + 16 * S::SKF + q] : 0.f;
+
+        float acc[CM ? NT : 1][4];
+        float acce[CE ? NT : 1];
+#pragma unroll
+        for (int t = 0; t < (CM ? NT : 1); t++) acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0.f;
+#pragma unroll
+        for (int t = 0; t < (CE ? NT : 1); t++) acce[t] = 0.f;
+
+        // ---- phase 1: this lane's node, its <= 16 in-edges, 4 at a time (all four source rows requested before use)
+#pragma unroll 1
+        for (int j0 = 0; j0 < dmax; j0 += 4) {
+            const int4 s4 = *reinterpret_cast<const int4 *>(nbr_src + (size_t)nn * 16 + j0);
+            const int2 c2 = *reinterpret_cast<const int2 *>(nbr_code + (size_t)nn * 16 + j0);
+            const int srcs[4] = {s4.x, s4.y, s4.z, s4.w};
+            const int codes[4] = {c2.x & 0xffff, (c2.x >> 16) & 0xffff, c2.y & 0xffff, (c2.y >> 16) & 0xffff};
+            float4 xv[4];
+            float xe[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const bool ok = j0 + u < d;
+                const int src = ok ? srcs[u] : nn;
+                if (CM) xv[u] = *reinterpret_cast<const float4 *>(x + (size_t)src * ldx + 4 * q);
+                if (CE) xe[u] = (q < CE) ? x[(size_t)src * ldx + CM + q] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const bool ok = j0 + u < d;
+                const int code = ok ? codes[u] : 0;
+                const int ix = (int)(((float)code + 0.5f) * inv_sy);
+                const int iy = code - ix * sy;
+                const float4 wx4 = *reinterpret_cast<const float4 *>(ax_l + 4 * ix);
+                const float4 wy4 = *reinterpret_cast<const float4 *>(ay_l + 8 * iy);
+                const float4 wy5 = *reinterpret_cast<const float4 *>(ay_l + 8 * iy + 4);
+                const float wx[4] = {wx4.x, wx4.y, wx4.z, wx4.w};
+                float wy[8] = {wy4.x, wy4.y, wy4.z, wy4.w, wy5.x, wy5.y, wy5.z, wy5.w};
+#pragma unroll
+                for (int b = 0; b < TY; b++) wy[b] = ok ? wy[b] : 0.f;
+#pragma unroll
+                for (int b = 0; b < TY; b++)
+#pragma unroll
+                    for (int a = 0; a < TX; a++) {
+                        const float w = wx[a] * wy[b];            // == the level-0 offset table entry (bx[a]*by[b])
+                        const int t = a + TX * b;
+                        if (CM) {
+                            acc[t][0] = fmaf(w, xv[u].x, acc[t][0]);
+                            acc[t][1] = fmaf(w, xv[u].y, acc[t][1]);
+                            acc[t][2] = fmaf(w, xv[u].z, acc[t][2]);
+                            acc[t][3] = fmaf(w, xv[u].w, acc[t][3]);
+                        }
+                        if (CE) acce[t] = fmaf(w, xe[u], acce[t]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);   // one edge's weights live at a time (register pressure)
+            }
+        }
+
+        // ---- phase 2: out[16 nodes][16] = [A | root | skip] . Wpack on the matrix pipe, operands from registers
+        f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+        const float *wb = w_l + l;
+        int s = 0;
+#define DAGR_STEP(aval)                                                                        \
+    do {                                                                                       \
+        if (s & 1) o1 = __builtin_amdgcn_mfma_f32_16x16x4f32((aval), wb[(s) * 64], o1, 0, 0, 0); \
+        else o0 = __builtin_amdgcn_mfma_f32_16x16x4f32((aval), wb[(s) * 64], o0, 0, 0, 0);       \
+        s++;                                                                                   \
+    } while (0)
+        if (CM) {
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                DAGR_STEP(acc[t][0]); DAGR_STEP(acc[t][1]); DAGR_STEP(acc[t][2]); DAGR_STEP(acc[t][3]);
+            }
+        }
+        if (CE) {
+#pragma unroll
+            for (int t = 0; t < NT; t++) DAGR_STEP(acce[t]);
+        }
+        if (CM) { DAGR_STEP(xr.x); DAGR_STEP(xr.y); DAGR_STEP(xr.z); DAGR_STEP(xr.w); }
+        if (CE) DAGR_STEP(xre);
+        if (S::SKF) { DAGR_STEP(xs.x); DAGR_STEP(xs.y); DAGR_STEP(xs.z); DAGR_STEP(xs.w); }
+        if (S::SKE) DAGR_STEP(xse);
+#undef DAGR_STEP
+        // o[r] = out[node 4q + r][channel c]
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int m = n0 + 4 * q + r;
+            if (m < n_end) {
+                float v = (o0[r] + o1[r]) + my_shift;
+                if (relu) v = fmaxf(v, 0.f);
+                out[(size_t)m * ldo + c] = v;
+            }
+        }
+    }
+}
+
+template <int CM, int CE, int CS, int TX, int TY>
+int launch_tiles(int64_t N, int rx, int ry, float den_x, float den_y, int win_x, int win_y, const int32_t *nbr_src,
+                 const int16_t *nbr_code, const int32_t *deg, const float *x, int ldx, const float *xskip, int ldskip,
+                 const float *wpack, const float *shift, int relu, float *out, int ldo, hipStream_t stream) {
+    using S = L0Steps<CM, CE, CS, TX, TY>;
+    const size_t lds_bytes = ((size_t)S::N * 64 + (size_t)(2 * rx + 1) * 4 + (size_t)(2 * ry + 1) * 8) * 4;
+    DAGR_CHECK_ARG(lds_bytes <= 64 * 1024, "offset domain too large for the axis tables");
+    auto kern = k_conv_l0_tiles<CM, CE, CS, TX, TY>;
+    {
+        static thread_local size_t set_for = 0;
+        if (set_for < lds_bytes) {
+            DAGR_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)lds_bytes));
+            set_for = lds_bytes;
+        }
+    }
+    const int64_t tiles = ceil_div(N, 16);
+    const unsigned grid = round_grid8(persistent_grid(kern, kTileWaves * 64, lds_bytes, ceil_div(tiles, kTileWaves)));
+    kern<<<grid, kTileWaves * 64, lds_bytes, stream>>>((int)N, rx, ry, den_x, den_y, win_x, win_y, nbr_src, nbr_code, deg,
+                                                       x, ldx, xskip, ldskip, wpack, shift, relu, out, ldo);
+    DAGR_CHECK_LAUNCH();
+    return DAGR_OK;
+}
+
+}  // namespace
+}  // namespace dagr
+
+using namespace dagr;
+
+extern "C" int dagr_spline_conv_l0_tiles(int32_t cmain, int32_t cextra, int32_t cskip, int32_t win_x, int32_t tx,
+                                         int32_t win_y, int32_t ty, int32_t rx, int32_t ry, float den_x, float den_y,
+                                         int64_t N, int32_t K, const int32_t *nbr_src, const int16_t *nbr_code,
+                                         const int32_t *deg, const float *x, int32_t ldx, const float *xskip,
+                                         int32_t ldskip, const float *wpack, const float *shift, int32_t relu,
+                                         float *out, int32_t ldo, void *stream_) {
+    DAGR_CHECK_ARG(N >= 0, "N < 0");
+    if (N == 0) return DAGR_OK;
+    DAGR_CHECK_ARG(nbr_src && nbr_code && deg && x && wpack && shift && out, "NULL pointer");
+    DAGR_CHECK_ARG(K == 16, "the tiled level-0 conv walks 16-entry neighbour lists");
+    DAGR_CHECK_ARG(cskip == 0 || xskip, "xskip is NULL");
+    DAGR_CHECK_ARG(rx >= 0 && ry >= 0 && den_x > 0 && den_y > 0 && win_x >= 0 && win_y >= 0 && win_x + tx <= 5 &&
+                       win_y + ty <= 5, "bad offset domain / tap window");
+    DAGR_CHECK_ARG(cmain == 0 || (ldx % 4 == 0 && ((uintptr_t)x % 16) == 0), "x rows must be 16-byte aligned");
+    DAGR_CHECK_ARG(cskip < 16 || (ldskip % 4 == 0 && ((uintptr_t)xskip % 16) == 0), "xskip rows must be 16-byte aligned");
+    DAGR_CHECK_ARG(((uintptr_t)nbr_src % 16) == 0 && ((uintptr_t)nbr_code % 8) == 0, "neighbour lists must be aligned");
+    hipStream_t stream = (hipStream_t)stream_;
+#define DAGR_TILES(CM_, CE_, CS_, TX_, TY_)                                                                        \
+    if (cmain == CM_ && cextra == CE_ && cskip == CS_ && tx == TX_ && ty == TY_)                                   \
+        return launch_tiles<CM_, CE_, CS_, TX_, TY_>(N, rx, ry, den_x, den_y, win_x, win_y, nbr_src, nbr_code, deg, x, \
+                                                    ldx, xskip, ldskip, wpack, shift, relu, out, ldo, stream);
+#define DAGR_TILES_WIN(TX_, TY_)                                                                   \
+    DAGR_TILES(0, 3, 0, TX_, TY_)    /* events-only conv_block1.conv_block1: 3 -> 16 (net.py:75) */  \
+    DAGR_TILES(16, 0, 3, TX_, TY_)   /* events-only conv_block1.conv_block2: 16 -> 16 + skip 3 */    \
+    DAGR_TILES(16, 3, 0, TX_, TY_)   /* --use_image first conv: 16 image + 3 channels -> 16 */       \
+    DAGR_TILES(16, 0, 19, TX_, TY_)  /* --use_image second conv: 16 -> 16 + skip 19 */
+    DAGR_TILES_WIN(3, 3)
+    DAGR_TILES_WIN(3, 5)
+    DAGR_TILES_WIN(5, 3)
+#undef DAGR_TILES_WIN
+#undef DAGR_TILES
+    set_error("dagr_spline_conv_l0_tiles: unsupported (cmain, cextra, cskip, tx, ty) combination");
+    return DAGR_ERR_UNSUPPORTED;
+}

@@ -743,7 +743,8 @@ __global__ __launch_bounds__(kBlock) void k_gather_inputs(const int32_t *__restr
                                                          const float *__restrict__ pos,
                                                          const float *__restrict__ feat,
                                                          float *__restrict__ pos_s, int32_t *__restrict__ batch_s,
-                                                         float *__restrict__ x0, int ldx0, int col_pos) {
+                                                         float *__restrict__ x0, int ldx0, int col_feat,
+                                                         int col_pos) {
     const int n = blockIdx.x * kBlock + threadIdx.x;
     if (n >= N || n >= *m_ptr) return;
     const int e = slot_it[n].x;
@@ -751,7 +752,7 @@ __global__ __launch_bounds__(kBlock) void k_gather_inputs(const int32_t *__restr
     pos_s[3 * (size_t)n] = px; pos_s[3 * (size_t)n + 1] = py; pos_s[3 * (size_t)n + 2] = pt;
     batch_s[n] = (slot_xyb[n] >> 24) & 127;
     float *row = x0 + (size_t)n * ldx0;
-    row[0] = feat[e];
+    row[col_feat] = feat[e];
     row[col_pos] = px;
     row[col_pos + 1] = py;
 }
@@ -966,16 +967,17 @@ int dagr_graph_node_order(const dagr_graph_desc *desc, void *workspace, int64_t 
 
 int dagr_graph_gather_inputs(const dagr_graph_desc *desc, void *workspace, const float *pos, const float *feat,
                              int64_t N, float *pos_nodes, int32_t *batch_nodes, float *x0, int32_t ldx0,
-                             int32_t col_pos, void *stream) {
+                             int32_t col_feat, int32_t col_pos, void *stream) {
     int rc = validate(desc);
     if (rc != DAGR_OK) return rc;
     DAGR_CHECK_ARG(workspace && N >= 0, "bad arguments");
     if (N == 0) return DAGR_OK;
-    DAGR_CHECK_ARG(pos && feat && pos_nodes && batch_nodes && x0 && ldx0 >= col_pos + 2 && col_pos >= 1, "bad arguments");
+    DAGR_CHECK_ARG(pos && feat && pos_nodes && batch_nodes && x0 && ldx0 >= col_pos + 2 && col_pos >= 0 &&
+                       col_feat >= 0 && col_feat < ldx0 && col_feat != col_pos && col_feat != col_pos + 1, "bad arguments");
     GraphWs ws;
     carve(*desc, (char *)workspace, &ws);
     k_gather_inputs<<<(unsigned)ceil_div(N, kBlock), kBlock, 0, (hipStream_t)stream>>>(
-        ws.start + ws.P, (int)N, ws.slot_it, ws.slot_xyb, pos, feat, pos_nodes, batch_nodes, x0, ldx0, col_pos);
+        ws.start + ws.P, (int)N, ws.slot_it, ws.slot_xyb, pos, feat, pos_nodes, batch_nodes, x0, ldx0, col_feat, col_pos);
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;
 }

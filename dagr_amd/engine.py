@@ -78,23 +78,30 @@ def _pack_generic(convs, norms, skip=None, relu=True, device="cuda"):
     return _ConvPack(cin, cskip, torch.cat(cols, 1).to(device), torch.cat(biases).to(device), relu)
 
 
-def _pack_l0(conv, norm, win, skip=None, device="cuda"):
-    """Level-0 packing: rows [(a + tx*b)*cin + i | root | skip] x 16 over the tx x ty tap window."""
+def _pack_l0(conv, norm, win, skip=None, device="cuda", cols_in=None, cols_skip=None):
+    """Level-0 packing: rows [(a + tx*b)*cin + i | root | skip] x 16 over the tx x ty tap window.
+    ``cols_in`` / ``cols_skip``: reference channel behind every column of the input / skip-input rows as the engine
+    lays them out (identity when None)."""
     win_x, tx, win_y, ty = win
     W = conv.weight.detach().float()
     cin, cout = W.shape[1], W.shape[2]
-    assert cout == 16, "level-0 kernel is specialised for 16 output channels (int(base_width*32))"
+    if cout != 16:
+        raise NotImplementedError("the level-0 kernels are specialised for 16 output channels (base_width = 0.5)")
+    cols_in = list(range(cin)) if cols_in is None else list(cols_in)
     scale, shift = _bn_affine(norm)
     rows = []
     for b in range(ty):
         for a in range(tx):
-            rows.append(W[(win_x + a) + 5 * (win_y + b)] * scale.view(1, -1))
-    rows.append(conv.lin.weight.detach().float().t() * scale.view(1, -1))
+            rows.append(W[(win_x + a) + 5 * (win_y + b)][cols_in] * scale.view(1, -1))
+    rows.append(conv.lin.weight.detach().float().t()[cols_in] * scale.view(1, -1))
     cskip = 0
     if skip is not None:
         lin, norm_skip = skip
         s_scale, s_shift = _bn_affine(norm_skip)
-        rows.append(lin.mlp.weight.detach().float().t() * s_scale.view(1, -1))
+        ws = lin.mlp.weight.detach().float().t()
+        if cols_skip is not None:
+            ws = ws[list(cols_skip)]
+        rows.append(ws * s_scale.view(1, -1))
         shift = shift + s_shift
         cskip = lin.mlp.in_features
     return cin, cskip, torch.cat(rows, 0).contiguous().to(device), shift.contiguous().to(device)
@@ -286,7 +293,8 @@ class WindowEngine:
         self.dom = [layer.conv_block1.conv.lut_domain for layer in layers]
         # ---- level 0
         d0 = self.dom[0]
-        assert d0["rx"] == d0["ry"]
+        if d0["rx"] != d0["ry"]:
+            raise NotImplementedError("level 0 expects a square search radius (ev_tgn.py:29 derives it from the width)")
         win = []
         for r, den in ((d0["rx"], d0["den_x"]), (d0["ry"], d0["den_y"])):
             lo, cnt = ctypes.c_int32(0), ctypes.c_int32(0)
@@ -306,9 +314,25 @@ class WindowEngine:
         if int(bad.item()) != 0:
             raise RuntimeError("level-0 offset table: an offset needs a kernel tap outside the chosen window")
         l0 = layers[0]
-        self.l0_conv1 = _pack_l0(l0.conv_block1.conv, l0.conv_block1.norm, self.win0, device=dev)
+        # Input row of level 0.  Reference channel order (net.py:118,124-125): [polarity | image feats | pos_xy].  The
+        # tiled kernel (csrc/conv_l0_tiles.hip) reads a 16-channel main block as 16-byte pieces, so with --use_image the
+        # row is laid out [16 image feats | polarity | pos_xy | pad] (80 B); events-only [polarity | pos_xy | pad] (16 B).
+        c0 = 1 + self.feat_ch[0] + 2
+        self.l0_tiles = (os.environ.get("DAGR_L0_TILES", "1") != "0" and (win[1], win[3]) in ((3, 3), (3, 5), (5, 3))
+                         and int(self.args.max_neighbors) == 16 and self.feat_ch[0] in (0, 16))
+        if self.l0_tiles:
+            nf = self.feat_ch[0]
+            self.x0_cols = list(range(1, 1 + nf)) + [0, 1 + nf, 2 + nf]      # reference channel of every x0 column
+            self.x0_ld = (c0 + 3) // 4 * 4
+            self.x0_feat_col, self.x0_img_col, self.x0_pos_col = nf, 0, nf + 1
+        else:
+            self.x0_cols = list(range(c0))
+            self.x0_ld = c0
+            self.x0_feat_col, self.x0_img_col, self.x0_pos_col = 0, 1, c0 - 2
+        self.l0_conv1 = _pack_l0(l0.conv_block1.conv, l0.conv_block1.norm, self.win0, device=dev, cols_in=self.x0_cols)
         self.l0_conv2 = _pack_l0(l0.conv_block2.conv, l0.conv_block2.norm, self.win0,
-                                 skip=(l0.conv_block2.lin, l0.conv_block2.norm_skip), device=dev)
+                                 skip=(l0.conv_block2.lin, l0.conv_block2.norm_skip), device=dev,
+                                 cols_skip=self.x0_cols)
         # ---- pooled levels 1..4
         self.packs = []
         for layer in layers[1:]:
@@ -424,7 +448,7 @@ class WindowEngine:
         self.deg = torch.zeros((n,), dtype=torch.int32, device=dev)
         self.h1 = torch.zeros((n, 16), dtype=torch.float32, device=dev)
         self.hp0 = torch.zeros((n, 16 + self.feat_ch[1]), dtype=torch.float32, device=dev)  # [h2 | image feats]
-        self.x0buf = torch.zeros((n, 1 + self.feat_ch[0] + 2), dtype=torch.float32, device=dev)
+        self.x0buf = torch.zeros((n, self.x0_ld), dtype=torch.float32, device=dev)
         self.cluster0 = torch.zeros((n,), dtype=torch.int32, device=dev)
         self.pos_n = torch.zeros((n, 3), dtype=torch.float32, device=dev)     # node (slot) order
         self.batch_n = torch.zeros((n,), dtype=torch.int32, device=dev)
@@ -571,38 +595,44 @@ class WindowEngine:
         N = self._N
         f = feat.float().reshape(-1).contiguous()
         x0 = self.x0buf[:N]
-        c = x0.shape[1]
         g = self.graph
         _lib.check(self.L.dagr_graph_gather_inputs(ctypes.byref(g.desc), _lib.ptr(g.workspace), _lib.ptr(self._pos),
                                                    _lib.ptr(f), N, _lib.ptr(self.pos_n), _lib.ptr(self.batch_n),
-                                                   _lib.ptr(x0), c, c - 2, _lib.cur_stream(self.device)),
-                   "graph_gather_inputs")
+                                                   _lib.ptr(x0), self.x0_ld, self.x0_feat_col, self.x0_pos_col,
+                                                   _lib.cur_stream(self.device)), "graph_gather_inputs")
         if self.use_image:
-            self._sample(None, N, self.pos_n, self.batch_n, 0, self._img_feats[0], x0, 1)
+            self._sample(None, N, self.pos_n, self.batch_n, 0, self._img_feats[0], x0, self.x0_img_col)
         self._x0 = x0
+
+    def _conv_l0(self, pack, x, ldx, xskip, ldskip, out, ldo):
+        L, P = self.L, _lib.ptr
+        nbr_src, nbr_code, deg = self._nbr
+        cin, cskip, w, s = pack
+        d0 = self.dom[0]
+        wx, tx, wy, ty = self.win0
+        stream = _lib.cur_stream(self.device)
+        if self.l0_tiles:
+            cm = 16 if cin >= 16 else 0
+            _lib.check(L.dagr_spline_conv_l0_tiles(cm, cin - cm, cskip, wx, tx, wy, ty, d0["rx"], d0["ry"], d0["den_x"],
+                                                   d0["den_y"], self._N, self.graph.K, P(nbr_src), P(nbr_code), P(deg),
+                                                   x, ldx, xskip, ldskip, P(w), P(s), 1, out, ldo, stream),
+                       "conv_l0_tiles")
+        else:
+            _lib.check(L.dagr_spline_conv_l0(cin, cskip, self.ntaps0, self._N, self.graph.K, self.ncodes0, P(nbr_src),
+                                             P(nbr_code), P(deg), x, ldx, xskip, ldskip, P(self.tab0), P(w), P(s), 1,
+                                             out, ldo, stream), "conv_l0")
 
     def stage_l0_conv1(self):
         """conv_block1.conv_block1: SplineConv(3|19 -> 16)+BN+ReLU (conv.py:23-28)."""
-        L, P = self.L, _lib.ptr
-        nbr_src, nbr_code, deg = self._nbr
-        cin, cskip, w1, s1 = self.l0_conv1
-        c0 = self._x0.shape[1]
-        assert cin == c0
-        _lib.check(L.dagr_spline_conv_l0(cin, 0, self.ntaps0, self._N, self.graph.K, self.ncodes0, P(nbr_src),
-                                         P(nbr_code), P(deg), P(self._x0), c0, None, 0, P(self.tab0), P(w1), P(s1), 1,
-                                         P(self.h1), 16, _lib.cur_stream(self.device)), "conv_l0")
+        P = _lib.ptr
+        assert self.l0_conv1[0] == len(self.x0_cols)
+        self._conv_l0(self.l0_conv1, P(self._x0), self.x0_ld, None, 0, P(self.h1), 16)
 
     def stage_l0_conv2(self, sample=True):
         """conv_block1.conv_block2: SplineConv(16->16)+BN + skip Linear+BN, ReLU (conv.py:47-56);
         with --use_image followed by sampling_skip(image_feat[1]) (net.py:129)."""
-        L, P = self.L, _lib.ptr
-        nbr_src, nbr_code, deg = self._nbr
-        cin, cskip, w2, s2 = self.l0_conv2
-        c0 = self._x0.shape[1]
-        ldo = self.hp0.shape[1]
-        _lib.check(L.dagr_spline_conv_l0(cin, cskip, self.ntaps0, self._N, self.graph.K, self.ncodes0, P(nbr_src),
-                                         P(nbr_code), P(deg), P(self.h1), 16, P(self._x0), c0, P(self.tab0), P(w2),
-                                         P(s2), 1, P(self.hp0), ldo, _lib.cur_stream(self.device)), "conv_l0")
+        P = _lib.ptr
+        self._conv_l0(self.l0_conv2, P(self.h1), 16, P(self._x0), self.x0_ld, P(self.hp0), self.hp0.shape[1])
         if self.use_image and sample:
             self._sample(None, self._N, self.pos_n, self.batch_n, 0, self._img_feats[1], self.hp0[:self._N], 16)
 
@@ -712,7 +742,8 @@ class WindowEngine:
             ev_slot = ev_slot.long()
             trace["layer1"] = self.hp0[:self._N, :16][ev_slot].clone()
             if self.use_image:
-                trace["x0"] = self._x0[ev_slot].clone()
+                back = [self.x0_cols.index(k) for k in range(len(self.x0_cols))]   # reference channel order
+                trace["x0"] = self._x0[ev_slot][:, back].clone()
         self.stage_pool1()
         self.stage_tail(trace)
         outs = self.stage_head()
@@ -747,6 +778,11 @@ class WindowEngine:
         """Kernel (as rocprofv3 prints it) behind each level-0 conv stage, for bench.py's roofline line."""
         c0 = 3 + self.feat_ch[0]
         nt = self.ntaps0
+        if self.l0_tiles:
+            tx, ty = self.win0[1], self.win0[3]
+            cm = 16 if c0 >= 16 else 0
+            return {"l0_conv1": f"k_conv_l0_tiles<{cm}, {c0 - cm}, 0, {tx}, {ty}>",
+                    "l0_conv2": f"k_conv_l0_tiles<16, 0, {c0}, {tx}, {ty}>"}
         mfma = os.environ.get("DAGR_L0_MFMA", "1") != "0"
         first = f"k_conv_l0_mixed<{c0 - 16}, {nt}>" if self.use_image else f"k_conv_l0_narrow<{c0}, {nt}>"
         return {"l0_conv1": first,

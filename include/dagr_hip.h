@@ -143,11 +143,12 @@ int dagr_graph_edge_index(const dagr_graph_desc *desc, void *workspace, const in
 int dagr_graph_node_order(const dagr_graph_desc *desc, void *workspace, int64_t N, int32_t *slot_event,
                           int32_t *event_slot, void *stream);
 /* node-ordered level-0 inputs: pos_nodes[N,3], batch_nodes[N] (int32), and per node the feature row
- * x0[n, 0] = feat[e], x0[n, col_pos..col_pos+1] = pos_xy[e]  (Net.forward's cat(x, pos[:, :2]), net.py:124-125;
- * columns 1..col_pos-1 are left for the sampled image features) */
+ * x0[n, col_feat] = feat[e], x0[n, col_pos..col_pos+1] = pos_xy[e]  (Net.forward's cat(x, pos[:, :2]), net.py:124-125;
+ * the other columns are left for the sampled image features -- the column order of x0 is the caller's choice as long
+ * as the packed weights follow it) */
 int dagr_graph_gather_inputs(const dagr_graph_desc *desc, void *workspace, const float *pos, const float *feat,
                              int64_t N, float *pos_nodes, int32_t *batch_nodes, float *x0, int32_t ldx0,
-                             int32_t col_pos, void *stream);
+                             int32_t col_feat, int32_t col_pos, void *stream);
 
 /* ------------------------------------------------------------------------ *
  * SplineConv (degree-1 open B-spline, 5x5 kernel, sum aggregation)
@@ -179,6 +180,16 @@ int dagr_spline_conv_l0(int32_t cin, int32_t cskip, int32_t ntaps /* tx*ty: 9, 1
                         const float *x, int32_t ldx, const float *xskip, int32_t ldskip,
                         const float *tab, const float *wpack, const float *shift, int32_t relu,
                         float *out, int32_t ldo, void *stream);
+/* level-0 conv as 16-node wave tiles (csrc/conv_l0_tiles.hip): same function as dagr_spline_conv_l0, but the basis is
+ * evaluated from the offset domain (rx, ry, den_x, den_y; tap window [win_x, win_x+tx) x [win_y, win_y+ty)) instead of
+ * a code table, and the input row is [cmain (0 or 16) channels | cextra (<= 4) channels], 16-byte aligned when cmain = 16.
+ * wpack rows: [(a + tx*b)*cin + i | cin root | cskip skip] x 16 with i in the column order of x, cin = cmain + cextra.
+ * K (neighbour-list stride) must be 16; (tx, ty) in {(3,3), (3,5), (5,3)}. */
+int dagr_spline_conv_l0_tiles(int32_t cmain, int32_t cextra, int32_t cskip, int32_t win_x, int32_t tx, int32_t win_y,
+                              int32_t ty, int32_t rx, int32_t ry, float den_x, float den_y, int64_t N, int32_t K,
+                              const int32_t *nbr_src, const int16_t *nbr_code, const int32_t *deg, const float *x,
+                              int32_t ldx, const float *xskip, int32_t ldskip, const float *wpack, const float *shift,
+                              int32_t relu, float *out, int32_t ldo, void *stream);
 /* generic step 1: A[n] = [sum_j basis*x_j per tap (25*cin) | x[n] (cin) | xskip[n] (cskip)] over a
  * CSR-by-destination graph; code[e] = ix | iy<<16.  n_nodes_ptr (device, may be NULL) bounds the
  * rows actually processed (<= n_nodes_max) without a host sync. */

@@ -13,6 +13,13 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
+def _err(a, b):
+    """1e-4 "abs/rel" (SURVEY 8d): absolute below magnitude 1, relative above -- with random weights and image
+    features the full-size windows reach |x| ~ 1e3, where one fp32 ulp is already 1.2e-4."""
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).abs() / (1 + b.abs())).max().item() if a.numel() else 0.0
+
+
 def _setup(W, H, B, seed=0, **over):
     from dagr_amd.model.networks.dagr import DAGR
     torch.manual_seed(seed)
@@ -63,7 +70,7 @@ def _compare(args, model, sd, W, H, B, x, y, t, p, b, pos, image=None):
         d0 = (tr_h["x0"].cpu()[:, :c] - tr_o["x0_image"]).abs().max().item()
         assert d0 < 1e-5, f"sampled level-0 image features differ by {d0}"
     # level 0 features
-    d = (tr_h["layer1"].cpu() - tr_o["layer1"]["x"]).abs().max().item()
+    d = _err(tr_h["layer1"], tr_o["layer1"]["x"])
     assert d < TOL, f"layer1 features differ by {d}"
     # pooled levels
     for k in range(1, 5):
@@ -71,26 +78,32 @@ def _compare(args, model, sd, W, H, B, x, y, t, p, b, pos, image=None):
         assert ho["x"].shape[0] == oo["x"].shape[0], f"pool{k}: cluster count {ho['x'].shape[0]} vs {oo['x'].shape[0]}"
         c = oo["x"].shape[1]
         assert (ho["batch"].cpu().long() == oo["batch"]).all(), f"pool{k}: batch"
-        dp = (ho["pos"].cpu() - oo["pos"]).abs().max().item()
-        assert dp < 1e-6, f"pool{k}: pos differs by {dp}"
         assert (ho["pos"].cpu()[:, :2] == oo["pos"][:, :2]).all(), f"pool{k}: rounded xy not identical"
-        dx = (ho["x"].cpu()[:, :c] - oo["x"]).abs().max().item()
+        # pooled t is a plain mean: the engine sums exactly (fixed point), the oracle sequentially in fp32 -- on voxels
+        # with hundreds of members (S-edges at full size) the ORACLE's rounding reaches a few 1e-6
+        dp = (ho["pos"].cpu()[:, 2] - oo["pos"][:, 2]).abs().max().item() if oo["pos"].numel() else 0.0
+        assert dp < 4e-6, f"pool{k}: mean t differs by {dp}"
+        dx = _err(ho["x"][:, :c], oo["x"])
         assert dx < TOL, f"pool{k}: x differs by {dx}"
         assert (ho["x"].cpu()[:, c:c + 2] == ho["pos"].cpu()[:, :2]).all()
         eh = _sorted_cols(_edges_from_csr(ho["rowptr"], ho["col"]))
         eo = _sorted_cols(oo["edge_index"].numpy())
         assert eh.shape == eo.shape and (eh == eo).all(), f"pool{k}: coarse edges differ"
         hl, ol = tr_h[f"layer{k + 1}"], tr_o[f"layer{k + 1}"]
-        dl = (hl["x"].cpu() - ol["x"]).abs().max().item()
+        dl = _err(hl["x"], ol["x"])
         assert dl < TOL, f"layer{k + 1} features differ by {dl}"
     # dense head maps (raw logits) and decoded outputs
     dense_h = eng._fused_dense if image is not None else tr_h["head_dense"]
     for i, dm in enumerate(dense_h):
         cls_o, reg_o, obj_o = raw_o[i]
         ref = torch.cat([reg_o, obj_o, cls_o], 1)
-        dd = (dm.cpu() - ref).abs().max().item()
+        dd = _err(dm, ref)
         assert dd < TOL, f"head scale {i + 1} differs by {dd}"
-    rel = ((out_h.cpu() - out_o).abs() / (1 + out_o.abs())).max().item()
+    # decoded outputs (dagr.py:306-312): xy and the sigmoids directly; w, h = exp(logit) * stride are compared as
+    # logits (an absolute logit error IS the relative error of the exponential)
+    oh, oo_ = out_h.cpu(), out_o
+    rel = max(_err(oh[..., :2], oo_[..., :2]), _err(oh[..., 4:], oo_[..., 4:]),
+              _err(torch.log(oh[..., 2:4]), torch.log(oo_[..., 2:4])))
     assert rel < TOL, f"decoded outputs differ by {rel}"
     return out_h
 
@@ -265,5 +278,44 @@ def test_dagr_l_resnet50_b8():
     args, model, sd = _setup(W, H, B, seed=10, use_image=True, img_net="resnet50", net_stem_width=1.0,
                              yolo_stem_width=1.0)
     with torch.no_grad():
-        _compare(args, model, sd, W, H, B, *_events(syn.edges_window, 30000, B, W, H, seed=3234),
+        # (seed 3234 holds a voxel of > 300 events whose mean x lands within fp32 noise of a round_to_pixel boundary:
+        # test_round_to_pixel_near_tie_follows_the_exact_mean covers that case on its own)
+        _compare(args, model, sd, W, H, B, *_events(syn.edges_window, 30000, B, W, H, seed=3235),
                  image=_bench_image(B, H, W, 79))
+
+
+def test_round_to_pixel_near_tie_follows_the_exact_mean():
+    """Pooled positions are cluster means floored to the pixel grid (pooling.py:47-49,67,86).  The reference sums with
+    float atomics (order-dependent), the oracle sequentially in fp32, the engine exactly (64-bit fixed point): on a
+    voxel whose mean lands within fp32 noise of a pixel boundary the three may legitimately differ.  The engine's
+    contract: the reference's fp32 formula applied to the correctly-rounded exact mean.  Constructed case: 313 events
+    in one voxel with sum(x) = 312 (mod 313), i.e. frac(mean_x * W + 1e-5 * W) within 1e-5 of an integer."""
+    from oracle import ops as oo
+    W, H, B = 320, 215, 1
+    args, model, sd = _setup(W, H, B, seed=11)
+    n = 313
+    rng = np.random.default_rng(0)
+    for target in (312, 311, 0, 1):       # residues around the boundary (and two safe ones)
+        x = rng.integers(8, 12, n)        # one 5.7-px-wide level-1 voxel column: x in [8, 11]
+        k = 0
+        while int(x.sum()) % n != target and k < n:     # nudge single events inside the voxel until the residue fits
+            if x[k] < 11:
+                x[k] += 1
+            k += 1
+        assert int(x.sum()) % n == target and x.min() >= 6 and x.max() <= 11
+        y = np.full(n, 3, np.int64)
+        t = np.sort(rng.integers(960000, 1000000, n)); t[-1] = 1000000 - 1
+        p = np.ones(n, np.int8); b = np.zeros(n, np.int64)
+        pos = syn.format_data_np(x, y, t, W, H)
+        dev = torch.device("cuda:0")
+        eng = model.engine()
+        tr = {}
+        eng.forward_raw(torch.from_numpy(pos).to(dev), torch.from_numpy(p.astype(np.float32)).view(-1, 1).to(dev),
+                        torch.from_numpy(b).to(dev), trace=tr)
+        eng.check_status()
+        got = tr["pool1"]["pos"].cpu()
+        assert got.shape[0] == 1
+        mean = torch.from_numpy(pos.astype(np.float64).mean(0).astype(np.float32))      # correctly-rounded exact mean
+        want_xy = oo.round_to_pixel(mean[:2].view(1, 2), 1 / torch.Tensor([[W, H]]))
+        assert torch.equal(got[:, :2], want_xy), (target, got[:, :2], want_xy)
+        assert abs(float(got[0, 2]) - float(mean[2])) < 1e-7
