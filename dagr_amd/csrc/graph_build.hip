@@ -111,6 +111,14 @@ __global__ __launch_bounds__(kBlock) void k_count(const void *__restrict__ pos_,
     }
     const int b = (int)batch[e];
     ev_t[e] = t;
+    // status[6]: set when timestamps are not non-decreasing in event order inside a sample.  Ids then do not order time,
+    // and the search kernels fall back from the two binary searches per pixel to the reference's linear FIFO walk.
+    if (e > 0 && (int)batch[e - 1] == b) {
+        int tp;
+        if (kIntPos) tp = static_cast<const int32_t *>(pos_)[3 * (int64_t)(e - 1) + 2];
+        else tp = (int)(fT * static_cast<const float *>(pos_)[3 * (int64_t)(e - 1) + 2] + 1e-3f);
+        if (tp > t) status[6] = 1;
+    }
     if (x < 0 || x >= W || y < 0 || y >= H || b < 0 || b >= B) {
         // The reference would index its FIFO volume out of bounds here; we flag and drop the
         // event from the pixel index (it keeps its self loop).
@@ -392,6 +400,27 @@ __global__ __launch_bounds__(kBlock) void k_search(const int32_t *__restrict__ m
 //   * most pixels hold 0 or 1 visible events: a round in which no lane has more than one takes a
 //     ballot/popcount cut (the sequential "first K in spiral order" becomes a prefix popcount);
 //     rounds with a multi-event pixel fall back to the exact prefix-sum walk.
+
+// Admissible sources of one pixel for destination (e, t): the visible FIFO entries are the slots [lo_vis, bnd) of the
+// pixel's segment, ids ascending.  "Older than the destination" (ev_graph.cu:64) is a prefix [lo_vis, hi); when ids
+// order time (status[6] == 0) "dt <= delta" (ev_graph.cu:69) is a suffix [lo, hi) of it: two binary searches instead of
+// the reference's newest-first walk over up to Q entries.  Returns [lo, hi); the walk order newest-first is hi-1 .. lo.
+__device__ __forceinline__ void admissible_range(const int2 *__restrict__ slot_it, int lo_vis, int bnd, int e, int t,
+                                                 float delta_t, int &lo, int &hi) {
+    int a = lo_vis, b = bnd;                 // first slot in [a, b) with id >= e
+    while (a < b) {
+        const int m = (a + b) >> 1;
+        if (slot_it[m].x < e) a = m + 1; else b = m;
+    }
+    hi = a;
+    a = lo_vis; b = hi;                      // first slot in [a, b) with dt <= delta
+    while (a < b) {
+        const int m = (a + b) >> 1;
+        if ((float)(t - slot_it[m].y) > delta_t) a = m + 1; else b = m;
+    }
+    lo = a;
+}
+
 constexpr int kTileRounds = 15;  // ceil(15*15 / 16)
 
 __global__ __launch_bounds__(kBlock) void k_search_tiled(const int32_t *__restrict__ m_ptr, int W, int H, int K, int Q,
@@ -421,6 +450,7 @@ __global__ __launch_bounds__(kBlock) void k_search_tiled(const int32_t *__restri
         pc[m] = (s < S) ? (((sy + r) * 17 + (sx + r)) | (((sx + r) * side + (sy + r)) << 16)) : -1;
     }
     long long edges_acc = 0;
+    const bool sorted_t = status[6] == 0;    // ids order time: per-pixel binary searches are exact
     // every block sweeps a contiguous range of slots (= a run of pixels along image rows): consecutive
     // destinations share most of their neighbourhood, so offsets and candidates come out of L1/L2
     const int M = node_list ? *node_list_count : *m_ptr;   // list mode: only the nodes the row kernel deferred
@@ -492,6 +522,22 @@ __global__ __launch_bounds__(kBlock) void k_search_tiled(const int32_t *__restri
                             nbr_code[row + slot] = (int16_t)ecode;
                         }
                         total += __popc(bits);
+                    } else if (sorted_t) {
+                        int v = 0, lo = 0, hi = 0;
+                        if (vis[j] > 1) {
+                            admissible_range(slot_it, bnd[j] - vis[j], bnd[j], e, t, delta_t, lo, hi);
+                            v = min(hi - lo, K);
+                        } else if (vis[j] == 1) {
+                            v = ok0 ? 1 : 0;
+                            hi = bnd[j]; lo = hi - v;
+                        }
+                        const int incl = group16_inclusive_scan(v);
+                        int slot = total + incl - v;
+                        total += __shfl(incl, 15, 16);
+                        for (int k = 0; k < v && slot < K; k++, slot++) {
+                            nbr_src[row + slot] = hi - 1 - k;          // newest first
+                            nbr_code[row + slot] = (int16_t)ecode;
+                        }
                     } else {
                         int v = 0;
                         if (vis[j] > 0) {
@@ -544,7 +590,7 @@ __global__ __launch_bounds__(kBlock) void k_search_tiled(const int32_t *__restri
 // benchmark stream) instead of to its (2r+1)^2 pixels.  Neighbourhoods with more than kRowCap
 // candidates (dense scenes, where the position-centric kernel exits after the first ring anyway) are
 // appended to a list that k_search_tiled processes afterwards.
-constexpr int kRowCap = 128;
+constexpr int kRowCap = 320;
 
 __global__ __launch_bounds__(kBlock) void k_search_rows(const int32_t *__restrict__ m_ptr, int W, int H, int K, int r,
                                                        float delta_t, const int32_t *__restrict__ slot_xyb,
@@ -558,6 +604,8 @@ __global__ __launch_bounds__(kBlock) void k_search_rows(const int32_t *__restric
     __shared__ unsigned char sp_rank[256];      // spiral index of offset (dy + r) * 16 + (dx + r)
     __shared__ int row_lo[G][16], row_base[G][17];
     __shared__ int v_key[G][kRowCap], v_src[G][kRowCap];
+    __shared__ int def_buf[kBlock / 64][64];
+    int wcnt = 0;    // entries of this wave's deferral buffer (uniform over the wave's active lanes)
     const int side = 2 * r + 1;
     const int S = side * side;
     for (int s = threadIdx.x; s < S; s += kBlock) {
@@ -617,10 +665,31 @@ __global__ __launch_bounds__(kBlock) void k_search_rows(const int32_t *__restric
         const int C = __shfl(incl, 15, 16);
         const int lo_cur = lo, len_cur = len;
         me = me1; c = c1; me1 = me2; c1 = c2; lo = lo1; len = len1;   // rotate the pipeline
-        if (C > kRowCap) {   // defer to the position-centric kernel
-            if (l == 0) node_list[atomicAdd(node_list_count, 1)] = n;
-            continue;
+        // Dense neighbourhoods are deferred to the position-centric kernel.  The list append is aggregated per wave
+        // (LDS buffer, one global atomic per ~48 entries): one atomicAdd per destination on a single counter
+        // serialises at ~350 M/s and was the whole cost of this kernel on dense windows (4.5 ms at 1.6 M deferrals).
+        const bool defer = C > kRowCap;
+        {
+            const unsigned long long dmask = __ballot(defer && l == 0);
+            if (dmask) {
+                const int lane64 = threadIdx.x & 63;
+                if (defer && l == 0) def_buf[threadIdx.x >> 6][wcnt + __popcll(dmask & ((1ull << lane64) - 1ull))] = n;
+                wcnt += __popcll(dmask);
+                if (wcnt > 64 - 4) {
+                    __builtin_amdgcn_wave_barrier();
+                    // written by the wave's first lane group: it runs the most iterations of this loop, so it is
+                    // active whenever any group of the wave still is (the others may have left the loop already)
+                    int base = 0;
+                    if (lane64 == 0) base = atomicAdd(node_list_count, wcnt);
+                    base = __shfl(base, 0, 64);
+                    if (lane64 < 16)
+                        for (int i = lane64; i < wcnt; i += 16) node_list[base + i] = def_buf[threadIdx.x >> 6][i];
+                    wcnt = 0;
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
         }
+        if (defer) continue;
         row_lo[grp][l] = lo_cur;
         row_base[grp][l] = incl - len_cur;
         if (l == 15) row_base[grp][16] = C;
@@ -690,6 +759,17 @@ __global__ __launch_bounds__(kBlock) void k_search_rows(const int32_t *__restric
         const int total = 1 + min(V, K - 1);
         if (l == 0) { deg[n] = total; edges_acc += total; }
         __builtin_amdgcn_wave_barrier();  // LDS lists are reused by the next destination
+    }
+    {   // flush the wave's deferral buffer (lane group 0 of a wave runs the most iterations: its count is the wave's)
+        const int lane64 = threadIdx.x & 63;
+        wcnt = __shfl(wcnt, 0, 64);
+        __builtin_amdgcn_wave_barrier();
+        if (wcnt > 0) {
+            int base = 0;
+            if (lane64 == 0) base = atomicAdd(node_list_count, wcnt);
+            base = __shfl(base, 0, 64);
+            if (lane64 < wcnt) node_list[base + lane64] = def_buf[threadIdx.x >> 6][lane64];
+        }
     }
     if (l == 0 && edges_acc) atomicAdd(reinterpret_cast<unsigned long long *>(status + 2), (unsigned long long)edges_acc);
 }

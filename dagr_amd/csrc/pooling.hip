@@ -213,9 +213,12 @@ __global__ __launch_bounds__(kBlock) void k_pool_l0_cells(dagr_pool_desc d, int 
         s_off[wv][lane] = incl - len;
         if (lane == 63) s_off[wv][64] = total;
         __builtin_amdgcn_wave_barrier();
-        for (int i0 = 0; i0 < total; i0 += 8) {
+        // 16 members in flight per wave (4 lane groups x 4): the walk is a chain of dependent loads (slot -> pos /
+        // neighbour codes / feature row), so its pace on event-dense voxels (S-edges: hundreds of members) is set by how
+        // many are outstanding
+        for (int i0 = 0; i0 < total; i0 += 16) {
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
+            for (int h = 0; h < 4; h++) {
                 const int i = i0 + 4 * h + g;
                 if (i >= total) continue;
                 // row of member i: the last j with off[j] <= i (empty rows share their successor's offset)
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_l0_cells(dagr_pool_desc d, int 
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) nbm |= __shfl_xor(nbm, off, 64);
         nbm &= ~(1 << 12);   // own cell
-        if (lane == 0 && nbm) ws.nbmask[raw] = nbm;
+        if (lane == 0 && nbm) atomicOr(&ws.nbmask[raw], nbm);
     }
     if (cnt > 0 && g == 0) {
         // this wave is the only non-atomic writer of slot `raw`; leak events of sample b-1 may hit it

@@ -79,3 +79,28 @@ class Batch(Data):
         out.batch = torch.cat([torch.full((n,), i, dtype=torch.long) for i, n in enumerate(n_nodes)])
         out._num_graphs = len(data_list)
         return out
+
+
+class DataLoader:
+    """The slice of ``torch_geometric.data.DataLoader`` the test scripts use (``run_test.py:48``,
+    ``run_test_interframe.py:69``): sequential or sampler-ordered batches collated with ``Batch.from_data_list``;
+    ``indices`` restricts the loader to this rank's batches (window sharding, ``dagr_amd/parallel.py``)."""
+
+    def __init__(self, dataset, batch_size=1, shuffle=False, sampler=None, follow_batch=(), drop_last=False,
+                 num_workers=0, batches=None):
+        if shuffle:
+            raise NotImplementedError("evaluation loaders are not shuffled")
+        self.dataset, self.batch_size = dataset, int(batch_size)
+        self.order = list(sampler) if sampler is not None else list(range(len(dataset)))
+        self.follow_batch, self.drop_last = tuple(follow_batch), bool(drop_last)
+        n = len(self.order) // self.batch_size if drop_last else -(-len(self.order) // self.batch_size)
+        self.batches = list(range(n)) if batches is None else [b for b in batches if b < n]
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __iter__(self):
+        B = self.batch_size
+        for k in self.batches:
+            idx = self.order[k * B:(k + 1) * B]
+            yield Batch.from_data_list([self.dataset[i] for i in idx], follow_batch=self.follow_batch)

@@ -441,7 +441,7 @@ class WindowEngine:
         self.max_events = n
         bb = self.model.backbone
         tgn = bb.events_to_graph
-        self.graph = tgn.init_graph_creator(self.W, self.H, self.time_window, self.B, dev, max_events=n)
+        self.graph = tgn.window_builder(self.W, self.H, self.time_window, self.B, dev, max_events=n)
         K = self.graph.K
         self.nbr_src = torch.zeros((n, K), dtype=torch.int32, device=dev)
         self.nbr_code = torch.zeros((n, K), dtype=torch.int16, device=dev)

@@ -1,0 +1,181 @@
+"""Module-level operators over libdagr_hip for graphs in the reference's representation (PyG ``Data``: ``x``, ``pos``,
+``batch``, ``edge_index int64[2,E]`` = (source, destination), ``edge_attr`` = T.Cartesian values).
+
+``DAGR.forward`` runs whole windows through ``dagr_amd.engine`` (device-resident levels, no host synchronisation).  The
+functions here back the ``forward`` of the individual layer modules, so that each of them is a ``Data -> Data`` callable
+like its reference twin (``model/layers/*.py``) and a maintainer can swap one layer at a time: the graph is brought into
+the kernels' CSR-by-destination form with a few torch ops, and every contraction / pooling / scatter is the C entry
+point the engine uses (include/dagr_hip.h)."""
+import ctypes
+
+import torch
+
+from ... import _lib
+
+
+def csr_by_destination(edge_index, num_nodes):
+    """(rowptr int32[n+1], col int32[E], perm int64[E]): edges sorted by (destination, source) -- the order
+    ``ToSparseTensor`` establishes (spline_conv.py:12,52-54)."""
+    src, dst = edge_index[0].long(), edge_index[1].long()
+    perm = torch.argsort(dst * num_nodes + src, stable=True)
+    counts = torch.bincount(dst, minlength=num_nodes)
+    rowptr = torch.zeros(num_nodes + 1, dtype=torch.int32, device=edge_index.device)
+    rowptr[1:] = torch.cumsum(counts, 0).int()
+    return rowptr, src[perm].int().contiguous(), perm
+
+
+def lut_codes(edge_attr, domain):
+    """``message_lut``'s integer table coordinates (spline_conv.py:41-42) packed as ix | iy << 16."""
+    rm = domain["remap"].to(edge_attr.device)
+    ix = (edge_attr[:, 0] * rm[0, 0] + rm[0, 2] + 1e-3).long()
+    iy = (edge_attr[:, 1] * rm[1, 1] + rm[1, 2] + 1e-3).long()
+    return (ix | (iy << 16)).int().contiguous()
+
+
+def graph_csr(data):
+    """CSR of ``data``'s graph, cached on the object like the reference caches ``adj_t`` (spline_conv.py:51-54)."""
+    cached = getattr(data, "_dagr_csr", None)
+    n = data.x.shape[0]
+    if cached is None or cached[3] != (n, data.edge_index.data_ptr(), data.edge_index.shape[1]):
+        rowptr, col, perm = csr_by_destination(data.edge_index, n)
+        cached = (rowptr, col, perm, (n, data.edge_index.data_ptr(), data.edge_index.shape[1]))
+        data._dagr_csr = cached
+    return cached[:3]
+
+
+def spline_conv(conv, x, rowptr, col, code, norm=None, skip=None, xskip=None, relu=False):
+    """out = act(BN(sum_j x_j . What(code_j) + x . root (+ bias)) (+ BN_skip(xskip . Wskip))) on a CSR graph."""
+    from ...engine import _pack_generic
+    if conv.lut_domain is None:
+        raise RuntimeError("call init_lut() / DAGR.cache_luts() first: the kernels evaluate the spline basis on the integer "
+                           "offset domain the reference tabulates (spline_conv.py:16-37)")
+    L, P = _lib.lib(), _lib.ptr
+    dev = x.device
+    n = x.shape[0]
+    pack = _pack_generic([conv], [norm], skip=skip, relu=relu, device=dev)
+    out = torch.empty((n, pack.N), dtype=torch.float32, device=dev)
+    if n == 0:
+        return out
+    x = x.float().contiguous()
+    counts = torch.tensor([n, col.shape[0]], dtype=torch.int32, device=dev)
+    dom = conv.lut_domain
+    stream = _lib.cur_stream(dev)
+    xs, lds = (None, 0) if xskip is None else (xskip.float().contiguous(), xskip.shape[1])
+    if L.dagr_spline_conv_fused_lds_bytes(pack.cin, pack.cskip) <= 160 * 1024:
+        _lib.check(L.dagr_spline_conv_fused(P(counts), n, P(rowptr), P(col), P(code), P(x), x.shape[1], pack.cin, P(xs),
+                                            lds, pack.cskip, dom["rx"], dom["ry"], dom["den_x"], dom["den_y"], P(pack.Wq),
+                                            P(pack.bias), P(out), pack.N, pack.N, 1 if relu else 0, stream),
+                   "spline_conv_fused")
+        return out
+    lda = (pack.K + 3) // 4 * 4
+    A = torch.empty((n, lda), dtype=torch.float32, device=dev)
+    _lib.check(L.dagr_spline_tap_aggregate(P(counts), n, P(rowptr), P(col), P(code), P(x), x.shape[1], pack.cin, P(xs), lds,
+                                           pack.cskip, dom["rx"], dom["ry"], dom["den_x"], dom["den_y"], P(A), lda, stream),
+               "tap_aggregate")
+    _lib.check(L.dagr_gemm_bias_act(P(counts), n, P(A), lda, P(pack.Wm), pack.ldw, P(pack.bias), P(out), pack.N, pack.K,
+                                    pack.N, 1 if relu else 0, stream), "gemm")
+    return out
+
+
+def conv_on_data(conv, data, norm=None, skip=None, xskip=None, relu=False):
+    rowptr, col, perm = graph_csr(data)
+    code = lut_codes(data.edge_attr[perm], conv.lut_domain) if col.shape[0] else col
+    return spline_conv(conv, data.x, rowptr, col, code, norm=norm, skip=skip, xskip=xskip, relu=relu)
+
+
+def cartesian(pos, edge_index, max_value):
+    """``T.Cartesian(norm=True, cat=False, max_value)``: (pos[src] - pos[dst]) / (2 max) + 0.5."""
+    if edge_index.shape[1] == 0:
+        return torch.zeros((0, pos.shape[1]), dtype=pos.dtype, device=pos.device)
+    return (pos[edge_index[0]] - pos[edge_index[1]]) / (2 * max_value) + 0.5
+
+
+def voxel_pool(pool, data):
+    """``Pooling.forward`` (pooling.py:51-97) through ``dagr_pool_csr``; reads back the two output counts."""
+    L, P = _lib.lib(), _lib.ptr
+    dev = data.x.device
+    n, C = data.x.shape
+    if n == 0:
+        return data
+    vs = pool.voxel_size.detach().float().cpu()
+    g = ((torch.Tensor([0.9999999, 0.9999999]) - 0) / vs[:2]).to(torch.int64) + 1
+    B = int(pool.batch_size)
+    desc = _lib.PoolDesc(batch_size=B, channels=C, gx=int(g[0]), gy=int(g[1]), vx=float(vs[0]), vy=float(vs[1]),
+                         inv_w=float(pool.wh_inv[0, 0]), inv_h=float(pool.wh_inv[0, 1]),
+                         two_max=float(torch.as_tensor(2 * pool.transform.max, dtype=torch.float32)), r00=1.0, r02=0.0,
+                         r11=1.0, r12=0.0, rx=1 << 14, ry=1 << 14, aggr=0 if pool.aggr == "max" else 1, append_pos=0)
+    key = (str(dev), C)
+    ws = pool.__dict__.setdefault("_dagr_ws", {}).get(key)
+    stream = _lib.cur_stream(dev)
+    if ws is None:
+        nbytes = L.dagr_pool_workspace_bytes(ctypes.byref(desc))
+        if nbytes == 0:
+            raise RuntimeError("libdagr_hip: " + L.dagr_last_error().decode())
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _lib.check(L.dagr_pool_workspace_init(ctypes.byref(desc), P(ws), nbytes, stream), "pool_ws_init")
+        pool._dagr_ws[key] = ws
+    T = int(g[0]) * int(g[1]) * (B + 1)
+    rowptr, col, _ = graph_csr(data)
+    i32 = dict(dtype=torch.int32, device=dev)
+    x_out = torch.zeros((T, C), dtype=torch.float32, device=dev)
+    pos_out = torch.zeros((T, 3), dtype=torch.float32, device=dev)
+    batch_out, counts = torch.zeros((T,), **i32), torch.zeros((2,), **i32)
+    rowptr_out = torch.zeros((T + 2,), **i32)
+    e_cap = T * 64
+    col_out, code_out = torch.zeros((e_cap,), **i32), torch.zeros((e_cap,), **i32)
+    n_ptr = torch.tensor([n], **i32)
+    batch = (data.batch if data.batch is not None else torch.zeros(n, dtype=torch.int64, device=dev)).int().contiguous()
+    scratch = torch.zeros((n,), **i32)
+    _lib.check(L.dagr_pool_csr(ctypes.byref(desc), P(ws), P(n_ptr), n, P(data.x.float().contiguous()), C,
+                               P(data.pos.float().contiguous()), P(batch), P(rowptr), P(col), P(scratch), P(x_out), C, 0,
+                               P(pos_out), P(batch_out), P(counts), P(rowptr_out), P(col_out), P(code_out),
+                               ctypes.c_void_p(counts.data_ptr() + 4), e_cap, stream), "pool_csr")
+    nc, ne = [int(v) for v in counts.tolist()]
+    flags = ctypes.c_int32(0)
+    _lib.check(L.dagr_pool_status(ctypes.byref(desc), P(ws), ctypes.byref(flags), stream), "pool_status")
+    if flags.value & ~8:       # bit 3 (LUT range) is meaningless here: no consumer table was given
+        raise RuntimeError(f"pooling flagged {flags.value:#x}")
+    dst = torch.repeat_interleave(torch.arange(nc, device=dev), (rowptr_out[1:nc + 1] - rowptr_out[:nc]).long())
+    src = col_out[:ne].long()
+    order = torch.argsort(src * max(nc, 1) + dst, stable=True)    # edge_index.unique(dim=-1): by source, then destination
+    ei = torch.stack([src[order], dst[order]])
+    out = data.__class__()
+    out.__dict__.update({k: v for k, v in data.__dict__.items() if not k.startswith("_dagr")})
+    out.x, out.pos, out.batch, out.edge_index = x_out[:nc], pos_out[:nc], batch_out[:nc].long(), ei
+    out.edge_attr = cartesian(out.pos, ei, pool.transform.max)
+    return out
+
+
+def to_dense(x, pos, pooling, batch, batch_size):
+    """``to_dense`` (spline_conv.py:80-107): node rows scattered into a zeroed [B, C, H, W] map."""
+    L, P = _lib.lib(), _lib.ptr
+    dev = x.device
+    Wc, Hc = [int(v) for v in (1 / pooling[:2].float().cpu() + 1e-3).long()]
+    n, C = x.shape
+    dense = torch.zeros((batch_size, C, Hc, Wc), dtype=torch.float32, device=dev)
+    if n == 0:
+        return dense
+    winner = torch.zeros((batch_size * Hc * Wc,), dtype=torch.int32, device=dev)
+    status = torch.zeros((1,), dtype=torch.int32, device=dev)
+    n_ptr = torch.tensor([n], dtype=torch.int32, device=dev)
+    _lib.check(L.dagr_to_dense(P(n_ptr), n, P(x.float().contiguous()), C, C, P(pos.float().contiguous()),
+                               P(batch.int().contiguous()), float(pooling[0]), float(pooling[1]), batch_size, Hc, Wc,
+                               P(winner), P(dense), P(status), _lib.cur_stream(dev)), "to_dense")
+    return dense
+
+
+def sample_features(data, image_feat, width, height):
+    """``sample_features`` (net.py:193-221) of an NCHW feature map at the nodes of ``data``."""
+    L, P = _lib.lib(), _lib.ptr
+    dev = data.x.device
+    n = data.pos.shape[0]
+    Bf, C, h, w = image_feat.shape
+    out = torch.empty((n, C), dtype=torch.float32, device=dev)
+    if n == 0:
+        return out
+    nhwc = image_feat.float().permute(0, 2, 3, 1).contiguous()
+    batch = data.batch if data.batch is not None else torch.zeros(n, dtype=torch.int64, device=dev)
+    b64 = 1 if batch.dtype == torch.int64 else 0
+    _lib.check(L.dagr_sample_features(None, n, P(data.pos.float().contiguous()), P(batch.contiguous()), b64, P(nhwc), Bf, h,
+                                      w, C, int(width), int(height), P(out), C, 0, _lib.cur_stream(dev)), "sample_features")
+    return out

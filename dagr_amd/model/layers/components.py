@@ -32,3 +32,8 @@ class Cartesian(torch.nn.Module):
     def __init__(self, norm=True, cat=False, max_value=None):
         super().__init__()
         self.norm, self.cat, self.max = norm, cat, max_value
+
+    def forward(self, data):                                    # components.py:30-35
+        from . import _ops
+        data.edge_attr = _ops.cartesian(data.pos, data.edge_index, self.max)
+        return data

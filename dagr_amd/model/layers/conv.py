@@ -1,11 +1,19 @@
-"""Parameter holders with the reference's names for ``src/dagr/model/layers/conv.py``: ``ConvBlock`` (:10-28:
-``conv``, ``norm``), ``ConvBlockWithSkip`` (:31-56: + ``lin``, ``norm_skip``), ``Layer`` (:59-72: ``conv_block1``,
-``conv_block2``).  They do not execute anything themselves: the engine packs conv + BN(eval) + ReLU
-(+ skip Linear + BN) into one fused contraction per block (``dagr_amd/engine.py``)."""
+"""Mirror of ``src/dagr/model/layers/conv.py``: ``ConvBlock`` (:10-28: ``conv``, ``norm``), ``ConvBlockWithSkip``
+(:31-56: + ``lin``, ``norm_skip``), ``Layer`` (:59-72: ``conv_block1``, ``conv_block2``), same names and state_dict.
+Whole windows go through ``dagr_amd/engine.py``; each module is ALSO a ``Data -> Data`` callable like its reference
+twin (eval mode), evaluated as ONE fused contraction -- conv + BN(eval) + ReLU (+ skip Linear + BN) -- by the kernels
+behind ``dagr_spline_conv_fused`` (``_ops.py``)."""
 import torch
 
+from . import _ops
 from .components import BatchNormData, Linear
 from .spline_conv import MySplineConv
+from ..utils import shallow_copy
+
+
+def _eval_only(m):
+    if m.training:
+        raise NotImplementedError("training mode (batch statistics, backward) is outside this stack: call .eval()")
 
 
 def _require_relu(args):
@@ -20,6 +28,11 @@ class ConvBlock(torch.nn.Module):
         self.conv = MySplineConv(in_channels, out_channels, args=args, bias=False, degree=degree)
         self.norm = BatchNormData(in_channels=out_channels)
 
+    def forward(self, data):                                    # conv.py:23-28
+        _eval_only(self)
+        data.x = _ops.conv_on_data(self.conv, data, norm=self.norm, relu=True)
+        return data
+
 
 class ConvBlockWithSkip(ConvBlock):
     """relu(norm(conv(h)) + norm_skip(lin(x_in)))"""
@@ -29,6 +42,12 @@ class ConvBlockWithSkip(ConvBlock):
         self.lin = Linear(skip_in_channel, out_channel, bias=False)
         self.norm_skip = BatchNormData(in_channels=out_channel)
 
+    def forward(self, data, data_skip):                         # conv.py:47-56
+        _eval_only(self)
+        data.x = _ops.conv_on_data(self.conv, data, norm=self.norm, skip=(self.lin, self.norm_skip), xskip=data_skip.x,
+                                   relu=True)
+        return data
+
 
 class Layer(torch.nn.Module):
     def __init__(self, in_channels, out_channels, args):
@@ -36,3 +55,8 @@ class Layer(torch.nn.Module):
         self.in_channel, self.out_channel = in_channels, out_channels
         self.conv_block1 = ConvBlock(in_channels, out_channels, args)
         self.conv_block2 = ConvBlockWithSkip(out_channels, out_channels, in_channels, args=args)
+
+    def forward(self, data):                                    # conv.py:68-72
+        data_skip = shallow_copy(data)
+        data = self.conv_block1(data)
+        return self.conv_block2(data, data_skip)

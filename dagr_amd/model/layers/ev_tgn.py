@@ -1,14 +1,28 @@
-"""Mirror of ``src/dagr/model/layers/ev_tgn.py`` (EV_TGN :19-58): lazily creates the graph builder
-from the first batch's (width, height, time_window, num_graphs); ``reset`` semantics as the
-reference (every eval call resets)."""
+"""Mirror of ``src/dagr/model/layers/ev_tgn.py`` (EV_TGN :19-58).
+
+``forward(events, reset)`` is the reference's: it lazily creates the stateful ``SlidingWindowGraph`` from the first
+batch's (width, height, time_window, num_graphs), resets it on ``reset=True`` calls, and writes ``events.edge_index``
+(int64[2, E], event ids, destinations ascending, self loop first) -- including ``reset=False`` calls, whose new nodes
+attach to the running graph.  ``DAGR.forward`` on whole ``reset=True`` windows does not go through it: the engine asks
+``window_builder()`` for the fused single-window builder (csrc/graph_build.hip), which produces the same edge set as
+fixed-stride neighbour lists without the FIFO volume."""
 import torch
 
-from ...graph.ev_graph import WindowGraphBuilder
+from ...graph.ev_graph import SlidingWindowGraph, WindowGraphBuilder
 
 
 def _get_value_as_int(obj, key):
     val = getattr(obj, key)
     return int(val) if isinstance(val, (int, float)) else int(val[0])
+
+
+def denormalize_pos(events):
+    """``ev_tgn.py:11-16``: int(pos * [W, H, T] + 1e-3)."""
+    if hasattr(events, "pos_denorm"):
+        return events.pos_denorm
+    denorm = torch.tensor([_get_value_as_int(events, "width"), _get_value_as_int(events, "height"),
+                           _get_value_as_int(events, "time_window")], device=events.pos.device)
+    return (denorm.view(1, -1) * events.pos + 1e-3).int()
 
 
 class EV_TGN(torch.nn.Module):
@@ -18,11 +32,32 @@ class EV_TGN(torch.nn.Module):
         self.max_neighbors = args.max_neighbors
         self.max_queue_size = 128  # ev_tgn.py:24
         self.graph_creators = None
+        self._builder = None
 
-    def init_graph_creator(self, width, height, time_window, batch_size, device, max_events=1 << 16):
-        delta_t_us = int(self.radius * time_window)   # ev_tgn.py:28
-        radius = int(self.radius * width + 1)          # ev_tgn.py:29
-        self.graph_creators = WindowGraphBuilder(width, height, batch_size, self.max_neighbors,
-                                                 self.max_queue_size, radius, delta_t_us,
-                                                 time_window=time_window, max_events=max_events, device=device)
-        return self.graph_creators
+    def _geometry(self, width, time_window):
+        return int(self.radius * width + 1), int(self.radius * time_window)     # ev_tgn.py:29, :28
+
+    def init_graph_creator(self, data):
+        width, height = _get_value_as_int(data, "width"), _get_value_as_int(data, "height")
+        radius, delta_t_us = self._geometry(width, _get_value_as_int(data, "time_window"))
+        self.graph_creators = SlidingWindowGraph(width=width, height=height, max_num_neighbors=self.max_neighbors,
+                                                 max_queue_size=self.max_queue_size, batch_size=data.num_graphs,
+                                                 radius=radius, delta_t_us=delta_t_us)
+
+    def window_builder(self, width, height, time_window, batch_size, device, max_events=1 << 16):
+        radius, delta_t_us = self._geometry(width, time_window)
+        self._builder = WindowGraphBuilder(width, height, batch_size, self.max_neighbors, self.max_queue_size, radius,
+                                           delta_t_us, time_window=time_window, max_events=max_events, device=device)
+        return self._builder
+
+    def forward(self, events, reset=True):
+        if getattr(events, "batch", None) is None:
+            events.batch = torch.zeros(events.pos.shape[0], dtype=torch.long, device=events.pos.device)
+        if self.graph_creators is None:
+            self.init_graph_creator(events)
+        elif reset:
+            self.graph_creators.reset()
+        pos = denormalize_pos(events)
+        events.edge_index = self.graph_creators.forward(events.batch.int(), pos, delete_nodes=False,
+                                                        collect_edges=reset).long()
+        return events

@@ -20,6 +20,12 @@ class Pooling(torch.nn.Module):
         self.batch_size = batch_size
         self.max_num_voxels = batch_size * self.num_grid_cells
 
+    def forward(self, data):
+        """``pooling.py:51-97``: voxel clusters, max / mean features, mean position floored to the pixel grid, the unique
+        coarse edges without self loops and their Cartesian attributes."""
+        from . import _ops
+        return _ops.voxel_pool(self, data)
+
     @property
     def num_grid_cells(self):
         return int((1 / self.voxel_size + 1e-3).int().prod())

@@ -56,7 +56,22 @@ class MySplineConv(torch.nn.Module):
         self.lut_domain = dict(rx=int(rx), ry=int(ry), remap=remap, den_x=den_x, den_y=den_y,
                                height=int(height), width=int(width))
 
+    def forward(self, data):
+        """``spline_conv.py:49-62``: ``data.x <- conv(data.x)`` over ``data.edge_index`` / ``edge_attr`` (+ root, + bias)."""
+        from . import _ops
+        data.x = _ops.conv_on_data(self, data)
+        return data
+
 
 class SplineConvToDense(MySplineConv):
     """Conv (with bias) + scatter into a dense [B,C,H,W] map (spline_conv.py:80-118)."""
-    pass
+
+    def forward(self, data, batch_size=None):
+        from . import _ops
+        data = MySplineConv.forward(self, data)
+        batch = data.batch if getattr(data, "batch", None) is not None else \
+            torch.zeros(len(data.x), dtype=torch.long, device=data.x.device)
+        if batch_size is None:
+            batch_size = getattr(self, "batch_size", None) or (int(batch.max().item()) + 1 if len(batch) else 1)
+        self.batch_size = batch_size
+        return _ops.to_dense(data.x, data.pos, data.pooling, batch, batch_size)

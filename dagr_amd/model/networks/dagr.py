@@ -57,6 +57,49 @@ class GNNHead(YOLOXHeadParams):
             self.cnn_head = CNNHead(num_classes=num_classes, strides=strides, in_channels=in_channels_cnn)
         self.strides = list(strides)
 
+    # -- dagr.py:179-236,283-312 (eval branch), module by module ---------------------------------------------
+    def process_feature(self, x, stem, cls_conv, reg_conv, cls_pred, reg_pred, obj_pred, batch_size):
+        from ..utils import shallow_copy
+        x = stem(x)
+        cls_feat = cls_conv(shallow_copy(x))
+        reg_feat = reg_conv(x)
+        cls_output = cls_pred(cls_feat, batch_size=batch_size)
+        reg_output = reg_pred(shallow_copy(reg_feat), batch_size=batch_size)
+        obj_output = obj_pred(reg_feat, batch_size=batch_size)
+        return cls_output, reg_output, obj_output
+
+    def forward(self, xin, output_sizes=None):
+        """Decoded ``[B, n_anchors, 5 + num_classes]`` from the backbone outputs (and the image outputs with
+        ``--use_image``); ``--no_events`` returns the image branch's own detections (dagr.py:283-284)."""
+        if self.training:
+            raise NotImplementedError("training losses are outside this stack")
+        out_cnn = None
+        if self.use_image:
+            xin, image_feat = xin
+            image_feat = [torch.nn.functional.interpolate(f, o) for f, o in zip(image_feat, output_sizes)]
+            out_cnn = self.cnn_head(image_feat)
+        batch_size = len(out_cnn["cls_output"][0]) if self.use_image else self.batch_size
+        maps, image_maps = [], []
+        for k, g in enumerate(xin):
+            s = str(k + 1)
+            cls_o, reg_o, obj_o = self.process_feature(g, *(getattr(self, n + s) for n in
+                                                            ("stem", "cls_conv", "reg_conv", "cls_pred", "reg_pred",
+                                                             "obj_pred")), batch_size=batch_size)
+            if out_cnn is not None:
+                cls_o = cls_o + out_cnn["cls_output"][k]
+                reg_o = reg_o + out_cnn["reg_output"][k]
+                obj_o = obj_o + out_cnn["obj_output"][k]
+                image_maps.append(torch.cat([out_cnn["reg_output"][k], out_cnn["obj_output"][k].sigmoid(),
+                                             out_cnn["cls_output"][k].sigmoid()], 1))
+            maps.append(torch.cat([reg_o, obj_o.sigmoid(), cls_o.sigmoid()], 1))
+        out = image_maps if self.no_events else maps
+        outputs = torch.cat([o.flatten(start_dim=2) for o in out], dim=2).permute(0, 2, 1).contiguous()
+        from ..utils import init_grid_and_stride
+        grid, stride = init_grid_and_stride([o.shape[-2:] for o in out], self.strides, outputs)
+        outputs[..., :2] = (outputs[..., :2] + grid) * stride
+        outputs[..., 2:4] = torch.exp(outputs[..., 2:4]) * stride
+        return outputs
+
 
 class DAGR(torch.nn.Module):
     def __init__(self, args, height, width):
@@ -103,6 +146,13 @@ class DAGR(torch.nn.Module):
                 for name in ("cls_pred", "reg_pred", "obj_pred"):
                     getattr(h, name + s).init_lut(height=height, width=width, Mx=M, rx=rx, ry=ry)
         self._engine = None  # parameters / domains changed: rebuild the device-side plan lazily
+
+    def forward_modules(self, x, reset=True):
+        """The eval forward as the reference wires it (``YOLOX.forward``: head(backbone(x))), every layer through its own
+        module-level operator instead of the window engine.  Same decoded outputs; used to check the operator API and
+        for ``reset=False`` calls on the layers that support them."""
+        x.reset = reset
+        return self.head(self.backbone(x), output_sizes=self.backbone.get_output_sizes()[-self.head.num_scales:])
 
     def _weights_stamp(self):
         """Cheap fingerprint of everything the engine snapshots (packed, BN-folded weights; the folded copy of the

@@ -67,5 +67,42 @@ class Net(torch.nn.Module):
                                 transform=Cartesian(norm=True, cat=False, max_value=pool_max[k]), aggr=pool_aggr[k],
                                 keep_temporal_ordering=args.keep_temporal_ordering))
 
+    def forward(self, data, reset=True):
+        """``Net.forward`` (net.py:108-190), module by module (eval mode): graph -> [image features] -> Cartesian edge
+        attributes -> Layer / Pooling x 4; returns ``[out3, out4][-num_scales:]`` (+ the image outputs).  Whole windows
+        are faster through ``DAGR.forward`` / the engine; this is the same computation as separate operators."""
+        from ..layers import _ops
+        from ..utils import shallow_copy
+        if self.use_image:
+            image_feat, image_outputs = self.net(data.image)
+        if hasattr(data, "reset"):
+            reset = data.reset
+        data = self.events_to_graph(data, reset=reset)
+
+        def with_image(d, k):
+            return torch.cat((d.x, _ops.sample_features(d, image_feat[k].detach(), self.width, self.height)), dim=1)
+        if self.use_image:
+            data.x = with_image(data, 0)
+        data = self.edge_attrs(data)
+        data.edge_attr = torch.clamp(data.edge_attr, min=0, max=1)
+        outputs = []
+        for k, name in enumerate(self.LAYER_NAMES):
+            data.x = torch.cat((data.x, data.pos[:, :2]), dim=1)
+            data = getattr(self, name)(data)
+            if k == 3:
+                out3 = shallow_copy(data)
+                out3.pooling = self.pool3.voxel_size[:3]
+                outputs.append(out3)
+            if k == 4:
+                data.pooling = self.pool4.voxel_size[:3]
+                outputs.append(data)
+                break
+            if self.use_image:
+                data.x = with_image(data, k + 1)
+            data = getattr(self, f"pool{k + 1}")(data)
+        if self.use_image:
+            return outputs[-self.num_scales:], image_outputs[-self.num_scales:]
+        return outputs[-self.num_scales:]
+
     def get_output_sizes(self):  # net.py:103-106
         return [(1 / p.voxel_size[:2] + 1e-3).cpu().int().numpy().tolist()[::-1] for p in (self.pool3, self.pool4)]

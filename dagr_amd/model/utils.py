@@ -72,3 +72,28 @@ def convert_to_evaluation_format(data):
         bbox[:, 2:4] += bbox[:, :2]
         targets.append({"boxes": bbox[:, :4], "labels": bbox[:, 4].long()})
     return targets
+
+
+def shallow_copy(data):
+    """``model/utils.py:158-166``: a new ``Data`` sharing graph tensors with ``data`` but owning a copy of ``x`` (the
+    cached CSR of the graph is shared, the reference's ``adj_t`` is not carried over -- it is recomputed there)."""
+    out = data.__class__()
+    keep = ("edge_index", "edge_attr", "pos", "batch", "pooling", "num_image_channels", "skipped", "pooled", "width",
+            "height", "time_window", "_dagr_csr")
+    for k in keep:
+        if k in data.__dict__:
+            out.__dict__[k] = data.__dict__[k]
+    out.x = data.x.clone()
+    return out
+
+
+def init_grid_and_stride(hw, strides, like):
+    """``model/utils.py:119-134``: anchor grid and stride per output cell, concatenated over the scales."""
+    grids, all_strides = [], []
+    for (hsize, wsize), stride in zip(hw, strides):
+        yv, xv = torch.meshgrid(torch.arange(hsize), torch.arange(wsize), indexing="ij")
+        grid = torch.stack((xv, yv), 2).view(1, -1, 2)
+        grids.append(grid)
+        all_strides.append(torch.full((1, grid.shape[1], 1), stride))
+    return (torch.cat(grids, dim=1).to(like.dtype).to(like.device),
+            torch.cat(all_strides, dim=1).to(like.dtype).to(like.device))

@@ -30,3 +30,62 @@ def format_data(data, normalizer=None):
         data.x = x.float()
     data.t = None
     return data
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Detection records and the evaluation buffer (src/dagr/utils/buffers.py:46-122).
+DETECTION_DTYPE = [("t", "<u8"), ("x", "<f4"), ("y", "<f4"), ("w", "<f4"), ("h", "<f4"), ("class_id", "u1"),
+                   ("class_confidence", "<f4")]
+
+
+def detections_to_records(det, t):
+    """One image's detections ``{boxes[x1,y1,x2,y2], labels[, scores]}`` -> the structured array the reference writes
+    (``bbox_t_to_ndarray`` buffers.py:46-66 / ``to_npy`` run_test_interframe.py:21-32).  Ground-truth dicts carry no
+    scores: the confidence column is dropped for them, as the reference does."""
+    import numpy as np
+    boxes = np.asarray(det["boxes"].cpu() if torch.is_tensor(det["boxes"]) else det["boxes"], dtype=np.float32)
+    labels = np.asarray(det["labels"].cpu() if torch.is_tensor(det["labels"]) else det["labels"])
+    has_scores = "scores" in det
+    rec = np.zeros((len(boxes),), dtype=DETECTION_DTYPE if has_scores else DETECTION_DTYPE[:-1])
+    rec["t"] = t
+    if len(boxes):
+        rec["x"], rec["y"] = boxes[:, 0], boxes[:, 1]
+        rec["w"], rec["h"] = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
+        rec["class_id"] = labels
+        if has_scores:
+            rec["class_confidence"] = np.asarray(det["scores"].cpu() if torch.is_tensor(det["scores"]) else det["scores"])
+    return rec
+
+
+class DetectionBuffer:
+    """Collects detections / ground truth of a test run on the host (buffers.py:100-122).  ``compute`` hands them to the
+    COCO evaluation (``utils/coco_eval.py`` over pycocotools in the reference) when that package exists."""
+
+    def __init__(self, height, width, classes):
+        self.height, self.width, self.classes = height, width, classes
+        self.detections, self.ground_truth = [], []
+
+    def update(self, detections, groundtruth, dataset=None, height=None, width=None):
+        self.detections.extend({k: v.cpu() for k, v in d.items()} for d in detections)
+        self.ground_truth.extend({k: v.cpu() for k, v in d.items()} for d in groundtruth)
+
+    def compile(self, sequences, timestamps):
+        def by_sequence(items):
+            import numpy as np
+            out = {}
+            for det, seq, t in zip(items, sequences, timestamps):
+                out.setdefault(seq, []).append(detections_to_records(det, t))
+            return {k: np.concatenate(v) for k, v in out.items()}
+        return by_sequence(self.detections), by_sequence(self.ground_truth)
+
+    def compute(self):
+        try:
+            import pycocotools  # noqa: F401
+        except ImportError as e:
+            raise RuntimeError("mAP needs pycocotools (src/dagr/utils/coco_eval.py:64-94), which this image lacks: run "
+                               "with no_eval=True and evaluate the saved detection records elsewhere") from e
+        from .coco_eval import evaluate_detection   # only importable with pycocotools
+        out = evaluate_detection(self.ground_truth, self.detections, height=self.height, width=self.width,
+                                 classes=self.classes)
+        self.detections, self.ground_truth = [], []
+        return {k.replace("AP", "mAP"): v for k, v in out.items()}

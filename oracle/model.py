@@ -167,7 +167,8 @@ def sample_features(pos, batch, image_feat, width, height):
     return s.view(feat.shape[1], -1).t()
 
 
-def net_forward(sd, args, nc, pos, feat, batch, edge_index, use_lut=True, image_feat=None, trace=None):
+def net_forward(sd, args, nc, pos, feat, batch, edge_index, use_lut=True, image_feat=None, trace=None,
+                exact_pos_mean=False):
     """``Net.forward`` (net.py:108-190) after ``events_to_graph``.  pos fp32[N,3] normalised,
     feat fp32[N,1], batch int64[N], edge_index int64[2,E].  Returns [out3, out4][-num_scales:].
     ``trace`` (dict) receives per-stage tensors for layer-by-layer parity tests."""
@@ -197,7 +198,7 @@ def net_forward(sd, args, nc, pos, feat, batch, edge_index, use_lut=True, image_
     for k in range(4):
         if image_feat is not None:
             g.x = torch.cat((g.x, sample_features(g.pos, g.batch, image_feat[k + 1], W, H)), dim=1)
-        res = ops.pooling(nc.pools[k], g.x, g.pos, g.batch, g.edge_index)
+        res = ops.pooling(nc.pools[k], g.x, g.pos, g.batch, g.edge_index, exact_mean=exact_pos_mean)
         if res is not None:  # pooling.py:52-53 returns the input untouched on an empty graph
             g = Graph(*res)
         rec(f"pool{k + 1}", g)
@@ -273,7 +274,7 @@ def head_forward(sd, args, nc, outs, batch_size, use_lut=True, cnn_out=None, tra
 
 
 def forward_events(sd, args, height, width, x, y, t, p, b, batch_size, use_lut=True, trace=None,
-                   time_window=1000000, image_feat=None, cnn_out=None):
+                   time_window=1000000, image_feat=None, cnn_out=None, exact_pos_mean=False):
     """Whole hot path for one window batch from raw events (int arrays): format_data
     (utils/buffers.py:33-44) -> EV_TGN (layers/ev_tgn.py:39-58) -> Net -> GNNHead eval."""
     nc = NetConstants(args, height, width)
@@ -289,5 +290,6 @@ def forward_events(sd, args, height, width, x, y, t, p, b, batch_size, use_lut=T
     ei = torch.from_numpy(ei)
     if trace is not None:
         trace["edge_index"] = ei.clone()
-    outs = net_forward(sd, args, nc, pos, feat, batch, ei, use_lut=use_lut, image_feat=image_feat, trace=trace)
+    outs = net_forward(sd, args, nc, pos, feat, batch, ei, use_lut=use_lut, image_feat=image_feat, trace=trace,
+                       exact_pos_mean=exact_pos_mean)
     return head_forward(sd, args, nc, outs, batch_size, use_lut=use_lut, cnn_out=cnn_out, trace=trace)

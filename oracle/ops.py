@@ -226,9 +226,17 @@ class PoolingParams:
         self.cart_max = cart_max
 
 
-def pooling(pp, x, pos, batch, edge_index):
+def pooling(pp, x, pos, batch, edge_index, exact_mean=False):
     """``Pooling.forward`` (``pooling.py:51-97``), self_loop=False, keep_temporal_ordering=False,
-    bn=None.  Returns (x, pos, batch, edge_index, edge_attr[E,3])."""
+    bn=None.  Returns (x, pos, batch, edge_index, edge_attr[E,3]).
+
+    ``exact_mean``: the cluster position is a mean that is then FLOORED to the pixel grid (pooling.py:47-49,86), so its
+    last bits decide an integer.  The reference sums it with float atomics on the GPU (torch_scatter: order unspecified),
+    a CPU restatement sums sequentially in fp32 (the default here, held to the reference's own code by the golden
+    fixtures), the HIP engine sums exactly.  On voxels with hundreds of members the fp32 orders differ from each other and
+    from the exact value by ~1e-4 px, enough to flip the floor about once per full-size S-edges window batch.  With
+    ``exact_mean=True`` the mean is the correctly-rounded exact one (float64 accumulation): the form the full-size GPU
+    parity tests compare against."""
     if x.shape[0] == 0:
         return None
     pos4 = torch.cat([pos, batch.float().view(-1, 1)], dim=-1)
@@ -240,7 +248,7 @@ def pooling(pp, x, pos, batch, edge_index):
     if ei.shape[1] > 0:
         ei = ei.unique(dim=-1)
     new_batch = batch[perm]
-    new_pos = scatter_mean(pos, cluster, n)
+    new_pos = scatter_mean(pos.double(), cluster, n).float() if exact_mean else scatter_mean(pos, cluster, n)
     if pp.aggr == "max":
         new_x = scatter_max(x, cluster, n)
     else:

@@ -1,0 +1,112 @@
+"""Shared pieces of the test scripts: flags, the (synthetic) dataset / sharded loader, model + EMA set-up exactly as
+``scripts/run_test.py:52-59`` does it, and the record writer of ``scripts/run_test_interframe.py:21-45``."""
+import argparse
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dagr import parallel                                        # noqa: E402
+from dagr.data import DataLoader                                 # noqa: E402
+from dagr.data.augment import Augmentations                      # noqa: E402
+from dagr.data.synthetic_data import SyntheticWindows            # noqa: E402
+from dagr.model.networks.dagr import DAGR                        # noqa: E402
+from dagr.model.networks.ema import ModelEMA                     # noqa: E402
+from dagr.utils.args import MODEL_CONFIGS, model_args            # noqa: E402
+from dagr.utils.buffers import detections_to_records             # noqa: E402
+from dagr.utils.testing_weights import randomize_                # noqa: E402
+
+
+def flags(description, extra=None):
+    p = argparse.ArgumentParser(description=description, formatter_class=argparse.RawDescriptionHelpFormatter)
+    p.add_argument("--config", default="dagr-s", choices=sorted(MODEL_CONFIGS))
+    p.add_argument("--checkpoint", type=Path, default=None, help="torch.load(path)['ema'] -> ema.ema (strict)")
+    p.add_argument("--output_directory", type=Path, default=Path("run_test_out"))
+    p.add_argument("--batch_size", type=int, default=8)
+    p.add_argument("--windows", type=int, default=32)
+    p.add_argument("--events_per_window", type=int, default=50000)
+    p.add_argument("--width", type=int, default=640)
+    p.add_argument("--height", type=int, default=480)
+    p.add_argument("--stream", default="uniform", choices=["uniform", "edges"])
+    p.add_argument("--use_image", action="store_true")
+    p.add_argument("--img_net", default="resnet50")
+    if extra:
+        extra(p)
+    return p
+
+
+def distributed():
+    """(world, rank, device) of a ``torch.distributed.run`` launch (one process per GPU); backend "nccl" = RCCL."""
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    else:
+        dev = torch.device("cpu")
+    if world > 1 and not torch.distributed.is_initialized():
+        torch.distributed.init_process_group("nccl" if dev.type == "cuda" else "gloo",
+                                             **({"device_id": dev} if dev.type == "cuda" else {}))
+    return world, rank, dev
+
+
+def dataset_and_loader(a, world, rank):
+    """The dataset and THIS rank's loader: batch k holds windows [k*B, (k+1)*B) (drop_last=True, run_test.py:48) and
+    goes to rank k mod G -- independent windows, no collective on the data path."""
+    ds = SyntheticWindows(a.windows, a.events_per_window, a.width, a.height, a.stream, a.use_image,
+                          transform=Augmentations.transform_testing)
+    n_batches = len(ds) // a.batch_size
+    loader = DataLoader(ds, follow_batch=["bbox", "bbox0"], batch_size=a.batch_size, shuffle=False, drop_last=True,
+                        batches=parallel.shard_indices(n_batches, rank, world))
+    return ds, loader
+
+
+def build_model(a, ds, dev):
+    """run_test.py:52-59: DAGR(args, height, width).cuda() -> ModelEMA -> checkpoint['ema'] (strict) -> cache_luts."""
+    args = model_args(a.config, batch_size=a.batch_size, use_image=a.use_image, img_net=a.img_net)
+    model = DAGR(args, height=ds.height, width=ds.width)
+    if a.checkpoint is None:
+        model = randomize_(model, seed=0)
+    model = model.to(dev)
+    ema = ModelEMA(model)
+    if a.checkpoint is not None:
+        ema.ema.load_state_dict(torch.load(a.checkpoint, map_location=dev)["ema"])
+    else:
+        ema.ema.load_state_dict(model.state_dict())
+    ema.ema.cache_luts(radius=args.radius, height=ds.height, width=ds.width)
+    return args, ema.ema
+
+
+def detection_rows(detections, device):
+    """Per-window detection dicts ({boxes, scores, labels, sequence, t, [window]}) -> float rows
+    (sequence number, t, x1, y1, x2, y2, score, label) for the gather."""
+    rows = []
+    for d in detections:
+        n = len(d["boxes"])
+        if n:
+            seq = float(int("".join(c for c in str(d["sequence"]) if c.isdigit()) or 0))
+            rows.append(np.concatenate([np.full((n, 1), seq), np.full((n, 1), float(d["t"])), d["boxes"],
+                                        d["scores"].reshape(-1, 1), d["labels"].reshape(-1, 1).astype(np.float64)], 1))
+    arr = np.concatenate(rows, 0) if rows else np.zeros((0, 8))
+    return torch.from_numpy(arr).to(torch.float64).to(device)
+
+
+def gather_and_save(rows, output_directory, rank, prefix="synthetic"):
+    """One gather of the run's detections (variable length), then rank 0 writes ``detections_<sequence>.npy`` with the
+    record layout of run_test_interframe.py:21-45, sorted by time."""
+    allrows = parallel.gather_detections(rows).cpu().numpy()
+    if rank != 0:
+        return None
+    output_directory.mkdir(parents=True, exist_ok=True)
+    files = {}
+    for seq in np.unique(allrows[:, 0]) if len(allrows) else []:
+        r = allrows[allrows[:, 0] == seq]
+        r = r[np.argsort(r[:, 1], kind="stable")]
+        rec = detections_to_records(dict(boxes=r[:, 2:6], scores=r[:, 6], labels=r[:, 7]), r[:, 1].astype(np.uint64))
+        path = output_directory / f"detections_{prefix}{int(seq):03d}.npy"
+        np.save(path, rec)
+        files[path.name] = len(rec)
+    return files

@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""Twin of the reference's ``scripts/run_test_interframe.py`` (:47-90): for ``--num_interframe_steps`` offsets
+``n_us in linspace(0, 50000, steps)`` the dataset is truncated to the first ``n_us`` microseconds after each frame
+(``dataset.set_num_us``, dsec_data.py:114-115,159-161), every truncated window goes through
+``run_test_with_visualization(..., compile_detections=True)``, and all detections are written per sequence sorted by
+timestamp (``save_detections``, :34-45).  The (window x offset) grid is embarrassingly parallel: under
+``torch.distributed.run`` the window batches of every offset are sharded over the ranks, one gather at the end."""
+import time
+
+import numpy as np
+import torch
+
+import _common as C
+from dagr.utils.logging import log_hparams, set_up_logging_directory
+from dagr.utils.testing import run_test_with_visualization
+
+
+def main(argv=None, model_factory=None):
+    a = C.flags(__doc__, lambda p: p.add_argument("--num_interframe_steps", type=int, default=10)).parse_args(argv)
+    world, rank, dev = C.distributed()
+    torch.manual_seed(42)
+    np.random.seed(42)
+    ds, loader = C.dataset_and_loader(a, world, rank)
+    args, net = (model_factory or C.build_model)(a, ds, dev)
+    out_dir = set_up_logging_directory("synthetic", "detection", a.output_directory, exp_name="run_test_interframe")
+    if rank == 0:
+        log_hparams(args)
+    detections = []
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for n_us in np.linspace(0, 50000, a.num_interframe_steps):
+            loader.dataset.set_num_us(int(n_us))
+            _, one_offset = run_test_with_visualization(loader, net, dataset="synthetic", compile_detections=True,
+                                                        no_eval=True)
+            detections.extend(one_offset)
+    files = C.gather_and_save(C.detection_rows(detections, dev), out_dir, rank)
+    if rank == 0:
+        print(f"{a.num_interframe_steps} offsets x {len(ds) // a.batch_size * a.batch_size} windows on {world} GPU(s) in "
+              f"{time.perf_counter() - t0:.2f} s -> {out_dir}: {files}")
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    return out_dir
+
+
+if __name__ == "__main__":
+    main()

@@ -63,8 +63,10 @@ def _compare(args, model, sd, W, H, B, x, y, t, p, b, pos, image=None):
         # engine sampled, so this checks sample_features + fusion, not MIOpen-vs-CPU conv rounding
         image_feat = [f.detach().float().cpu().contiguous() for f in eng._img_feats]
         cnn_out = {k: [o.detach().float().cpu().contiguous() for o in v] for k, v in eng._cnn_out.items()}
+    # exact_pos_mean: see oracle/ops.py:pooling -- the floor of a pooled position hangs on the last bits of a mean whose
+    # summation order the reference leaves unspecified; the engine's contract is the exact mean
     out_o, raw_o = om.forward_events(sd, args, H, W, x, y, t, p, b, B, trace=tr_o, image_feat=image_feat,
-                                     cnn_out=cnn_out)
+                                     cnn_out=cnn_out, exact_pos_mean=True)
     if image is not None:
         c = tr_o["x0_image"].shape[1]
         d0 = (tr_h["x0"].cpu()[:, :c] - tr_o["x0_image"]).abs().max().item()
@@ -79,10 +81,8 @@ def _compare(args, model, sd, W, H, B, x, y, t, p, b, pos, image=None):
         c = oo["x"].shape[1]
         assert (ho["batch"].cpu().long() == oo["batch"]).all(), f"pool{k}: batch"
         assert (ho["pos"].cpu()[:, :2] == oo["pos"][:, :2]).all(), f"pool{k}: rounded xy not identical"
-        # pooled t is a plain mean: the engine sums exactly (fixed point), the oracle sequentially in fp32 -- on voxels
-        # with hundreds of members (S-edges at full size) the ORACLE's rounding reaches a few 1e-6
         dp = (ho["pos"].cpu()[:, 2] - oo["pos"][:, 2]).abs().max().item() if oo["pos"].numel() else 0.0
-        assert dp < 4e-6, f"pool{k}: mean t differs by {dp}"
+        assert dp < 1e-6, f"pool{k}: mean t differs by {dp}"
         dx = _err(ho["x"][:, :c], oo["x"])
         assert dx < TOL, f"pool{k}: x differs by {dx}"
         assert (ho["x"].cpu()[:, c:c + 2] == ho["pos"].cpu()[:, :2]).all()
@@ -99,12 +99,15 @@ def _compare(args, model, sd, W, H, B, x, y, t, p, b, pos, image=None):
         ref = torch.cat([reg_o, obj_o, cls_o], 1)
         dd = _err(dm, ref)
         assert dd < TOL, f"head scale {i + 1} differs by {dd}"
-    # decoded outputs (dagr.py:306-312): xy and the sigmoids directly; w, h = exp(logit) * stride are compared as
-    # logits (an absolute logit error IS the relative error of the exponential)
+    # decoded outputs (dagr.py:306-312): the sigmoids directly; the box terms with the decode undone -- xy =
+    # (logit + grid) * stride cancels where logit ~ -grid, and w, h = exp(logit) * stride turns an absolute logit error
+    # into a relative one, so both are held to the tolerance in the logit domain -- plus a loose direct bound
     oh, oo_ = out_h.cpu(), out_o
-    rel = max(_err(oh[..., :2], oo_[..., :2]), _err(oh[..., 4:], oo_[..., 4:]),
-              _err(torch.log(oh[..., 2:4]), torch.log(oo_[..., 2:4])))
+    grid, stride = eng.grid_cache.cpu(), eng.stride_cache.cpu()
+    un = lambda o: torch.cat([o[..., :2] / stride - grid, torch.log(o[..., 2:4] / stride)], -1)
+    rel = max(_err(un(oh), un(oo_)), _err(oh[..., 4:], oo_[..., 4:]))
     assert rel < TOL, f"decoded outputs differ by {rel}"
+    assert _err(oh[..., :4], oo_[..., :4]) < 100 * TOL
     return out_h
 
 
@@ -278,9 +281,7 @@ def test_dagr_l_resnet50_b8():
     args, model, sd = _setup(W, H, B, seed=10, use_image=True, img_net="resnet50", net_stem_width=1.0,
                              yolo_stem_width=1.0)
     with torch.no_grad():
-        # (seed 3234 holds a voxel of > 300 events whose mean x lands within fp32 noise of a round_to_pixel boundary:
-        # test_round_to_pixel_near_tie_follows_the_exact_mean covers that case on its own)
-        _compare(args, model, sd, W, H, B, *_events(syn.edges_window, 30000, B, W, H, seed=3235),
+        _compare(args, model, sd, W, H, B, *_events(syn.edges_window, 30000, B, W, H, seed=3234),
                  image=_bench_image(B, H, W, 79))
 
 

@@ -1,5 +1,5 @@
-"""Script-level drop-in (scripts/run_test.py, twin of the reference's scripts/run_test.py:31-66): a tiny synthetic run
-writes the detection record file of utils/buffers.py:46-66."""
+"""Script-level drop-in (scripts/run_test.py, scripts/run_test_interframe.py: twins of the reference's scripts of the same
+names): tiny synthetic runs write per-sequence detection record files with the layout of run_test_interframe.py:21-45."""
 import os
 import subprocess
 import sys
@@ -9,18 +9,35 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NAMES = ("t", "x", "y", "w", "h", "class_id", "class_confidence")
+
+
+def _run(script, out, *extra):
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", script), "--windows", "6", "--batch_size", "2",
+           "--events_per_window", "3000", "--width", "320", "--height", "215", "--stream", "edges",
+           "--output_directory", str(out), *extra]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stdout
 
 
 def test_run_test_script_writes_detection_records(tmp_path):
     out = tmp_path / "out"
-    cmd = [sys.executable, os.path.join(ROOT, "scripts", "run_test.py"), "--windows", "6", "--batch_size", "2",
-           "--events_per_window", "3000", "--width", "320", "--height", "215", "--stream", "edges",
-           "--output_directory", str(out)]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
-    rec = np.load(out / "detections.npy")
-    assert rec.dtype.names == ("window", "t", "x", "y", "w", "h", "class_id", "class_confidence")
-    assert len(rec) > 0 and set(np.unique(rec["window"])) <= set(range(6))
-    assert (np.diff(rec["window"].astype(np.int64)) >= 0).all()          # restored window order
+    stdout = _run("run_test.py", out)
+    rec = np.load(out / "synthetic" / "detection" / "run_test" / "detections_synthetic000.npy")
+    assert rec.dtype.names == NAMES
+    assert len(rec) > 0 and (np.diff(rec["t"].astype(np.int64)) >= 0).all()                 # sorted by timestamp
+    assert set(np.unique(rec["t"])) <= {50000 * (w + 1) for w in range(6)}                   # t1 of the six windows
     assert (rec["w"] > 0).all() and (rec["h"] > 0).all() and (rec["class_confidence"] >= 0.001).all()
-    assert "6 windows, 18000 events" in r.stdout
+    assert "6 windows on 1 GPU(s)" in stdout
+
+
+def test_run_test_interframe_script(tmp_path):
+    out = tmp_path / "out"
+    stdout = _run("run_test_interframe.py", out, "--num_interframe_steps", "3")
+    rec = np.load(out / "synthetic" / "detection" / "run_test_interframe" / "detections_synthetic000.npy")
+    assert rec.dtype.names == NAMES and len(rec) > 0
+    # three offsets (0, 25 ms, 50 ms after each frame) x six windows: the timestamps are t0 + n_us
+    want = {50000 * w + off for w in range(6) for off in (0, 25000, 50000)}
+    assert set(np.unique(rec["t"])) <= want and (np.diff(rec["t"].astype(np.int64)) >= 0).all()
+    assert "3 offsets x 6 windows" in stdout
