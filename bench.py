@@ -285,6 +285,10 @@ def stage_timings(rig, slots, n_events_step):
     stages["pool1"] = time_gpu(eng.stage_pool1, iters)
     stages["tail"] = time_gpu(eng.stage_tail, iters)
     stages["head"] = time_gpu(lambda: eng._decode(eng.stage_head()), iters)
+    if eng.tail_graph and not use_image:
+        # what forward_raw actually runs after pool1: tail + both heads + decode as ONE replayed HIP graph (head scale 1
+        # beside pool4 / layer5 / head scale 2); `tail` and `head` above are the same kernels launched one by one
+        stages["tail_head_graph"] = time_gpu(eng._replay_tail, iters, warm=4)
     kernels = {k: dict(ms=round(v, 4), alg_MB=round(ab[k] / 1e6, 2) if k in ab else None,
                        alg_GBs=round(ab[k] / 1e9 / (v / 1e3), 1) if k in ab else None)
                for k, v in stages.items()}
@@ -309,8 +313,11 @@ def stage_timings(rig, slots, n_events_step):
                     compulsory_bytes=int(floor), floor_us=round(floor_us, 1),
                     x_over_floor=round(stages[dom] * 1e3 / floor_us, 1),
                     alg_bytes_per_launch=int(ab[dom]), launch_ms=round(stages[dom], 4))
+    total = sum(v for k, v in stages.items() if k != "tail_head_graph")
+    if "tail_head_graph" in stages:
+        total += stages["tail_head_graph"] - stages["tail"] - stages["head"]
     return dict(roofline=roofline, stages=kernels, edges_per_step=int(ne), levels=levels, radius=r,
-                batch_latency_ms=round(sum(stages.values()), 4))
+                batch_latency_ms=round(total, 4))
 
 
 def latency_sweep(W, H, use_image, img_net, dev, Ns, n_warm, n_timed):

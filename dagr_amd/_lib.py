@@ -90,8 +90,15 @@ SIGNATURES = {
                                             c_i32, c_i32, c_i32, c_void_p, c_i32, c_i32, c_void_p]),
     "dagr_nms_batched": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_float, c_float, c_void_p,
                                         c_void_p, c_void_p, c_void_p]),
+    "dagr_decode_heads": (ctypes.c_int, [c_void_p, c_i32, c_i32, c_float, c_void_p, c_i32, c_i32, c_float, c_i32, c_i32,
+                                         c_void_p, c_void_p]),
     "dagr_postprocess": (ctypes.c_int, [c_void_p, c_i32, c_i32, c_i32, c_float, c_float, c_float, c_void_p, c_void_p,
                                         c_void_p]),
+    "dagr_masked_lin": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i64, c_i32, c_i32, c_void_p]),
+    "dagr_masked_lin_no_bias": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i64, c_i32, c_i32, c_void_p]),
+    "dagr_masked_isdiff": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_i64, c_i32, c_void_p]),
+    "dagr_masked_inplace_BN": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                              c_i64, c_i32, c_void_p]),
     "dagr_debug_calibrate": (ctypes.c_int, [c_i32, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p]),
     "dagr_spline_conv_fused_lds_bytes": (c_size_t, [c_i32, c_i32]),
     "dagr_spline_conv_fused": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32,

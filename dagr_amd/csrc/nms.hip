@@ -6,6 +6,8 @@
 // broken by ascending anchor index (torchvision leaves them unspecified).
 #include "common.hpp"
 
+#include <algorithm>
+
 namespace dagr {
 namespace {
 constexpr int kMaxAnchors = 1024;
@@ -192,6 +194,30 @@ __global__ __launch_bounds__(kBlock) void k_postprocess(const float *__restrict_
     }
     if (threadIdx.x == 0) n_keep[b] = total;
 }
+// collect_outputs + decode_outputs of the eval head (model/networks/dagr.py:283-312) for up to two scales in one launch:
+// dense maps [B, 5+C, Hs, Ws] (reg 4 | obj 1 | cls C, raw logits) -> out[B, A, 5+C] with A = sum Hs*Ws, anchors of a scale
+// in row-major (y, x) order; xy = (logit + grid) * stride, wh = exp(logit) * stride, obj / cls = sigmoid(logit).
+__global__ __launch_bounds__(kBlock) void k_decode_heads(const float *__restrict__ d0, int H0, int W0, float s0,
+                                                        const float *__restrict__ d1, int H1, int W1, float s1, int B,
+                                                        int CH, float *__restrict__ out) {
+    const int A0 = H0 * W0, A1 = d1 ? H1 * W1 : 0, A = A0 + A1;
+    const int64_t total = (int64_t)B * A * CH;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int ch = (int)(i % CH);
+        const int a = (int)((i / CH) % A);
+        const int b = (int)(i / ((int64_t)CH * A));
+        const bool first = a < A0;
+        const int cell = first ? a : a - A0;
+        const int Ws = first ? W0 : W1, HW = first ? A0 : A1;
+        const float stride = first ? s0 : s1;
+        const float v = (first ? d0 : d1)[((size_t)b * CH + ch) * HW + cell];
+        float r;
+        if (ch < 2) r = (v + (float)(ch == 0 ? cell % Ws : cell / Ws)) * stride;
+        else if (ch < 4) r = expf(v) * stride;
+        else r = 1.0f / (1.0f + expf(-v));
+        out[i] = r;
+    }
+}
 }  // namespace
 }  // namespace dagr
 
@@ -224,6 +250,20 @@ extern "C" int dagr_postprocess(const float *pred, int32_t B, int32_t A, int32_t
     while (Apad < A) Apad <<= 1;
     k_postprocess<<<B, kBlock, 0, (hipStream_t)stream>>>(pred, A, Apad, num_classes, conf_threshold, iou_threshold,
                                                          class_offset, det, n_keep);
+    DAGR_CHECK_LAUNCH();
+    return DAGR_OK;
+}
+
+extern "C" int dagr_decode_heads(const float *dense0, int32_t H0, int32_t W0, float stride0, const float *dense1,
+                                 int32_t H1, int32_t W1, float stride1, int32_t B, int32_t channels, float *out,
+                                 void *stream) {
+    DAGR_CHECK_ARG(B >= 0 && channels >= 5 && H0 > 0 && W0 > 0 && (!dense1 || (H1 > 0 && W1 > 0)), "bad sizes");
+    if (B == 0) return DAGR_OK;
+    DAGR_CHECK_ARG(dense0 && out, "NULL pointer");
+    const int64_t total = (int64_t)B * (H0 * W0 + (dense1 ? H1 * W1 : 0)) * channels;
+    const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(total, kBlock), 1024);
+    k_decode_heads<<<grid, kBlock, 0, (hipStream_t)stream>>>(dense0, H0, W0, stride0, dense1, H1, W1, stride1, B, channels,
+                                                            out);
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;
 }

@@ -279,6 +279,10 @@ class WindowEngine:
         self.fuse_convs = os.environ.get("DAGR_FUSE_CONVS", "1") != "0"
         self.fast_coarse_edges = os.environ.get("DAGR_FAST_COARSE_EDGES", "1") != "0"
         self.fuse_image_epilogues = os.environ.get("DAGR_IMG_EPILOGUES", "1") != "0"
+        self.overlap_heads = os.environ.get("DAGR_OVERLAP_HEADS", "1") != "0"
+        self.tail_graph = os.environ.get("DAGR_TAIL_GRAPH", "1") != "0"
+        self._head_stream = self._head_join = self._graph = self._graph_out = None
+        self._graph_warm = 0
         self._prepare(bb, head)
         self.max_events = 0
         self._alloc_events(int(max_events))
@@ -406,6 +410,9 @@ class WindowEngine:
             for p in self.head_packs[i]:
                 lda_max = max(lda_max, self.levels[lvl - 1].T * (p.K + 3))
         self.A = torch.zeros((lda_max,), dtype=torch.float32, device=dev)
+        # second scratch for head scale 1 when it overlaps layer5 on a side stream (only the unfused convs touch it)
+        lda2 = max([self.levels[self.head_levels[0] - 1].T * (p.K + 3) for p in self.head_packs[0]])
+        self.A2 = torch.zeros((lda2 if self.num_scales > 1 else 1,), dtype=torch.float32, device=dev)
         self.head_buf = []
         for i, lvl in enumerate(self.head_levels):
             T = self.levels[lvl - 1].T
@@ -454,10 +461,11 @@ class WindowEngine:
         self.batch_n = torch.zeros((n,), dtype=torch.int32, device=dev)
 
     # ------------------------------------------------------------------------------- kernels
-    def _conv_generic(self, lvl, pack, x, ldx, xskip, ldskip, out, ldo, dom, stream, code=None):
+    def _conv_generic(self, lvl, pack, x, ldx, xskip, ldskip, out, ldo, dom, stream, code=None, scratch=None):
         L = self.L
         P = _lib.ptr
         code = lvl.code if code is None else code
+        scratch = self.A if scratch is None else scratch
         if self.fuse_convs and L.dagr_spline_conv_fused_lds_bytes(pack.cin, pack.cskip) <= 160 * 1024:
             # tap aggregation + contraction in one launch (A tile lives in LDS)
             _lib.check(L.dagr_spline_conv_fused(P(lvl.counts), lvl.T, P(lvl.rowptr), P(lvl.col), P(code), x, ldx,
@@ -468,8 +476,8 @@ class WindowEngine:
         lda = (pack.K + 3) // 4 * 4    # 16-byte aligned rows for the MFMA GEMM's float4 loads
         _lib.check(L.dagr_spline_tap_aggregate(P(lvl.counts), lvl.T, P(lvl.rowptr), P(lvl.col), P(code),
                                                x, ldx, pack.cin, xskip, ldskip, pack.cskip, dom["rx"], dom["ry"],
-                                               dom["den_x"], dom["den_y"], P(self.A), lda, stream), "tap_aggregate")
-        _lib.check(L.dagr_gemm_bias_act(P(lvl.counts), lvl.T, P(self.A), lda, P(pack.Wm), pack.ldw, P(pack.bias),
+                                               dom["den_x"], dom["den_y"], P(scratch), lda, stream), "tap_aggregate")
+        _lib.check(L.dagr_gemm_bias_act(P(lvl.counts), lvl.T, P(scratch), lda, P(pack.Wm), pack.ldw, P(pack.bias),
                                         out, ldo, pack.K, pack.N, 1 if pack.relu else 0, stream), "gemm")
 
     # -------------------------------------------------------------------------------- stages
@@ -652,66 +660,108 @@ class WindowEngine:
                                   P(l1.code), ctypes.c_void_p(l1.counts.data_ptr() + 4), l1.e_cap,
                                   _lib.cur_stream(self.device)), "pool_l0")
 
-    def stage_tail(self, trace=None):
-        """layer2..layer5 with pool2..pool4 (net.py:137-184)."""
+    def _stage_level(self, k, trace=None):
+        """Layer k+2 on pooled level k+1 (conv pair), then -- for k < 3 -- [sampling_skip] + pool k+2 (net.py:137-184)."""
         L, P = self.L, _lib.ptr
         stream = _lib.cur_stream(self.device)
+        lvl = self.levels[k]
+        c1, c2 = self.packs[k]
+        dom = self.dom[k + 1]
+        ldx = lvl.x.shape[1]
+        self._conv_generic(lvl, c1, P(lvl.x), ldx, None, 0, P(lvl.h1), c1.N, dom, stream)
+        ldh = lvl.hp.shape[1]
+        self._conv_generic(lvl, c2, P(lvl.h1), c1.N, P(lvl.x), ldx, P(lvl.hp), ldh, dom, stream)
+        if trace is not None:
+            trace[f"pool{k + 1}"] = self._level_snapshot(lvl, lvl.x)
+            trace[f"layer{k + 2}"] = self._level_snapshot(lvl, lvl.hp[:, :lvl.cout])
+
+    def _stage_pool(self, k):
+        """[sampling_skip(image_feat[k+2])] + pool k+2: level k+1 -> level k+2 (net.py:142-146,155-159,171-175)."""
+        L, P = self.L, _lib.ptr
+        stream = _lib.cur_stream(self.device)
+        lvl, nxt = self.levels[k], self.levels[k + 1]
+        ldh = lvl.hp.shape[1]
+        if self.use_image:
+            self._sample(P(lvl.counts), lvl.T, lvl.pos, lvl.batch, 0, self._img_feats[k + 2], lvl.hp, lvl.cout)
+        d = self.pool_desc[k + 1]
+        _lib.check(L.dagr_pool_csr(ctypes.byref(d), P(self.pool_ws[k + 1]), P(lvl.counts), lvl.T, P(lvl.hp),
+                                   ldh, P(lvl.pos), P(lvl.batch), P(lvl.rowptr), P(lvl.col),
+                                   P(lvl.cluster), P(nxt.x), nxt.x.shape[1], 0, P(nxt.pos), P(nxt.batch),
+                                   P(nxt.counts), P(nxt.rowptr), P(nxt.col), P(nxt.code),
+                                   ctypes.c_void_p(nxt.counts.data_ptr() + 4), nxt.e_cap, stream), "pool_csr")
+
+    def stage_tail(self, trace=None):
+        """layer2..layer5 with pool2..pool4 (net.py:137-184)."""
         for k in range(4):
-            lvl = self.levels[k]
-            c1, c2 = self.packs[k]
-            dom = self.dom[k + 1]
-            ldx = lvl.x.shape[1]
-            self._conv_generic(lvl, c1, P(lvl.x), ldx, None, 0, P(lvl.h1), c1.N, dom, stream)
-            ldh = lvl.hp.shape[1]
-            self._conv_generic(lvl, c2, P(lvl.h1), c1.N, P(lvl.x), ldx, P(lvl.hp), ldh, dom, stream)
-            if trace is not None:
-                trace[f"pool{k + 1}"] = self._level_snapshot(lvl, lvl.x)
-                trace[f"layer{k + 2}"] = self._level_snapshot(lvl, lvl.hp[:, :lvl.cout])
+            self._stage_level(k, trace)
             if k < 3:
-                if self.use_image:   # sampling_skip(image_feat[k+2]) (net.py:142,155,171)
-                    self._sample(P(lvl.counts), lvl.T, lvl.pos, lvl.batch, 0, self._img_feats[k + 2], lvl.hp, lvl.cout)
-                nxt = self.levels[k + 1]
-                d = self.pool_desc[k + 1]
-                _lib.check(L.dagr_pool_csr(ctypes.byref(d), P(self.pool_ws[k + 1]), P(lvl.counts), lvl.T, P(lvl.hp),
-                                           ldh, P(lvl.pos), P(lvl.batch), P(lvl.rowptr), P(lvl.col),
-                                           P(lvl.cluster), P(nxt.x), nxt.x.shape[1], 0, P(nxt.pos), P(nxt.batch),
-                                           P(nxt.counts), P(nxt.rowptr), P(nxt.col), P(nxt.code),
-                                           ctypes.c_void_p(nxt.counts.data_ptr() + 4), nxt.e_cap, stream), "pool_csr")
+                self._stage_pool(k)
+
+    def _stage_head_scale(self, i, scratch=None):
+        """GNNHead.process_feature of scale i + to_dense (dagr.py:179-190; spline_conv.py:80-118)."""
+        L, P = self.L, _lib.ptr
+        stream = _lib.cur_stream(self.device)
+        lvln = self.head_levels[i]
+        lvl = self.levels[lvln - 1]
+        stem, cr, cls, ro = self.head_packs[i]
+        hb = self.head_buf[i]
+        dom = self.head_dom[i]
+        code = self.head_code[i]
+        if code is not None:
+            rm = dom["remap"]
+            _lib.check(L.dagr_pool_recode(P(lvl.counts), lvl.T, P(lvl.rowptr), P(lvl.col), P(lvl.pos),
+                                          self.pool_desc[lvln - 1].two_max, float(rm[0, 0]), float(rm[0, 2]),
+                                          float(rm[1, 1]), float(rm[1, 2]), dom["rx"], dom["ry"], P(code),
+                                          lvl.e_cap, ctypes.c_void_p(self.status.data_ptr() + 4), stream),
+                       "pool_recode")
+        nr = self.n_reg
+        self._conv_generic(lvl, stem, P(lvl.hp), lvl.hp.shape[1], None, 0, P(hb["stem"]), nr, dom, stream, code, scratch)
+        self._conv_generic(lvl, cr, P(hb["stem"]), nr, None, 0, P(hb["cr"]), 2 * nr, dom, stream, code, scratch)
+        pred = hb["pred"]
+        npred = pred.shape[1]
+        # pred columns: [reg(4) | obj(1) | cls(num_classes)] = order of collect_outputs (dagr.py:300-302)
+        self._conv_generic(lvl, ro, ctypes.c_void_p(hb["cr"].data_ptr() + 4 * nr), 2 * nr, None, 0, P(pred), npred,
+                           dom, stream, code, scratch)
+        self._conv_generic(lvl, cls, P(hb["cr"]), 2 * nr, None, 0, ctypes.c_void_p(pred.data_ptr() + 4 * 5), npred,
+                           dom, stream, code, scratch)
+        Hc, Wc = self.out_sizes[i]
+        vox = self.head_vox[i]
+        _lib.check(L.dagr_to_dense(P(lvl.counts), lvl.T, P(pred), npred, npred, P(lvl.pos), P(lvl.batch),
+                                   float(vox[0]), float(vox[1]), self.B, Hc, Wc, P(hb["winner"]), P(hb["dense"]),
+                                   P(self.status), stream), "to_dense")
+        return hb["dense"]
 
     def stage_head(self):
         """GNNHead.process_feature per scale + to_dense (dagr.py:179-236)."""
-        L, P = self.L, _lib.ptr
-        stream = _lib.cur_stream(self.device)
-        outs = []
-        for i, lvln in enumerate(self.head_levels):
-            lvl = self.levels[lvln - 1]
-            stem, cr, cls, ro = self.head_packs[i]
-            hb = self.head_buf[i]
-            dom = self.head_dom[i]
-            code = self.head_code[i]
-            if code is not None:
-                rm = dom["remap"]
-                _lib.check(L.dagr_pool_recode(P(lvl.counts), lvl.T, P(lvl.rowptr), P(lvl.col), P(lvl.pos),
-                                              self.pool_desc[lvln - 1].two_max, float(rm[0, 0]), float(rm[0, 2]),
-                                              float(rm[1, 1]), float(rm[1, 2]), dom["rx"], dom["ry"], P(code),
-                                              lvl.e_cap, ctypes.c_void_p(self.status.data_ptr() + 4), stream),
-                           "pool_recode")
-            nr = self.n_reg
-            self._conv_generic(lvl, stem, P(lvl.hp), lvl.hp.shape[1], None, 0, P(hb["stem"]), nr, dom, stream, code)
-            self._conv_generic(lvl, cr, P(hb["stem"]), nr, None, 0, P(hb["cr"]), 2 * nr, dom, stream, code)
-            pred = hb["pred"]
-            npred = pred.shape[1]
-            # pred columns: [reg(4) | obj(1) | cls(num_classes)] = order of collect_outputs (dagr.py:300-302)
-            self._conv_generic(lvl, ro, ctypes.c_void_p(hb["cr"].data_ptr() + 4 * nr), 2 * nr, None, 0, P(pred), npred,
-                               dom, stream, code)
-            self._conv_generic(lvl, cls, P(hb["cr"]), 2 * nr, None, 0, ctypes.c_void_p(pred.data_ptr() + 4 * 5), npred,
-                               dom, stream, code)
-            Hc, Wc = self.out_sizes[i]
-            vox = self.head_vox[i]
-            _lib.check(L.dagr_to_dense(P(lvl.counts), lvl.T, P(pred), npred, npred, P(lvl.pos), P(lvl.batch),
-                                       float(vox[0]), float(vox[1]), self.B, Hc, Wc, P(hb["winner"]), P(hb["dense"]),
-                                       P(self.status), stream), "to_dense")
-            outs.append(hb["dense"])
+        return [self._stage_head_scale(i) for i in range(len(self.head_levels))]
+
+    def _tail_and_head(self, trace=None):
+        """Levels 1..4 and both head scales with the dependency structure the graph has: head scale 1 only needs level 3
+        (out3), so it runs on a side stream next to pool4 -> layer5 -> head scale 2 (net.py:166-186, dagr.py:213-236)."""
+        first = self.head_levels[0]                  # 3 when both scales exist, 4 with num_scales = 1
+        outs = [None] * len(self.head_levels)
+        cur = torch.cuda.current_stream(self.device)
+        forked = False
+        for k in range(4):
+            self._stage_level(k, trace)
+            if k + 1 == first and first == 3 and trace is None and self.overlap_heads:
+                if self._head_stream is None:
+                    self._head_stream = torch.cuda.Stream(self.device)
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                self._head_stream.wait_event(ev)
+                with torch.cuda.stream(self._head_stream):
+                    outs[0] = self._stage_head_scale(0, scratch=self.A2)
+                    self._head_join = torch.cuda.Event()
+                    self._head_join.record(self._head_stream)
+                forked = True
+            if k < 3:
+                self._stage_pool(k)
+        for i in range(len(self.head_levels)):
+            if outs[i] is None:
+                outs[i] = self._stage_head_scale(i)
+        if forked:
+            cur.wait_event(self._head_join)
         return outs
 
     def forward_raw(self, pos, feat, batch, image=None, trace=None, image_handle=None):
@@ -745,11 +795,28 @@ class WindowEngine:
                 back = [self.x0_cols.index(k) for k in range(len(self.x0_cols))]   # reference channel order
                 trace["x0"] = self._x0[ev_slot][:, back].clone()
         self.stage_pool1()
-        self.stage_tail(trace)
-        outs = self.stage_head()
+        if trace is None and self.tail_graph and not self.use_image:
+            return self._replay_tail()
+        outs = self._tail_and_head(trace)
         if trace is not None:
             trace["head_dense"] = [o.clone() for o in outs]
         return self._decode(outs)
+
+    def _replay_tail(self):
+        """Everything after pool1 has launch shapes that do not depend on the window (node / edge counts stay on the
+        device): ~70 small dependent launches, captured once as a HIP graph and replayed -- the host then issues ONE
+        launch for them, which is what bounds single-window latency at small N.  (Events-only: with --use_image the tail
+        samples this window's freshly allocated feature maps.)"""
+        if self._graph is None:
+            if self._graph_warm < 2:                 # lazy one-time work (function attributes, allocator) stays eager
+                self._graph_warm += 1
+                return self._decode(self._tail_and_head())
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self._decode(self._tail_and_head())
+            self._graph, self._graph_out = g, out
+        self._graph.replay()
+        return self._graph_out.clone()   # the graph's output buffer is rewritten by the next window
 
     def _decode(self, dense_maps):
         """collect_outputs + decode_outputs (dagr.py:283-312) on the tiny dense maps (torch ops)."""
@@ -763,11 +830,20 @@ class WindowEngine:
         return self._decode_maps(dense_maps)
 
     def _decode_maps(self, dense_maps):
-        hybrid = [torch.cat([o[:, :4], o[:, 4:].sigmoid()], 1) for o in dense_maps]
-        outputs = torch.cat([o.flatten(start_dim=2) for o in hybrid], dim=2).permute(0, 2, 1).contiguous()
-        outputs[..., :2] = (outputs[..., :2] + self.grid_cache) * self.stride_cache
-        outputs[..., 2:4] = torch.exp(outputs[..., 2:4]) * self.stride_cache
-        return outputs
+        """collect_outputs + decode_outputs (dagr.py:283-312) in one launch (dagr_decode_heads)."""
+        P = _lib.ptr
+        d = [m.contiguous() for m in dense_maps]
+        self._keep_maps = d
+        CH = d[0].shape[1]
+        A = sum(m.shape[2] * m.shape[3] for m in d)
+        out = torch.empty((self.B, A, CH), dtype=torch.float32, device=self.device)
+        second = d[1] if len(d) > 1 else None
+        _lib.check(self.L.dagr_decode_heads(P(d[0]), d[0].shape[2], d[0].shape[3], float(self.strides[0]), P(second),
+                                            second.shape[2] if second is not None else 0,
+                                            second.shape[3] if second is not None else 0,
+                                            float(self.strides[1]) if second is not None else 0.0, self.B, CH, P(out),
+                                            _lib.cur_stream(self.device)), "decode_heads")
+        return out
 
     def _level_snapshot(self, lvl, x):
         n, e = [int(v) for v in lvl.counts.tolist()]
@@ -805,11 +881,8 @@ class WindowEngine:
         if st[1]:
             raise RuntimeError("head: LUT coordinate outside the head's table (dagr_pool_recode)")
 
-    def forward_data(self, data):
-        """``DAGR.forward`` input contract: ``data`` after ``format_data`` (pos fp32[N,3] normalised,
-        x fp32[N,1], batch)."""
-        batch = data.batch if getattr(data, "batch", None) is not None else \
-            torch.zeros(data.pos.shape[0], dtype=torch.int64, device=data.pos.device)
+    def check_batch(self, data):
+        """Host-side validation of a batch against the engine's constants (no device read-back)."""
         ng = getattr(data, "num_graphs", None)
         if ng is not None and int(ng) > self.B:
             raise RuntimeError(f"batch of {int(ng)} windows, but the model was built with batch_size = {self.B}")
@@ -819,4 +892,11 @@ class WindowEngine:
                 v = int(v[0]) if hasattr(v, "__len__") else int(v)
                 if v != want:
                     raise RuntimeError(f"data.{name} = {v}, but the model was built for {want}")
+
+    def forward_data(self, data):
+        """``DAGR.forward`` input contract: ``data`` after ``format_data`` (pos fp32[N,3] normalised,
+        x fp32[N,1], batch)."""
+        batch = data.batch if getattr(data, "batch", None) is not None else \
+            torch.zeros(data.pos.shape[0], dtype=torch.int64, device=data.pos.device)
+        self.check_batch(data)
         return self.forward_raw(data.pos.float(), data.x.float(), batch, image=getattr(data, "image", None))

@@ -116,6 +116,8 @@ class DAGR(torch.nn.Module):
                             pretrain_cnn=args.pretrain_cnn, args=args)
         self._engine = None
         self._engine_stamp = None
+        self._window = None          # events since the last reset=True call (DAGR.forward(reset=False))
+        self._streaming = False
         if bool(args.no_events) and not bool(args.use_image):
             raise ValueError("--no_events returns the image branch's detections (dagr.py:283-284): it needs --use_image")
         if bool(getattr(args, "keep_temporal_ordering", False)):
@@ -187,10 +189,27 @@ class DAGR(torch.nn.Module):
     def forward(self, x, reset=True, return_targets=True, filtering=True):
         if self.training:
             raise NotImplementedError("training (losses, backward) is outside this round's scope")
-        if not reset:
-            raise NotImplementedError("incremental (reset=False) inference is not implemented")
         eng = self.engine()
-        outputs = eng.forward_data(x)
+        if self._window is None:
+            from ...asynchronous import StreamingWindow
+            self._window = StreamingWindow()
+        if reset:
+            self._window.reset()
+            self._streaming = False
+        if not reset or self._streaming:
+            # dagr.py:90 `x.reset = reset` -> ev_tgn.py:45-56: the new events attach to the running graph.  The running
+            # window lives on the device and is re-evaluated as a whole (dagr_amd/asynchronous/__init__.py): the
+            # outputs equal one reset=True call on all events so far, which is what the reference's asynchronous
+            # model guarantees for its incremental update (evaluate_flops.py:139-147).
+            self._streaming = True
+        eng.check_batch(x)
+        if self._streaming:
+            self._window.push(x)
+            pos, feat, batch = self._window.tensors()
+            outputs = eng.forward_raw(pos, feat, batch, image=self._window.image)
+        else:
+            self._window.push(x)             # a later reset=False call continues from this window
+            outputs = eng.forward_data(x)
         detections = postprocess_network_output(outputs, self.backbone.num_classes, self.conf_threshold,
                                                 self.nms_threshold, filtering=filtering, height=self.height,
                                                 width=self.width)

@@ -316,6 +316,13 @@ int dagr_nms_batched(const float *boxes, const float *scores, const int32_t *cls
                      int32_t B, int32_t A, float iou_threshold, float class_offset,
                      int32_t *order_out, int32_t *keep_out, int32_t *n_keep, void *stream);
 
+/* collect_outputs + decode_outputs of the eval head (model/networks/dagr.py:283-312; grid/stride cache of
+ * model/utils.py:119-134) for one or two scales in one launch: dense logit maps [B, channels = 5+C, Hs, Ws] (reg | obj |
+ * cls) -> out[B, A, channels], A = H0*W0 (+ H1*W1), xy = (logit + cell) * stride, wh = exp(logit) * stride, the rest
+ * sigmoid.  dense1 may be NULL (num_scales = 1). */
+int dagr_decode_heads(const float *dense0, int32_t H0, int32_t W0, float stride0, const float *dense1, int32_t H1,
+                      int32_t W1, float stride1, int32_t B, int32_t channels, float *out, void *stream);
+
 /* The whole of postprocess_network_output (model/utils.py:61-110, filtering=True) for a window batch in ONE launch:
  * pred[B,A,5+C] = decoded head outputs (cx, cy, w, h, obj, cls...) -> cxcywh->xyxy in the reference's op order,
  * class max / argmax, score = obj*class_conf, mask (score*class_conf >= conf_threshold), class-offset greedy NMS.
@@ -323,6 +330,28 @@ int dagr_nms_batched(const float *boxes, const float *scores, const int32_t *cls
  * (ties: ascending anchor); rows beyond are unspecified.  A <= 1024. */
 int dagr_postprocess(const float *pred, int32_t B, int32_t A, int32_t num_classes, float conf_threshold,
                      float iou_threshold, float class_offset, float *det, int32_t *n_keep, void *stream);
+
+/* ------------------------------------------------------------------------ *
+ * 1:1 replacements of the reference's native module `asy_tools` (src/dagr/asynchronous/asy_tools/main.cu:239-244): the
+ * masked row operators of the asynchronous per-event network update.  indices int64[K] = rows (nodes) that changed;
+ * feature matrices are [num_nodes, C] fp32 row-major; only the selected rows are read / written, in place.
+ *   dagr_masked_lin          <- masked_lin(indices, x_in, x_out, weight[Cout,Cin], bias[Cout], add)      main.cu:220-236
+ *   dagr_masked_lin_no_bias  <- masked_lin_no_bias(indices, x_in, x_out, weight, add)                    main.cu:198-216
+ *   dagr_masked_isdiff       <- masked_isdiff(indices, x_old, x_new, atol, rtol): marks unchanged rows with -1 in
+ *                               `indices`; the caller compacts (`indices[indices > -1]`, main.cu:138)     main.cu:112-139
+ *   dagr_masked_inplace_BN   <- masked_inplace_BN(indices, x, x_out, mean, var, weight, bias, eps)       main.cu:69-96
+ * Same argument order as the reference, then the shapes (K, Cin, Cout / C) and the stream.  add != 0: accumulate onto
+ * x_out instead of overwriting it.
+ * ------------------------------------------------------------------------ */
+int dagr_masked_lin(const int64_t *indices, const float *x_in, float *x_out, const float *weight, const float *bias,
+                    int32_t add, int64_t K, int32_t Cin, int32_t Cout, void *stream);
+int dagr_masked_lin_no_bias(const int64_t *indices, const float *x_in, float *x_out, const float *weight, int32_t add,
+                            int64_t K, int32_t Cin, int32_t Cout, void *stream);
+int dagr_masked_isdiff(int64_t *indices, const float *x_old, const float *x_new, float atol, float rtol, int64_t K,
+                       int32_t C, void *stream);
+int dagr_masked_inplace_BN(const int64_t *indices, const float *x, float *x_out, const float *running_mean,
+                           const float *running_var, const float *weight, const float *bias, float eps, int64_t K,
+                           int32_t C, void *stream);
 
 /* Profiling aid (not on the product path): streams a known number of bytes so that rocprofv3's
  * FETCH_SIZE / WRITE_SIZE can be calibrated on this library's access patterns.

@@ -12,7 +12,26 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REF_LIB = os.path.join(_HERE, "_ref", "libev_graph_ref.so")
+REF_ASY_LIB = os.path.join(_HERE, "_ref", "libasy_tools_ref.so")
 _lib = None
+_asy = None
+
+
+def asy_available():
+    return os.path.exists(REF_ASY_LIB) and torch.cuda.is_available()
+
+
+def asy_lib():
+    """The reference's own asy_tools kernels (src/dagr/asynchronous/asy_tools/main.cu via oracle/ref_driver_asy.hip)."""
+    global _asy
+    if _asy is None:
+        _asy = ctypes.CDLL(REF_ASY_LIB)
+        vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+        _asy.ref_masked_lin.argtypes = [vp, ci, vp, vp, ci, vp, vp, ci, ci, ci]
+        _asy.ref_masked_lin_no_bias.argtypes = [vp, ci, vp, vp, ci, vp, ci, ci, ci]
+        _asy.ref_masked_isdiff.argtypes = [vp, ci, vp, vp, ci, ci, cf, cf]
+        _asy.ref_masked_inplace_BN.argtypes = [vp, ci, vp, vp, ci, ci, vp, vp, vp, vp, cf]
+    return _asy
 
 
 def available():

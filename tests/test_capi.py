@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_functions():
     src = open(os.path.join(ROOT, "include", "dagr_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(dagr_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(dagr_[A-Za-z0-9_]+)\s*\(", src)))
 
 
 def test_header_symbols_exported_and_bound():

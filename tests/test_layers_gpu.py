@@ -21,7 +21,10 @@ TOL = 1e-4
 
 def _err(a, b):
     a, b = a.float().cpu(), b.float().cpu()
-    return ((a - b).abs() / (1 + b.abs())).max().item() if a.numel() else 0.0
+    if not a.numel():
+        return 0.0
+    unit = max(1.0, float(b.pow(2).mean().sqrt()))
+    return ((a - b).abs() / (unit + b.abs())).max().item()
 
 
 def _model(W, H, B, seed=0, **over):
@@ -86,17 +89,21 @@ def test_layer_pooling_and_dense_modules_match_the_oracle():
         assert torch.equal(data.pos.cpu()[:, :2], res[1][:, :2]) and _err(data.pos, res[1]) < 1e-6
         assert torch.equal(data.batch.cpu(), res[2]) and _err(data.x, res[0]) < TOL
         assert _err(data.edge_attr, res[4]) < 1e-6
-        # SplineConvToDense on this level (any conv with a bias + the level's own LUT)
-        pred = copy.deepcopy(model.head.reg_pred1)
+        # SplineConvToDense on this level: a fresh 16 -> 5 predictor with a bias, the level's own LUT domain
+        from dagr_amd.model.layers.spline_conv import SplineConvToDense
+        torch.manual_seed(1)
+        pred = SplineConvToDense(data.x.shape[1], 5, bias=True, args=args)
+        with torch.no_grad():
+            pred.bias.uniform_(-0.5, 0.5)
+        pred = pred.cuda()
         rx, ry, M = luts[1]
         pred.init_lut(height=H, width=W, Mx=M, rx=rx, ry=ry)
-        data.x = data.x[:, :pred.in_channels].contiguous()
+        sd2 = {"p." + k: v.detach().cpu() for k, v in pred.state_dict().items()}
         data.pooling = bb.pool1.voxel_size[:3]
         dense = pred(data, batch_size=B)
         og_ = om.Graph(*res)
-        og_.x = og_.x[:, :pred.in_channels]
         og_.pooling = nc.pools[0].voxel_size[:3]
-        want = om._pred_to_dense(sd, "head.reg_pred1.", og_, (rx, ry, M, H, W), B)
+        want = om._pred_to_dense(sd2, "p.", og_, (rx, ry, M, H, W), B)
         assert dense.shape == want.shape and _err(dense, want) < TOL
 
 
