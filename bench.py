@@ -161,7 +161,7 @@ def cpu_baseline(model_cpu, model_sd, W, H, n_events, n_windows, stream, use_ima
 class Rig:
     """One model on the device + its engines / streams + resident synthetic slots."""
 
-    def __init__(self, W, H, B, use_image, img_net, n_eng, dev):
+    def __init__(self, W, H, B, use_image, img_net, n_eng, dev, low_latency=False):
         from dagr_amd.engine import WindowEngine
         self.W, self.H, self.B, self.use_image, self.dev = W, H, B, use_image, dev
         self.args, model = make_model(W, H, B, use_image=use_image, img_net=img_net)
@@ -170,6 +170,8 @@ class Rig:
         self.model.cache_luts(width=W, height=H, radius=self.args.radius)
         eng = self.model.engine()
         self.engines = [eng] + [WindowEngine(self.model) for _ in range(n_eng - 1)]
+        for e in self.engines:       # throughput rigs keep the GPU full from several streams; latency rigs run one window
+            e.set_low_latency(low_latency)
         self.streams = [torch.cuda.Stream(dev) for _ in range(n_eng)] if n_eng > 1 else [torch.cuda.current_stream(dev)]
         self.num_classes = self.model.backbone.num_classes
 
@@ -285,10 +287,12 @@ def stage_timings(rig, slots, n_events_step):
     stages["pool1"] = time_gpu(eng.stage_pool1, iters)
     stages["tail"] = time_gpu(eng.stage_tail, iters)
     stages["head"] = time_gpu(lambda: eng._decode(eng.stage_head()), iters)
-    if eng.tail_graph and not use_image:
-        # what forward_raw actually runs after pool1: tail + both heads + decode as ONE replayed HIP graph (head scale 1
+    if not use_image:
+        # what a latency-mode engine runs after pool1: tail + both heads + decode as ONE replayed HIP graph (head scale 1
         # beside pool4 / layer5 / head scale 2); `tail` and `head` above are the same kernels launched one by one
+        eng.set_low_latency(True)
         stages["tail_head_graph"] = time_gpu(eng._replay_tail, iters, warm=4)
+        eng.set_low_latency(False)
     kernels = {k: dict(ms=round(v, 4), alg_MB=round(ab[k] / 1e6, 2) if k in ab else None,
                        alg_GBs=round(ab[k] / 1e9 / (v / 1e3), 1) if k in ab else None)
                for k, v in stages.items()}
@@ -314,8 +318,6 @@ def stage_timings(rig, slots, n_events_step):
                     x_over_floor=round(stages[dom] * 1e3 / floor_us, 1),
                     alg_bytes_per_launch=int(ab[dom]), launch_ms=round(stages[dom], 4))
     total = sum(v for k, v in stages.items() if k != "tail_head_graph")
-    if "tail_head_graph" in stages:
-        total += stages["tail_head_graph"] - stages["tail"] - stages["head"]
     return dict(roofline=roofline, stages=kernels, edges_per_step=int(ne), levels=levels, radius=r,
                 batch_latency_ms=round(total, 4))
 
@@ -327,7 +329,7 @@ def latency_sweep(W, H, use_image, img_net, dev, Ns, n_warm, n_timed):
     from dagr_amd.model.utils import postprocess_device
     out = {}
     for B in (1, 8):
-        rig = Rig(W, H, B, use_image, img_net, 1, dev)
+        rig = Rig(W, H, B, use_image, img_net, 1, dev, low_latency=True)
         eng = rig.engines[0]
         for sname, gen in (("uniform", syn.uniform_window), ("edges", syn.edges_window)):
             for N in Ns:
@@ -439,8 +441,9 @@ def main():
 
     if rank == 0 and world == 1 and not a.no_latency:
         Ns = [int(v) for v in a.latency_n.split(",") if v]
-        lat = {"protocol": f"one window batch at a time on one engine, device idle at window start, HIP events around "
-                           f"forward + post-processing; {a.latency_warmup} warm-up + {a.latency_windows} timed windows"}
+        lat = {"protocol": f"one window batch at a time on one engine in latency mode (tail + heads replayed as a HIP "
+                           f"graph), device idle at window start, HIP events around forward + post-processing; "
+                           f"{a.latency_warmup} warm-up + {a.latency_windows} timed windows"}
         lat["events_only"] = latency_sweep(W, H, False, a.img_net, dev, Ns, a.latency_warmup, a.latency_windows)
         if use_image:
             lat["image_" + a.img_net] = latency_sweep(W, H, True, a.img_net, dev, Ns, a.latency_warmup,

@@ -99,9 +99,16 @@ SIGNATURES = {
     "dagr_masked_isdiff": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_i64, c_i32, c_void_p]),
     "dagr_masked_inplace_BN": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                               c_i64, c_i32, c_void_p]),
+    "dagr_downsample_events": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_i32, c_i32, c_void_p,
+                                              c_void_p, c_void_p]),
     "dagr_debug_calibrate": (ctypes.c_int, [c_i32, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p]),
     "dagr_spline_conv_fused_lds_bytes": (c_size_t, [c_i32, c_i32]),
     "dagr_spline_conv_fused": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32,
+                                              c_void_p, c_i32, c_i32, c_i32, c_i32, c_float, c_float, c_void_p,
+                                              c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p]),
+    "dagr_spline_conv_tiles_pack_elems": (c_size_t, [c_i32, c_i32, c_i32]),
+    "dagr_spline_conv_tiles_pack": (ctypes.c_int, [c_void_p, c_i32, c_i32, c_i32, c_i32, c_void_p]),
+    "dagr_spline_conv_tiles": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32,
                                               c_void_p, c_i32, c_i32, c_i32, c_i32, c_float, c_float, c_void_p,
                                               c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p]),
     "dagr_add_relu": (ctypes.c_int, [c_void_p, c_void_p, c_i64, c_void_p]),

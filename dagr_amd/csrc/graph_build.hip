@@ -44,7 +44,7 @@ struct GraphWs {
     int32_t *slot_xyb;  // [Nmax] x | y<<12 | b<<24 per CSR slot
     int32_t *ev_slot;   // [Nmax] CSR slot of every event (-1: dropped)
     int32_t *long_list; // [Nmax/kShortSeg + 1] pixels whose segment is longer than kShortSeg
-    int32_t *status;    // [8]: 0 n_long, 1 flags, 2..3 num_edges (uint64), 4 last N
+    int32_t *status;    // [8]: 0 n_long, 1 flags, 2..3 num_edges (uint64), 5 / 7 deferral list lengths, 6 unsorted timestamps
     int64_t P;
 };
 
@@ -590,8 +590,12 @@ __global__ __launch_bounds__(kBlock) void k_search_tiled(const int32_t *__restri
 // benchmark stream) instead of to its (2r+1)^2 pixels.  Neighbourhoods with more than kRowCap
 // candidates (dense scenes, where the position-centric kernel exits after the first ring anyway) are
 // appended to a list that k_search_tiled processes afterwards.
-constexpr int kRowCap = 320;
+// kRowCap candidates per neighbourhood: the key list is the kernel's LDS footprint (16 KiB per workgroup at 256, which
+// keeps the occupancy of the sparse case); 256 covers uniform streams up to ~350 k events per 640x480 window.  Denser
+// neighbourhoods go to the position-centric kernel.  (LIST_IN re-sweeps a deferral list; kept for experiments.)
+constexpr int kRowCap = 256;
 
+template <int CAP, bool LIST_IN>
 __global__ __launch_bounds__(kBlock) void k_search_rows(const int32_t *__restrict__ m_ptr, int W, int H, int K, int r,
                                                        float delta_t, const int32_t *__restrict__ slot_xyb,
                                                        const int32_t *__restrict__ start,
@@ -599,11 +603,13 @@ __global__ __launch_bounds__(kBlock) void k_search_rows(const int32_t *__restric
                                                        int32_t *__restrict__ nbr_src, int16_t *__restrict__ nbr_code,
                                                        int32_t *__restrict__ deg, int32_t *__restrict__ status,
                                                        int32_t *__restrict__ node_list,
-                                                       int32_t *__restrict__ node_list_count) {
+                                                       int32_t *__restrict__ node_list_count,
+                                                       const int32_t *__restrict__ node_in,
+                                                       const int32_t *__restrict__ node_in_count) {
     constexpr int G = kBlock / 16;
     __shared__ unsigned char sp_rank[256];      // spiral index of offset (dy + r) * 16 + (dx + r)
     __shared__ int row_lo[G][16], row_base[G][17];
-    __shared__ int v_key[G][kRowCap], v_src[G][kRowCap];
+    __shared__ int v_key[G][CAP];   // (spiral rank << 20) | (0xFFFFF - position in its row range): the source slot follows
     __shared__ int def_buf[kBlock / 64][64];
     int wcnt = 0;    // entries of this wave's deferral buffer (uniform over the wave's active lanes)
     const int side = 2 * r + 1;
@@ -619,7 +625,8 @@ __global__ __launch_bounds__(kBlock) void k_search_rows(const int32_t *__restric
     const int gshift = threadIdx.x & 48;
     const unsigned lt_mask = (1u << l) - 1u;
     long long edges_acc = 0;
-    const int M = *m_ptr;
+    const int M = LIST_IN ? *node_in_count : *m_ptr;     // list mode: only the nodes the first sweep deferred
+    if (M <= 0) return;
     const int Gd = gridDim.x, nx = (Gd % 8 == 0) ? 8 : 1;
     const int xcd = blockIdx.x % nx, lb = blockIdx.x / nx, bpx = Gd / nx;
     const int chunk = (M + nx - 1) / nx;
@@ -628,8 +635,9 @@ __global__ __launch_bounds__(kBlock) void k_search_rows(const int32_t *__restric
     const int n_end = min(min(M, (xcd + 1) * chunk), n_begin + per_block);
     // Software pipeline over this lane group's destinations: the dependent chain {id,t | x,y,b} -> row bounds ->
     // candidates is three HBM latencies; the first two are issued one and two destinations ahead.
-    auto load_node = [&](int n, int2 &me, int &c) {
-        const int nn = min(n, M - 1);
+    auto node_of = [&](int i) { return LIST_IN ? node_in[min(i, M - 1)] : min(i, M - 1); };
+    auto load_node = [&](int i, int2 &me, int &c) {
+        const int nn = node_of(i);
         me = slot_it[nn];
         c = slot_xyb[nn];
     };
@@ -651,11 +659,12 @@ __global__ __launch_bounds__(kBlock) void k_search_rows(const int32_t *__restric
         load_node(n_begin + grp + G, me1, c1);
         load_rows(c, lo, len);
     }
-    for (int n = n_begin + grp; n < n_end; n += G) {
+    for (int ni = n_begin + grp; ni < n_end; ni += G) {
+        const int n = node_of(ni);
         // next destinations' loads (results are used one iteration later)
         int2 me2;
         int c2, lo1, len1;
-        load_node(n + 2 * G, me2, c2);
+        load_node(ni + 2 * G, me2, c2);
         load_rows(c1, lo1, len1);
         const int e = me.x, t = me.y;
         const int x = c & 4095;
@@ -668,7 +677,7 @@ __global__ __launch_bounds__(kBlock) void k_search_rows(const int32_t *__restric
         // Dense neighbourhoods are deferred to the position-centric kernel.  The list append is aggregated per wave
         // (LDS buffer, one global atomic per ~48 entries): one atomicAdd per destination on a single counter
         // serialises at ~350 M/s and was the whole cost of this kernel on dense windows (4.5 ms at 1.6 M deferrals).
-        const bool defer = C > kRowCap;
+        const bool defer = C > CAP;
         {
             const unsigned long long dmask = __ballot(defer && l == 0);
             if (dmask) {
@@ -734,7 +743,6 @@ __global__ __launch_bounds__(kBlock) void k_search_rows(const int32_t *__restric
                 if (valid) {
                     const int pidx = V + __popc(bits & lt_mask);
                     v_key[grp][pidx] = key;
-                    v_src[grp][pidx] = sv[q];
                 }
                 V += __popc(bits);
             }
@@ -752,7 +760,7 @@ __global__ __launch_bounds__(kBlock) void k_search_rows(const int32_t *__restric
             if (rk < K - 1) {
                 int sx, sy;
                 spiral_offset(mk >> 20, sx, sy);
-                nbr_src[row + 1 + rk] = v_src[grp][vi];
+                nbr_src[row + 1 + rk] = row_lo[grp][sy + r] + (0xFFFFF - (mk & 0xFFFFF));   // row range start + position
                 nbr_code[row + 1 + rk] = (int16_t)((sx + r) * side + (sy + r));
             }
         }
@@ -953,12 +961,13 @@ int dagr_graph_build_window(const dagr_graph_desc *desc, void *workspace, const 
     if (2 * desc->radius + 2 <= 16) {
         // fast path: candidate-centric row kernel; dense neighbourhoods are deferred (list in ev_rank, which
         // is dead after k_scatter; counter in status[5]) to the position-centric tiled kernel
-        static const unsigned res_rows = persistent_grid(k_search_rows, kBlock, 0, 1 << 30);
+        // (the deferral list lives in ev_rank, dead after k_scatter; its counter is status[5])
+        static const unsigned res_rows = persistent_grid(k_search_rows<kRowCap, false>, kBlock, 0, 1 << 30);
         static const unsigned res_tiled = persistent_grid(k_search_tiled, kBlock, 0, 1 << 30);
         const unsigned gR = round_grid8(std::min<int64_t>(ceil_div(N * 16, kBlock), res_rows));
-        k_search_rows<<<gR, kBlock, 0, stream>>>(ws.start + ws.P, W, H, desc->max_neighbors, desc->radius,
-                                                 (float)desc->delta_t_us, ws.slot_xyb, ws.start, ws.slot_it, nbr_src,
-                                                 nbr_code, deg, ws.status, ws.ev_rank, ws.status + 5);
+        k_search_rows<kRowCap, false><<<gR, kBlock, 0, stream>>>(
+            ws.start + ws.P, W, H, desc->max_neighbors, desc->radius, (float)desc->delta_t_us, ws.slot_xyb, ws.start,
+            ws.slot_it, nbr_src, nbr_code, deg, ws.status, ws.ev_rank, ws.status + 5, nullptr, nullptr);
         DAGR_CHECK_LAUNCH();
         const unsigned gT = round_grid8(std::min<int64_t>(ceil_div(N * 16, kBlock), res_tiled));
         k_search_tiled<<<gT, kBlock, 0, stream>>>(ws.start + ws.P, W, H, desc->max_neighbors, desc->queue_size,

@@ -49,6 +49,15 @@ class _ConvPack:
         Wp[: self.K, : self.N] = Wm[:, : self.N]
         # [g, j, kk, c, nn] -> [c, g, kk, nn, j]  (lane l = 16 kk + nn)
         self.Wq = Wp.view(K16 // 16, 4, 4, N16 // 16, 16).permute(3, 0, 2, 4, 1).contiguous()
+        # operand order of dagr_spline_conv_tiles ([column tile][k-step][lane]); None when the channel counts do not fit it
+        self.Wt = None
+        if cin % 16 <= 4 and cskip % 16 <= 4:
+            L = _lib.lib()
+            host = Wm[:, : self.N].detach().float().cpu().contiguous()
+            wt = torch.empty((L.dagr_spline_conv_tiles_pack_elems(cin, cskip, self.N),), dtype=torch.float32)
+            _lib.check(L.dagr_spline_conv_tiles_pack(ctypes.c_void_p(host.data_ptr()), self.N, cin, cskip, self.N,
+                                                     ctypes.c_void_p(wt.data_ptr())), "conv_tiles_pack")
+            self.Wt = wt.to(Wm.device)
 
 
 def _pack_generic(convs, norms, skip=None, relu=True, device="cuda"):
@@ -232,7 +241,8 @@ class _Level:
         self.e_cap = T * 64
         i32 = dict(dtype=torch.int32, device=device)
         f32 = dict(dtype=torch.float32, device=device)
-        self.x = torch.zeros((T, cin), **f32)        # pooled features + pos[:, :2]
+        # pooled features + pos[:, :2]; row stride padded to 16 bytes (the tiled conv reads 16-byte channel quads)
+        self.x = torch.zeros((T, (cin + 3) // 4 * 4), **f32)
         self.pos = torch.zeros((T, 3), **f32)
         self.batch = torch.zeros((T,), **i32)
         self.rowptr = torch.zeros((T + 2,), **i32)
@@ -277,10 +287,18 @@ class WindowEngine:
         self._img_stream = None
         self._net_f = self._cnn_f = None
         self.fuse_convs = os.environ.get("DAGR_FUSE_CONVS", "1") != "0"
+        # dagr_spline_conv_tiles (register-tiled pooled conv, csrc/conv_pooled_tiles.hip): correct for any K, but measured
+        # slower than k_conv_fused on these levels (tail 0.53 vs 0.42 ms at B = 8, 0.26 vs 0.22 ms at B = 1): off by default
+        self.pooled_tiles = os.environ.get("DAGR_POOLED_TILES", "0") != "0"
+        self.tiles_max_nodes = int(os.environ.get("DAGR_TILES_MAX_NODES", "8192"))
         self.fast_coarse_edges = os.environ.get("DAGR_FAST_COARSE_EDGES", "1") != "0"
         self.fuse_image_epilogues = os.environ.get("DAGR_IMG_EPILOGUES", "1") != "0"
-        self.overlap_heads = os.environ.get("DAGR_OVERLAP_HEADS", "1") != "0"
-        self.tail_graph = os.environ.get("DAGR_TAIL_GRAPH", "1") != "0"
+        # Latency mode (one window batch at a time, e.g. DAGR.forward): head scale 1 runs beside pool4 / layer5 / head scale
+        # 2 and everything after pool1 is replayed as one HIP graph -- the host issues one launch instead of ~70.  When
+        # several engines keep the GPU full on their own streams (bench.py's throughput rigs) both cost throughput
+        # (measured, events-only, 3 engines: 696 M events/s plain, 620 M with the side stream, 594 M with graph replay),
+        # so such callers switch it off with set_low_latency(False).
+        self.set_low_latency(os.environ.get("DAGR_LOW_LATENCY", "1") != "0")
         self._head_stream = self._head_join = self._graph = self._graph_out = None
         self._graph_warm = 0
         self._prepare(bb, head)
@@ -440,6 +458,11 @@ class WindowEngine:
         self.grid_cache = torch.cat(grids, dim=1).float().to(dev)
         self.stride_cache = torch.cat(strides, dim=1).float().to(dev)
 
+    def set_low_latency(self, on):
+        self.overlap_heads = bool(on) and os.environ.get("DAGR_OVERLAP_HEADS", "1") != "0"
+        self.tail_graph = bool(on) and os.environ.get("DAGR_TAIL_GRAPH", "1") != "0"
+        return self
+
     def _alloc_events(self, n):
         if n <= self.max_events:
             return
@@ -466,6 +489,15 @@ class WindowEngine:
         P = _lib.ptr
         code = lvl.code if code is None else code
         scratch = self.A if scratch is None else scratch
+        # small levels (<= 8 k node slots): the register-tiled conv, one workgroup per (16 nodes, 16 columns); larger ones
+        # (level 1 of a B = 8 batch) walk their edges once per tile for all columns in k_conv_fused
+        if self.pooled_tiles and pack.Wt is not None and lvl.T <= self.tiles_max_nodes \
+                and (pack.cin < 16 or ldx % 4 == 0) and (pack.cskip < 16 or ldskip % 4 == 0):
+            _lib.check(L.dagr_spline_conv_tiles(P(lvl.counts), lvl.T, P(lvl.rowptr), P(lvl.col), P(code), x, ldx, pack.cin,
+                                                xskip, ldskip, pack.cskip, dom["rx"], dom["ry"], dom["den_x"],
+                                                dom["den_y"], P(pack.Wt), P(pack.bias), out, ldo, pack.N,
+                                                1 if pack.relu else 0, stream), "spline_conv_tiles")
+            return
         if self.fuse_convs and L.dagr_spline_conv_fused_lds_bytes(pack.cin, pack.cskip) <= 160 * 1024:
             # tap aggregation + contraction in one launch (A tile lives in LDS)
             _lib.check(L.dagr_spline_conv_fused(P(lvl.counts), lvl.T, P(lvl.rowptr), P(lvl.col), P(code), x, ldx,

@@ -209,6 +209,18 @@ int dagr_spline_conv_fused(const int32_t *n_nodes_ptr, int32_t n_nodes_max, cons
                            const float *xskip, int32_t ldskip, int32_t cskip, int32_t rx, int32_t ry,
                            float den_x, float den_y, const float *Wq, const float *bias, float *C, int32_t ldc,
                            int32_t N, int32_t relu, void *stream);
+/* the same contraction as 16-node wave tiles (csrc/conv_pooled_tiles.hip): any K, no A matrix and no LDS tile -- lanes
+ * keep A[tap][channel quad] in registers and feed the f32 MFMA from there; one workgroup per (node tile, column tile[s]).
+ * cin and cskip must be 16 k + (0..4); x / xskip rows 16-byte aligned when they hold >= 16 channels.
+ * Wt = dagr_spline_conv_tiles_pack(Wm): the [K, N] matrix of dagr_gemm_bias_act laid out [column tile][k-step][lane]
+ * (dagr_spline_conv_tiles_pack_elems floats; pack runs on HOST arrays). */
+size_t dagr_spline_conv_tiles_pack_elems(int32_t cin, int32_t cskip, int32_t N);
+int dagr_spline_conv_tiles_pack(const float *Wm_host, int32_t ldw, int32_t cin, int32_t cskip, int32_t N, float *Wt_host);
+int dagr_spline_conv_tiles(const int32_t *n_nodes_ptr, int32_t n_nodes_max, const int32_t *rowptr, const int32_t *col,
+                           const int32_t *code, const float *x, int32_t ldx, int32_t cin, const float *xskip,
+                           int32_t ldskip, int32_t cskip, int32_t rx, int32_t ry, float den_x, float den_y,
+                           const float *Wt, const float *bias, float *C, int32_t ldc, int32_t N, int32_t relu,
+                           void *stream);
 /* generic step 2: C[M,N] = act(A[M,K] . Wm[K,N] + bias[N]); M = min(*m_ptr, m_max) */
 int dagr_gemm_bias_act(const int32_t *m_ptr, int32_t m_max, const float *A, int32_t lda,
                        const float *Wm, int32_t ldw, const float *bias, float *C, int32_t ldc,
@@ -352,6 +364,18 @@ int dagr_masked_isdiff(int64_t *indices, const float *x_old, const float *x_new,
 int dagr_masked_inplace_BN(const int64_t *indices, const float *x, float *x_out, const float *running_mean,
                            const float *running_var, const float *weight, const float *bias, float eps, int64_t K,
                            int32_t C, void *stream);
+
+/* ------------------------------------------------------------------------ *
+ * Event-stream downsampling -- scripts/downsample_events.py:91-124 (downsample_events / _filter_events_resize)
+ *   Events grouped by output cell (x / fx, y / fy) in time order: order[N] = event ids sorted (stably) by cell,
+ *   run_cell[n_runs] / run_end[n_runs] = the cells that occur and the cumulative end of their runs in `order`
+ *   (torch.sort + unique_consecutive + cumsum, as graph/utils.py:9-13 prepares pixels).  polarity int8[N] in {-1,+1};
+ *   change_map fp32[Ho*Wo] = the integrator state, carried from chunk to chunk; keep[N] (uint8) = 1 where the event
+ *   passes.  The surviving events keep their order; their coordinates are x / fx, y / fy.
+ * ------------------------------------------------------------------------ */
+int dagr_downsample_events(const int32_t *order, const int32_t *run_cell, const int32_t *run_end, int32_t n_runs,
+                           const int8_t *polarity, int32_t fx, int32_t fy, float *change_map, uint8_t *keep,
+                           void *stream);
 
 /* Profiling aid (not on the product path): streams a known number of bytes so that rocprofv3's
  * FETCH_SIZE / WRITE_SIZE can be calibrated on this library's access patterns.

@@ -123,6 +123,12 @@ def test_forward_reset_false_equals_one_call_on_all_events(over):
         again, = model(batch_of([(0, 4000)] * B), reset=True, return_targets=False)      # a reset starts over
     for a, b, c in zip(full, det, again):
         for key in ("boxes", "scores", "labels"):
-            assert torch.equal(a[key], b[key]), key
-            assert torch.equal(a[key], c[key]), key
+            if over:    # the image branch is PyTorch-ROCm convolutions (split-K kernels accumulate with atomics): equal to
+                # fp32 rounding from call to call, not bit for bit
+                assert a[key].shape == b[key].shape == c[key].shape, key
+                assert torch.allclose(a[key].float(), b[key].float(), rtol=1e-4, atol=1e-3), key
+                assert torch.allclose(a[key].float(), c[key].float(), rtol=1e-4, atol=1e-3), key
+            else:
+                assert torch.equal(a[key], b[key]), key
+                assert torch.equal(a[key], c[key]), key
     assert sum(len(d["boxes"]) for d in full) > 0

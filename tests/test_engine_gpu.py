@@ -334,7 +334,7 @@ def test_tail_graph_replay_matches_eager_launches():
     W, H, B = 320, 215, 2
     args, model, sd = _setup(W, H, B, seed=12)
     dev = torch.device("cuda:0")
-    eng = model.engine()
+    eng = model.engine().set_low_latency(True)
     wins = []
     for seed in (41, 43):
         x, y, t, p, b, pos = _events(syn.edges_window, 4000, B, W, H, seed=seed)

@@ -104,7 +104,10 @@ def test_layer_pooling_and_dense_modules_match_the_oracle():
         og_ = om.Graph(*res)
         og_.pooling = nc.pools[0].voxel_size[:3]
         want = om._pred_to_dense(sd2, "p.", og_, (rx, ry, M, H, W), B)
-        assert dense.shape == want.shape and _err(dense, want) < TOL
+        bad = ((dense.cpu() - want).abs() > 1e-3).nonzero()
+        assert dense.shape == want.shape and _err(dense, want) < TOL, (len(bad), bad[:6].tolist(),
+                                                                       dense.cpu()[tuple(bad[0])].item() if len(bad) else None,
+                                                                       want[tuple(bad[0])].item() if len(bad) else None)
 
 
 @pytest.mark.parametrize("over", [{}, dict(use_image=True, img_net="resnet18")])
