@@ -62,7 +62,7 @@ struct L0Steps {
 constexpr int kTileWaves = 4;   // waves per workgroup (each owns its tiles; they share the weight image in LDS)
 
 template <int CM, int CE, int CS, int TX, int TY>
-__global__ __launch_bounds__(kTileWaves * 64, 3) void k_conv_l0_tiles(
+__global__ __launch_bounds__(kTileWaves * 64, 2) void k_conv_l0_tiles(
     int N, int rx, int ry, float den_x, float den_y, int win_x, int win_y, const int32_t *__restrict__ nbr_src,
     const int16_t *__restrict__ nbr_code, const int32_t *__restrict__ deg, const float *__restrict__ x, int ldx,
     const float *__restrict__ xskip, int ldskip, const float *__restrict__ wpack, const float *__restrict__ shift,
@@ -103,21 +103,65 @@ __global__ __launch_bounds__(kTileWaves * 64, 3) void k_conv_l0_tiles(
     const int n_begin = xcd * chunk + lb * per_block;
     const int n_end = min(min(N, (xcd + 1) * chunk), n_begin + per_block);
 
+    // Software pipeline over this wave's tiles.  Per tile the dependent chain is {degree, neighbour row} -> source rows ->
+    // FMAs; with ~200 registers per lane only two waves share a SIMD, so the chain is shortened instead of hidden: the
+    // neighbour row of the NEXT tile is requested while this tile's source rows are in flight, and all (<= 16) source
+    // rows of a tile are requested before the first one is consumed (two batches of 8).
+    auto load_meta = [&](int n0_, int &d_, int4(&s_)[4], int2(&c_)[4]) {
+        const int n_ = n0_ + c;
+        const bool ok_ = n0_ < n_end && n_ < n_end;
+        const int nn_ = ok_ ? n_ : min(n0_, n_end - 1);
+        d_ = ok_ ? deg[nn_] : 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            s_[k] = *reinterpret_cast<const int4 *>(nbr_src + (size_t)nn_ * 16 + 4 * k);
+            c_[k] = *reinterpret_cast<const int2 *>(nbr_code + (size_t)nn_ * 16 + 4 * k);
+        }
+    };
+    int d_nx;
+    int4 s_nx[4];
+    int2 c_nx[4];
+    if (n_begin + 16 * wv < n_end) load_meta(n_begin + 16 * wv, d_nx, s_nx, c_nx);
     for (int n0 = n_begin + 16 * wv; n0 < n_end; n0 += 16 * kTileWaves) {
         const int n = n0 + c;
         const bool valid = n < n_end;
         const int nn = valid ? n : n0;                  // a row that exists, for the predicated-off lanes
-        const int d = valid ? deg[n] : 0;
+        const int d = d_nx;
+        int srcs[16], codes[16];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            srcs[4 * k] = s_nx[k].x; srcs[4 * k + 1] = s_nx[k].y; srcs[4 * k + 2] = s_nx[k].z; srcs[4 * k + 3] = s_nx[k].w;
+            codes[4 * k] = c_nx[k].x & 0xffff; codes[4 * k + 1] = (c_nx[k].x >> 16) & 0xffff;
+            codes[4 * k + 2] = c_nx[k].y & 0xffff; codes[4 * k + 3] = (c_nx[k].y >> 16) & 0xffff;
+        }
         int dmax = d;
 #pragma unroll
         for (int off = 1; off < 16; off <<= 1) dmax = max(dmax, __shfl_xor(dmax, off, 16));
-        // root / skip operands of phase 2: requested now, consumed at the end
+        // source rows: first batch of 8, and the second one when any node of the tile has more than 8 in-edges
+        float4 xv[16];
+        float xe[16];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int src = (u < d) ? srcs[u] : nn;
+            if (CM) xv[u] = *reinterpret_cast<const float4 *>(x + (size_t)src * ldx + 4 * q);
+            if (CE) xe[u] = (q < CE) ? x[(size_t)src * ldx + CM + q] : 0.f;
+        }
+        if (dmax > 8) {
+#pragma unroll
+            for (int u = 8; u < 16; u++) {
+                const int src = (u < d) ? srcs[u] : nn;
+                if (CM) xv[u] = *reinterpret_cast<const float4 *>(x + (size_t)src * ldx + 4 * q);
+                if (CE) xe[u] = (q < CE) ? x[(size_t)src * ldx + CM + q] : 0.f;
+            }
+        }
+        // root / skip operands of phase 2 and the next tile's neighbour row: requested now, consumed later
         float4 xr = make_float4(0.f, 0.f, 0.f, 0.f), xs = make_float4(0.f, 0.f, 0.f, 0.f);
         float xre = 0.f, xse = 0.f;
         if (CM) xr = *reinterpret_cast<const float4 *>(x + (size_t)nn * ldx + 4 * q);
         if (CE) xre = (q < CE) ? x[(size_t)nn * ldx + CM + q] : 0.f;
         if (S::SKF) xs = *reinterpret_cast<const float4 *>(xskip + (size_t)nn * ldskip + 4 * q);
         if (S::SKE) xse = (q < S::SKE) ? xskip[(size_t)nn * ldskip + 16 * S::SKF + q] : 0.f;
+        load_meta(n0 + 16 * kTileWaves, d_nx, s_nx, c_nx);
 
         float acc[CM ? NT : 1][4];
         float acce[CE ? NT : 1];
@@ -126,51 +170,43 @@ __global__ __launch_bounds__(kTileWaves * 64, 3) void k_conv_l0_tiles(
 #pragma unroll
         for (int t = 0; t < (CE ? NT : 1); t++) acce[t] = 0.f;
 
-        // ---- phase 1: this lane's node, its <= 16 in-edges, 4 at a time (all four source rows requested before use)
-#pragma unroll 1
-        for (int j0 = 0; j0 < dmax; j0 += 4) {
-            const int4 s4 = *reinterpret_cast<const int4 *>(nbr_src + (size_t)nn * 16 + j0);
-            const int2 c2 = *reinterpret_cast<const int2 *>(nbr_code + (size_t)nn * 16 + j0);
-            const int srcs[4] = {s4.x, s4.y, s4.z, s4.w};
-            const int codes[4] = {c2.x & 0xffff, (c2.x >> 16) & 0xffff, c2.y & 0xffff, (c2.y >> 16) & 0xffff};
-            float4 xv[4];
-            float xe[4];
+        // ---- phase 1: this lane's node, its <= 16 in-edges.  (Requesting the basis rows of edge u+1 before the FMAs of edge
+        // u was measured: 3-10 % slower -- more live registers, no shorter chain.)
+        auto edge = [&](int u) {
+            const bool ok = u < d;
+            const int code = ok ? codes[u] : 0;
+            const int ix = (int)(((float)code + 0.5f) * inv_sy);
+            const int iy = code - ix * sy;
+            const float4 wx4 = *reinterpret_cast<const float4 *>(ax_l + 4 * ix);
+            const float4 wy4 = *reinterpret_cast<const float4 *>(ay_l + 8 * iy);
+            const float4 wy5 = *reinterpret_cast<const float4 *>(ay_l + 8 * iy + 4);
+            const float wx[4] = {wx4.x, wx4.y, wx4.z, wx4.w};
+            float wy[8] = {wy4.x, wy4.y, wy4.z, wy4.w, wy5.x, wy5.y, wy5.z, wy5.w};
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const bool ok = j0 + u < d;
-                const int src = ok ? srcs[u] : nn;
-                if (CM) xv[u] = *reinterpret_cast<const float4 *>(x + (size_t)src * ldx + 4 * q);
-                if (CE) xe[u] = (q < CE) ? x[(size_t)src * ldx + CM + q] : 0.f;
-            }
+            for (int b = 0; b < TY; b++) wy[b] = ok ? wy[b] : 0.f;
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const bool ok = j0 + u < d;
-                const int code = ok ? codes[u] : 0;
-                const int ix = (int)(((float)code + 0.5f) * inv_sy);
-                const int iy = code - ix * sy;
-                const float4 wx4 = *reinterpret_cast<const float4 *>(ax_l + 4 * ix);
-                const float4 wy4 = *reinterpret_cast<const float4 *>(ay_l + 8 * iy);
-                const float4 wy5 = *reinterpret_cast<const float4 *>(ay_l + 8 * iy + 4);
-                const float wx[4] = {wx4.x, wx4.y, wx4.z, wx4.w};
-                float wy[8] = {wy4.x, wy4.y, wy4.z, wy4.w, wy5.x, wy5.y, wy5.z, wy5.w};
+            for (int b = 0; b < TY; b++)
 #pragma unroll
-                for (int b = 0; b < TY; b++) wy[b] = ok ? wy[b] : 0.f;
-#pragma unroll
-                for (int b = 0; b < TY; b++)
-#pragma unroll
-                    for (int a = 0; a < TX; a++) {
-                        const float w = wx[a] * wy[b];            // == the level-0 offset table entry (bx[a]*by[b])
-                        const int t = a + TX * b;
-                        if (CM) {
-                            acc[t][0] = fmaf(w, xv[u].x, acc[t][0]);
-                            acc[t][1] = fmaf(w, xv[u].y, acc[t][1]);
-                            acc[t][2] = fmaf(w, xv[u].z, acc[t][2]);
-                            acc[t][3] = fmaf(w, xv[u].w, acc[t][3]);
-                        }
-                        if (CE) acce[t] = fmaf(w, xe[u], acce[t]);
+                for (int a = 0; a < TX; a++) {
+                    const float w = wx[a] * wy[b];            // == the level-0 offset table entry (bx[a]*by[b])
+                    const int t = a + TX * b;
+                    if (CM) {
+                        acc[t][0] = fmaf(w, xv[u].x, acc[t][0]);
+                        acc[t][1] = fmaf(w, xv[u].y, acc[t][1]);
+                        acc[t][2] = fmaf(w, xv[u].z, acc[t][2]);
+                        acc[t][3] = fmaf(w, xv[u].w, acc[t][3]);
                     }
-                __builtin_amdgcn_sched_barrier(0);   // one edge's weights live at a time (register pressure)
-            }
+                    if (CE) acce[t] = fmaf(w, xe[u], acce[t]);
+                }
+            __builtin_amdgcn_sched_barrier(0);   // one edge's weights live at a time (register pressure)
+        };
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (u < dmax) edge(u);               // group-uniform
+        if (dmax > 8) {
+#pragma unroll
+            for (int u = 8; u < 16; u++)
+                if (u < dmax) edge(u);
         }
 
         // ---- phase 2: out[16 nodes][16] = [A | root | skip] . Wpack on the matrix pipe, operands from registers

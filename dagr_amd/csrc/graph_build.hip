@@ -596,7 +596,7 @@ __global__ __launch_bounds__(kBlock) void k_search_tiled(const int32_t *__restri
 constexpr int kRowCap = 256;
 
 template <int CAP, bool LIST_IN>
-__global__ __launch_bounds__(kBlock) void k_search_rows(const int32_t *__restrict__ m_ptr, int W, int H, int K, int r,
+__global__ __launch_bounds__(kBlock, 7) void k_search_rows(const int32_t *__restrict__ m_ptr, int W, int H, int K, int r,
                                                        float delta_t, const int32_t *__restrict__ slot_xyb,
                                                        const int32_t *__restrict__ start,
                                                        const int2 *__restrict__ slot_it,
