@@ -590,10 +590,11 @@ __global__ __launch_bounds__(kBlock) void k_search_tiled(const int32_t *__restri
 // benchmark stream) instead of to its (2r+1)^2 pixels.  Neighbourhoods with more than kRowCap
 // candidates (dense scenes, where the position-centric kernel exits after the first ring anyway) are
 // appended to a list that k_search_tiled processes afterwards.
-// kRowCap candidates per neighbourhood: the key list is the kernel's LDS footprint (16 KiB per workgroup at 256, which
-// keeps the occupancy of the sparse case); 256 covers uniform streams up to ~350 k events per 640x480 window.  Denser
-// neighbourhoods go to the position-centric kernel.  (LIST_IN re-sweeps a deferral list; kept for experiments.)
-constexpr int kRowCap = 256;
+// kRowCap candidates per neighbourhood: the key list is the kernel's LDS footprint (20 KiB per workgroup at 320: seven
+// workgroups per CU, the occupancy its 72 registers allow anyway); 320 covers uniform streams up to ~430 k events per
+// 640x480 window.  Denser neighbourhoods go to the position-centric kernel.  (LIST_IN re-sweeps a deferral list; kept
+// for experiments.)
+constexpr int kRowCap = 320;
 
 template <int CAP, bool LIST_IN>
 __global__ __launch_bounds__(kBlock, 7) void k_search_rows(const int32_t *__restrict__ m_ptr, int W, int H, int K, int r,
@@ -752,6 +753,28 @@ __global__ __launch_bounds__(kBlock, 7) void k_search_rows(const int32_t *__rest
         if (l == 0) {
             nbr_src[row] = n;  // self loop first (ev_graph.cu:44-46)
             nbr_code[row] = (int16_t)(r * side + r);
+        }
+        // Dense neighbourhoods hold far more admissible candidates than the K-1 that survive, and the rank counting
+        // below is quadratic in their number: first drop everything beyond the spiral-rank bin (16 positions per bin,
+        // one bin per lane) in which the K-1'th candidate falls.
+        if (V > 32) {
+            int cntb = 0;
+            for (int j = 0; j < V; j++) cntb += ((v_key[grp][j] >> 24) == l) ? 1 : 0;
+            const int incl_b = group16_inclusive_scan(cntb);
+            const unsigned reach = (unsigned)(__ballot(incl_b >= K - 1) >> gshift) & 0xffffu;
+            const int bstar = reach ? (__ffs(reach) - 1) : 15;
+            int Wk = 0;
+            for (int base = 0; base < V; base += 16) {
+                const int vi = base + l;
+                const int key = vi < V ? v_key[grp][vi] : 0x7fffffff;
+                const bool keep = vi < V && (key >> 24) <= bstar;
+                const unsigned bits = (unsigned)(__ballot(keep) >> gshift) & 0xffffu;
+                __builtin_amdgcn_wave_barrier();
+                if (keep) v_key[grp][Wk + __popc(bits & lt_mask)] = key;   // in place: writes stay below this step's reads
+                Wk += __popc(bits);
+                __builtin_amdgcn_wave_barrier();
+            }
+            V = Wk;
         }
         for (int vi = l; vi < V; vi += 16) {
             const int mk = v_key[grp][vi];

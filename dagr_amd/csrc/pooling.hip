@@ -30,6 +30,8 @@ namespace {
 constexpr int kRowSlots = 64;           // coarse in-degree bound per cluster (flagged if exceeded)
 constexpr int kLeakCap = 8192;          // in-edges of t == 1.0 nodes handled apart (beyond: generic path)
 constexpr int kMaxChunks = 9;           // up to 144 feature channels at level 0
+constexpr int kCellCap = 256;           // members of a level-0 voxel walked by its own wave; the rest is split (k_pool_l0_overflow)
+constexpr int kOverWaves = 16;          // waves sharing the tail of an event-dense voxel
 constexpr double kPosScale = 1099511627776.0;  // 2^40
 constexpr double kFeatScale = 4294967296.0;    // 2^32
 
@@ -46,6 +48,7 @@ struct PoolWs {
     int32_t *status;     // [4]: 0 flags (sticky); 1 = bitmap path not applicable to this window, 2 = #leak_edges (cleared by rearm)
     int32_t *nbmask;     // [T] level 0: 5x5 bitmap of neighbouring source cells, zero between calls
     int2 *leak_edges;    // [kLeakCap] level 0: (dst raw, src raw) of the in-edges of t == 1.0 nodes; count = status[2]
+    int32_t *over_list;  // [T] level 0: cells with more than kCellCap members (their tail is split over waves); count = status[3]
 };
 
 __host__ __device__ inline size_t pool_carve(const dagr_pool_desc &d, char *base, PoolWs *ws) {
@@ -69,6 +72,7 @@ __host__ __device__ inline size_t pool_carve(const dagr_pool_desc &d, char *base
     w.status = (int32_t *)take(16);
     w.nbmask = (int32_t *)take((T + 9) * 4);
     w.leak_edges = (int2 *)take((size_t)kLeakCap * 8);
+    w.over_list = (int32_t *)take((T + 9) * 4);
     if (ws) *ws = w;
     return off;
 }
@@ -147,7 +151,8 @@ __global__ __launch_bounds__(kBlock) void k_pool_accumulate(dagr_pool_desc d, co
 // members are then walked as one flat list, 8 in flight (4 lane groups x 2, 16 lanes = 16 channels / 16
 // neighbour slots each) -- walking row by row instead costs two dependent HBM latencies per pixel row.
 template <int MC, int AGGR>   // accumulator chunks of 16 channels held in registers; 0 = max, 1 = mean
-__global__ __launch_bounds__(kBlock) void k_pool_l0_cells(dagr_pool_desc d, int W, int H,
+__device__ __forceinline__ void pool_l0_cell(int cell, int i_first, int i_stride, int i_limit, bool list_overflow,
+                                             dagr_pool_desc d, int W, int H,
                                                          const int32_t *__restrict__ xlo,  // [gx+1] pixel bounds
                                                          const int32_t *__restrict__ ylo,  // [gy+1]
                                                          const int32_t *__restrict__ start,
@@ -161,9 +166,6 @@ __global__ __launch_bounds__(kBlock) void k_pool_l0_cells(dagr_pool_desc d, int 
                                                          const int32_t *__restrict__ slot_xyb, int K, int r) {
     __shared__ int s_a[kBlock / 64][64], s_off[kBlock / 64][65];
     const int lane = threadIdx.x & 63, l = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
-    const int cell = blockIdx.x * (kBlock / 64) + wv;
-    const int ncell = d.gx * d.gy * d.batch_size;
-    if (cell >= ncell) return;
     const int cx = cell % d.gx, cy = (cell / d.gx) % d.gy, b = cell / (d.gx * d.gy);
     const int x0 = xlo[cx], x1 = xlo[cx + 1] - 1, y0 = ylo[cy], y1 = ylo[cy + 1] - 1;
     const int C = d.channels;
@@ -216,11 +218,15 @@ __global__ __launch_bounds__(kBlock) void k_pool_l0_cells(dagr_pool_desc d, int 
         // 16 members in flight per wave (4 lane groups x 4): the walk is a chain of dependent loads (slot -> pos /
         // neighbour codes / feature row), so its pace on event-dense voxels (S-edges: hundreds of members) is set by how
         // many are outstanding
-        for (int i0 = 0; i0 < total; i0 += 16) {
+        // a wave walks members [i_first, i_limit) in steps of i_stride: the voxel's own wave takes the first kCellCap, the
+        // tail of an event-dense voxel (S-edges: thousands of members) is listed and shared by kOverWaves waves
+        if (list_overflow && lane == 0 && total > i_limit) ws.over_list[atomicAdd(&ws.status[3], 1)] = cell;
+        const int i_end = min(total, i_limit);
+        for (int i0 = i_first; i0 < i_end; i0 += i_stride) {
 #pragma unroll
             for (int h = 0; h < 4; h++) {
                 const int i = i0 + 4 * h + g;
-                if (i >= total) continue;
+                if (i >= i_end) continue;
                 // row of member i: the last j with off[j] <= i (empty rows share their successor's offset)
                 int j = 0;
 #pragma unroll
@@ -344,6 +350,47 @@ __global__ __launch_bounds__(kBlock) void k_pool_l0_cells(dagr_pool_desc d, int 
     }
 }
 
+
+template <int MC, int AGGR>
+__global__ __launch_bounds__(kBlock) void k_pool_l0_cells(dagr_pool_desc d, int W, int H, const int32_t *__restrict__ xlo,
+                                                         const int32_t *__restrict__ ylo,
+                                                         const int32_t *__restrict__ start,
+                                                         const int2 *__restrict__ slot_it, const float *__restrict__ x,
+                                                         int ldx, const float *__restrict__ pos, PoolWs ws,
+                                                         const int16_t *__restrict__ nbr_code,
+                                                         const int32_t *__restrict__ nbr_src,
+                                                         const int32_t *__restrict__ deg,
+                                                         const int32_t *__restrict__ slot_xyb, int K, int r) {
+    const int cell = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (cell >= d.gx * d.gy * d.batch_size) return;
+    pool_l0_cell<MC, AGGR>(cell, 0, 16, kCellCap, true, d, W, H, xlo, ylo, start, slot_it, x, ldx, pos, ws, nbr_code, nbr_src,
+                           deg, slot_xyb, K, r);
+}
+
+// tails of the listed event-dense voxels: kOverWaves waves per voxel, persistent over the list
+template <int MC, int AGGR>
+__global__ __launch_bounds__(kBlock) void k_pool_l0_overflow(dagr_pool_desc d, int W, int H,
+                                                            const int32_t *__restrict__ xlo,
+                                                            const int32_t *__restrict__ ylo,
+                                                            const int32_t *__restrict__ start,
+                                                            const int2 *__restrict__ slot_it,
+                                                            const float *__restrict__ x, int ldx,
+                                                            const float *__restrict__ pos, PoolWs ws,
+                                                            const int16_t *__restrict__ nbr_code,
+                                                            const int32_t *__restrict__ nbr_src,
+                                                            const int32_t *__restrict__ deg,
+                                                            const int32_t *__restrict__ slot_xyb, int K, int r) {
+    const int n_items = ws.status[3] * kOverWaves;
+    const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int n_waves = gridDim.x * (kBlock / 64);
+    for (int it = wave; it < n_items; it += n_waves) {
+        const int cell = ws.over_list[it / kOverWaves], part = it % kOverWaves;
+        pool_l0_cell<MC, AGGR>(cell, kCellCap + 16 * part, 16 * kOverWaves, INT_MAX, false, d, W, H, xlo, ylo, start, slot_it,
+                               x, ldx, pos, ws, nbr_code, nbr_src, deg, slot_xyb, K, r);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // level 0: cluster of every event (for the coarse edges)
 __global__ __launch_bounds__(kBlock) void k_pool_l0_event_cluster(dagr_pool_desc d, int N,
                                                                  const float *__restrict__ pos,
@@ -420,7 +467,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_rearm(int T, PoolWs ws) {
     ws.cnt[raw] = 0;
     ws.perm[raw] = -1;
     ws.nbmask[raw] = 0;
-    if (raw == 0) { ws.status[1] = 0; ws.status[2] = 0; }
+    if (raw == 0) { ws.status[1] = 0; ws.status[2] = 0; ws.status[3] = 0; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -684,6 +731,7 @@ int dagr_pool_workspace_init(const dagr_pool_desc *desc, void *workspace, size_t
     DAGR_CHECK_HIP(hipMemsetAsync(ws.rowcnt, 0, (T + 9) * 4, stream));
     DAGR_CHECK_HIP(hipMemsetAsync(ws.status, 0, 16, stream));
     DAGR_CHECK_HIP(hipMemsetAsync(ws.nbmask, 0, (T + 9) * 4, stream));
+    DAGR_CHECK_HIP(hipMemsetAsync(ws.over_list, 0, (T + 9) * 4, stream));
     // feature accumulators: ordered-int minimum for max, 0 for mean
     {
         const size_t n = T * (size_t)desc->channels;
@@ -750,11 +798,14 @@ int dagr_pool_l0(const dagr_pool_desc *desc, void *pool_ws, const dagr_graph_des
 #define DAGR_POOL_L0_A(MC, AG)                                                                                        \
     k_pool_l0_cells<MC, AG><<<(unsigned)ceil_div(ncell, kBlock / 64), kBlock, 0, stream>>>(                           \
         *desc, gdesc->width, gdesc->height, xlo, ylo, start, slot_it, x, ldx, pos, ws, fast_edges ? nbr_code : nullptr, \
+        nbr_src, deg, graph_ws_slot_xyb(gdesc, graph_ws), K, gdesc->radius);                                         \
+    k_pool_l0_overflow<MC, AG><<<(unsigned)(2 * device_cu_count()), kBlock, 0, stream>>>(                             \
+        *desc, gdesc->width, gdesc->height, xlo, ylo, start, slot_it, x, ldx, pos, ws, fast_edges ? nbr_code : nullptr, \
         nbr_src, deg, graph_ws_slot_xyb(gdesc, graph_ws), K, gdesc->radius)
 #define DAGR_POOL_L0(MC)                                                                                              \
     do {                                                                                                              \
-        if (desc->aggr == 0) DAGR_POOL_L0_A(MC, 0);                                                                   \
-        else DAGR_POOL_L0_A(MC, 1);                                                                                   \
+        if (desc->aggr == 0) { DAGR_POOL_L0_A(MC, 0); }                                                               \
+        else { DAGR_POOL_L0_A(MC, 1); }                                                                               \
     } while (0)
         if (nchk <= 1) DAGR_POOL_L0(1);
         else if (nchk <= 2) DAGR_POOL_L0(2);

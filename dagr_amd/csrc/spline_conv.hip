@@ -73,6 +73,42 @@ __global__ __launch_bounds__(kBlock) void k_tap_aggregate(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Backward of the tap aggregation (training path, first slice): A[n] = [sum_edges basis * x[src] per tap | x[n] | ..]
+// is linear in x, so with gA = dL/dA (from the GEMM's backward, a plain library GEMM) the input gradient is its
+// transpose: gx[src] += sum_{taps of the edge} basis * gA[dst][tap], plus the root copy gx[n] += gA[n][25 cin + .].
+// One wave per destination node, lanes stride the channels; float atomics (order-dependent rounding, as torch_scatter's
+// own backward has it).  gx must be zero-initialised by the caller.
+__global__ __launch_bounds__(kBlock) void k_tap_scatter_grad(const int32_t *__restrict__ n_nodes_ptr, int n_nodes_max,
+                                                            const int32_t *__restrict__ rowptr,
+                                                            const int32_t *__restrict__ col,
+                                                            const int32_t *__restrict__ code,
+                                                            const float *__restrict__ gA, int lda, int cin, int rx,
+                                                            int ry, float den_x, float den_y, float *__restrict__ gx,
+                                                            int ldg) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * kAggWaves + (threadIdx.x >> 6);
+    const int n_nodes = n_nodes_ptr ? min(*n_nodes_ptr, n_nodes_max) : n_nodes_max;
+    if (n >= n_nodes) return;
+    const float *row = gA + (size_t)n * lda;
+    for (int i = lane; i < cin; i += 64) atomicAdd(gx + (size_t)n * ldg + i, row[25 * cin + i]);
+    const int e0 = rowptr[n], e1 = rowptr[n + 1];
+    for (int e = e0; e < e1; e++) {
+        const int src = col[e];
+        const int c = code[e];
+        const Axis ax = spline_axis(c & 0xffff, rx, den_x);
+        const Axis ay = spline_axis(c >> 16, ry, den_y);
+        const float b00 = ax.b0 * ay.b0, b10 = ax.b1 * ay.b0, b01 = ax.b0 * ay.b1, b11 = ax.b1 * ay.b1;
+        const float *a00 = row + (ax.k0 + 5 * ay.k0) * cin;
+        const float *a10 = row + (ax.k1 + 5 * ay.k0) * cin;
+        const float *a01 = row + (ax.k0 + 5 * ay.k1) * cin;
+        const float *a11 = row + (ax.k1 + 5 * ay.k1) * cin;
+        for (int i = lane; i < cin; i += 64)
+            atomicAdd(gx + (size_t)src * ldg + i, b00 * a00[i] + b10 * a10[i] + b01 * a01[i] + b11 * a11[i]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Generic path, step 2: C[M,N] = act(A[M,K] . Wm[K,N] + bias[N]).  fp32, LDS-tiled 64x64x16,
 // 256 threads x (4x4) outputs.  M is bounded on the device (*m_ptr) so no host sync is needed.
@@ -886,6 +922,20 @@ int dagr_spline_tap_aggregate(const int32_t *n_nodes_ptr, int32_t n_nodes_max, c
     }
     k_tap_aggregate<<<(unsigned)ceil_div(n_nodes_max, kAggWaves), kBlock, lds_bytes, (hipStream_t)stream>>>(
         n_nodes_ptr, n_nodes_max, rowptr, col, code, x, ldx, cin, xskip, ldskip, cskip, rx, ry, den_x, den_y, A, lda);
+    DAGR_CHECK_LAUNCH();
+    return DAGR_OK;
+}
+
+int dagr_spline_tap_scatter_grad(const int32_t *n_nodes_ptr, int32_t n_nodes_max, const int32_t *rowptr,
+                                 const int32_t *col, const int32_t *code, const float *grad_A, int32_t lda, int32_t cin,
+                                 int32_t rx, int32_t ry, float den_x, float den_y, float *grad_x, int32_t ldg,
+                                 void *stream) {
+    DAGR_CHECK_ARG(n_nodes_max >= 0, "n_nodes_max < 0");
+    if (n_nodes_max == 0) return DAGR_OK;
+    DAGR_CHECK_ARG(rowptr && col && code && grad_A && grad_x, "NULL pointer");
+    DAGR_CHECK_ARG(cin >= 1 && lda >= 26 * cin && ldg >= cin, "bad strides");
+    k_tap_scatter_grad<<<(unsigned)ceil_div(n_nodes_max, kAggWaves), kBlock, 0, (hipStream_t)stream>>>(
+        n_nodes_ptr, n_nodes_max, rowptr, col, code, grad_A, lda, cin, rx, ry, den_x, den_y, grad_x, ldg);
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;
 }

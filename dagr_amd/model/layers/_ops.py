@@ -80,6 +80,10 @@ def spline_conv(conv, x, rowptr, col, code, norm=None, skip=None, xskip=None, re
 def conv_on_data(conv, data, norm=None, skip=None, xskip=None, relu=False):
     rowptr, col, perm = graph_csr(data)
     code = lut_codes(data.edge_attr[perm], conv.lut_domain) if col.shape[0] else col
+    if norm is None and skip is None and not relu and torch.is_grad_enabled() and \
+            (data.x.requires_grad or conv.weight.requires_grad):
+        from .autograd import spline_conv_autograd       # plain conv with gradients (training path, first slice)
+        return spline_conv_autograd(conv, data.x, rowptr, col, code)
     return spline_conv(conv, data.x, rowptr, col, code, norm=norm, skip=skip, xskip=xskip, relu=relu)
 
 
