@@ -590,10 +590,9 @@ __global__ __launch_bounds__(kBlock) void k_search_tiled(const int32_t *__restri
 // benchmark stream) instead of to its (2r+1)^2 pixels.  Neighbourhoods with more than kRowCap
 // candidates (dense scenes, where the position-centric kernel exits after the first ring anyway) are
 // appended to a list that k_search_tiled processes afterwards.
-// kRowCap candidates per neighbourhood: the key list is the kernel's LDS footprint (20 KiB per workgroup at 320: seven
-// workgroups per CU, the occupancy its 72 registers allow anyway); 320 covers uniform streams up to ~430 k events per
-// 640x480 window.  Denser neighbourhoods go to the position-centric kernel.  (LIST_IN re-sweeps a deferral list; kept
-// for experiments.)
+// kRowCap candidates per neighbourhood: the key list is the kernel's LDS footprint (20 KiB per workgroup); 320 covers
+// uniform streams up to ~430 k events per 640x480 window.  Denser neighbourhoods go to the position-centric kernel.
+// (LIST_IN re-sweeps a deferral list; kept for experiments.)
 constexpr int kRowCap = 320;
 
 template <int CAP, bool LIST_IN>
@@ -610,7 +609,11 @@ __global__ __launch_bounds__(kBlock, 7) void k_search_rows(const int32_t *__rest
     constexpr int G = kBlock / 16;
     __shared__ unsigned char sp_rank[256];      // spiral index of offset (dy + r) * 16 + (dx + r)
     __shared__ int row_lo[G][16], row_base[G][17];
-    __shared__ int v_key[G][CAP];   // (spiral rank << 20) | (0xFFFFF - position in its row range): the source slot follows
+    // candidate keys, (spiral rank << 20) | (0xFFFFF - position in its row range): the source slot follows from the key.
+    // Dynamic LDS on purpose: with the size visible the compiler's occupancy estimate (made against 64 KiB) drops to 4
+    // waves per SIMD at CAP = 320 and it stops holding the kernel to the 72 registers that 7 waves need; the hardware
+    // has 160 KiB per CU and runs 6 workgroups of this kernel.
+    extern __shared__ int v_key_dyn[];
     __shared__ int def_buf[kBlock / 64][64];
     int wcnt = 0;    // entries of this wave's deferral buffer (uniform over the wave's active lanes)
     const int side = 2 * r + 1;
@@ -623,6 +626,7 @@ __global__ __launch_bounds__(kBlock, 7) void k_search_rows(const int32_t *__rest
     __syncthreads();
     const int l = threadIdx.x & 15;
     const int grp = threadIdx.x >> 4;
+    int *const v_keys = v_key_dyn + grp * CAP;
     const int gshift = threadIdx.x & 48;
     const unsigned lt_mask = (1u << l) - 1u;
     long long edges_acc = 0;
@@ -743,7 +747,7 @@ __global__ __launch_bounds__(kBlock, 7) void k_search_rows(const int32_t *__rest
                 const unsigned bits = (unsigned)(__ballot(valid) >> gshift) & 0xffffu;
                 if (valid) {
                     const int pidx = V + __popc(bits & lt_mask);
-                    v_key[grp][pidx] = key;
+                    v_keys[pidx] = key;
                 }
                 V += __popc(bits);
             }
@@ -759,27 +763,27 @@ __global__ __launch_bounds__(kBlock, 7) void k_search_rows(const int32_t *__rest
         // one bin per lane) in which the K-1'th candidate falls.
         if (V > 32) {
             int cntb = 0;
-            for (int j = 0; j < V; j++) cntb += ((v_key[grp][j] >> 24) == l) ? 1 : 0;
+            for (int j = 0; j < V; j++) cntb += ((v_keys[j] >> 24) == l) ? 1 : 0;
             const int incl_b = group16_inclusive_scan(cntb);
             const unsigned reach = (unsigned)(__ballot(incl_b >= K - 1) >> gshift) & 0xffffu;
             const int bstar = reach ? (__ffs(reach) - 1) : 15;
             int Wk = 0;
             for (int base = 0; base < V; base += 16) {
                 const int vi = base + l;
-                const int key = vi < V ? v_key[grp][vi] : 0x7fffffff;
+                const int key = vi < V ? v_keys[vi] : 0x7fffffff;
                 const bool keep = vi < V && (key >> 24) <= bstar;
                 const unsigned bits = (unsigned)(__ballot(keep) >> gshift) & 0xffffu;
                 __builtin_amdgcn_wave_barrier();
-                if (keep) v_key[grp][Wk + __popc(bits & lt_mask)] = key;   // in place: writes stay below this step's reads
+                if (keep) v_keys[Wk + __popc(bits & lt_mask)] = key;   // in place: writes stay below this step's reads
                 Wk += __popc(bits);
                 __builtin_amdgcn_wave_barrier();
             }
             V = Wk;
         }
         for (int vi = l; vi < V; vi += 16) {
-            const int mk = v_key[grp][vi];
+            const int mk = v_keys[vi];
             int rk = 0;
-            for (int j = 0; j < V; j++) rk += (v_key[grp][j] < mk) ? 1 : 0;
+            for (int j = 0; j < V; j++) rk += (v_keys[j] < mk) ? 1 : 0;
             if (rk < K - 1) {
                 int sx, sy;
                 spiral_offset(mk >> 20, sx, sy);
@@ -985,10 +989,11 @@ int dagr_graph_build_window(const dagr_graph_desc *desc, void *workspace, const 
         // fast path: candidate-centric row kernel; dense neighbourhoods are deferred (list in ev_rank, which
         // is dead after k_scatter; counter in status[5]) to the position-centric tiled kernel
         // (the deferral list lives in ev_rank, dead after k_scatter; its counter is status[5])
-        static const unsigned res_rows = persistent_grid(k_search_rows<kRowCap, false>, kBlock, 0, 1 << 30);
+        constexpr size_t rows_lds = (size_t)(kBlock / 16) * kRowCap * 4;
+        static const unsigned res_rows = persistent_grid(k_search_rows<kRowCap, false>, kBlock, rows_lds, 1 << 30);
         static const unsigned res_tiled = persistent_grid(k_search_tiled, kBlock, 0, 1 << 30);
         const unsigned gR = round_grid8(std::min<int64_t>(ceil_div(N * 16, kBlock), res_rows));
-        k_search_rows<kRowCap, false><<<gR, kBlock, 0, stream>>>(
+        k_search_rows<kRowCap, false><<<gR, kBlock, rows_lds, stream>>>(
             ws.start + ws.P, W, H, desc->max_neighbors, desc->radius, (float)desc->delta_t_us, ws.slot_xyb, ws.start,
             ws.slot_it, nbr_src, nbr_code, deg, ws.status, ws.ev_rank, ws.status + 5, nullptr, nullptr);
         DAGR_CHECK_LAUNCH();

@@ -263,11 +263,20 @@ def pooling(pp, x, pos, batch, edge_index, exact_mean=False):
 
 # --------------------------------------------------------------------------- to_dense
 def to_dense(x, pos, pooling_size, batch, batch_size):
-    """``spline_conv.py:80-107``: zeroed [B,C,H,W]; ``dense[batch, :, est_y, est_x] = x`` (index_put,
-    duplicates: last writer wins on CPU)."""
+    """``spline_conv.py:80-107``: zeroed [B,C,H,W]; ``dense[batch, :, est_y, est_x] = x`` (index_put).
+
+    Nodes that share a cell (QUIRK-1's t = 1.0 clusters always do) make that index_put write duplicates, whose order
+    torch leaves undefined: its CPU kernel splits the rows over threads once the tensor is large enough (seen with
+    101 classes x 106 nodes: the first duplicate survived) and the CUDA kernel is a race.  Oracle and engine pin the
+    single-threaded CPU order -- the highest node index wins -- by dropping the losers before the write."""
     W, H = (1 / pooling_size[:2] + 1e-3).long()
     C = x.shape[-1]
     dense = torch.zeros((batch_size, C, int(H), int(W)), dtype=x.dtype)
     est_x, est_y = (pos[:, :2] / pooling_size[:2]).t().long()
-    dense[batch.long(), :, est_y, est_x] = x
+    b = batch.long()
+    cell = (b * int(H) + est_y) * int(W) + est_x
+    order = torch.arange(x.shape[0])
+    last = torch.full((batch_size * int(H) * int(W),), -1, dtype=torch.long).scatter_reduce_(0, cell, order, "amax")
+    keep = last[cell] == order
+    dense[b[keep], :, est_y[keep], est_x[keep]] = x[keep]
     return dense

@@ -39,6 +39,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import refpy_fakes  # noqa: E402  (only use_reference_package(); this generator keeps its own stubs)
 
 
 class _Stub(types.ModuleType):
@@ -61,7 +63,7 @@ def _stub(name):
 
 
 def import_reference():
-    sys.path.insert(0, "/root/reference/src")
+    refpy_fakes.use_reference_package("/root/reference/src")
     mods = None
     for _ in range(60):
         try:
@@ -76,8 +78,7 @@ def import_reference():
             break
         except ModuleNotFoundError as e:
             _stub(e.name)
-            for k in [k for k in sys.modules if k == "dagr" or k.startswith("dagr.")]:
-                del sys.modules[k]
+            refpy_fakes.use_reference_package("/root/reference/src")     # drops the half-imported dagr.* modules
     assert mods is not None
     return mods
 
@@ -296,7 +297,7 @@ def main():
     sys.argv = argv0
     out["flags_json"] = np.frombuffer(json.dumps(flags, sort_keys=True).encode(), dtype=np.uint8)
 
-    path = os.path.join(ROOT, "tests", "golden", "ref_py_functions.npz")
+    path = os.path.join(os.environ.get("GOLDEN_OUT", os.path.join(ROOT, "tests", "golden")), "ref_py_functions.npz")
     np.savez_compressed(path, **{k: (v.numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in out.items()})
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
 

@@ -38,7 +38,7 @@ CASES = [  # name, W, H, B, events/sample, stream, seed, model overrides
 def main():
     import refpy_fakes
     refpy_fakes.install()
-    sys.path.insert(0, "/root/reference/src")
+    refpy_fakes.use_reference_package("/root/reference/src")
     import dagr.model.networks.dagr as rdagr
     from oracle import model as om
     from dagr_amd.model.networks.dagr import DAGR as MirrorDAGR
@@ -106,7 +106,7 @@ def main():
         out[f"vox{i}_idx"] = getattr(rmp, "__get_global_cluster_index")(module, p2).numpy()
     out["vox_sizes"] = ps.numpy()
 
-    path = os.path.join(ROOT, "tests", "golden", "ref_py_model.npz")
+    path = os.path.join(os.environ.get("GOLDEN_OUT", os.path.join(ROOT, "tests", "golden")), "ref_py_model.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")
 

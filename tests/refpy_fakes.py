@@ -248,3 +248,19 @@ def install():
     for name in ("detectron2", "detectron2.evaluation", "detectron2.evaluation.fast_eval_api", "pycocotools",
                  "pycocotools.coco"):
         _module(name)
+
+
+def use_reference_package(src="/root/reference/src"):
+    """Make ``import dagr.<x>`` resolve to the REFERENCE's sources.  The repository ships its own top-level ``dagr`` package
+    (an alias of ``dagr_amd``), which as a regular package would win over the reference's ``src/dagr`` (a namespace
+    package: no ``__init__.py``) whatever the order of ``sys.path`` -- the golden generators must not end up comparing the
+    mirror with itself."""
+    import os
+    import types
+    for name in [m for m in sys.modules if m == "dagr" or m.startswith("dagr.")]:
+        del sys.modules[name]
+    pkg = types.ModuleType("dagr")
+    pkg.__path__ = [os.path.join(src, "dagr")]
+    sys.modules["dagr"] = pkg
+    sys.path.insert(0, src)
+    return pkg

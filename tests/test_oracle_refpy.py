@@ -58,6 +58,23 @@ def test_to_dense():
     assert torch.equal(got, T("dense_out"))
 
 
+def test_to_dense_shared_cells_keep_the_highest_node_whatever_the_thread_count():
+    """Duplicate (batch, cell) targets: torch's index_put order is undefined (and not sequential on CPU from ~10^4
+    written elements on); the oracle pins "highest node index survives" = the reference on one thread."""
+    g = torch.Generator().manual_seed(3)
+    n, C, B = 400, 101, 3
+    size = torch.tensor([1 / 7, 1 / 5, 1.0])
+    pos = torch.rand((n, 3), generator=g) * 0.999
+    pos[200:] = pos[:200]                                    # every cell hit at least twice
+    batch = torch.randint(0, B, (200,), generator=g).repeat(2)
+    x = torch.randn((n, C), generator=g)
+    want = torch.zeros((B, C, 5, 7))
+    ex, ey = (pos[:, :2] / size[:2]).t().long()
+    for i in range(n):
+        want[int(batch[i]), :, int(ey[i]), int(ex[i])] = x[i]
+    assert torch.equal(oo.to_dense(x, pos, size, batch, B), want)
+
+
 def test_head_decode():
     """decode_outputs + init_grid_and_stride as restated at the end of oracle.model.head_forward."""
     hw, strides = [tuple(int(v) for v in r) for r in G["dec_hw"]], [int(s) for s in G["dec_strides"]]

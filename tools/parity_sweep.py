@@ -25,22 +25,39 @@ for k in range(n_cases):
     gen = syn.uniform_window if rng.integers(0, 2) else syn.edges_window
     n = int(rng.integers(1500, 9000))
     seed = seed0 + k
-    kind = int(rng.integers(0, 10))      # 0-1: image fusion (resnet18), 2: dagr-l widths, else dagr-s events-only
+    kind = int(rng.integers(0, 10))      # 0-1: image fusion (resnet18), 2: dagr-l widths, 3: one head scale, else dagr-s
     over = {}
     image = None
     if kind <= 1:
         over = dict(use_image=True, img_net="resnet18")
     elif kind == 2:
         over = dict(net_stem_width=1.0, yolo_stem_width=1.0)
-    if rng.integers(0, 4) == 0:
+    elif kind == 3:
+        over = dict(num_scales=1, dataset="ncaltech101")
+    dense = int(rng.integers(0, 8))
+    if dense <= 1:
         n = int(rng.integers(15000, 40000))      # dense: > 128 candidates per neighbourhood, FIFO pressure
+    elif dense == 2:
+        n = int(rng.integers(60000, 130000))     # very dense: position-centric search, voxels beyond the per-wave cap
     args, model, sd = T._setup(W, H, B, seed=seed, **over)
     if kind <= 1:
         import torch
         image = torch.rand((B, 3, H, W), generator=torch.Generator().manual_seed(seed)).cuda()
     import torch
     with torch.no_grad():
-        T._compare(args, model, sd, W, H, B, *T._events(gen, n, B, W, H, seed=seed * 7 + 1), image=image)
+        ev = T._events(gen, n, B, W, H, seed=seed * 7 + 1)
+        if kind == 3:
+            T._compare_one_scale(args, model, sd, W, H, B, *ev)
+        else:
+            out = T._compare(args, model, sd, W, H, B, *ev, image=image).clone()
+            if kind > 3:      # latency mode (graph replay + head overlap) must reproduce the launch-by-launch outputs
+                eng = model.engine().set_low_latency(True)
+                dev = out.device
+                inp = (torch.from_numpy(ev[5]).to(dev), torch.from_numpy(ev[3].astype(np.float32)).view(-1, 1).to(dev),
+                       torch.from_numpy(ev[4]).to(dev))
+                for _ in range(4):
+                    again = eng.forward_raw(*inp)
+                assert torch.equal(again, out), "graph replay differs"
     print(f"case {k}: {W}x{H} B={B} {gen.__name__} n={n}/sample kind={kind} seed={seed}: ok ({time.time() - t0:.0f} s)",
           flush=True)
     del model
