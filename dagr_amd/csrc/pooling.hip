@@ -17,9 +17,16 @@
 //     (pixel rows of a voxel are contiguous slot ranges) -- no atomics except for the rare leak events.
 //     Coarser levels (<= 2240*(B+1) nodes): atomics into the same accumulators.
 //   * coarse edges: per destination cluster a 64-slot open-addressing set of source clusters
-//     (atomicCAS), then one wave per cluster sorts its row; rows -> CSR; each edge gets the integer
-//     LUT coordinate the next SplineConv needs, computed with the reference's float formula
-//     (T.Cartesian then spline_conv.py:41-42).
+//     (atomicCAS) -- or, from level 0, two 5x5 bitmaps of source cells -- then one wave per cluster sorts
+//     its row; rows -> CSR; each edge gets the integer LUT coordinate the next SplineConv needs, computed
+//     with the reference's float formula (T.Cartesian then spline_conv.py:41-42).
+//   * three launches per pooling step: (A) gather -- members into the accumulators AND the coarse edges, keyed by
+//     the raw (table) ids so that nothing waits for the relabelling; (S) one workgroup scans the occupancy flags and
+//     the row sizes together (new ids + row pointers); (C) one wave per table slot writes the pooled node, sorts its
+//     row and emits the CSR edges with their LUT coordinates.  (C) reads the positions of the source clusters
+//     from their accumulators while other waves finalize theirs, so the position/count accumulators exist twice
+//     and alternate between calls (device-side epoch): (C) of call n re-arms the pair call n-1 used.  The chain was
+//     8 (pooled levels) / 12 (level 0) dependent launches of ~4.5 us each before.
 #include <climits>
 
 #include "common.hpp"
@@ -28,7 +35,6 @@ namespace dagr {
 namespace {
 
 constexpr int kRowSlots = 64;           // coarse in-degree bound per cluster (flagged if exceeded)
-constexpr int kLeakCap = 8192;          // in-edges of t == 1.0 nodes handled apart (beyond: generic path)
 constexpr int kMaxChunks = 9;           // up to 144 feature channels at level 0
 constexpr int kCellCap = 256;           // members of a level-0 voxel walked by its own wave; the rest is split (k_pool_l0_overflow)
 constexpr int kOverWaves = 16;          // waves sharing the tail of an event-dense voxel
@@ -39,16 +45,18 @@ struct PoolWs {
     int32_t *occupied;   // [T+1] flags, zero between calls
     int32_t *newid;      // [T+1] exclusive scan (newid[T] = number of clusters)
     int32_t *scan_tmp;
-    long long *possum;   // [T][3] fixed point 2^-40
-    int32_t *cnt;        // [T]
+    long long *possum;   // [2][T][3] fixed point 2^-40 (pair `epoch & 1` is the one being filled)
+    int32_t *cnt;        // [2][T]
     int32_t *perm;       // [T] max member index (consecutive_cluster's perm on CPU)
     long long *xacc;     // [T][C]: ordered-int max (low 32 bits) or fixed-point sum
-    int32_t *rows;       // [T][64] source-cluster sets, -1 = empty
+    int32_t *rows;       // [T][64] source-cluster sets, -1 = empty (raw ids on the 3-launch path)
     int32_t *rowcnt;     // [T+1]
-    int32_t *status;     // [4]: 0 flags (sticky); 1 = bitmap path not applicable to this window, 2 = #leak_edges (cleared by rearm)
-    int32_t *nbmask;     // [T] level 0: 5x5 bitmap of neighbouring source cells, zero between calls
-    int2 *leak_edges;    // [kLeakCap] level 0: (dst raw, src raw) of the in-edges of t == 1.0 nodes; count = status[2]
+    int32_t *status;     // [8]: 0 flags (sticky); 3 = #over_list (cleared by the scan / rearm); 4 = epoch
+    unsigned long long *nbmask;  // [T] level 0: 5x5 bitmaps of source cells, zero between calls: bits 0-24 cells of the
+                                 // slot's own sample plane, bits 32-56 cells of the plane below (sources of the slot's
+                                 // t == 1.0 members, QUIRK-1)
     int32_t *over_list;  // [T] level 0: cells with more than kCellCap members (their tail is split over waves); count = status[3]
+    int T;
 };
 
 __host__ __device__ inline size_t pool_carve(const dagr_pool_desc &d, char *base, PoolWs *ws) {
@@ -60,22 +68,27 @@ __host__ __device__ inline size_t pool_carve(const dagr_pool_desc &d, char *base
         return base ? base + o : nullptr;
     };
     PoolWs w;
-    w.occupied = (int32_t *)take((T + 9) * 4);
-    w.newid = (int32_t *)take((T + 9) * 4);
+    w.occupied = (int32_t *)take((T + 32) * 4);
+    w.newid = (int32_t *)take((T + 32) * 4);
     w.scan_tmp = (int32_t *)take(((T + 1 + kScanTile - 1) / kScanTile + 8) * 4);
-    w.possum = (long long *)take(T * 3 * 8);
-    w.cnt = (int32_t *)take(T * 4);
+    w.possum = (long long *)take(2 * T * 3 * 8);
+    w.cnt = (int32_t *)take(2 * T * 4);
     w.perm = (int32_t *)take(T * 4);
     w.xacc = (long long *)take(T * (size_t)d.channels * 8);
     w.rows = (int32_t *)take(T * (size_t)kRowSlots * 4);
-    w.rowcnt = (int32_t *)take((T + 9) * 4);
-    w.status = (int32_t *)take(16);
-    w.nbmask = (int32_t *)take((T + 9) * 4);
-    w.leak_edges = (int2 *)take((size_t)kLeakCap * 8);
+    w.rowcnt = (int32_t *)take((T + 32) * 4);
+    w.status = (int32_t *)take(32);
+    w.nbmask = (unsigned long long *)take((T + 9) * 8);
     w.over_list = (int32_t *)take((T + 9) * 4);
+    w.T = (int)T;
     if (ws) *ws = w;
     return off;
 }
+
+// the position / count accumulators of the pair being filled (before the scan of this call) ...
+__device__ __forceinline__ int ws_pair(const PoolWs &ws) { return ws.status[4] & 1; }
+__device__ __forceinline__ long long *ws_possum(const PoolWs &ws, int pair) { return ws.possum + (size_t)pair * ws.T * 3; }
+__device__ __forceinline__ int32_t *ws_cnt(const PoolWs &ws, int pair) { return ws.cnt + (size_t)pair * ws.T; }
 
 __device__ __forceinline__ int enc_f(float f) {
     const int i = __float_as_int(f);
@@ -109,12 +122,37 @@ __device__ __forceinline__ float div_floor(float a, float b) {
     return floordiv;
 }
 
+// coarse edges: insert source cluster `cs` into the slot set of destination row `cd`; true = this call added it
+__device__ __forceinline__ bool row_insert(int32_t *__restrict__ rows, int cd, int cs, int32_t *status) {
+    int32_t *row = rows + (size_t)cd * kRowSlots;
+    unsigned h = ((unsigned)cs * 2654435761u) >> 26;  // 6 bits
+    for (int probe = 0; probe < kRowSlots; probe++) {
+        // L2-coherent read (sc1): neighbouring nodes insert the same few sources over and over; a stale
+        // L1 line would send every one of them to the atomic
+        const int cur = __hip_atomic_load(&row[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == cs) return false;
+        if (cur == -1) {
+            const int old = atomicCAS(&row[h], -1, cs);
+            if (old == -1) return true;
+            if (old == cs) return false;
+        }
+        h = (h + 1) & (kRowSlots - 1);
+    }
+    atomicOr(status, 2);  // more than 64 distinct sources
+    return false;
+}
+
 // ---------------------------------------------------------------------------------------------
-// generic level: one thread per (node, channel)
+// pooled levels, launch (A): one thread per (node, channel) merges the node into its cluster's accumulators; the
+// same threads then walk the node's in-edges (thread `ch` takes edges ch, ch + C, ...) and insert
+// (source cluster -> this cluster) into the destination's slot set -- by raw ids, the source's recomputed from its
+// position, so the edges wait neither for the relabelling nor for a cluster-id pass over the nodes.
 __global__ __launch_bounds__(kBlock) void k_pool_accumulate(dagr_pool_desc d, const int32_t *__restrict__ n_ptr,
                                                            int n_max, const float *__restrict__ x, int ldx,
                                                            const float *__restrict__ pos,
-                                                           const int32_t *__restrict__ batch, PoolWs ws,
+                                                           const int32_t *__restrict__ batch,
+                                                           const int32_t *__restrict__ rowptr,
+                                                           const int32_t *__restrict__ col, PoolWs ws,
                                                            int32_t *__restrict__ cluster_raw_out) {
     const int n_nodes = n_ptr ? min(*n_ptr, n_max) : n_max;
     const int C = d.channels;
@@ -134,14 +172,25 @@ __global__ __launch_bounds__(kBlock) void k_pool_accumulate(dagr_pool_desc d, co
         atomicAdd(reinterpret_cast<unsigned long long *>(ws.xacc + (size_t)raw * C + ch),
                   (unsigned long long)(long long)llrint((double)v * kFeatScale));
     if (ch == 0) {
+        const int pair = ws_pair(ws);
         cluster_raw_out[n] = raw;
         ws.occupied[raw] = 1;
-        atomicAdd(&ws.cnt[raw], 1);
+        atomicAdd(&ws_cnt(ws, pair)[raw], 1);
         atomicMax(&ws.perm[raw], n);
 #pragma unroll
         for (int k = 0; k < 3; k++)
-            atomicAdd(reinterpret_cast<unsigned long long *>(ws.possum + (size_t)raw * 3 + k),
+            atomicAdd(reinterpret_cast<unsigned long long *>(ws_possum(ws, pair) + (size_t)raw * 3 + k),
                       (unsigned long long)(long long)llrint((double)pos[3 * n + k] * kPosScale));
+    }
+    if (rowptr) {
+        const int e1 = rowptr[n + 1];
+        for (int e = rowptr[n] + ch; e < e1; e += C) {
+            const int src = col[e];
+            bool oks;
+            const int rs = cluster_raw(pos[3 * src], pos[3 * src + 1], pos[3 * src + 2], batch[src], d, oks);
+            if (!oks || rs == raw) continue;
+            if (row_insert(ws.rows, raw, rs, ws.status)) atomicAdd(&ws.rowcnt[raw], 1);
+        }
     }
 }
 
@@ -180,10 +229,13 @@ __device__ __forceinline__ void pool_l0_cell(int cell, int i_first, int i_stride
     long long ps0 = 0, ps1 = 0, ps2 = 0;
     int cnt = 0, pmax = -1;
     const int raw = cx + d.gx * (cy + d.gy * b);
+    const int pair = ws_pair(ws);
+    long long *w_possum = ws_possum(ws, pair);
+    int32_t *w_cnt = ws_cnt(ws, pair);
     // Coarse edges without a hash set: a source lies within r pixels of its destination, r <= 2 cells (checked by
     // the caller), so the source cells of this voxel's in-edges form a 5x5 bitmap around it.  Lower pixel bounds
     // of the cells cx-1 .. cx+2 (and rows): the source's cell = cx-2 + #(bounds <= its pixel).
-    int nbm = 0;
+    int nbm = 0, nbm_up = 0, nbm_low = 0;   // this slot's sources; the slot above: sources in its own plane / in this one
     int bx[4], by[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -246,16 +298,12 @@ __device__ __forceinline__ void pool_l0_cell(int cell, int i_first, int i_stride
                     if (!leak) {
                         nbm |= 1 << (dcy * 5 + dcx);
                     } else {
-                        // QUIRK-1: a t == 1.0 node belongs to cluster raw + gx*gy, so its in-edges are not this
-                        // voxel's; its sources may be t == 1.0 nodes themselves.  Few per window: listed apart.
+                        // QUIRK-1: a t == 1.0 node belongs to cluster raw + gx*gy (the same cell one sample plane up), so
+                        // its in-edges are that slot's: from this plane's cells, or -- sources that are t == 1.0 nodes
+                        // themselves -- from the slot's own plane
                         const int src = nbr_src[(size_t)s * K + l];
-                        const int rs = raw + (dcx - 2) + d.gx * (dcy - 2) + (pos[3 * (size_t)src + 2] >= 1.0f ? cells : 0);
-                        const int rdst = raw + cells;
-                        if (rs != rdst) {
-                            const int at = atomicAdd(&ws.status[2], 1);
-                            if (at < kLeakCap) ws.leak_edges[at] = make_int2(rdst, rs);
-                            else ws.status[1] = 1;   // pathological window: generic path
-                        }
+                        if (pos[3 * (size_t)src + 2] >= 1.0f) nbm_up |= 1 << (dcy * 5 + dcx);
+                        else nbm_low |= 1 << (dcy * 5 + dcx);
                     }
                 }
                 if (leak) {
@@ -275,13 +323,13 @@ __device__ __forceinline__ void pool_l0_cell(int cell, int i_first, int i_stride
                     }
                     if (l == 0) {
                         ws.occupied[rl] = 1;
-                        atomicAdd(&ws.cnt[rl], 1);
+                        atomicAdd(&w_cnt[rl], 1);
                         atomicMax(&ws.perm[rl], id);
-                        atomicAdd(reinterpret_cast<unsigned long long *>(ws.possum + (size_t)rl * 3 + 0),
+                        atomicAdd(reinterpret_cast<unsigned long long *>(w_possum + (size_t)rl * 3 + 0),
                                   (unsigned long long)(long long)llrint((double)px * kPosScale));
-                        atomicAdd(reinterpret_cast<unsigned long long *>(ws.possum + (size_t)rl * 3 + 1),
+                        atomicAdd(reinterpret_cast<unsigned long long *>(w_possum + (size_t)rl * 3 + 1),
                                   (unsigned long long)(long long)llrint((double)py * kPosScale));
-                        atomicAdd(reinterpret_cast<unsigned long long *>(ws.possum + (size_t)rl * 3 + 2),
+                        atomicAdd(reinterpret_cast<unsigned long long *>(w_possum + (size_t)rl * 3 + 2),
                                   (unsigned long long)(long long)llrint((double)pt * kPosScale));
                     }
                     continue;
@@ -321,9 +369,16 @@ __device__ __forceinline__ void pool_l0_cell(int cell, int i_first, int i_stride
     }
     if (nbr_code) {
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) nbm |= __shfl_xor(nbm, off, 64);
-        nbm &= ~(1 << 12);   // own cell
-        if (lane == 0 && nbm) atomicOr(&ws.nbmask[raw], nbm);
+        for (int off = 1; off < 64; off <<= 1) {
+            nbm |= __shfl_xor(nbm, off, 64);
+            nbm_up |= __shfl_xor(nbm_up, off, 64);
+            nbm_low |= __shfl_xor(nbm_low, off, 64);
+        }
+        nbm &= ~(1 << 12);      // own cell = self loops
+        nbm_up &= ~(1 << 12);
+        if (lane == 0 && nbm) atomicOr(&ws.nbmask[raw], (unsigned long long)(unsigned)nbm);
+        if (lane == 0 && (nbm_up | nbm_low))
+            atomicOr(&ws.nbmask[raw + cells], ((unsigned long long)(unsigned)nbm_low << 32) | (unsigned)nbm_up);
     }
     if (cnt > 0 && g == 0) {
         // this wave is the only non-atomic writer of slot `raw`; leak events of sample b-1 may hit it
@@ -341,11 +396,11 @@ __device__ __forceinline__ void pool_l0_cell(int cell, int i_first, int i_stride
         }
         if (l == 0) {
             ws.occupied[raw] = 1;
-            atomicAdd(&ws.cnt[raw], cnt);
+            atomicAdd(&w_cnt[raw], cnt);
             atomicMax(&ws.perm[raw], pmax);
-            atomicAdd(reinterpret_cast<unsigned long long *>(ws.possum + (size_t)raw * 3 + 0), (unsigned long long)ps0);
-            atomicAdd(reinterpret_cast<unsigned long long *>(ws.possum + (size_t)raw * 3 + 1), (unsigned long long)ps1);
-            atomicAdd(reinterpret_cast<unsigned long long *>(ws.possum + (size_t)raw * 3 + 2), (unsigned long long)ps2);
+            atomicAdd(reinterpret_cast<unsigned long long *>(w_possum + (size_t)raw * 3 + 0), (unsigned long long)ps0);
+            atomicAdd(reinterpret_cast<unsigned long long *>(w_possum + (size_t)raw * 3 + 1), (unsigned long long)ps1);
+            atomicAdd(reinterpret_cast<unsigned long long *>(w_possum + (size_t)raw * 3 + 2), (unsigned long long)ps2);
         }
     }
 }
@@ -397,9 +452,9 @@ __global__ __launch_bounds__(kBlock) void k_pool_l0_event_cluster(dagr_pool_desc
                                                                  const int32_t *__restrict__ batch32,
                                                                  const int64_t *__restrict__ batch64,
                                                                  int32_t *__restrict__ cluster_raw_out,
-                                                                 int32_t *__restrict__ status, int only_if_leak) {
+                                                                 int32_t *__restrict__ status) {
     const int n = blockIdx.x * kBlock + threadIdx.x;
-    if (n >= N || (only_if_leak && status[1] == 0)) return;
+    if (n >= N) return;
     bool ok;
     const int b = batch32 ? batch32[n] : (int)batch64[n];
     const int raw = cluster_raw(pos[3 * (size_t)n], pos[3 * (size_t)n + 1], pos[3 * (size_t)n + 2], b, d, ok);
@@ -408,7 +463,20 @@ __global__ __launch_bounds__(kBlock) void k_pool_l0_event_cluster(dagr_pool_desc
 }
 
 // ---------------------------------------------------------------------------------------------
-// finalize: one thread per (table slot, channel).  Writes the pooled node and re-arms the slot.
+// pooled position of table slot `raw` from the accumulators of `pair`: mean, then round_to_pixel
+// (pooling.py:47-49): floor((pos + 1e-5) / wh_inv) * wh_inv on x, y.  Every reader of a cluster's position goes
+// through this one function (the node itself and, for the LUT coordinates, each of its out-edges).
+__device__ __forceinline__ void cluster_pos(const PoolWs &ws, int pair, int raw, int cnt, const dagr_pool_desc &d,
+                                            float (&p)[3]) {
+    const long long *ps = ws_possum(ws, pair) + (size_t)raw * 3;
+#pragma unroll
+    for (int k = 0; k < 3; k++) p[k] = (float)(((double)ps[k] / kPosScale) / (double)cnt);
+    p[0] = div_floor(p[0] + 1e-5f, d.inv_w) * d.inv_w;
+    p[1] = div_floor(p[1] + 1e-5f, d.inv_h) * d.inv_h;
+}
+
+// finalize of the generic level-0 path (no neighbour codes / wide radius): one thread per (table slot, channel).
+// Writes the pooled node and re-arms the slot.
 __global__ __launch_bounds__(kBlock) void k_pool_finalize(dagr_pool_desc d, PoolWs ws,
                                                          const int32_t *__restrict__ batch32,
                                                          const int64_t *__restrict__ batch64,
@@ -421,7 +489,8 @@ __global__ __launch_bounds__(kBlock) void k_pool_finalize(dagr_pool_desc d, Pool
     const int raw = (int)(gid / C), ch = (int)(gid % C);
     if (raw >= T) return;
     if (gid == 0) *n_out = ws.newid[T];
-    const int cnt = ws.cnt[raw];
+    const int pair = ws_pair(ws);
+    const int cnt = ws_cnt(ws, pair)[raw];
     long long *acc = ws.xacc + (size_t)raw * C + ch;
     if (cnt > 0) {
         const int c = ws.newid[raw];
@@ -431,11 +500,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_finalize(dagr_pool_desc d, Pool
         x_out[(size_t)c * ldo + xoff + ch] = v;
         if (ch == 0) {
             float p[3];
-#pragma unroll
-            for (int k = 0; k < 3; k++) p[k] = (float)(((double)ws.possum[(size_t)raw * 3 + k] / kPosScale) / (double)cnt);
-            // round_to_pixel (pooling.py:47-49): floor((pos + 1e-5) / wh_inv) * wh_inv on x, y
-            p[0] = div_floor(p[0] + 1e-5f, d.inv_w) * d.inv_w;
-            p[1] = div_floor(p[1] + 1e-5f, d.inv_h) * d.inv_h;
+            cluster_pos(ws, pair, raw, cnt, d, p);
             pos_out[3 * c] = p[0]; pos_out[3 * c + 1] = p[1]; pos_out[3 * c + 2] = p[2];
             const int pm = ws.perm[raw];
             batch_out[c] = batch32 ? batch32[pm] : (int)batch64[pm];
@@ -451,7 +516,8 @@ __global__ __launch_bounds__(kBlock) void k_pool_finalize(dagr_pool_desc d, Pool
     *acc = 0ll;
     if (d.aggr == 0) *reinterpret_cast<int *>(acc) = kEncMin;
     if (ch == 0) {
-        ws.possum[(size_t)raw * 3] = 0; ws.possum[(size_t)raw * 3 + 1] = 0; ws.possum[(size_t)raw * 3 + 2] = 0;
+        long long *ps = ws_possum(ws, pair) + (size_t)raw * 3;
+        ps[0] = 0; ps[1] = 0; ps[2] = 0;
     }
 }
 
@@ -464,82 +530,13 @@ __global__ void k_fill_enc_min(long long *p, size_t n) {
 __global__ __launch_bounds__(kBlock) void k_pool_rearm(int T, PoolWs ws) {
     const int raw = blockIdx.x * kBlock + threadIdx.x;
     if (raw >= T) return;
-    ws.cnt[raw] = 0;
+    ws_cnt(ws, ws_pair(ws))[raw] = 0;
     ws.perm[raw] = -1;
-    ws.nbmask[raw] = 0;
-    if (raw == 0) { ws.status[1] = 0; ws.status[2] = 0; ws.status[3] = 0; }
+    ws.nbmask[raw] = 0ull;
+    if (raw == 0) ws.status[3] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
-// coarse edges: insert (source cluster -> destination cluster) into the destination's slot set
-__device__ __forceinline__ void row_insert(int32_t *__restrict__ rows, int cd, int cs, int32_t *status) {
-    int32_t *row = rows + (size_t)cd * kRowSlots;
-    unsigned h = ((unsigned)cs * 2654435761u) >> 26;  // 6 bits
-    for (int probe = 0; probe < kRowSlots; probe++) {
-        // L2-coherent read (sc1): neighbouring nodes insert the same few sources over and over; a stale
-        // L1 line would send every one of them to the atomic
-        const int cur = __hip_atomic_load(&row[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cur == cs) return;
-        if (cur == -1) {
-            const int old = atomicCAS(&row[h], -1, cs);
-            if (old == -1 || old == cs) return;
-        }
-        h = (h + 1) & (kRowSlots - 1);
-    }
-    atomicOr(status, 2);  // more than 64 distinct sources
-}
-
-// level 0 fast path: the 5x5 source-cell bitmaps of k_pool_l0_cells -> slot sets (one thread per cell).
-// In-edges of t == 1.0 nodes (their cluster ids leave the pixel grid, QUIRK-1) come from k_rows_from_leaks.
-__global__ __launch_bounds__(kBlock) void k_rows_from_masks(dagr_pool_desc d, PoolWs ws) {
-    const int raw = blockIdx.x * kBlock + threadIdx.x;
-    const int ncell = d.gx * d.gy * d.batch_size;
-    if (raw >= ncell || ws.status[1] != 0) return;
-    int m = ws.nbmask[raw];
-    if (m == 0) return;
-    int32_t *row = ws.rows + (size_t)ws.newid[raw] * kRowSlots;
-    int i = 0;
-    while (m) {
-        const int bit = __ffs(m) - 1;
-        m &= m - 1;
-        const int dcx = bit % 5 - 2, dcy = bit / 5 - 2;
-        row[i++] = ws.newid[raw + dcx + d.gx * dcy];
-    }
-}
-
-// ... plus the listed in-edges of t == 1.0 nodes (a handful to a few hundred per window): one wave per listed
-// edge.  The first occurrence of a (dst, src) pair owns the insertion, so concurrent waves always hold
-// distinct values: the wave reads the whole slot row at once, returns if the value is there (the bitmap kernel
-// may have stored it), else claims the first empty slot with a CAS and re-reads if another wave took it.
-__global__ __launch_bounds__(kBlock) void k_rows_from_leaks(PoolWs ws) {
-    if (ws.status[1] != 0) return;
-    const int n = min(ws.status[2], kLeakCap);
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    if (i >= n) return;
-    const int2 e = ws.leak_edges[i];
-    bool dup = false;
-    for (int j = lane; j < i; j += 64) {
-        const int2 o = ws.leak_edges[j];
-        dup |= (o.x == e.x && o.y == e.y);
-    }
-    if (__ballot(dup)) return;
-    const int cs = ws.newid[e.y];
-    int32_t *row = ws.rows + (size_t)ws.newid[e.x] * kRowSlots;
-    for (int attempt = 0; attempt < kRowSlots; attempt++) {
-        const int cur = __hip_atomic_load(&row[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__ballot(cur == cs)) return;
-        const unsigned long long empty = __ballot(cur == -1);
-        if (!empty) break;
-        const int slot = __ffsll((long long)empty) - 1;
-        int old = 0;
-        if (lane == 0) old = atomicCAS(&row[slot], -1, cs);
-        old = __shfl(old, 0, 64);
-        if (old == -1 || old == cs) return;
-    }
-    if (lane == 0) atomicOr(&ws.status[0], 2);
-}
-
 // level 0: fixed-stride neighbour lists.  Nodes are in pixel order, so a workgroup sweeping a contiguous
 // run of nodes sees the same few (source cluster -> destination cluster) pairs over and over: a small
 // LDS cache of recently inserted pairs filters them, each distinct pair of a wave is then inserted once
@@ -548,8 +545,7 @@ __global__ __launch_bounds__(kBlock) void k_coarse_edges_ell(int N, int K, const
                                                             const int32_t *__restrict__ deg,
                                                             const int32_t *__restrict__ cluster_raw_in,
                                                             const int32_t *__restrict__ newid, int32_t *rows,
-                                                            int32_t *status, int only_if_leak) {
-    if (only_if_leak && status[1] == 0) return;   // the bitmap path covers this window
+                                                            int32_t *status) {
     __shared__ unsigned long long seen[256];
     seen[threadIdx.x] = ~0ull;
     __syncthreads();
@@ -585,26 +581,6 @@ __global__ __launch_bounds__(kBlock) void k_coarse_edges_ell(int N, int K, const
             pending &= ~__ballot(same);
             if (same) has = false;
         }
-    }
-}
-
-// pooled levels: CSR; one thread per destination node
-__global__ __launch_bounds__(kBlock) void k_coarse_edges_csr(const int32_t *__restrict__ n_ptr, int n_max,
-                                                            const int32_t *__restrict__ rowptr,
-                                                            const int32_t *__restrict__ col,
-                                                            const int32_t *__restrict__ cluster_raw_in,
-                                                            const int32_t *__restrict__ newid, int32_t *rows,
-                                                            int32_t *status) {
-    const int n_nodes = n_ptr ? min(*n_ptr, n_max) : n_max;
-    const int n = blockIdx.x * kBlock + threadIdx.x;
-    if (n >= n_nodes) return;
-    const int rd = cluster_raw_in[n];
-    if (rd < 0) return;
-    const int cd = newid[rd];
-    for (int e = rowptr[n]; e < rowptr[n + 1]; e++) {
-        const int rs = cluster_raw_in[col[e]];
-        if (rs == rd || rs < 0) continue;
-        row_insert(rows, cd, newid[rs], status);
     }
 }
 
@@ -688,6 +664,169 @@ __global__ __launch_bounds__(kBlock) void k_recode(const int32_t *__restrict__ n
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// launch (S): one workgroup scans the occupancy flags (-> consecutive ids, torch.unique's order) and the row sizes
+// (-> CSR row pointers of the relabelled clusters) of the T + 1 table slots together, 16 consecutive slots per thread
+// and 16 Ki slots per round; clears both inputs, closes the epoch.  Row sizes: the insert counters (pooled levels) or
+// the population of the cell bitmaps (level 0).
+template <bool MASKS>
+__global__ __launch_bounds__(1024) void k_pool_scan(PoolWs ws, int32_t *__restrict__ n_out,
+                                                   int32_t *__restrict__ rowptr_out, int32_t *__restrict__ e_out) {
+    constexpr int PER = 16;
+    __shared__ int w_occ[16], w_cnt[16];
+    __shared__ int carry[2];
+    const int n = ws.T + 1;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (threadIdx.x == 0) { carry[0] = 0; carry[1] = 0; }
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024 * PER) {
+        const int i0 = base + threadIdx.x * PER;
+        int occ[PER], cnt[PER];
+        if (i0 + PER <= n) {       // (the tables are padded: whole int4 rounds stay inside the allocation)
+#pragma unroll
+            for (int k = 0; k < PER; k += 4) {
+                const int4 a = *reinterpret_cast<const int4 *>(ws.occupied + i0 + k);
+                occ[k] = a.x; occ[k + 1] = a.y; occ[k + 2] = a.z; occ[k + 3] = a.w;
+                *reinterpret_cast<int4 *>(ws.occupied + i0 + k) = make_int4(0, 0, 0, 0);
+                if (!MASKS) {
+                    const int4 c = *reinterpret_cast<const int4 *>(ws.rowcnt + i0 + k);
+                    cnt[k] = c.x; cnt[k + 1] = c.y; cnt[k + 2] = c.z; cnt[k + 3] = c.w;
+                    *reinterpret_cast<int4 *>(ws.rowcnt + i0 + k) = make_int4(0, 0, 0, 0);
+                }
+            }
+            if (MASKS) {
+#pragma unroll
+                for (int k = 0; k < PER; k++) cnt[k] = (i0 + k < ws.T) ? __popcll(ws.nbmask[i0 + k]) : 0;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const bool in = i0 + k < n;
+                occ[k] = in ? ws.occupied[i0 + k] : 0;
+                if (MASKS) cnt[k] = (i0 + k < ws.T) ? __popcll(ws.nbmask[i0 + k]) : 0;
+                else cnt[k] = in ? ws.rowcnt[i0 + k] : 0;
+                if (in) {
+                    ws.occupied[i0 + k] = 0;
+                    if (!MASKS) ws.rowcnt[i0 + k] = 0;
+                }
+            }
+        }
+        int s_occ = 0, s_cnt = 0;
+#pragma unroll
+        for (int k = 0; k < PER; k++) { s_occ += occ[k]; s_cnt += cnt[k]; }
+        const int i_occ = wave_inclusive_scan(s_occ), i_cnt = wave_inclusive_scan(s_cnt);
+        if (lane == 63) { w_occ[wid] = i_occ; w_cnt[wid] = i_cnt; }
+        __syncthreads();
+        int b_occ = carry[0], b_cnt = carry[1], t_occ = 0, t_cnt = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int a = w_occ[k], c = w_cnt[k];
+            if (k < wid) { b_occ += a; b_cnt += c; }
+            t_occ += a; t_cnt += c;
+        }
+        int e_occ = b_occ + i_occ - s_occ, e_cnt = b_cnt + i_cnt - s_cnt;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            if (i0 + k < n) {
+                ws.newid[i0 + k] = e_occ;
+                if (occ[k]) rowptr_out[e_occ] = e_cnt;
+            }
+            e_occ += occ[k]; e_cnt += cnt[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { carry[0] += t_occ; carry[1] += t_cnt; }
+        __syncthreads();
+    }
+    const int nc = carry[0], ne = carry[1];
+    for (int c = nc + threadIdx.x; c <= ws.T; c += 1024) rowptr_out[c] = ne;   // rows past the last cluster are empty
+    if (threadIdx.x == 0) {
+        *n_out = nc;
+        *e_out = ne;
+        ws.status[3] = 0;
+        ws.status[4] ^= 1;      // the next call fills the other accumulator pair; launch (C) reads the one just filled
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch (C): one wave per table slot.  Writes the pooled node (features: lanes over channels), turns the slot's
+// source set -- 64 hashed raw ids (pooled levels) or the two cell bitmaps (level 0) -- into its sorted CSR row with the
+// LUT coordinate of every edge, and re-arms what the slot owns: its feature accumulators, perm, its set, and the
+// position/count accumulators of the OTHER pair (the one the previous call left behind).
+template <bool MASKS>
+__global__ __launch_bounds__(kBlock) void k_pool_emit(dagr_pool_desc d, PoolWs ws, const int32_t *__restrict__ batch32,
+                                                     const int64_t *__restrict__ batch64, float *__restrict__ x_out,
+                                                     int ldo, int xoff, float *__restrict__ pos_out,
+                                                     int32_t *__restrict__ batch_out,
+                                                     const int32_t *__restrict__ rowptr_out, int32_t *__restrict__ col,
+                                                     int32_t *__restrict__ code, int e_cap) {
+    const int lane = threadIdx.x & 63;
+    const int raw = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (raw >= ws.T) return;
+    const int pair = ws_pair(ws) ^ 1;          // the scan has closed the epoch
+    const int cnt = ws_cnt(ws, pair)[raw];
+    if (lane == 0) ws_cnt(ws, pair ^ 1)[raw] = 0;
+    if (lane < 3) ws_possum(ws, pair ^ 1)[(size_t)raw * 3 + lane] = 0ll;
+    if (cnt == 0) return;                      // empty slot: nothing was accumulated, no set entries
+    const int C = d.channels;
+    const int c = ws.newid[raw];
+    for (int ch = lane; ch < C; ch += 64) {
+        long long *acc = ws.xacc + (size_t)raw * C + ch;
+        float v;
+        if (d.aggr == 0) v = dec_f((int)(*acc));
+        else v = (float)(((double)(*acc) / kFeatScale) / (double)cnt);
+        x_out[(size_t)c * ldo + xoff + ch] = v;
+        *acc = 0ll;
+        if (d.aggr == 0) *reinterpret_cast<int *>(acc) = kEncMin;
+    }
+    float p[3];
+    cluster_pos(ws, pair, raw, cnt, d, p);
+    if (lane == 0) {
+        pos_out[3 * c] = p[0]; pos_out[3 * c + 1] = p[1]; pos_out[3 * c + 2] = p[2];
+        const int pm = ws.perm[raw];
+        batch_out[c] = batch32 ? batch32[pm] : (int)batch64[pm];
+        if (d.append_pos) {       // net.py:137-138, see k_pool_finalize
+            x_out[(size_t)c * ldo + xoff + C] = p[0];
+            x_out[(size_t)c * ldo + xoff + C + 1] = p[1];
+        }
+        ws.perm[raw] = -1;
+    }
+    // the slot's sources in ascending raw id (= ascending new id), one per lane
+    int v = -1, rank = 0;
+    if (MASKS) {
+        const unsigned long long m = ws.nbmask[raw];
+        if (lane == 0) ws.nbmask[raw] = 0ull;
+        // bit j of `ord` = j-th candidate in ascending id: the 25 cells of the plane below, then the 25 of this plane
+        const unsigned long long ord = ((m >> 32) & 0x1ffffffull) | ((m & 0x1ffffffull) << 25);
+        if (lane < 50 && ((ord >> lane) & 1ull)) {
+            const int k = lane < 25 ? lane : lane - 25;
+            v = raw + (k % 5 - 2) + d.gx * (k / 5 - 2) - (lane < 25 ? d.gx * d.gy : 0);
+            rank = __popcll(ord & ((1ull << lane) - 1ull));
+        }
+    } else {
+        int32_t *row = ws.rows + (size_t)raw * kRowSlots;
+        v = row[lane];
+        row[lane] = -1;
+        for (int k = 0; k < 64; k++) {
+            const int o = __shfl(v, k, 64);
+            rank += (o >= 0 && o < v) ? 1 : 0;
+        }
+    }
+    if (v < 0) return;
+    const int o = rowptr_out[c] + rank;
+    if (o >= e_cap) { atomicOr(ws.status, 4); return; }
+    float q[3];
+    cluster_pos(ws, pair, v, ws_cnt(ws, pair)[v], d, q);
+    // T.Cartesian(norm=True, max_value=M): (pos[src] - pos[dst]) / (2M) + 0.5 ; then the LUT index
+    // of message_lut (spline_conv.py:41-42): trunc(attr * R00 + R02 + 1e-3)
+    const float ax = (q[0] - p[0]) / d.two_max + 0.5f;
+    const float ay = (q[1] - p[1]) / d.two_max + 0.5f;
+    const int ix = (int)((ax * d.r00 + d.r02) + 1e-3f);
+    const int iy = (int)((ay * d.r11 + d.r12) + 1e-3f);
+    if (ix < 0 || ix > 2 * d.rx || iy < 0 || iy > 2 * d.ry) atomicOr(ws.status, 8);
+    col[o] = ws.newid[v];
+    code[o] = (ix & 0xffff) | (iy << 16);
+}
+
 }  // namespace
 }  // namespace dagr
 
@@ -722,15 +861,15 @@ int dagr_pool_workspace_init(const dagr_pool_desc *desc, void *workspace, size_t
     }
     hipStream_t stream = (hipStream_t)stream_;
     const int64_t T = (int64_t)desc->gx * desc->gy * (desc->batch_size + 1);
-    DAGR_CHECK_HIP(hipMemsetAsync(ws.occupied, 0, (T + 9) * 4, stream));
-    DAGR_CHECK_HIP(hipMemsetAsync(ws.newid, 0, (T + 9) * 4, stream));
-    DAGR_CHECK_HIP(hipMemsetAsync(ws.possum, 0, T * 3 * 8, stream));
-    DAGR_CHECK_HIP(hipMemsetAsync(ws.cnt, 0, T * 4, stream));
+    DAGR_CHECK_HIP(hipMemsetAsync(ws.occupied, 0, (T + 32) * 4, stream));
+    DAGR_CHECK_HIP(hipMemsetAsync(ws.newid, 0, (T + 32) * 4, stream));
+    DAGR_CHECK_HIP(hipMemsetAsync(ws.possum, 0, 2 * T * 3 * 8, stream));
+    DAGR_CHECK_HIP(hipMemsetAsync(ws.cnt, 0, 2 * T * 4, stream));
     DAGR_CHECK_HIP(hipMemsetAsync(ws.perm, 0xff, T * 4, stream));
     DAGR_CHECK_HIP(hipMemsetAsync(ws.rows, 0xff, T * (size_t)kRowSlots * 4, stream));
-    DAGR_CHECK_HIP(hipMemsetAsync(ws.rowcnt, 0, (T + 9) * 4, stream));
-    DAGR_CHECK_HIP(hipMemsetAsync(ws.status, 0, 16, stream));
-    DAGR_CHECK_HIP(hipMemsetAsync(ws.nbmask, 0, (T + 9) * 4, stream));
+    DAGR_CHECK_HIP(hipMemsetAsync(ws.rowcnt, 0, (T + 32) * 4, stream));
+    DAGR_CHECK_HIP(hipMemsetAsync(ws.status, 0, 32, stream));
+    DAGR_CHECK_HIP(hipMemsetAsync(ws.nbmask, 0, (T + 9) * 8, stream));
     DAGR_CHECK_HIP(hipMemsetAsync(ws.over_list, 0, (T + 9) * 4, stream));
     // feature accumulators: ordered-int minimum for max, 0 for mean
     {
@@ -815,28 +954,29 @@ int dagr_pool_l0(const dagr_pool_desc *desc, void *pool_ws, const dagr_graph_des
 #undef DAGR_POOL_L0_A
         DAGR_CHECK_LAUNCH();
     }
+    if (fast_edges) {
+        // (S) ids + row pointers from the occupancy flags and the bitmap populations, (C) nodes + CSR rows
+        k_pool_scan<true><<<1, 1024, 0, stream>>>(ws, n_out, rowptr_out, e_out);
+        DAGR_CHECK_LAUNCH();
+        k_pool_emit<true><<<(unsigned)ceil_div(T, kBlock / 64), kBlock, 0, stream>>>(
+            *desc, ws, b32, b64, x_out, ldo, xoff, pos_out, batch_out, rowptr_out, col_out, code_out, e_cap);
+        DAGR_CHECK_LAUNCH();
+        return DAGR_OK;
+    }
+    // generic path (no neighbour codes, or sources more than two cells away): relabel, finalize, hash the edges
     DAGR_CHECK_HIP(exclusive_scan_i32(ws.occupied, ws.newid, T + 1, ws.scan_tmp, true, stream));
     k_pool_finalize<<<(unsigned)ceil_div((int64_t)T * desc->channels, kBlock), kBlock, 0, stream>>>(
         *desc, ws, b32, b64, x_out, ldo, xoff, pos_out, batch_out, n_out);
     DAGR_CHECK_LAUNCH();
     if (N > 0) {
-        // generic path: always when the bitmaps are off, else only for windows that overflow the t == 1.0 edge list
-        // (device-side flag, no host sync: the kernels return at once otherwise)
         k_pool_l0_event_cluster<<<(unsigned)ceil_div(N, kBlock), kBlock, 0, stream>>>(
-            *desc, (int)N, pos, batch_nodes, nullptr, cluster_scratch, ws.status, fast_edges ? 1 : 0);
+            *desc, (int)N, pos, batch_nodes, nullptr, cluster_scratch, ws.status);
         DAGR_CHECK_LAUNCH();
         DAGR_CHECK_ARG(K <= kBlock, "max_neighbors too large");
         const unsigned gE = round_grid8(std::min<int64_t>(ceil_div(N, kBlock / K), 256 * 8));
         k_coarse_edges_ell<<<gE, kBlock, 0, stream>>>((int)N, K, nbr_src, deg, cluster_scratch, ws.newid, ws.rows,
-                                                      ws.status, fast_edges ? 1 : 0);
+                                                      ws.status);
         DAGR_CHECK_LAUNCH();
-        if (fast_edges) {
-            const int ncell = desc->gx * desc->gy * desc->batch_size;
-            k_rows_from_masks<<<(unsigned)ceil_div(ncell, kBlock), kBlock, 0, stream>>>(*desc, ws);
-            DAGR_CHECK_LAUNCH();
-            k_rows_from_leaks<<<(unsigned)ceil_div(kLeakCap, kBlock / 64), kBlock, 0, stream>>>(ws);
-            DAGR_CHECK_LAUNCH();
-        }
     }
     return pool_tail(desc, ws, b32, b64, x_out, ldo, xoff, pos_out, batch_out, n_out, rowptr_out, col_out, code_out,
                      e_out, e_cap, stream);
@@ -858,21 +998,15 @@ int dagr_pool_csr(const dagr_pool_desc *desc, void *pool_ws, const int32_t *n_pt
     if (n_max > 0) {
         DAGR_CHECK_ARG(x && pos && batch && rowptr && col && cluster_scratch, "NULL input");
         k_pool_accumulate<<<(unsigned)ceil_div((int64_t)n_max * desc->channels, kBlock), kBlock, 0, stream>>>(
-            *desc, n_ptr, n_max, x, ldx, pos, batch, ws, cluster_scratch);
+            *desc, n_ptr, n_max, x, ldx, pos, batch, rowptr, col, ws, cluster_scratch);
         DAGR_CHECK_LAUNCH();
     }
-    DAGR_CHECK_HIP(exclusive_scan_i32(ws.occupied, ws.newid, T + 1, ws.scan_tmp, true, stream));
-    k_pool_finalize<<<(unsigned)ceil_div((int64_t)T * desc->channels, kBlock), kBlock, 0, stream>>>(
-        *desc, ws, batch, nullptr, x_out, ldo, xoff, pos_out, batch_out, n_out);
+    k_pool_scan<false><<<1, 1024, 0, stream>>>(ws, n_out, rowptr_out, e_out);
     DAGR_CHECK_LAUNCH();
-    if (n_max > 0) {
-        k_coarse_edges_csr<<<(unsigned)ceil_div(n_max, kBlock), kBlock, 0, stream>>>(n_ptr, n_max, rowptr, col,
-                                                                                   cluster_scratch, ws.newid, ws.rows,
-                                                                                   ws.status);
-        DAGR_CHECK_LAUNCH();
-    }
-    return pool_tail(desc, ws, batch, nullptr, x_out, ldo, xoff, pos_out, batch_out, n_out, rowptr_out, col_out,
-                     code_out, e_out, e_cap, stream);
+    k_pool_emit<false><<<(unsigned)ceil_div(T, kBlock / 64), kBlock, 0, stream>>>(
+        *desc, ws, batch, nullptr, x_out, ldo, xoff, pos_out, batch_out, rowptr_out, col_out, code_out, e_cap);
+    DAGR_CHECK_LAUNCH();
+    return DAGR_OK;
 }
 
 int dagr_pool_status(const dagr_pool_desc *desc, void *pool_ws, int32_t *flags_host, void *stream) {

@@ -206,7 +206,7 @@ def _compare_one_scale(args, model, sd, W, H, B, x, y, t, p, b, pos):
 def test_coarse_edge_bitmap_and_generic_paths_agree():
     """pool1's coarse edges: the per-voxel 5x5 bitmap path and the generic per-edge set insertion give the same
     CSR: on a window without t == 1.0 events, on one whose last events sit at t == 1.0 as the dataset makes them
-    (QUIRK-1: their in-edges go through the side list), and on one where every event does (device-side fallback)."""
+    (QUIRK-1: their in-edges land in the bitmaps of the slot one sample plane up), and on one where every event does."""
     W, H, B = 320, 215, 2
     args, model, sd = _setup(W, H, B, seed=4)
     dev = torch.device("cuda:0")
@@ -218,7 +218,7 @@ def test_coarse_edge_bitmap_and_generic_paths_agree():
         if with_leak == 1:
             tt[last] = 1000000                                            # pos[:, 2] == 1.0 (QUIRK-1)
         elif with_leak == 2:
-            tt[:] = 1000000                                               # every node: overflows the side list
+            tt[:] = 1000000                                               # every node is a t == 1.0 node
         pp = syn.format_data_np(x, y, tt, W, H)
         assert (pp[:, 2].max() >= 1.0) == (with_leak > 0)
         snaps = []
