@@ -299,6 +299,26 @@ int dagr_to_dense(const int32_t *n_ptr, int32_t n_max, const float *x, int32_t l
                   const float *pos, const int32_t *batch, float vx, float vy, int32_t batch_size,
                   int32_t Hc, int32_t Wc, int32_t *winner_scratch, float *dense, int32_t *status, void *stream);
 
+/* ------------------------------------------------------------------------ *
+ * training path (scripts/train_ncaltech101.py:41-74): backward halves the reference gets from
+ * torch_scatter's / torch's autograd.  The forward entry points above are reused unchanged.
+ * ------------------------------------------------------------------------ */
+/* Pooling's feature aggregation, max (pooling.py:74-75, torch_scatter.scatter_max): arg[c, ch] = lowest node index
+ * among cluster c's members whose x equals x_pooled[c, ch] (the CPU reducer's first maximum).  cluster int32[n] =
+ * consecutive cluster id of each node (-1: outside the grid); arg int32[n_clusters, channels]. */
+int dagr_pool_argmax(const int32_t *cluster, int32_t n, const float *x, int32_t ldx, int32_t channels,
+                     const float *x_pooled, int32_t ldp, int32_t n_clusters, int32_t *arg, void *stream);
+/* grad_x[n, ch] = grad_pooled[cluster[n], ch] where arg[cluster[n], ch] == n, else 0 (aggr 0, max), or
+ * grad_pooled[cluster[n], ch] / count[cluster[n]] (aggr 1, mean: _avg_pool_x, pooling.py:77).  Fully written. */
+int dagr_pool_grad(const int32_t *cluster, int32_t n, int32_t channels, int32_t aggr, const int32_t *arg,
+                   const int32_t *count, const float *grad_pooled, int32_t ldg, float *grad_x, int32_t ldgx,
+                   void *stream);
+/* to_dense (spline_conv.py:80-107) backward: grad_x[n, :] = grad_dense[batch[n], :, cy, cx] for the node that
+ * survived in its cell (winner = the scratch dagr_to_dense filled), 0 for overwritten / out-of-map nodes. */
+int dagr_to_dense_grad(int32_t n, int32_t channels, const float *pos, const int32_t *batch, float vx, float vy,
+                       int32_t batch_size, int32_t Hc, int32_t Wc, const int32_t *winner, const float *grad_dense,
+                       float *grad_x, int32_t ldgx, void *stream);
+
 /* y = relu(y + z) in place over n floats (16-byte aligned buffers of identical layout): the residual join of the
  * image branch's ResNet blocks (reference: torchvision Bottleneck/BasicBlock.forward, used by
  * src/dagr/model/networks/net_img.py:42-86) in one pass instead of add + clamp. */
