@@ -82,25 +82,49 @@ class Batch(Data):
 
 
 class DataLoader:
-    """The slice of ``torch_geometric.data.DataLoader`` the test scripts use (``run_test.py:48``,
-    ``run_test_interframe.py:69``): sequential or sampler-ordered batches collated with ``Batch.from_data_list``;
-    ``indices`` restricts the loader to this rank's batches (window sharding, ``dagr_amd/parallel.py``)."""
+    """The slice of ``torch_geometric.data.DataLoader`` the scripts use (``run_test.py:48``, ``run_test_interframe.py:69``,
+    ``train_ncaltech101.py:121-125``): sequential, sampler-ordered or shuffled batches collated with
+    ``Batch.from_data_list``.  Two ways to split the work over ranks (``dagr_amd/parallel.py``), neither needs a collective:
+    ``batches`` restricts the loader to this rank's batches (independent evaluation windows); ``shard=(rank, world)`` cuts
+    EVERY batch into ``world`` equal slices (data-parallel training: all ranks walk the same seeded permutation, so the
+    union of their slices is the global batch)."""
 
     def __init__(self, dataset, batch_size=1, shuffle=False, sampler=None, follow_batch=(), drop_last=False,
-                 num_workers=0, batches=None):
-        if shuffle:
-            raise NotImplementedError("evaluation loaders are not shuffled")
+                 num_workers=0, batches=None, shard=None, seed=0):
         self.dataset, self.batch_size = dataset, int(batch_size)
         self.order = list(sampler) if sampler is not None else list(range(len(dataset)))
         self.follow_batch, self.drop_last = tuple(follow_batch), bool(drop_last)
         n = len(self.order) // self.batch_size if drop_last else -(-len(self.order) // self.batch_size)
         self.batches = list(range(n)) if batches is None else [b for b in batches if b < n]
+        self.shuffle, self.seed, self.epoch = bool(shuffle), int(seed), 0
+        self.shard = shard
+        if shard is not None and self.batch_size % shard[1]:
+            raise ValueError(f"batch_size {self.batch_size} does not split over {shard[1]} ranks")
 
     def __len__(self):
         return len(self.batches)
 
     def __iter__(self):
         B = self.batch_size
+        order = self.order
+        if self.shuffle:
+            g = torch.Generator().manual_seed(self.seed + self.epoch)
+            order = [self.order[i] for i in torch.randperm(len(self.order), generator=g).tolist()]
+            self.epoch += 1
         for k in self.batches:
-            idx = self.order[k * B:(k + 1) * B]
-            yield Batch.from_data_list([self.dataset[i] for i in idx], follow_batch=self.follow_batch)
+            idx = order[k * B:(k + 1) * B]
+            if self.shard is not None:
+                rank, world = self.shard
+                per = len(idx) // world
+                idx = idx[rank * per:(rank + 1) * per]
+            yield Batch.from_data_list([self._fetch(i) for i in idx], follow_batch=self.follow_batch)
+
+    def _fetch(self, i):
+        """Sample i of this epoch.  Shuffled (training) loaders draw the sample's random augmentations from a generator
+        state derived from (seed, epoch, i), inside a forked RNG scope: the same sample is augmented the same way whatever
+        the number of ranks or the order the ranks visit it in, and the caller's RNG stream is left untouched."""
+        if not self.shuffle:
+            return self.dataset[i]
+        with torch.random.fork_rng(devices=[]):
+            torch.manual_seed((self.seed * 1000003 + self.epoch) * 1000003 + int(i))
+            return self.dataset[i]

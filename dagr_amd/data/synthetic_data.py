@@ -46,3 +46,51 @@ class SyntheticWindows:
             d.image = torch.randint(0, 256, (1, 3, self.height, self.width), dtype=torch.uint8,
                                     generator=torch.Generator().manual_seed(self.seed + int(w)))
         return self.transform(d) if self.transform is not None else d
+
+
+class SyntheticObjects:
+    """Labelled synthetic samples with the interface of the reference's ``NCaltech101`` (``height``, ``width``,
+    ``classes``, ``__getitem__`` -> ``Data`` with one ``bbox`` row (x, y, w, h, class, 1)): a rectangle whose outline
+    (class 0) or diagonals + outline (class 1) fires events with pixel jitter over the last 50 ms, plus uniform noise.
+    What the training script runs on where the N-Caltech101 files (h5) cannot be read: enough structure for the loss
+    to fall, none of the real data's statistics."""
+    classes = ["outline", "cross"]
+
+    def __init__(self, n_samples, n_events=20000, width=240, height=180, seed=7, transform=None, noise=0.2):
+        self.n, self.n_events, self.width, self.height = int(n_samples), int(n_events), int(width), int(height)
+        self.seed, self.transform, self.noise = int(seed), transform, float(noise)
+        self.num_classes = len(self.classes)
+        self.time_window = 1000000
+        if transform is not None and hasattr(transform, "transforms"):
+            from .augment import init_transforms
+            init_transforms(transform.transforms, self.height, self.width)
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        rng = np.random.default_rng(self.seed + int(i))
+        W, H, N = self.width, self.height, self.n_events
+        cls = int(rng.integers(0, 2))
+        w, h = rng.uniform(0.25, 0.5) * W, rng.uniform(0.25, 0.5) * H
+        x0, y0 = rng.uniform(2, W - w - 2), rng.uniform(2, H - h - 2)
+        n_obj = int(N * (1 - self.noise))
+        u = rng.uniform(0, 1, n_obj)
+        side = rng.integers(0, 4 if cls == 0 else 6, n_obj)
+        px = np.where(side == 0, x0 + u * w, np.where(side == 1, x0 + u * w, np.where(side == 2, x0, np.where(
+            side == 3, x0 + w, x0 + u * w))))
+        py = np.where(side == 0, y0, np.where(side == 1, y0 + h, np.where(side == 2, y0 + u * h, np.where(
+            side == 3, y0 + u * h, np.where(side == 4, y0 + u * h, y0 + (1 - u) * h)))))
+        px = np.concatenate([px + rng.normal(0, 1.0, n_obj), rng.uniform(0, W, N - n_obj)])
+        py = np.concatenate([py + rng.normal(0, 1.0, n_obj), rng.uniform(0, H, N - n_obj)])
+        ok = (px >= 0) & (px < W) & (py >= 0) & (py < H)
+        px, py = px[ok].astype(np.int16), py[ok].astype(np.int16)
+        t = np.sort(rng.integers(0, 50000, len(px))).astype(np.int64)
+        t = (self.time_window - 1 + t - t[-1]).astype(np.int32)
+        p = rng.choice(np.array([-1, 1], dtype=np.int8), len(px))
+        order = rng.permutation(len(px))
+        px, py = px[order], py[order]                     # positions are not correlated with time
+        bbox = np.array([[x0, y0, w, h, cls, 1]], dtype=np.float32)
+        d = to_data(x=px, y=py, t=t, p=p, bbox=bbox, t0=int(t[0]), t1=int(t[-1]), width=W, height=H,
+                    time_window=self.time_window, sequence=f"objects{int(i):05d}")
+        return self.transform(d) if self.transform is not None else d

@@ -146,6 +146,19 @@ def voxel_pool(pool, data):
     out = data.__class__()
     out.__dict__.update({k: v for k, v in data.__dict__.items() if not k.startswith("_dagr")})
     out.x, out.pos, out.batch, out.edge_index = x_out[:nc], pos_out[:nc], batch_out[:nc].long(), ei
+    if torch.is_grad_enabled() and data.x.requires_grad:
+        # training path: attach the backward of the feature aggregation (torch_scatter's autograd in the reference).
+        # scratch holds each node's raw voxel id; the output clusters are the occupied voxels in ascending id order.
+        from types import SimpleNamespace
+        from .autograd import PoolFeatFn
+        raw = scratch.long()
+        valid = raw >= 0
+        uniq, inv = torch.unique(raw[valid], return_inverse=True)
+        if uniq.numel() != nc:
+            raise RuntimeError(f"pooling: {uniq.numel()} occupied voxels but {nc} output clusters")
+        cluster = torch.full((n,), -1, **i32)
+        cluster[valid] = inv.int()
+        out.x = PoolFeatFn.apply(data.x, cluster, 0 if pool.aggr == "max" else 1, SimpleNamespace(pooled=x_out[:nc]))
     out.edge_attr = cartesian(out.pos, ei, pool.transform.max)
     return out
 
@@ -156,6 +169,9 @@ def to_dense(x, pos, pooling, batch, batch_size):
     dev = x.device
     Wc, Hc = [int(v) for v in (1 / pooling[:2].float().cpu() + 1e-3).long()]
     n, C = x.shape
+    if torch.is_grad_enabled() and x.requires_grad:
+        from .autograd import ToDenseFn
+        return ToDenseFn.apply(x, pos, batch, float(pooling[0]), float(pooling[1]), int(batch_size), Hc, Wc)
     dense = torch.zeros((batch_size, C, Hc, Wc), dtype=torch.float32, device=dev)
     if n == 0:
         return dense

@@ -6,7 +6,11 @@
   * forward: tap aggregation (HIP) + one GEMM (hipBLASLt through torch);
   * backward: ``grad_Wm = A^T . g`` and ``grad_A = g . Wm^T`` are plain library GEMMs, ``grad_x`` is the transposed
     aggregation (``dagr_spline_tap_scatter_grad``), ``grad_bias = sum g``.
-BatchNorm in training mode, pooling backward and the YOLOX loss are not built yet."""
+``PoolFeatFn`` / ``ToDenseFn`` attach the backward of the voxel pooling's feature aggregation (torch_scatter's
+``scatter_max`` / ``scatter_mean`` autograd, pooling.py:74-77) and of ``to_dense`` (an ``index_put``, spline_conv.py:80-107)
+to the forward entry points the eval path already uses; both backwards are gathers (csrc/train_ops.hip).  BatchNorm in
+training mode is ``torch.nn.BatchNorm1d`` (the reference's BatchNormData wraps the same module), the loss is
+``networks/yolox_loss.py``."""
 import torch
 
 from ... import _lib
@@ -63,3 +67,77 @@ def spline_conv_autograd(conv, x, rowptr, col, code):
         raise RuntimeError("call init_lut() / DAGR.cache_luts() first")
     return SplineConvFn.apply(x, conv.weight, conv.lin.weight, conv.bias, rowptr, col, code, d["rx"], d["ry"], d["den_x"],
                               d["den_y"])
+
+
+class PoolFeatFn(torch.autograd.Function):
+    """x -> pooled x of ``dagr_pool_csr`` (already computed: ``holder.pooled``) with the gradient the reference gets from
+    torch_scatter: max routes each (cluster, channel) gradient to the first member holding the maximum, mean spreads
+    it evenly.  ``cluster`` int32[n]: consecutive cluster id per node, -1 for nodes outside the grid."""
+
+    @staticmethod
+    def forward(ctx, x, cluster, aggr, holder):
+        L, P = _lib.lib(), _lib.ptr
+        pooled = holder.pooled
+        n, C = x.shape
+        nc = pooled.shape[0]
+        stream = _lib.cur_stream(x.device)
+        arg = count = None
+        if aggr == 0:
+            arg = torch.empty((max(nc, 1), C), dtype=torch.int32, device=x.device)
+            xc = x.detach().float().contiguous()
+            _lib.check(L.dagr_pool_argmax(P(cluster), n, P(xc), C, C, P(pooled), pooled.stride(0), nc, P(arg), stream),
+                       "pool_argmax")
+        else:
+            count = torch.bincount(cluster[cluster >= 0].long(), minlength=max(nc, 1)).int()
+        ctx.save_for_backward(cluster, arg if arg is not None else count)
+        ctx.meta = (n, C, aggr)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, g):
+        L, P = _lib.lib(), _lib.ptr
+        cluster, aux = ctx.saved_tensors
+        n, C, aggr = ctx.meta
+        g = g.float().contiguous()
+        gx = torch.empty((n, C), dtype=torch.float32, device=g.device)
+        if n:
+            _lib.check(L.dagr_pool_grad(P(cluster), n, C, aggr, P(aux) if aggr == 0 else None,
+                                        P(aux) if aggr == 1 else None, P(g), g.stride(0) if g.shape[0] else C, P(gx), C,
+                                        _lib.cur_stream(g.device)), "pool_grad")
+        return gx, None, None, None
+
+
+class ToDenseFn(torch.autograd.Function):
+    """``to_dense`` (spline_conv.py:80-107): rows scattered into a zeroed [B, C, Hc, Wc] map; backward gathers the map's
+    gradient at the cell of every node that survived there."""
+
+    @staticmethod
+    def forward(ctx, x, pos, batch, vx, vy, batch_size, Hc, Wc):
+        L, P = _lib.lib(), _lib.ptr
+        dev = x.device
+        n, C = x.shape
+        dense = torch.zeros((batch_size, C, Hc, Wc), dtype=torch.float32, device=dev)
+        winner = torch.full((batch_size * Hc * Wc,), -1, dtype=torch.int32, device=dev)
+        pos = pos.float().contiguous()
+        batch = batch.int().contiguous()
+        if n:
+            status = torch.zeros((1,), dtype=torch.int32, device=dev)
+            n_ptr = torch.tensor([n], dtype=torch.int32, device=dev)
+            _lib.check(L.dagr_to_dense(P(n_ptr), n, P(x.detach().float().contiguous()), C, C, P(pos), P(batch), vx, vy,
+                                       batch_size, Hc, Wc, P(winner), P(dense), P(status), _lib.cur_stream(dev)),
+                       "to_dense")
+        ctx.save_for_backward(pos, batch, winner)
+        ctx.meta = (n, C, vx, vy, batch_size, Hc, Wc)
+        return dense
+
+    @staticmethod
+    def backward(ctx, g):
+        L, P = _lib.lib(), _lib.ptr
+        pos, batch, winner = ctx.saved_tensors
+        n, C, vx, vy, B, Hc, Wc = ctx.meta
+        g = g.float().contiguous()
+        gx = torch.empty((n, C), dtype=torch.float32, device=g.device)
+        if n:
+            _lib.check(L.dagr_to_dense_grad(n, C, P(pos), P(batch), vx, vy, B, Hc, Wc, P(winner), P(g), P(gx), C,
+                                            _lib.cur_stream(g.device)), "to_dense_grad")
+        return gx, None, None, None, None, None, None, None

@@ -1,8 +1,10 @@
 """Mirror of ``src/dagr/model/layers/conv.py``: ``ConvBlock`` (:10-28: ``conv``, ``norm``), ``ConvBlockWithSkip``
 (:31-56: + ``lin``, ``norm_skip``), ``Layer`` (:59-72: ``conv_block1``, ``conv_block2``), same names and state_dict.
 Whole windows go through ``dagr_amd/engine.py``; each module is ALSO a ``Data -> Data`` callable like its reference
-twin (eval mode), evaluated as ONE fused contraction -- conv + BN(eval) + ReLU (+ skip Linear + BN) -- by the kernels
-behind ``dagr_spline_conv_fused`` (``_ops.py``)."""
+twin: in eval mode ONE fused contraction -- conv + BN(eval) + ReLU (+ skip Linear + BN) -- by the kernels behind
+``dagr_spline_conv_fused`` (``_ops.py``); in training mode the reference's op sequence (conv.py:23-28,47-56) with the
+differentiable SplineConv of ``autograd.py`` and batch-statistics BatchNorm (``torch.nn.BatchNorm1d``, which is what the
+reference's BatchNormData wraps)."""
 import torch
 
 from . import _ops
@@ -11,9 +13,13 @@ from .spline_conv import MySplineConv
 from ..utils import shallow_copy
 
 
-def _eval_only(m):
-    if m.training:
-        raise NotImplementedError("training mode (batch statistics, backward) is outside this stack: call .eval()")
+def _bn(norm, x):
+    """BatchNormData.forward (components.py:9-12) on node features; a batch of < 2 rows has no batch statistics (torch
+    raises): such levels pass through the running statistics like an eval call."""
+    m = norm.module
+    if m.training and x.shape[0] < 2:
+        return torch.nn.functional.batch_norm(x, m.running_mean, m.running_var, m.weight, m.bias, False, 0.0, m.eps)
+    return m(x)
 
 
 def _require_relu(args):
@@ -29,7 +35,10 @@ class ConvBlock(torch.nn.Module):
         self.norm = BatchNormData(in_channels=out_channels)
 
     def forward(self, data):                                    # conv.py:23-28
-        _eval_only(self)
+        if self.training:
+            data = self.conv(data)
+            data.x = torch.relu(_bn(self.norm, data.x))
+            return data
         data.x = _ops.conv_on_data(self.conv, data, norm=self.norm, relu=True)
         return data
 
@@ -43,7 +52,11 @@ class ConvBlockWithSkip(ConvBlock):
         self.norm_skip = BatchNormData(in_channels=out_channel)
 
     def forward(self, data, data_skip):                         # conv.py:47-56
-        _eval_only(self)
+        if self.training:
+            data = self.conv(data)
+            skip = _bn(self.norm_skip, self.lin.mlp(data_skip.x))
+            data.x = torch.relu(_bn(self.norm, data.x) + skip)
+            return data
         data.x = _ops.conv_on_data(self.conv, data, norm=self.norm, skip=(self.lin, self.norm_skip), xskip=data_skip.x,
                                    relu=True)
         return data

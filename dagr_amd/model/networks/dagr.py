@@ -2,7 +2,8 @@
 and ``head`` = GNNHead), ``CNNHead`` (:106-122), ``GNNHead`` (:125-312, eval branch).  Sub-module
 names and parameter shapes follow the reference so ``ModelEMA(model).ema.load_state_dict(ckpt['ema'])``
 (scripts/run_test.py:57-58) works.  The forward pass is executed by ``dagr_amd.engine.WindowEngine``
-(hand-written HIP kernels behind include/dagr_hip.h); training losses are out of scope."""
+(hand-written HIP kernels behind include/dagr_hip.h) in eval mode; in training mode the layers run module by module
+with gradients (``model/layers/autograd.py``) and the head returns the YOLOX losses (``yolox_loss.py``)."""
 import torch
 
 from ..layers.conv import ConvBlock
@@ -68,30 +69,53 @@ class GNNHead(YOLOXHeadParams):
         obj_output = obj_pred(reg_feat, batch_size=batch_size)
         return cls_output, reg_output, obj_output
 
-    def forward(self, xin, output_sizes=None):
-        """Decoded ``[B, n_anchors, 5 + num_classes]`` from the backbone outputs (and the image outputs with
-        ``--use_image``); ``--no_events`` returns the image branch's own detections (dagr.py:283-284)."""
-        if self.training:
-            raise NotImplementedError("training losses are outside this stack")
+    def forward(self, xin, labels=None, imgs=None, output_sizes=None):
+        """Eval: decoded ``[B, n_anchors, 5 + num_classes]`` from the backbone outputs (and the image outputs with
+        ``--use_image``); ``--no_events`` returns the image branch's own detections (dagr.py:283-284).
+        Training (dagr.py:238-282): the YOLOX losses of the hybrid outputs (+ those of the image branch's own outputs
+        with ``--use_image``; only those with ``--pretrain_cnn``) as the 6-tuple ``get_losses`` returns."""
+        if output_sizes is None:
+            output_sizes = getattr(self, "output_sizes", None)
         out_cnn = None
+        image_labels = None
         if self.use_image:
             xin, image_feat = xin
+            if labels is not None:
+                labels, image_labels = labels
             image_feat = [torch.nn.functional.interpolate(f, o) for f, o in zip(image_feat, output_sizes)]
             out_cnn = self.cnn_head(image_feat)
         batch_size = len(out_cnn["cls_output"][0]) if self.use_image else self.batch_size
-        maps, image_maps = [], []
+        raw, image_raw = [], []          # per scale: [reg | obj | cls] logits
         for k, g in enumerate(xin):
             s = str(k + 1)
             cls_o, reg_o, obj_o = self.process_feature(g, *(getattr(self, n + s) for n in
                                                             ("stem", "cls_conv", "reg_conv", "cls_pred", "reg_pred",
                                                              "obj_pred")), batch_size=batch_size)
             if out_cnn is not None:
-                cls_o = cls_o + out_cnn["cls_output"][k]
-                reg_o = reg_o + out_cnn["reg_output"][k]
-                obj_o = obj_o + out_cnn["obj_output"][k]
-                image_maps.append(torch.cat([out_cnn["reg_output"][k], out_cnn["obj_output"][k].sigmoid(),
-                                             out_cnn["cls_output"][k].sigmoid()], 1))
-            maps.append(torch.cat([reg_o, obj_o.sigmoid(), cls_o.sigmoid()], 1))
+                # dagr.py:219-222,230-234: the image logits enter the hybrid sum detached
+                cls_o = cls_o + out_cnn["cls_output"][k].detach()
+                reg_o = reg_o + out_cnn["reg_output"][k].detach()
+                obj_o = obj_o + out_cnn["obj_output"][k].detach()
+                image_raw.append((out_cnn["reg_output"][k], out_cnn["obj_output"][k], out_cnn["cls_output"][k]))
+            raw.append((reg_o, obj_o, cls_o))
+        if self.training:
+            from .yolox_loss import detection_losses, output_and_grid
+
+            def losses(maps, lab):
+                outs, grids = zip(*(output_and_grid(torch.cat(m, 1), st) for m, st in zip(maps, self.strides)))
+                return detection_losses(lab, torch.cat(outs, 1), list(grids), self.strides[:len(maps)], self.num_classes)
+            if self.use_image:
+                # dagr.py:241-268: CNNHead always yields both scales; the image branch learns to detect on its own
+                both = [(out_cnn["reg_output"][k], out_cnn["obj_output"][k], out_cnn["cls_output"][k]) for k in (0, 1)]
+                loss_image = list(losses(both, image_labels))
+                if not self.pretrain_cnn:
+                    loss_events = losses(raw, labels)
+                    for i in range(5):
+                        loss_image[i] = loss_image[i] + loss_events[i]
+                return tuple(loss_image)
+            return losses(raw, labels)
+        maps = [torch.cat([r, o.sigmoid(), c.sigmoid()], 1) for r, o, c in raw]
+        image_maps = [torch.cat([r, o.sigmoid(), c.sigmoid()], 1) for r, o, c in image_raw]
         out = image_maps if self.no_events else maps
         outputs = torch.cat([o.flatten(start_dim=2) for o in out], dim=2).permute(0, 2, 1).contiguous()
         from ..utils import init_grid_and_stride
@@ -156,6 +180,20 @@ class DAGR(torch.nn.Module):
         x.reset = reset
         return self.head(self.backbone(x), output_sizes=self.backbone.get_output_sizes()[-self.head.num_scales:])
 
+    def forward_training(self, x):
+        """dagr.py:78-88 + ``YOLOX.forward`` (training branch): targets in (class, cx, cy, w, h) rows, the layers module
+        by module with gradients (differentiable SplineConv / pooling / to_dense over libdagr_hip, batch-statistics
+        BatchNorm), the YOLOX losses as a dict with the reference's keys."""
+        from ..utils import convert_to_training_format
+        targets = convert_to_training_format(x.bbox, x.bbox_batch, x.num_graphs)
+        if self.backbone.use_image:
+            targets = (targets, convert_to_training_format(x.bbox0, x.bbox0_batch, x.num_graphs))
+        self.head.output_sizes = self.backbone.get_output_sizes()[-self.head.num_scales:]
+        x.reset = True
+        loss, iou_loss, conf_loss, cls_loss, l1_loss, num_fg = self.head(self.backbone(x), targets, x)
+        return {"total_loss": loss, "iou_loss": iou_loss, "l1_loss": l1_loss, "conf_loss": conf_loss,
+                "cls_loss": cls_loss, "num_fg": num_fg}
+
     def _weights_stamp(self):
         """Cheap fingerprint of everything the engine snapshots (packed, BN-folded weights; the folded copy of the
         image branch): in-place edits bump ``_version``, ``.to()`` / ``load_state_dict`` on sub-modules
@@ -188,7 +226,7 @@ class DAGR(torch.nn.Module):
     # -- dagr.py:74-103 (eval branch) ----------------------------------------------------------
     def forward(self, x, reset=True, return_targets=True, filtering=True):
         if self.training:
-            raise NotImplementedError("training (losses, backward) is outside this round's scope")
+            return self.forward_training(x)
         eng = self.engine()
         if self._window is None:
             from ...asynchronous import StreamingWindow

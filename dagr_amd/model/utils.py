@@ -74,6 +74,23 @@ def convert_to_evaluation_format(data):
     return targets
 
 
+def convert_to_training_format(bbox, batch, batch_size):
+    """``model/utils.py:47-60``: per-sample rows (class, cx, cy, w, h) in pixels, zero-padded to 100 boxes."""
+    max_detections = 100
+    targets = torch.zeros((batch_size, max_detections, 5), dtype=torch.float32, device=bbox.device)
+    if bbox.shape[0] == 0:
+        return targets
+    # running index of every box inside its sample (boxes of a sample are contiguous, samples ascending)
+    first = torch.ones_like(batch, dtype=torch.bool)
+    first[1:] = batch[1:] != batch[:-1]
+    start = torch.arange(len(batch), device=batch.device)[first]
+    counter = torch.arange(len(batch), device=batch.device) - start[torch.cumsum(first.long(), 0) - 1]
+    rows = bbox[:, :5].clone().float()
+    rows[:, :2] += rows[:, 2:4] * .5                       # corner -> centre
+    targets[batch, counter] = torch.roll(rows, shifts=1, dims=1)
+    return targets
+
+
 def shallow_copy(data):
     """``model/utils.py:158-166``: a new ``Data`` sharing graph tensors with ``data`` but owning a copy of ``x`` (the
     cached CSR of the graph is shared, the reference's ``adj_t`` is not carried over -- it is recomputed there)."""

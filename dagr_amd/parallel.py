@@ -39,3 +39,25 @@ def restore_window_order(rows, window_col=0):
     ``run_test_interframe.py:34-45`` writes them in."""
     order = torch.argsort(rows[:, window_col], stable=True)
     return rows[order]
+
+
+def data_parallel(model, device, bucket_cap_mb=16):
+    """Data-parallel training replica (BASELINE config 5; the reference trains on one GPU, train_ncaltech101.py:130):
+    ``DistributedDataParallel`` over the default group -- gradients averaged by bucketed all-reduce (RCCL over xGMI on
+    GPUs) that overlaps the backward pass.  Choices that follow from this model and this fabric:
+      * the dense ``YOLOXHead`` module lists inside ``GNNHead`` (``stems``, ``cls_convs`` ... ``obj_preds``) exist only for
+        checkpoint compatibility and never run (dagr.py:137): they are frozen here so that the reducer does not wait for
+        gradients that never arrive (no ``find_unused_parameters`` graph walk per step);
+      * 16-MB buckets: dagr-l + head is O(10^7) parameters (~40 MB fp32), so three or four buckets let the first
+        all-reduce start while layer 2's backward still runs; a ring all-reduce over xGMI is bound by one ~153 GB/s link,
+        i.e. ~0.2 ms per bucket at 8 GPUs -- far below a step, so finer buckets would only add launch latency;
+      * ``broadcast_buffers=False``: BatchNorm running statistics stay per replica, as in the reference (no SyncBN)."""
+    head = getattr(model, "head", None)
+    if head is not None:
+        for name in ("stems", "cls_convs", "reg_convs", "cls_preds", "reg_preds", "obj_preds"):
+            sub = getattr(head, name, None)
+            if sub is not None:
+                sub.requires_grad_(False)
+    kw = dict(device_ids=[device.index], output_device=device.index) if device.type == "cuda" else {}
+    return torch.nn.parallel.DistributedDataParallel(model, broadcast_buffers=False, bucket_cap_mb=bucket_cap_mb,
+                                                     gradient_as_bucket_view=True, **kw)

@@ -165,9 +165,27 @@ def spline_conv(p, x, adj):
     return out
 
 
+_BATCH_STATISTICS = [False]
+
+
+class batch_statistics:
+    """Context: ``batch_norm_eval`` normalises with the statistics of the batch (``nn.BatchNorm1d`` in training mode,
+    what ``model.train()`` switches the reference's BatchNormData to: train_ncaltech101.py:49) instead of the running
+    ones.  The running buffers are left untouched (the oracle is functional)."""
+
+    def __enter__(self):
+        _BATCH_STATISTICS.append(True)
+
+    def __exit__(self, *exc):
+        _BATCH_STATISTICS.pop()
+
+
 def batch_norm_eval(x, bn):
     """PyG ``BatchNorm`` wraps ``nn.BatchNorm1d`` as ``.module`` (``components.py:9-12``); eval mode,
-    eps 1e-5 (restated at ``asynchronous/batch_norm.py:9-10`` and ``asy_tools/main.cu:66``)."""
+    eps 1e-5 (restated at ``asynchronous/batch_norm.py:9-10`` and ``asy_tools/main.cu:66``).  Inside
+    ``batch_statistics()``: training mode (biased batch variance, as torch normalises with)."""
+    if _BATCH_STATISTICS[-1] and x.shape[0] > 1:
+        return torch.nn.functional.batch_norm(x, None, None, bn["weight"], bn["bias"], training=True, eps=1e-5)
     return torch.nn.functional.batch_norm(x, bn["running_mean"], bn["running_var"], bn["weight"], bn["bias"],
                                           training=False, eps=1e-5)
 

@@ -1,0 +1,211 @@
+#!/usr/bin/env python
+"""Twin of the reference's ``scripts/train_ncaltech101.py`` (:41-182) on this stack, same flow through the same import
+paths (``dagr.*`` resolves to ``dagr_amd``): datasets with the training / testing augmentations -> loaders ->
+``DAGR(args, height, width).cuda()`` -> ``ModelEMA`` -> AdamW at ``l_r * sqrt(batch / 64)`` -> ``LambdaLR(LRSchedule)`` ->
+``Checkpointer`` -> per iteration: ``format_data`` -> ``model(data)`` (loss dict) -> backward -> ``clip_grad_value_`` ->
+NaN-gradient fix -> optimizer / scheduler step -> ``ema.update`` -> every third epoch a validation pass on ``ema.ema``.
+
+BASELINE config 5 runs it data-parallel: under ``torch.distributed.run`` (one process per GPU) every rank holds a
+replica, takes its slice of each global batch (``DataLoader(shard=(rank, world))``: same seeded permutation everywhere),
+and the gradients are averaged by ``DistributedDataParallel`` over RCCL -- bucketed all-reduce overlapped with the
+backward pass; BatchNorm statistics stay per replica (the reference has no SyncBN).  ``--batch_size`` is the GLOBAL batch
+(the learning-rate rule above refers to it).
+
+The N-Caltech101 reader needs h5py (absent here): with ``--dataset_directory`` it is used, without it the run is on
+``SyntheticObjects`` (labelled synthetic rectangles, 240 x 180).  mAP needs pycocotools; without it the validation pass
+reports the mean validation loss instead and the best-checkpoint logic keys on its negative.
+
+  python scripts/train_ncaltech101.py --epochs 3 --samples 256 --batch_size 16
+  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 scripts/train_ncaltech101.py --batch_size 64
+"""
+import argparse
+import random
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+import _common as C
+from dagr import parallel
+from dagr.data import DataLoader
+from dagr.data.augment import Augmentations
+from dagr.data.synthetic_data import SyntheticObjects
+from dagr.model.networks.dagr import DAGR
+from dagr.model.networks.ema import ModelEMA
+from dagr.utils.args import model_args
+from dagr.utils.buffers import format_data
+from dagr.utils.learning_rate_scheduler import LRSchedule
+from dagr.utils.logging import Checkpointer, log_hparams, set_up_logging_directory
+
+
+def flags():
+    p = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    p.add_argument("--dataset_directory", type=Path, default=None, help="root holding ncaltech101/{training,validation,annotations}")
+    p.add_argument("--output_directory", type=Path, default=Path("train_out"))
+    p.add_argument("--exp_name", default="train")
+    p.add_argument("--config", default="dagr-l", help="width preset; the N-Caltech101 settings of config/dagr-l-ncaltech.yaml apply")
+    p.add_argument("--batch_size", type=int, default=64, help="GLOBAL batch (config/dagr-l-ncaltech.yaml:14)")
+    p.add_argument("--epochs", type=int, default=801)
+    p.add_argument("--samples", type=int, default=512, help="synthetic training samples (no --dataset_directory)")
+    p.add_argument("--val_samples", type=int, default=64)
+    p.add_argument("--n_nodes", type=int, default=50000)
+    p.add_argument("--l_r", type=float, default=0.001)
+    p.add_argument("--weight_decay", type=float, default=0.00001)
+    p.add_argument("--clip", type=float, default=0.1)
+    p.add_argument("--max_iters", type=int, default=-1, help="stop after this many iterations (smoke runs)")
+    p.add_argument("--resume_checkpoint", type=Path, default=None)
+    return p
+
+
+def gradients_broken(model):
+    return any(p.grad is not None and bool(torch.isnan(p.grad).any()) for p in model.parameters())
+
+
+def fix_gradients(model):
+    """train_ncaltech101.py:36-39: NaN gradient entries become zeros before the step."""
+    for p in model.parameters():
+        if p.grad is not None:
+            torch.nan_to_num_(p.grad, nan=0.0)
+
+
+def train_epoch(loader, net, module, ema, scheduler, optimizer, clip, dev, log, max_iters=-1):
+    net.train()
+    for data in loader:
+        data = format_data(data.to(dev, non_blocking=True))
+        optimizer.zero_grad(set_to_none=True)
+        out = net(data)
+        loss = out["total_loss"]
+        loss.backward()                       # DDP: bucketed gradient all-reduce overlaps this call
+        torch.nn.utils.clip_grad_value_(module.parameters(), clip)
+        fix_gradients(module)
+        optimizer.step()
+        scheduler.step()
+        ema.update(module)
+        log.append({"loss": float(loss.detach()), "lr": float(scheduler.get_last_lr()[-1]),
+                    **{k: float(v) for k, v in out.items() if k != "total_loss"}})
+        if 0 < max_iters <= len(log):
+            return True
+    return False
+
+
+@torch.no_grad()
+def validate(loader, net, dev, dry_run_steps=-1):
+    """``run_test`` of the training script (:76-99): detections of ``ema.ema`` into the mAP buffer when pycocotools
+    exists; otherwise the mean training-mode loss of the validation batches (batch statistics, no parameter update)."""
+    from dagr.utils.buffers import DetectionBuffer
+    try:
+        import pycocotools  # noqa: F401
+        have_coco = True
+    except ImportError:
+        have_coco = False
+    if have_coco:
+        net.eval()
+        buf = DetectionBuffer(height=loader.dataset.height, width=loader.dataset.width, classes=loader.dataset.classes)
+        for i, data in enumerate(loader):
+            data = format_data(data.to(dev))
+            detections, targets = net(data)
+            buf.update(detections, targets, "ncaltech101", data.height[0], data.width[0])
+            if 0 < dry_run_steps == i:
+                break
+        return buf.compute()
+    was = net.training
+    net.train()
+    saved = {k: v.clone() for k, v in net.state_dict().items() if "running_" in k or "num_batches" in k}
+    tot, n = 0.0, 0
+    for i, data in enumerate(loader):
+        tot += float(net(format_data(data.to(dev)))["total_loss"])
+        n += 1
+        if 0 < dry_run_steps == i:
+            break
+    net.load_state_dict(saved, strict=False)       # the pass must not move the running statistics
+    net.train(was)
+    tot_t = torch.tensor([tot, float(n)], dtype=torch.float64, device=dev)
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.distributed.all_reduce(tot_t)
+    val = float(tot_t[0] / max(1.0, float(tot_t[1])))
+    return {"mAP": -val, "val_loss": val}
+
+
+def build(a, world, rank, dev, model_factory=None):
+    per_rank = a.batch_size // world
+    if per_rank * world != a.batch_size or per_rank < 1:
+        raise ValueError(f"--batch_size {a.batch_size} must be a positive multiple of the {world} ranks")
+    # config/dagr-l-ncaltech.yaml: one output scale, no flip, no zoom, 10 % translation
+    args = model_args(a.config, dataset="ncaltech101", num_scales=1, batch_size=per_rank, n_nodes=a.n_nodes,
+                      aug_trans=0.1, aug_p_flip=0, aug_zoom=1, l_r=a.l_r, weight_decay=a.weight_decay, clip=a.clip,
+                      tot_num_epochs=a.epochs)
+    aug = Augmentations(args)
+    if a.dataset_directory is not None:
+        from dagr.data.ncaltech101_data import NCaltech101
+        root = a.dataset_directory / "ncaltech101"
+        train_ds = NCaltech101(root, "training", aug.transform_training, num_events=args.n_nodes)
+        val_ds = NCaltech101(root, "validation", aug.transform_testing, num_events=args.n_nodes)
+    else:
+        train_ds = SyntheticObjects(a.samples, min(args.n_nodes, 20000), seed=7, transform=aug.transform_training)
+        val_ds = SyntheticObjects(a.val_samples, min(args.n_nodes, 20000), seed=100007, transform=aug.transform_testing)
+    follow = ["bbox", "bbox0"]
+    train_loader = DataLoader(train_ds, follow_batch=follow, batch_size=a.batch_size, shuffle=True, drop_last=True,
+                              shard=(rank, world), seed=42)
+    order = np.random.default_rng(42).permutation(len(val_ds)).tolist()     # :124 (a fixed random order)
+    val_loader = DataLoader(val_ds, sampler=order, follow_batch=follow, batch_size=a.batch_size, drop_last=True,
+                            shard=(rank, world))
+    if model_factory is not None:
+        model = model_factory(args, train_ds).to(dev)
+    else:
+        model = DAGR(args, height=train_ds.height, width=train_ds.width).to(dev)
+        model.cache_luts(width=train_ds.width, height=train_ds.height, radius=args.radius)
+    return args, train_loader, val_loader, model
+
+
+def main(argv=None, model_factory=None):
+    a = flags().parse_args(argv)
+    world, rank, dev = C.distributed()
+    seed = 42
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+    args, train_loader, val_loader, model = build(a, world, rank, dev, model_factory)
+    if rank == 0:
+        log_hparams(args)
+        print(f"Training with {sum(p.numel() for p in model.parameters())} number of parameters.")
+    ema = ModelEMA(model)
+    net = parallel.data_parallel(model, dev) if world > 1 else model
+    lr = float(args.l_r * np.sqrt(a.batch_size) / np.sqrt(64))                    # :132-133, nominal batch 64
+    optimizer = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=lr,
+                                  weight_decay=args.weight_decay)
+    schedule = LRSchedule(warmup_epochs=.3, num_iters_per_epoch=len(train_loader), tot_num_epochs=args.tot_num_epochs)
+    scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer=optimizer, lr_lambda=schedule)
+    out_dir = set_up_logging_directory("ncaltech101", "detection", a.output_directory, exp_name=a.exp_name)
+    ckpt = Checkpointer(output_directory=out_dir, model=model, optimizer=optimizer, scheduler=scheduler, ema=ema, args=args)
+    ckpt.mAP_max = float("-inf")            # the fallback metric (negative validation loss) is below the reference's 0
+    start_epoch = 0
+    if a.resume_checkpoint is not None:
+        start_epoch = ckpt.restore_checkpoint(a.resume_checkpoint, best=False)
+        if rank == 0:
+            print(f"Resume from checkpoint at epoch {start_epoch}")
+    log = []
+    t0 = time.perf_counter()
+    for epoch in range(start_epoch, args.tot_num_epochs):
+        stop = train_epoch(train_loader, net, model, ema, scheduler, optimizer, args.clip, dev, log, a.max_iters)
+        if rank == 0:
+            ckpt.checkpoint(epoch, name="last_model")
+            tail = log[-len(train_loader):] or log
+            print(f"epoch {epoch}: loss {np.mean([r['loss'] for r in tail]):.4f}  lr {log[-1]['lr']:.3e}  "
+                  f"{time.perf_counter() - t0:.1f} s")
+        if stop:
+            break
+        if epoch % 3 > 0:
+            continue
+        metrics = validate(val_loader, ema.ema if model_factory is None else model, dev)
+        if rank == 0:
+            print(f"epoch {epoch}: validation {metrics}")
+            ckpt.process(metrics, epoch)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    return out_dir, log
+
+
+if __name__ == "__main__":
+    main()

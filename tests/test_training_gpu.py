@@ -1,0 +1,198 @@
+"""GPU parity of the training path (BASELINE config 5): the differentiable operators over libdagr_hip
+(SplineConv, voxel pooling, to_dense) and the whole ``model.train()`` forward + backward against the CPU oracle pushed
+through torch autograd (oracle/ops.py with ``batch_statistics()``; the reference trains through torch_spline_conv /
+torch_scatter autograd on the same op sequence, train_ncaltech101.py:41-74, dagr.py:78-88,238-282).
+
+Bars: forward tensors 1e-4 (the eval bar); gradients 2e-3 of the tensor's largest magnitude (fp32 through ~14 convs with
+batch-statistics BatchNorm on both sides, atomics in the HIP scatter)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import graph as og
+from oracle import model as om
+from oracle import ops as oo
+from dagr_amd.data import Batch, Data
+from dagr_amd.utils import synthetic as syn
+from dagr_amd.utils.buffers import format_data
+from dagr_amd.utils.testing_weights import randomize_
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    if not a.numel():
+        return 0.0
+    return ((a - b).abs().max() / max(1e-12, float(b.abs().max()))).item()
+
+
+def _graph(W, H, B, n, seed):
+    x, y, t, p, b = syn.batch_windows(syn.edges_window, n, B, W, H, seed=seed)
+    pos = torch.from_numpy(syn.format_data_np(x, y, t, W, H))
+    r, dt = og.graph_params(0.01, W, 1000000)
+    d = og.denormalize_pos(pos.numpy(), W, H, 1000000)
+    ei = torch.from_numpy(og.build_window_graph(d[:, 0], d[:, 1], d[:, 2], b.astype(np.int32), W, H, B, r, dt, K=16, Q=128))
+    return pos, torch.from_numpy(b.astype(np.int64)), ei
+
+
+@pytest.mark.parametrize("aggr", ["max", "mean"])
+def test_pooling_backward_matches_scatter_autograd(aggr):
+    from dagr_amd.model.layers.components import Cartesian
+    from dagr_amd.model.layers.pooling import Pooling
+    W, H, B, C = 240, 180, 2, 8
+    pos, batch, ei = _graph(W, H, B, 1500, seed=11)
+    size = torch.tensor([1 / 14.0, 1 / 10.0, 1.0])
+    cart_max = float(2 * size[:2].max())
+    pool = Pooling(size, width=W, height=H, batch_size=B, transform=Cartesian(True, False, cart_max), aggr=aggr).cuda()
+    torch.manual_seed(3)
+    x = torch.randn(len(pos), C)
+    xo = x.clone().requires_grad_(True)
+    pp = oo.PoolingParams(size, W, H, B, cart_max, aggr=aggr)
+    x_ref, pos_ref, batch_ref, ei_ref, _ = oo.pooling(pp, xo, pos, batch, ei, exact_mean=True)
+    g = torch.randn_like(x_ref)
+    (x_ref * g).sum().backward()
+    xh = x.clone().cuda().requires_grad_(True)
+    data = Data(x=xh, pos=pos.cuda(), batch=batch.cuda(), edge_index=ei.cuda())
+    out = pool(data)
+    assert out.x.shape == x_ref.shape and torch.equal(out.batch.cpu(), batch_ref)
+    assert _rel(out.x, x_ref) < 1e-5
+    (out.x * g.cuda()).sum().backward()
+    assert _rel(xh.grad, xo.grad) < 1e-5
+
+
+def test_to_dense_backward_gathers_the_surviving_rows():
+    from dagr_amd.model.layers import _ops
+    B, C = 2, 5
+    pooling = torch.tensor([1 / 7.0, 1 / 5.0, 1.0])
+    torch.manual_seed(5)
+    cells = torch.randperm(35 * B)[:40]
+    b, cy, cx = cells // 35, (cells % 35) // 7, cells % 7
+    pos = torch.stack([(cx + 0.3) / 7, (cy + 0.6) / 5, torch.rand(40)], 1).float()
+    pos = torch.cat([pos, pos[:3]])                  # three shared cells: the later row survives, the earlier gets no gradient
+    b = torch.cat([b, b[:3]])
+    x = torch.randn(43, C)
+    xo = x.clone().requires_grad_(True)
+    ref = oo.to_dense(xo, pos, pooling, b, B)
+    g = torch.randn_like(ref)
+    (ref * g).sum().backward()
+    xh = x.clone().cuda().requires_grad_(True)
+    out = _ops.to_dense(xh, pos.cuda(), pooling.cuda(), b.cuda(), B)
+    assert torch.allclose(out.cpu(), ref.detach(), atol=0, rtol=0)
+    (out * g.cuda()).sum().backward()
+    assert torch.equal(xh.grad.cpu(), xo.grad)
+    assert float(xh.grad[:3].abs().sum()) == 0.0
+
+
+def _training_case(W, H, B, n, seed, **over):
+    from dagr_amd.model.networks.dagr import DAGR
+    torch.manual_seed(seed)
+    args = om.default_args(batch_size=B, **over)
+    model = randomize_(DAGR(args, height=H, width=W), seed=seed)
+    sd = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() and "running" not in k
+              else v.detach().clone()) for k, v in model.state_dict().items()}
+    model = model.cuda().train()
+    model.cache_luts(width=W, height=H, radius=args.radius)
+    samples, raw = [], []
+    rng = np.random.default_rng(seed)
+    for s in range(B):
+        x, y, t, p = syn.edges_window(n, W, H, seed=seed * 10 + s)
+        raw.append((x, y, t, p))
+        nb = 1 + s % 2
+        boxes = np.stack([rng.uniform(5, W / 2, nb), rng.uniform(5, H / 2, nb), rng.uniform(20, W / 3, nb),
+                          rng.uniform(20, H / 3, nb), rng.integers(0, 2, nb), np.ones(nb), np.zeros(nb)], 1)
+        samples.append(Data(x=torch.from_numpy(p.reshape(-1, 1)), pos=torch.from_numpy(np.stack([x, y], -1)),
+                            t=torch.from_numpy(t), width=W, height=H, time_window=1000000,
+                            bbox=torch.from_numpy(boxes.astype(np.float32)), sequence=f"s{s}"))
+    batch = Batch.from_data_list(samples, follow_batch=["bbox"])
+    ev = [np.concatenate([r[k] for r in raw]) for k in range(4)]
+    b = np.concatenate([np.full(len(r[0]), i, np.int64) for i, r in enumerate(raw)])
+    return args, model, sd, batch, ev, b
+
+
+def _oracle_losses(sd, args, H, W, ev, b, B, labels, num_classes):
+    from dagr_amd.model.networks.yolox_loss import detection_losses, output_and_grid   # host-side torch, device-agnostic
+    with oo.batch_statistics():
+        _, raw = om.forward_events(sd, args, H, W, ev[0], ev[1], ev[2], ev[3], b, B, use_lut=False)
+    nc = om.NetConstants(args, H, W)
+    outs, grids = zip(*(output_and_grid(torch.cat([r, o, c], 1), s) for (c, r, o), s in zip(raw, nc.strides)))
+    return detection_losses(labels, torch.cat(outs, 1), list(grids), nc.strides, num_classes), raw
+
+
+@pytest.mark.parametrize("case", [dict(W=240, H=180, B=2, n=2500, seed=1),
+                                  dict(W=320, H=215, B=3, n=1500, seed=2, over=dict(num_scales=1))],
+                         ids=["two_scales", "one_scale"])
+def test_training_loss_and_gradients_match_the_oracle(case):
+    from dagr_amd.model.utils import convert_to_training_format
+    W, H, B = case["W"], case["H"], case["B"]
+    args, model, sd, batch, ev, b = _training_case(W, H, B, case["n"], case["seed"], **case.get("over", {}))
+    labels = convert_to_training_format(batch.bbox, batch.bbox_batch, B)
+    ref, _ = _oracle_losses(sd, args, H, W, ev, b, B, labels, model.backbone.num_classes)
+    ref[0].backward()
+    out = model(format_data(batch.cuda()))
+    assert set(out) == {"total_loss", "iou_loss", "l1_loss", "conf_loss", "cls_loss", "num_fg"}
+    assert out["num_fg"] == ref[5], "SimOTA matched a different number of anchors"
+    for k, r in zip(("total_loss", "iou_loss", "conf_loss", "cls_loss"), (ref[0], ref[1], ref[2], ref[3])):
+        assert abs(float(out[k]) - float(r)) <= 1e-4 * max(1.0, abs(float(r))), (k, float(out[k]), float(r))
+    out["total_loss"].backward()
+    params = dict(model.named_parameters())
+    checked, worst = 0, (0.0, "")
+    for k, v in sd.items():
+        if not v.requires_grad or v.grad is None:
+            assert k not in params or params[k].grad is None or float(params[k].grad.abs().max()) == 0.0, k
+            continue
+        gh = params[k].grad
+        assert gh is not None, f"no gradient reached {k}"
+        e = _rel(gh, v.grad)
+        worst = max(worst, (e, k))
+        checked += 1
+    assert checked >= 60
+    assert worst[0] < 2e-3, worst
+    # batch statistics moved the running buffers (momentum 0.1), as nn.BatchNorm1d does in the reference
+    bn = model.backbone.conv_block1.conv_block1.norm.module
+    assert int(bn.num_batches_tracked) == 1 and float(bn.running_mean.abs().sum()) > 0
+
+
+def test_a_few_optimizer_steps_reduce_the_loss():
+    W, H, B = 240, 180, 2
+    args, model, _, batch, _, _ = _training_case(W, H, B, 2000, seed=4)
+    opt = torch.optim.AdamW(model.parameters(), lr=2e-3, weight_decay=1e-5)      # train_ncaltech101.py:134
+    losses = []
+    for _ in range(6):
+        opt.zero_grad(set_to_none=True)
+        out = model(format_data(batch.clone().cuda()))
+        out["total_loss"].backward()
+        torch.nn.utils.clip_grad_value_(model.parameters(), 0.1)                 # train_ncaltech101.py:61, clip: 0.1
+        opt.step()
+        losses.append(float(out["total_loss"]))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def test_train_script_on_the_hip_layers_then_evaluate_the_checkpoint(tmp_path):
+    """scripts/train_ncaltech101.py for a few iterations on SyntheticObjects (dagr-s widths, one scale), then the
+    checkpoint's ``ema`` state into a fresh model and an eval-mode forward through the window engine (run_test.py:54-62)."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "scripts"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    import train_ncaltech101 as T
+    from dagr_amd.data import DataLoader
+    from dagr_amd.data.synthetic_data import SyntheticObjects
+    from dagr_amd.model.networks.dagr import DAGR
+    from dagr_amd.model.networks.ema import ModelEMA
+    out_dir, log = T.main(["--config", "dagr-s", "--epochs", "1", "--samples", "12", "--val_samples", "4", "--batch_size", "4",
+                           "--n_nodes", "3000", "--output_directory", str(tmp_path), "--l_r", "0.002"])
+    assert len(log) == 3 and all(np.isfinite(r["loss"]) for r in log)
+    state = torch.load(out_dir / "last_model.pth", weights_only=False)
+    assert state["ema_updates"] == 3
+    ds = SyntheticObjects(4, 3000, seed=100007)
+    model = DAGR(state["args"], height=ds.height, width=ds.width).cuda()
+    ema = ModelEMA(model)
+    ema.ema.load_state_dict(state["ema"])                                      # strict, run_test.py:57-58
+    ema.ema.cache_luts(radius=state["args"].radius, height=ds.height, width=ds.width)
+    batch = next(iter(DataLoader(ds, batch_size=4, follow_batch=["bbox"])))
+    with torch.no_grad():
+        detections, targets = ema.ema(format_data(batch.cuda()))
+    assert len(detections) == 4 and len(targets) == 4 and all(torch.isfinite(d["boxes"]).all() for d in detections)
