@@ -92,7 +92,7 @@ SIGNATURES = {
     "dagr_pool_grad": (ctypes.c_int, [c_void_p, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_i32,
                                       c_void_p]),
     "dagr_to_dense_grad": (ctypes.c_int, [c_i32, c_i32, c_void_p, c_void_p, c_float, c_float, c_i32, c_i32, c_i32, c_void_p,
-                                          c_void_p, c_void_p, c_i32, c_void_p]),
+                                          c_void_p, c_i32, c_void_p]),
     "dagr_sample_features": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_void_p, c_i32, c_void_p, c_i32, c_i32, c_i32,
                                             c_i32, c_i32, c_i32, c_void_p, c_i32, c_i32, c_void_p]),
     "dagr_nms_batched": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_float, c_float, c_void_p,

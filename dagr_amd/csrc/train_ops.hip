@@ -1,12 +1,14 @@
 // train_ops.hip -- backward halves of the training path (BASELINE config 5).
 // The reference trains through torch_scatter's autograd (Pooling: scatter_max / scatter_mean, pooling.py:74-77) and
 // torch's index_put backward (to_dense, spline_conv.py:80-107).  Both are pure gathers once the forward's choice
-// (arg-max member per (cluster, channel); surviving node per map cell) is known, so neither needs an atomic:
+// (the arg-max member per (cluster, channel)) is known, so neither needs a float atomic:
 //   * k_pool_argmax : arg[c, ch] = LOWEST node index among the members of cluster c whose x equals the pooled maximum
 //                     (torch_scatter's CPU reducer keeps the first maximum; its CUDA kernel's choice among ties is
 //                     unspecified) -- the only atomic, an integer min
 //   * k_pool_grad   : gx[n, ch] = g[cluster[n], ch] if arg == n else 0   (max)   |   g[cluster[n], ch] / count (mean)
-//   * k_dense_grad  : gx[n, ch] = gdense[b, ch, cy, cx] if n survived in its cell else 0
+//   * k_dense_grad  : gx[n, ch] = gdense[b, ch, cy, cx] for EVERY node inside the map -- also the ones a later node of the
+//                     same cell overwrote: torch's index_put backward is grad[indices] over all written rows, and that is
+//                     what the reference back-propagates (held to its code by tests/golden/ref_py_model.npz, train_*)
 // All HBM streaming: 4 C n bytes read + 4 C n written per pass, coalesced along the channel axis.
 #include "common.hpp"
 
@@ -46,15 +48,15 @@ __global__ __launch_bounds__(kBlock) void k_pool_grad(const int32_t *__restrict_
 
 __global__ __launch_bounds__(kBlock) void k_dense_grad(int64_t total, int C, const float *__restrict__ pos,
                                                       const int32_t *__restrict__ batch, float vx, float vy, int B,
-                                                      int Hc, int Wc, const int32_t *__restrict__ winner,
-                                                      const float *__restrict__ gdense, float *__restrict__ gx,
+                                                      int Hc, int Wc, const float *__restrict__ gdense,
+                                                      float *__restrict__ gx,
                                                       int ldgx) {
     const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (gid >= total) return;
     const int n = (int)(gid / C), ch = (int)(gid % C);
     const int cx = (int)(pos[3 * n] / vx), cy = (int)(pos[3 * n + 1] / vy), b = batch[n];
     float v = 0.0f;
-    if (cx >= 0 && cx < Wc && cy >= 0 && cy < Hc && b >= 0 && b < B && winner[(b * Hc + cy) * Wc + cx] == n)
+    if (cx >= 0 && cx < Wc && cy >= 0 && cy < Hc && b >= 0 && b < B)
         v = gdense[(((size_t)b * C + ch) * Hc + cy) * Wc + cx];
     gx[(size_t)n * ldgx + ch] = v;
 }
@@ -96,14 +98,14 @@ int dagr_pool_grad(const int32_t *cluster, int32_t n, int32_t channels, int32_t 
 }
 
 int dagr_to_dense_grad(int32_t n, int32_t channels, const float *pos, const int32_t *batch, float vx, float vy,
-                       int32_t batch_size, int32_t Hc, int32_t Wc, const int32_t *winner, const float *gdense,
-                       float *gx, int32_t ldgx, void *stream_) {
+                       int32_t batch_size, int32_t Hc, int32_t Wc, const float *gdense, float *gx, int32_t ldgx,
+                       void *stream_) {
     DAGR_CHECK_ARG(n >= 0 && channels > 0 && batch_size > 0 && Hc > 0 && Wc > 0 && ldgx >= channels, "bad sizes");
     if (n == 0) return DAGR_OK;
-    DAGR_CHECK_ARG(pos && batch && winner && gdense && gx, "NULL pointer");
+    DAGR_CHECK_ARG(pos && batch && gdense && gx, "NULL pointer");
     const int64_t total = (int64_t)n * channels;
     k_dense_grad<<<(unsigned)ceil_div(total, kBlock), kBlock, 0, (hipStream_t)stream_>>>(
-        total, channels, pos, batch, vx, vy, batch_size, Hc, Wc, winner, gdense, gx, ldgx);
+        total, channels, pos, batch, vx, vy, batch_size, Hc, Wc, gdense, gx, ldgx);
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;
 }

@@ -109,7 +109,8 @@ class PoolFeatFn(torch.autograd.Function):
 
 class ToDenseFn(torch.autograd.Function):
     """``to_dense`` (spline_conv.py:80-107): rows scattered into a zeroed [B, C, Hc, Wc] map; backward gathers the map's
-    gradient at the cell of every node that survived there."""
+    gradient at the cell of every node -- overwritten duplicates included, as torch's index_put backward does in the
+    reference (pinned by the reference's own training branch: tests/golden/ref_py_model.npz)."""
 
     @staticmethod
     def forward(ctx, x, pos, batch, vx, vy, batch_size, Hc, Wc):
@@ -126,18 +127,18 @@ class ToDenseFn(torch.autograd.Function):
             _lib.check(L.dagr_to_dense(P(n_ptr), n, P(x.detach().float().contiguous()), C, C, P(pos), P(batch), vx, vy,
                                        batch_size, Hc, Wc, P(winner), P(dense), P(status), _lib.cur_stream(dev)),
                        "to_dense")
-        ctx.save_for_backward(pos, batch, winner)
+        ctx.save_for_backward(pos, batch)
         ctx.meta = (n, C, vx, vy, batch_size, Hc, Wc)
         return dense
 
     @staticmethod
     def backward(ctx, g):
         L, P = _lib.lib(), _lib.ptr
-        pos, batch, winner = ctx.saved_tensors
+        pos, batch = ctx.saved_tensors
         n, C, vx, vy, B, Hc, Wc = ctx.meta
         g = g.float().contiguous()
         gx = torch.empty((n, C), dtype=torch.float32, device=g.device)
         if n:
-            _lib.check(L.dagr_to_dense_grad(n, C, P(pos), P(batch), vx, vy, B, Hc, Wc, P(winner), P(g), P(gx), C,
+            _lib.check(L.dagr_to_dense_grad(n, C, P(pos), P(batch), vx, vy, B, Hc, Wc, P(g), P(gx), C,
                                             _lib.cur_stream(g.device)), "to_dense_grad")
         return gx, None, None, None, None, None, None, None

@@ -313,10 +313,11 @@ int dagr_pool_argmax(const int32_t *cluster, int32_t n, const float *x, int32_t 
 int dagr_pool_grad(const int32_t *cluster, int32_t n, int32_t channels, int32_t aggr, const int32_t *arg,
                    const int32_t *count, const float *grad_pooled, int32_t ldg, float *grad_x, int32_t ldgx,
                    void *stream);
-/* to_dense (spline_conv.py:80-107) backward: grad_x[n, :] = grad_dense[batch[n], :, cy, cx] for the node that
- * survived in its cell (winner = the scratch dagr_to_dense filled), 0 for overwritten / out-of-map nodes. */
+/* to_dense (spline_conv.py:80-107) backward: grad_x[n, :] = grad_dense[batch[n], :, cy, cx] for every node inside the
+ * map (0 outside) -- INCLUDING nodes whose row a later node of the same cell overwrote in the forward: torch's
+ * index_put backward gathers grad[indices] for all written rows, which is what the reference back-propagates. */
 int dagr_to_dense_grad(int32_t n, int32_t channels, const float *pos, const int32_t *batch, float vx, float vy,
-                       int32_t batch_size, int32_t Hc, int32_t Wc, const int32_t *winner, const float *grad_dense,
+                       int32_t batch_size, int32_t Hc, int32_t Wc, const float *grad_dense,
                        float *grad_x, int32_t ldgx, void *stream);
 
 /* y = relu(y + z) in place over n floats (16-byte aligned buffers of identical layout): the residual join of the

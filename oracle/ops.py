@@ -297,4 +297,18 @@ def to_dense(x, pos, pooling_size, batch, batch_size):
     last = torch.full((batch_size * int(H) * int(W),), -1, dtype=torch.long).scatter_reduce_(0, cell, order, "amax")
     keep = last[cell] == order
     dense[b[keep], :, est_y[keep], est_x[keep]] = x[keep]
+    if x.requires_grad and not bool(keep.all()):
+        # training: torch's index_put backward hands EVERY written row the gradient of its cell (grad_values =
+        # grad[indices]), the overwritten duplicates included -- that is what the reference back-propagates
+        # (spline_conv.py:105).  The losers add an exact zero here, which routes them the same gradient.
+        dense = _route_losers(dense, x, b, est_y, est_x, ~keep)
     return dense
+
+
+def _route_losers(dense, x, b, est_y, est_x, lose):
+    zero = x[lose] - x[lose].detach()
+    C = x.shape[1]
+    idx_b = b[lose].view(-1, 1).expand(-1, C)
+    idx_c = torch.arange(C).view(1, -1).expand(int(lose.sum()), -1)
+    return dense.index_put((idx_b, idx_c, est_y[lose].view(-1, 1).expand(-1, C), est_x[lose].view(-1, 1).expand(-1, C)),
+                           zero, accumulate=True)

@@ -1,0 +1,43 @@
+"""CPU oracle of one training forward (BASELINE config 5; ``scripts/train_ncaltech101.py:49-58``): ``model.train()`` ->
+``DAGR.forward`` training branch (dagr.py:78-88) -> ``YOLOX.forward`` -> ``GNNHead.forward`` losses (dagr.py:238-282).
+
+TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py.  The forward is ``oracle.model.forward_events`` on the non-LUT
+message path (``cache_luts`` is an evaluation-time step, run_test.py:59; training evaluates the spline basis on the edge
+attributes, spline_conv.py:64-78) with batch-statistics BatchNorm (``oracle.ops.batch_statistics``); torch autograd through
+those restatements gives the gradients the GPU path is compared with.  Pinned to the reference's own code by
+``tests/golden/ref_py_model.npz`` (training cases of tests/make_golden_refpy_model.py); the loss itself is third-party
+(``oracle/yolox_loss.py``: parity unpinned)."""
+import torch
+
+from . import model as om
+from . import ops
+from .yolox_loss import LossHead
+
+
+def sequential_counter(counts):
+    """``_sequential_counter`` (model/utils.py:136-156): [2, 3] -> [0, 1, 0, 1, 2]."""
+    return torch.cat([torch.arange(int(c)) for c in counts]) if len(counts) else torch.zeros(0, dtype=torch.long)
+
+
+def convert_to_training_format(bbox, batch, batch_size):
+    """``model/utils.py:47-60``: rows (x, y, w, h, class, ...) -> [B, 100, 5] of (class, cx, cy, w, h), zero padded."""
+    targets = torch.zeros((batch_size, 100, 5), dtype=torch.float32)
+    _, counts = torch.unique(batch, return_counts=True)
+    counter = sequential_counter(counts)
+    bbox = bbox.clone()
+    bbox[:, :2] += bbox[:, 2:4] * .5
+    bbox = torch.roll(bbox[:, :5], dims=1, shifts=1)
+    targets[batch, counter] = bbox
+    return targets
+
+
+def training_losses(sd, args, height, width, x, y, t, p, b, batch_size, bbox, bbox_batch):
+    """The 6-tuple of ``get_losses`` (total, 5*iou, obj, cls, l1 = 0, matched anchors / ground truths) for one batch of
+    windows; ``sd`` may hold leaf tensors that require grad."""
+    nc = om.NetConstants(args, height, width)
+    with ops.batch_statistics():
+        _, raw = om.forward_events(sd, args, height, width, x, y, t, p, b, batch_size, use_lut=False)
+    maps = [torch.cat([reg_o, obj_o, cls_o], 1) for (cls_o, reg_o, obj_o) in raw]      # collect_outputs, dagr.py:293-294
+    labels = convert_to_training_format(bbox, bbox_batch, batch_size)
+    head = LossHead(nc.num_classes if hasattr(nc, "num_classes") else maps[0].shape[1] - 5, len(maps))
+    return head.losses_from_maps(maps, nc.strides, labels)

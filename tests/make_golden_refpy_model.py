@@ -34,6 +34,15 @@ CASES = [  # name, W, H, B, events/sample, stream, seed, model overrides
                                                           dataset="ncaltech101")),
 ]
 
+TRAIN_CASES = [
+    ("train_s_b2", 240, 180, 2, 2500, "edges", 21, {}),
+    ("train_l_ncaltech_b3", 240, 180, 3, 1500, "edges", 22, dict(net_stem_width=1.0, yolo_stem_width=1.0, num_scales=1,
+                                                                dataset="ncaltech101")),
+]
+TRAIN_GRAD_KEYS = ["backbone.conv_block1.conv_block1.conv.weight", "backbone.conv_block1.conv_block2.lin.mlp.weight",
+                   "backbone.layer3.conv_block1.norm.module.weight", "backbone.layer5.conv_block2.conv.lin.weight",
+                   "head.stem1.conv.weight", "head.cls_pred1.bias", "head.reg_pred1.weight", "head.obj_pred2.bias"]
+
 
 def main():
     import refpy_fakes
@@ -69,6 +78,45 @@ def main():
         print(name, "outputs", tuple(outputs.shape), "edges", int(data.edge_index.shape[1]) if hasattr(data, "edge_index") else "-")
         out.update({f"{name}_x": x, f"{name}_y": y, f"{name}_t": t, f"{name}_p": p, f"{name}_b": b,
                     f"{name}_out": outputs.numpy()})
+    # ---- training mode (train_ncaltech101.py:49-58): the reference's own DAGR.forward training branch -> YOLOX.forward ->
+    # GNNHead.forward losses; no cache_luts (an evaluation-time step, run_test.py:59): MySplineConv evaluates the spline
+    # basis on the edge attributes; BatchNorm on batch statistics; the losses are the restated yolox ones
+    # (oracle/yolox_loss.py).  Stored: events, boxes, the six outputs, gradients of a few parameters along the depth.
+    for name, W, H, B, n, stream, seed, over in TRAIN_CASES:
+        args = om.default_args(batch_size=B, **over)
+        torch.manual_seed(seed)
+        mirror = randomize_(MirrorDAGR(args, height=H, width=W), seed=seed)
+        ref = rdagr.DAGR(argparse.Namespace(**vars(args)), height=H, width=W)
+        ref.load_state_dict(mirror.state_dict(), strict=True)
+        ref.train()
+        gen = syn.uniform_window if stream == "uniform" else syn.edges_window
+        x, y, t, p, b = syn.batch_windows(gen, n, B, W, H, seed=seed * 3 + 1)
+        rng = np.random.default_rng(seed)
+        counts = [1 + (s + seed) % 3 for s in range(B)]
+        counts[-1] = 0 if B > 2 else counts[-1]            # a sample without boxes
+        bbox = np.concatenate([np.stack([rng.uniform(5, W / 2, c), rng.uniform(5, H / 2, c), rng.uniform(20, W / 3, c),
+                                         rng.uniform(20, H / 3, c), rng.integers(0, 2, c).astype(float), np.ones(c),
+                                         np.zeros(c)], 1) for c in counts]).astype(np.float32)
+        bbox_batch = np.concatenate([np.full(c, s, np.int64) for s, c in enumerate(counts)])
+        data = refpy_fakes.Data(x=torch.from_numpy(p.astype(np.float32)).view(-1, 1),
+                                pos=torch.from_numpy(syn.format_data_np(x, y, t, W, H)), batch=torch.from_numpy(b),
+                                width=torch.tensor([W] * B), height=torch.tensor([H] * B),
+                                time_window=torch.tensor([1000000] * B), num_graphs=B,
+                                bbox=torch.from_numpy(bbox), bbox_batch=torch.from_numpy(bbox_batch))
+        losses = ref(data)
+        losses["total_loss"].backward()
+        grads = {k: v.grad for k, v in ref.named_parameters() if v.grad is not None}
+        picked = [k for k in TRAIN_GRAD_KEYS if k in grads]
+        print(name, {k: float(v) for k, v in losses.items()}, len(grads), "parameters with gradients")
+        out.update({f"{name}_x": x, f"{name}_y": y, f"{name}_t": t, f"{name}_p": p, f"{name}_b": b, f"{name}_bbox": bbox,
+                    f"{name}_bbox_batch": bbox_batch,
+                    f"{name}_losses": np.array([float(losses[k]) for k in ("total_loss", "iou_loss", "conf_loss",
+                                                                           "cls_loss", "l1_loss", "num_fg")]),
+                    f"{name}_grad_keys": np.array(picked),
+                    f"{name}_n_grads": np.array(len(grads))})
+        for k in picked:
+            out[f"{name}_grad:{k}"] = grads[k].numpy()
+
     # ---- EV_TGN over consecutive calls: reset=True, reset=False (nodes attach to the running graph), reset=True
     import dagr.model.layers.ev_tgn as rtgn
     W, H, B = 64, 48, 2

@@ -147,22 +147,32 @@ class BatchNorm(torch.nn.Module):
 
 # ------------------------------------------------------------------------------------------ yolox
 class YOLOX(torch.nn.Module):
+    """yolox.models.YOLOX: ``forward(x, targets)`` -- eval: head(backbone(x)); training: the head's six loss terms as a
+    dict (what ``DAGR.forward`` returns in training mode, dagr.py:86-88)."""
+
     def __init__(self, backbone=None, head=None):
         super().__init__()
         self.backbone, self.head = backbone, head
 
     def forward(self, x, targets=None):
-        assert not self.training
-        return self.head(self.backbone(x))
+        fpn_outs = self.backbone(x)
+        if self.training:
+            assert targets is not None
+            loss, iou_loss, conf_loss, cls_loss, l1_loss, num_fg = self.head(fpn_outs, targets, x)
+            return {"total_loss": loss, "iou_loss": iou_loss, "l1_loss": l1_loss, "conf_loss": conf_loss,
+                    "cls_loss": cls_loss, "num_fg": num_fg}
+        return self.head(fpn_outs)
 
 
 def _yolox_head_base():
     """yolox.models.YOLOXHead as far as the reference uses it: the dense conv towers (stems, cls/reg convs and
     preds) that CNNHead.forward runs and every checkpoint carries -- the host mirror's parameter-compatible
-    re-declaration (dagr_amd/model/networks/yolox_min.py)."""
+    re-declaration (dagr_amd/model/networks/yolox_min.py) -- and the training losses ``GNNHead`` inherits
+    (oracle/yolox_loss.py: the published algorithm, restated)."""
     from dagr_amd.model.networks.yolox_min import YOLOXHeadParams
+    from oracle.yolox_loss import YOLOXLossMixin
 
-    class YOLOXHead(YOLOXHeadParams):
+    class YOLOXHead(YOLOXHeadParams, YOLOXLossMixin):
         def __init__(self, num_classes, width=1.0, strides=(8, 16, 32), in_channels=(256, 512, 1024), act="silu",
                      depthwise=False):
             assert not depthwise
@@ -182,9 +192,7 @@ def _tv_resnet(name):
     return ctor
 
 
-class IOUloss(torch.nn.Module):
-    def __init__(self, reduction="none", loss_type="iou"):
-        super().__init__()
+from oracle.yolox_loss import IOUloss  # noqa: E402  (yolox.models.IOUloss, restated)
 
 
 # ------------------------------------------------------------------------------------------ ev_graph_cuda

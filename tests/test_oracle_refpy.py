@@ -287,3 +287,39 @@ def test_in_repo_restatements_of_third_party_primitives():
         pos4 = torch.cat([p2, torch.zeros(len(p2), 2)], 1)          # t = 0, sample 0
         got = oo.grid_cluster(pos4, pp.voxel_size, pp.start, pp.end)
         assert torch.equal(got, torch.from_numpy(GM[f"vox{i}_idx"]))
+
+
+@pytest.mark.parametrize("name,W,H,B,seed,over", [
+    ("train_s_b2", 240, 180, 2, 21, {}),
+    ("train_l_ncaltech_b3", 240, 180, 3, 22, dict(net_stem_width=1.0, yolo_stem_width=1.0, num_scales=1,
+                                                  dataset="ncaltech101")),
+])
+def test_training_forward_and_gradients_match_the_reference_code(name, W, H, B, seed, over):
+    """oracle.train.training_losses + torch autograd (what the GPU training tests compare the HIP path with) vs the
+    reference's OWN training branch -- DAGR.forward (dagr.py:78-88) -> YOLOX.forward -> GNNHead.forward (:238-282) over
+    Net / Layer / MySplineConv (spline-basis message) / Pooling / BatchNorm on batch statistics -- run on CPU by
+    tests/make_golden_refpy_model.py: the six outputs and the gradients of parameters along the depth of the network."""
+    from oracle import train as otr
+    from dagr_amd.model.networks.dagr import DAGR
+    from dagr_amd.model.utils import convert_to_training_format
+    from dagr_amd.utils.testing_weights import randomize_
+    args = om.default_args(batch_size=B, **over)
+    torch.manual_seed(seed)
+    model = randomize_(DAGR(args, height=H, width=W), seed=seed)
+    sd = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() and "running" not in k
+              else v.detach().clone()) for k, v in model.state_dict().items()}
+    bbox, bbox_batch = torch.from_numpy(GM[f"{name}_bbox"]), torch.from_numpy(GM[f"{name}_bbox_batch"])
+    # the mirror's target formatting == the reference's convert_to_training_format (run inside the golden forward)
+    assert torch.equal(convert_to_training_format(bbox, bbox_batch, B), otr.convert_to_training_format(bbox, bbox_batch, B))
+    out = otr.training_losses(sd, args, H, W, GM[f"{name}_x"], GM[f"{name}_y"], GM[f"{name}_t"], GM[f"{name}_p"],
+                              GM[f"{name}_b"], B, bbox, bbox_batch)
+    want = GM[f"{name}_losses"]          # total, iou, conf, cls, l1, num_fg
+    got = [float(out[0]), float(out[1]), float(out[2]), float(out[3]), float(out[4]), float(out[5])]
+    assert np.allclose(got, want, rtol=2e-6, atol=1e-6), (got, want.tolist())
+    out[0].backward()
+    n_grads = sum(1 for v in sd.values() if v.requires_grad and v.grad is not None)
+    assert n_grads == int(GM[f"{name}_n_grads"])
+    for k in GM[f"{name}_grad_keys"]:
+        g_ref = torch.from_numpy(GM[f"{name}_grad:{k}"])
+        g = sd[str(k)].grad
+        assert float((g - g_ref).abs().max()) <= 2e-5 * max(1e-6, float(g_ref.abs().max())), k

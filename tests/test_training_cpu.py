@@ -285,3 +285,31 @@ def test_train_script_data_parallel_equals_single_process(tmp_path):
     assert l1[-1]["loss"] < l1[0]["loss"]
     best = [p for p in os.listdir(os.path.join(str(tmp_path / "w2"), "ncaltech101", "detection", "train")) if "best" in p]
     assert best, "validation pass did not record a best checkpoint"
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_product_loss_equals_the_literal_oracle_restatement(seed):
+    """dagr_amd/model/networks/yolox_loss.py (vectorised) against oracle/yolox_loss.py (the published YOLOX code path,
+    loops and all) on random head maps: same assignment, same six outputs, same gradient."""
+    from oracle.yolox_loss import LossHead
+    g = torch.Generator().manual_seed(100 + seed)
+    B, C = 3, (2 if seed % 2 else 5)
+    shapes, strides = ([(10, 14), (5, 7)], [22, 43]) if seed % 3 else ([(5, 7)], [43])
+    maps = [torch.randn(B, 5 + C, h, w, generator=g) * 1.5 for h, w in shapes]
+    labels = torch.zeros(B, 100, 5)
+    for b in range(B):
+        for k in range(int(torch.randint(0, 4, (1,), generator=g))):
+            cx, cy = torch.rand(2, generator=g) * torch.tensor([300.0, 200.0])
+            wh = 15 + torch.rand(2, generator=g) * 120
+            labels[b, k] = torch.tensor([float(torch.randint(0, C, (1,), generator=g)), cx, cy, wh[0], wh[1]])
+    ref_maps = [m.clone().requires_grad_(True) for m in maps]
+    ref = LossHead(C, len(shapes)).losses_from_maps([m * 1 for m in ref_maps], strides, labels)   # (cat output: not a leaf)
+    my_maps = [m.clone().requires_grad_(True) for m in maps]
+    outs, grids = zip(*(yl.output_and_grid(m, s) for m, s in zip(my_maps, strides)))
+    mine = yl.detection_losses(labels, torch.cat(outs, 1), list(grids), strides, C)
+    for a, b in zip(mine, ref):
+        assert float(a) == pytest.approx(float(b), rel=1e-5, abs=1e-6)
+    ref[0].backward()
+    mine[0].backward()
+    for a, b in zip(my_maps, ref_maps):
+        assert torch.allclose(a.grad, b.grad, rtol=1e-4, atol=1e-6)

@@ -61,7 +61,7 @@ def test_pooling_backward_matches_scatter_autograd(aggr):
     assert _rel(xh.grad, xo.grad) < 1e-5
 
 
-def test_to_dense_backward_gathers_the_surviving_rows():
+def test_to_dense_backward_gathers_every_written_row():
     from dagr_amd.model.layers import _ops
     B, C = 2, 5
     pooling = torch.tensor([1 / 7.0, 1 / 5.0, 1.0])
@@ -69,7 +69,8 @@ def test_to_dense_backward_gathers_the_surviving_rows():
     cells = torch.randperm(35 * B)[:40]
     b, cy, cx = cells // 35, (cells % 35) // 7, cells % 7
     pos = torch.stack([(cx + 0.3) / 7, (cy + 0.6) / 5, torch.rand(40)], 1).float()
-    pos = torch.cat([pos, pos[:3]])                  # three shared cells: the later row survives, the earlier gets no gradient
+    pos = torch.cat([pos, pos[:3]])                  # three shared cells: the later row survives; index_put's backward
+    #                                                  still hands the overwritten rows their cell's gradient
     b = torch.cat([b, b[:3]])
     x = torch.randn(43, C)
     xo = x.clone().requires_grad_(True)
@@ -81,7 +82,7 @@ def test_to_dense_backward_gathers_the_surviving_rows():
     assert torch.allclose(out.cpu(), ref.detach(), atol=0, rtol=0)
     (out * g.cuda()).sum().backward()
     assert torch.equal(xh.grad.cpu(), xo.grad)
-    assert float(xh.grad[:3].abs().sum()) == 0.0
+    assert torch.equal(xh.grad[:3], xh.grad[40:43]) and float(xh.grad[:3].abs().sum()) > 0
 
 
 def _training_case(W, H, B, n, seed, **over):
@@ -110,30 +111,21 @@ def _training_case(W, H, B, n, seed, **over):
     return args, model, sd, batch, ev, b
 
 
-def _oracle_losses(sd, args, H, W, ev, b, B, labels, num_classes):
-    from dagr_amd.model.networks.yolox_loss import detection_losses, output_and_grid   # host-side torch, device-agnostic
-    with oo.batch_statistics():
-        _, raw = om.forward_events(sd, args, H, W, ev[0], ev[1], ev[2], ev[3], b, B, use_lut=False)
-    nc = om.NetConstants(args, H, W)
-    outs, grids = zip(*(output_and_grid(torch.cat([r, o, c], 1), s) for (c, r, o), s in zip(raw, nc.strides)))
-    return detection_losses(labels, torch.cat(outs, 1), list(grids), nc.strides, num_classes), raw
-
-
 @pytest.mark.parametrize("case", [dict(W=240, H=180, B=2, n=2500, seed=1),
                                   dict(W=320, H=215, B=3, n=1500, seed=2, over=dict(num_scales=1))],
                          ids=["two_scales", "one_scale"])
 def test_training_loss_and_gradients_match_the_oracle(case):
-    from dagr_amd.model.utils import convert_to_training_format
+    from oracle import train as otr
     W, H, B = case["W"], case["H"], case["B"]
     args, model, sd, batch, ev, b = _training_case(W, H, B, case["n"], case["seed"], **case.get("over", {}))
-    labels = convert_to_training_format(batch.bbox, batch.bbox_batch, B)
-    ref, _ = _oracle_losses(sd, args, H, W, ev, b, B, labels, model.backbone.num_classes)
+    # the oracle's training forward is pinned to the reference's own training branch (tests/test_oracle_refpy.py)
+    ref = otr.training_losses(sd, args, H, W, ev[0], ev[1], ev[2], ev[3], b, B, batch.bbox, batch.bbox_batch)
     ref[0].backward()
     out = model(format_data(batch.cuda()))
     assert set(out) == {"total_loss", "iou_loss", "l1_loss", "conf_loss", "cls_loss", "num_fg"}
     assert out["num_fg"] == ref[5], "SimOTA matched a different number of anchors"
     for k, r in zip(("total_loss", "iou_loss", "conf_loss", "cls_loss"), (ref[0], ref[1], ref[2], ref[3])):
-        assert abs(float(out[k]) - float(r)) <= 1e-4 * max(1.0, abs(float(r))), (k, float(out[k]), float(r))
+        assert abs(float(out[k]) - float(r)) <= 5e-4 * max(1.0, abs(float(r))), (k, float(out[k]), float(r))
     out["total_loss"].backward()
     params = dict(model.named_parameters())
     checked, worst = 0, (0.0, "")
