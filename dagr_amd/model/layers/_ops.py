@@ -77,12 +77,42 @@ def spline_conv(conv, x, rowptr, col, code, norm=None, skip=None, xskip=None, re
     return out
 
 
+EXACT_R = 1 << 14       # offset bias of the exact (training) codes: any |offset| < 16384 pixels fits 16 bits per axis
+
+
+def exact_codes(edge_attr, max_value, width, height):
+    """Integer pixel offsets of the edges recovered from their Cartesian attributes, attr = (pos[src] - pos[dst]) / (2 max)
+    + 0.5 with pos in sensor fractions, packed like ``lut_codes`` around the bias EXACT_R, plus the matching (den_x, den_y):
+    the kernels then evaluate the spline basis at pseudo = offset / den + 0.5 = the attribute itself.  This is the
+    training-mode message (PyG ``SplineConv.message`` on the float attributes, spline_conv.py:64-78): no table, hence none
+    of ``message_lut``'s index truncation -- which matters for the one-scale head, whose table covers another level's
+    domain (dagr.py:52-62)."""
+    den_x = float(torch.as_tensor(2 * max_value * width, dtype=torch.float32))
+    den_y = float(torch.as_tensor(2 * max_value * height, dtype=torch.float32))
+    dx = torch.round((edge_attr[:, 0] - 0.5) * den_x).int() + EXACT_R
+    dy = torch.round((edge_attr[:, 1] - 0.5) * den_y).int() + EXACT_R
+    return (dx | (dy << 16)).contiguous(), den_x, den_y
+
+
 def conv_on_data(conv, data, norm=None, skip=None, xskip=None, relu=False):
     rowptr, col, perm = graph_csr(data)
+    if conv.training:
+        # training mode (spline_conv.py:64-78 without init_lut's message_lut): exact basis at the edge's own offset
+        if conv.lut_domain is None or getattr(data, "edge_attr_max", None) is None:
+            raise RuntimeError("training-mode SplineConv needs the sensor size (init_lut / cache_luts) and the Cartesian "
+                               "maximum of the graph's edge attributes (set by Cartesian / Pooling.forward)")
+        if not (norm is None and skip is None and not relu):
+            raise RuntimeError("fused conv + BN epilogues are eval-mode only")
+        d = conv.lut_domain
+        code, den_x, den_y = exact_codes(data.edge_attr[perm], data.edge_attr_max, d["width"], d["height"]) \
+            if col.shape[0] else (col, 1.0, 1.0)
+        from .autograd import SplineConvFn
+        return SplineConvFn.apply(data.x, conv.weight, conv.lin.weight, conv.bias, rowptr, col, code, EXACT_R, EXACT_R,
+                                  den_x, den_y)
     code = lut_codes(data.edge_attr[perm], conv.lut_domain) if col.shape[0] else col
     if norm is None and skip is None and not relu and torch.is_grad_enabled() and \
             (data.x.requires_grad or conv.weight.requires_grad):
-        from .autograd import spline_conv_autograd       # plain conv with gradients (training path, first slice)
+        from .autograd import spline_conv_autograd       # eval-mode (LUT-domain) conv with gradients
         return spline_conv_autograd(conv, data.x, rowptr, col, code)
     return spline_conv(conv, data.x, rowptr, col, code, norm=norm, skip=skip, xskip=xskip, relu=relu)
 
@@ -160,6 +190,7 @@ def voxel_pool(pool, data):
         cluster[valid] = inv.int()
         out.x = PoolFeatFn.apply(data.x, cluster, 0 if pool.aggr == "max" else 1, SimpleNamespace(pooled=x_out[:nc]))
     out.edge_attr = cartesian(out.pos, ei, pool.transform.max)
+    out.edge_attr_max = pool.transform.max
     return out
 
 

@@ -36,4 +36,5 @@ class Cartesian(torch.nn.Module):
     def forward(self, data):                                    # components.py:30-35
         from . import _ops
         data.edge_attr = _ops.cartesian(data.pos, data.edge_index, self.max)
+        data.edge_attr_max = self.max       # read by the training-mode conv to recover exact pixel offsets
         return data
