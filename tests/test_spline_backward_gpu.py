@@ -12,8 +12,9 @@ from dagr_amd.data import Data
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("mode", ["train_exact_offsets", "eval_lut_domain"])
 @pytest.mark.parametrize("n,cin,cout,max_deg", [(300, 8, 6, 9), (1000, 66, 64, 12), (40, 3, 16, 30)])
-def test_spline_conv_gradients_match_float64_autograd(n, cin, cout, max_deg):
+def test_spline_conv_gradients_match_float64_autograd(n, cin, cout, max_deg, mode):
     from dagr_amd.model.layers.spline_conv import MySplineConv
     rng = np.random.default_rng(n + cin)
     args = om.default_args()
@@ -33,6 +34,10 @@ def test_spline_conv_gradients_match_float64_autograd(n, cin, cout, max_deg):
     attr = np.stack([dx / (2 * M * W_) + 0.5, dy / (2 * M * H_) + 0.5], 1).astype(np.float32)
     x = torch.from_numpy(rng.standard_normal((n, cin)).astype(np.float32)).cuda().requires_grad_(True)
     data = Data(x=x, edge_index=torch.from_numpy(np.stack([src, dst])).cuda(), edge_attr=torch.from_numpy(attr).cuda())
+    if mode == "eval_lut_domain":
+        conv.eval()                  # codes = message_lut's table coordinates (spline_conv.py:41-42)
+    else:
+        data.edge_attr_max = M       # training mode: exact offsets recovered from the attributes (Cartesian sets this)
     out = conv(data).x
     g = torch.from_numpy(rng.standard_normal((n, cout)).astype(np.float32)).cuda()
     out.backward(g)
