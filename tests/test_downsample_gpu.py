@@ -28,3 +28,20 @@ def test_downsample_matches_reference_loop(factor, stream):
         for k in ("x", "y", "t", "p"):
             assert np.array_equal(got[k].cpu().numpy().astype(np.int64), want[k].astype(np.int64)), (chunk, k)
         assert np.array_equal(cm_d.cpu().numpy(), cm_o)
+
+
+def test_downsample_script_on_the_device_matches_the_reference_main_loop(tmp_path):
+    """scripts/downsample_events.py end to end with the device kernel: 230 123 events in three chunks (the last one partial,
+    with the reference's {0, 1} polarities), the change map resident on the GPU in between -> the digests of the reference
+    script's own main loop (tests/golden/ref_py_data.npz)."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "scripts"))
+    import downsample_events as D
+    from tests.test_data_refpy import G, _check_stream_output, _stream_case
+    dst = tmp_path / "events_2x.npz"
+    counts = D.main(["--input_path", str(_stream_case(tmp_path)), "--output_path", str(dst), "--input_height", "48",
+                     "--input_width", "64", "--output_height", "24", "--output_width", "32"])
+    assert counts["t"] == int(G["stream_count"])
+    _check_stream_output(dst)
