@@ -11,6 +11,81 @@
 namespace dagr {
 namespace {
 constexpr int kMaxAnchors = 1024;
+constexpr int kMaskAnchors = 256, kMaskWords = kMaskAnchors / 64;
+
+// Greedy suppression over the score-sorted candidates (s_keep = candidate flags in, survivor flags out): box i, if still
+// alive when its turn comes, removes every later box j with IoU(i, j) > thr.  The chain over i is inherently sequential,
+// but the pairwise tests are not: for up to 256 candidates (DAGR has 175 anchors) all "i would suppress j" bits are
+// computed first -- one wave per row i, one ballot per 64 columns -- and the chain then only ORs 64-bit rows: one wave
+// walks it with the removed-set in four registers and the next row prefetched from LDS (~20 cycles per candidate
+// instead of a block-wide barrier per candidate: 66 us -> a few us per image at 175 anchors).  Same IoU expression,
+// same order, same result as the reference's torchvision.ops.nms on the offset boxes.
+__device__ __forceinline__ bool iou_above(const float4 bi, float area_i, const float4 bj, float thr) {
+    const float w = fmaxf(fminf(bi.z, bj.z) - fmaxf(bi.x, bj.x), 0.f);
+    const float h = fmaxf(fminf(bi.w, bj.w) - fmaxf(bi.y, bj.y), 0.f);
+    const float inter = w * h;
+    const float area_j = (bj.z - bj.x) * (bj.w - bj.y);
+    return inter / (area_i + area_j - inter) > thr;
+}
+
+__device__ void greedy_suppress(int A, const float4 *s_box, int *s_keep, float thr,
+                                unsigned long long (*s_mask)[kMaskWords]) {
+    if (A > kMaskAnchors) {      // generic path: one barrier per candidate
+        for (int i = 0; i < A; i++) {
+            if (s_keep[i]) {   // uniform: read after the barrier below
+                const float4 bi = s_box[i];
+                const float area_i = (bi.z - bi.x) * (bi.w - bi.y);
+                for (int j = i + 1 + threadIdx.x; j < A; j += kBlock)
+                    if (s_keep[j] && iou_above(bi, area_i, s_box[j], thr)) s_keep[j] = 0;
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = wave; i < A; i += kBlock / 64) {
+        const float4 bi = s_box[i];
+        const float area_i = (bi.z - bi.x) * (bi.w - bi.y);
+        const bool vi = s_keep[i] != 0;
+#pragma unroll
+        for (int w = 0; w < kMaskWords; w++) {
+            const int j = w * 64 + lane;
+            const bool hit = vi && j > i && j < A && s_keep[j] != 0 && iou_above(bi, area_i, s_box[j], thr);
+            const unsigned long long m = __ballot(hit);
+            if (lane == 0) s_mask[i][w] = m;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        unsigned long long removed[kMaskWords] = {0ull, 0ull, 0ull, 0ull};
+        unsigned long long cur[kMaskWords], nxt[kMaskWords];
+#pragma unroll
+        for (int w = 0; w < kMaskWords; w++) cur[w] = s_mask[0][w];
+#pragma unroll
+        for (int blk = 0; blk < kMaskWords; blk++) {
+            for (int bit = 0; bit < 64; bit++) {
+                const int i = blk * 64 + bit;
+                if (i >= A) break;
+                const int in = min(i + 1, A - 1);
+#pragma unroll
+                for (int w = 0; w < kMaskWords; w++) nxt[w] = s_mask[in][w];     // prefetch: independent of the chain
+                const bool alive = s_keep[i] != 0 && ((removed[blk] >> bit) & 1ull) == 0ull;
+                if (alive) {
+#pragma unroll
+                    for (int w = 0; w < kMaskWords; w++) removed[w] |= cur[w];
+                }
+#pragma unroll
+                for (int w = 0; w < kMaskWords; w++) cur[w] = nxt[w];
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < kMaskWords; w++) {
+            const int i = w * 64 + lane;
+            if (i < A && ((removed[w] >> lane) & 1ull)) s_keep[i] = 0;
+        }
+    }
+    __syncthreads();
+}
 
 __global__ __launch_bounds__(kBlock) void k_nms(const float *__restrict__ boxes, const float *__restrict__ scores,
                                                const int32_t *__restrict__ cls, const uint8_t *__restrict__ valid,
@@ -21,6 +96,7 @@ __global__ __launch_bounds__(kBlock) void k_nms(const float *__restrict__ boxes,
     __shared__ int s_idx[kMaxAnchors];
     __shared__ float4 s_box[kMaxAnchors];
     __shared__ int s_keep[kMaxAnchors];
+    __shared__ unsigned long long s_mask[kMaskAnchors][kMaskWords];
     __shared__ int s_count;
     const int b = blockIdx.x;
     const float *bx = boxes + (size_t)b * A * 4;
@@ -61,22 +137,7 @@ __global__ __launch_bounds__(kBlock) void k_nms(const float *__restrict__ boxes,
     }
     if (threadIdx.x == 0) s_count = 0;
     __syncthreads();
-    for (int i = 0; i < A; i++) {
-        if (s_keep[i]) {   // uniform: read after the barrier below
-            const float4 bi = s_box[i];
-            const float area_i = (bi.z - bi.x) * (bi.w - bi.y);
-            for (int j = i + 1 + threadIdx.x; j < A; j += kBlock) {
-                if (!s_keep[j]) continue;
-                const float4 bj = s_box[j];
-                const float w = fmaxf(fminf(bi.z, bj.z) - fmaxf(bi.x, bj.x), 0.f);
-                const float h = fmaxf(fminf(bi.w, bj.w) - fmaxf(bi.y, bj.y), 0.f);
-                const float inter = w * h;
-                const float area_j = (bj.z - bj.x) * (bj.w - bj.y);
-                if (inter / (area_i + area_j - inter) > thr) s_keep[j] = 0;
-            }
-        }
-        __syncthreads();
-    }
+    greedy_suppress(A, s_box, s_keep, thr, s_mask);
     for (int i = threadIdx.x; i < A; i += kBlock) {
         order_out[(size_t)b * A + i] = s_idx[i];
         keep_out[(size_t)b * A + i] = s_keep[i];
@@ -100,6 +161,7 @@ __global__ __launch_bounds__(kBlock) void k_postprocess(const float *__restrict_
     __shared__ int s_cls[kMaxAnchors];
     __shared__ float4 s_box[kMaxAnchors];     // class-offset boxes, score order
     __shared__ int s_keep[kMaxAnchors];
+    __shared__ unsigned long long s_mask[kMaskAnchors][kMaskWords];
     __shared__ int s_scan[4];
     const int b = blockIdx.x;
     const int ld = 5 + ncls;
@@ -154,22 +216,7 @@ __global__ __launch_bounds__(kBlock) void k_postprocess(const float *__restrict_
         s_keep[i] = ok ? 1 : 0;
     }
     __syncthreads();
-    for (int i = 0; i < A; i++) {
-        if (s_keep[i]) {
-            const float4 bi = s_box[i];
-            const float area_i = (bi.z - bi.x) * (bi.w - bi.y);
-            for (int j = i + 1 + threadIdx.x; j < A; j += kBlock) {
-                if (!s_keep[j]) continue;
-                const float4 bj = s_box[j];
-                const float w = fmaxf(fminf(bi.z, bj.z) - fmaxf(bi.x, bj.x), 0.f);
-                const float h = fmaxf(fminf(bi.w, bj.w) - fmaxf(bi.y, bj.y), 0.f);
-                const float inter = w * h;
-                const float area_j = (bj.z - bj.x) * (bj.w - bj.y);
-                if (inter / (area_i + area_j - inter) > nms_thr) s_keep[j] = 0;
-            }
-        }
-        __syncthreads();
-    }
+    greedy_suppress(A, s_box, s_keep, nms_thr, s_mask);
     // front-compaction: thread t owns the 4 consecutive sorted positions 4t .. 4t+3
     int mine[4], cnt = 0;
 #pragma unroll
