@@ -56,9 +56,11 @@ class SyntheticObjects:
     to fall, none of the real data's statistics."""
     classes = ["outline", "cross"]
 
-    def __init__(self, n_samples, n_events=20000, width=240, height=180, seed=7, transform=None, noise=0.2):
+    def __init__(self, n_samples, n_events=20000, width=240, height=180, seed=7, transform=None, noise=0.2,
+                 use_image=False):
         self.n, self.n_events, self.width, self.height = int(n_samples), int(n_events), int(width), int(height)
         self.seed, self.transform, self.noise = int(seed), transform, float(noise)
+        self.use_image = bool(use_image)       # DSEC-style samples: a frame with the object drawn in + bbox0
         self.num_classes = len(self.classes)
         self.time_window = 1000000
         if transform is not None and hasattr(transform, "transforms"):
@@ -91,6 +93,11 @@ class SyntheticObjects:
         order = rng.permutation(len(px))
         px, py = px[order], py[order]                     # positions are not correlated with time
         bbox = np.array([[x0, y0, w, h, cls, 1]], dtype=np.float32)
+        extra = {}
+        if self.use_image:
+            frame = rng.integers(0, 40, (3, H, W)).astype(np.uint8)
+            frame[cls, int(y0):int(y0 + h), int(x0):int(x0 + w)] += 150       # the object, brighter in its class channel
+            extra = dict(bbox0=bbox.copy(), image=torch.from_numpy(frame)[None])
         d = to_data(x=px, y=py, t=t, p=p, bbox=bbox, t0=int(t[0]), t1=int(t[-1]), width=W, height=H,
-                    time_window=self.time_window, sequence=f"objects{int(i):05d}")
+                    time_window=self.time_window, sequence=f"objects{int(i):05d}", **extra)
         return self.transform(d) if self.transform is not None else d

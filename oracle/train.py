@@ -31,13 +31,34 @@ def convert_to_training_format(bbox, batch, batch_size):
     return targets
 
 
-def training_losses(sd, args, height, width, x, y, t, p, b, batch_size, bbox, bbox_batch):
+def training_losses(sd, args, height, width, x, y, t, p, b, batch_size, bbox, bbox_batch, image_feat=None, cnn_out=None,
+                    bbox0=None, bbox0_batch=None):
     """The 6-tuple of ``get_losses`` (total, 5*iou, obj, cls, l1 = 0, matched anchors / ground truths) for one batch of
-    windows; ``sd`` may hold leaf tensors that require grad."""
+    windows; ``sd`` may hold leaf tensors that require grad.
+
+    ``--use_image`` (dagr.py:197-222,241-268): ``image_feat`` = the image branch's feature maps (sampled into the graph
+    DETACHED, net.py:118,129,...), ``cnn_out`` = the CNN head's raw maps on the resized image outputs (dict of lists
+    ``cls_output`` / ``reg_output`` / ``obj_output``; they enter the hybrid sum detached, and train on their own through a
+    second ``get_losses`` against the boxes of the EARLIER frame, ``bbox0``); the two loss tuples are added element-wise
+    for the first five entries, the sixth is the image branch's."""
     nc = om.NetConstants(args, height, width)
+    detached = None
+    if cnn_out is not None:
+        detached = {k: [m.detach() for m in v] for k, v in cnn_out.items()}
+        image_feat = [f.detach() for f in image_feat]
     with ops.batch_statistics():
-        _, raw = om.forward_events(sd, args, height, width, x, y, t, p, b, batch_size, use_lut=False)
+        _, raw = om.forward_events(sd, args, height, width, x, y, t, p, b, batch_size, use_lut=False,
+                                   image_feat=image_feat, cnn_out=detached)
     maps = [torch.cat([reg_o, obj_o, cls_o], 1) for (cls_o, reg_o, obj_o) in raw]      # collect_outputs, dagr.py:293-294
     labels = convert_to_training_format(bbox, bbox_batch, batch_size)
-    head = LossHead(nc.num_classes if hasattr(nc, "num_classes") else maps[0].shape[1] - 5, len(maps))
-    return head.losses_from_maps(maps, nc.strides, labels)
+    n_cls = maps[0].shape[1] - 5
+    events = LossHead(n_cls, len(maps)).losses_from_maps(maps, nc.strides, labels)
+    if cnn_out is None:
+        return events
+    image_maps = [torch.cat([cnn_out["reg_output"][k], cnn_out["obj_output"][k], cnn_out["cls_output"][k]], 1)
+                  for k in range(len(cnn_out["cls_output"]))]
+    labels0 = convert_to_training_format(bbox0, bbox0_batch, batch_size)
+    image = list(LossHead(n_cls, len(image_maps)).losses_from_maps(image_maps, nc.strides, labels0))
+    for i in range(5):
+        image[i] = image[i] + events[i]
+    return tuple(image)

@@ -31,6 +31,10 @@ def flags(description, extra=None):
     p.add_argument("--width", type=int, default=640)
     p.add_argument("--height", type=int, default=480)
     p.add_argument("--stream", default="uniform", choices=["uniform", "edges"])
+    p.add_argument("--dataset_directory", type=Path, default=None,
+                   help="DSEC root (run_test.py:45: DSEC(root, 'test', transform_testing, ...)); needs dsec-det + h5py + "
+                        "hdf5plugin.  Default: the synthetic event stream with the DSEC sample contract")
+    p.add_argument("--split", default="test")
     p.add_argument("--use_image", action="store_true")
     p.add_argument("--img_net", default="resnet50")
     if extra:
@@ -56,8 +60,15 @@ def distributed():
 def dataset_and_loader(a, world, rank):
     """The dataset and THIS rank's loader: batch k holds windows [k*B, (k+1)*B) (drop_last=True, run_test.py:48) and
     goes to rank k mod G -- independent windows, no collective on the data path."""
-    ds = SyntheticWindows(a.windows, a.events_per_window, a.width, a.height, a.stream, a.use_image,
-                          transform=Augmentations.transform_testing)
+    if getattr(a, "dataset_directory", None) is not None:
+        # run_test.py:45-46 / run_test_interframe.py:66-67: the DSEC test split, boxes >= 30 px diagonal, no size floor on
+        # height; the interframe script additionally restricts itself to perfect tracks
+        from dagr.data.dsec_data import DSEC
+        ds = DSEC(a.dataset_directory, a.split, Augmentations.transform_testing, debug=False, min_bbox_diag=15,
+                  min_bbox_height=10, only_perfect_tracks=bool(getattr(a, "num_interframe_steps", 0)), no_eval=True)
+    else:
+        ds = SyntheticWindows(a.windows, a.events_per_window, a.width, a.height, a.stream, a.use_image,
+                              transform=Augmentations.transform_testing)
     n_batches = len(ds) // a.batch_size
     loader = DataLoader(ds, follow_batch=["bbox", "bbox0"], batch_size=a.batch_size, shuffle=False, drop_last=True,
                         batches=parallel.shard_indices(n_batches, rank, world))

@@ -55,6 +55,8 @@ def flags():
     p.add_argument("--clip", type=float, default=0.1)
     p.add_argument("--max_iters", type=int, default=-1, help="stop after this many iterations (smoke runs)")
     p.add_argument("--resume_checkpoint", type=Path, default=None)
+    p.add_argument("--use_image", action="store_true", help="(train_dsec.py) fuse the image branch")
+    p.add_argument("--img_net", default="resnet50")
     return p
 
 
@@ -127,23 +129,34 @@ def validate(loader, net, dev, dry_run_steps=-1):
     return {"mAP": -val, "val_loss": val}
 
 
-def build(a, world, rank, dev, model_factory=None):
+def build(a, world, rank, dev, model_factory=None, preset="ncaltech101"):
     per_rank = a.batch_size // world
     if per_rank * world != a.batch_size or per_rank < 1:
         raise ValueError(f"--batch_size {a.batch_size} must be a positive multiple of the {world} ranks")
-    # config/dagr-l-ncaltech.yaml: one output scale, no flip, no zoom, 10 % translation
-    args = model_args(a.config, dataset="ncaltech101", num_scales=1, batch_size=per_rank, n_nodes=a.n_nodes,
-                      aug_trans=0.1, aug_p_flip=0, aug_zoom=1, l_r=a.l_r, weight_decay=a.weight_decay, clip=a.clip,
-                      tot_num_epochs=a.epochs)
+    common = dict(batch_size=per_rank, n_nodes=a.n_nodes, l_r=a.l_r, weight_decay=a.weight_decay, clip=a.clip,
+                  tot_num_epochs=a.epochs)
+    if preset == "dsec":
+        # config/dagr-*-dsec.yaml: two output scales, flip 0.5, zoom up to 1.5, 10 % translation; optional image branch
+        args = model_args(a.config, dataset="dsec", use_image=a.use_image, img_net=a.img_net, **common)
+    else:
+        # config/dagr-l-ncaltech.yaml: one output scale, no flip, no zoom, 10 % translation
+        args = model_args(a.config, dataset="ncaltech101", num_scales=1, aug_trans=0.1, aug_p_flip=0, aug_zoom=1, **common)
     aug = Augmentations(args)
-    if a.dataset_directory is not None:
+    if a.dataset_directory is not None and preset == "dsec":
+        from dagr.data.dsec_data import DSEC                    # train_dsec.py:125-128
+        root = a.dataset_directory / "dsec"
+        train_ds = DSEC(root=root, split="train", transform=aug.transform_training, min_bbox_diag=15, min_bbox_height=10)
+        val_ds = DSEC(root=root, split="val", transform=aug.transform_testing, min_bbox_diag=15, min_bbox_height=10)
+    elif a.dataset_directory is not None:
         from dagr.data.ncaltech101_data import NCaltech101
         root = a.dataset_directory / "ncaltech101"
         train_ds = NCaltech101(root, "training", aug.transform_training, num_events=args.n_nodes)
         val_ds = NCaltech101(root, "validation", aug.transform_testing, num_events=args.n_nodes)
     else:
-        train_ds = SyntheticObjects(a.samples, min(args.n_nodes, 20000), seed=7, transform=aug.transform_training)
-        val_ds = SyntheticObjects(a.val_samples, min(args.n_nodes, 20000), seed=100007, transform=aug.transform_testing)
+        size = dict(width=320, height=215, use_image=a.use_image) if preset == "dsec" else {}
+        train_ds = SyntheticObjects(a.samples, min(args.n_nodes, 20000), seed=7, transform=aug.transform_training, **size)
+        val_ds = SyntheticObjects(a.val_samples, min(args.n_nodes, 20000), seed=100007, transform=aug.transform_testing,
+                                  **size)
     follow = ["bbox", "bbox0"]
     train_loader = DataLoader(train_ds, follow_batch=follow, batch_size=a.batch_size, shuffle=True, drop_last=True,
                               shard=(rank, world), seed=42)
@@ -158,14 +171,14 @@ def build(a, world, rank, dev, model_factory=None):
     return args, train_loader, val_loader, model
 
 
-def main(argv=None, model_factory=None):
+def main(argv=None, model_factory=None, preset="ncaltech101"):
     a = flags().parse_args(argv)
     world, rank, dev = C.distributed()
     seed = 42
     torch.manual_seed(seed)
     np.random.seed(seed)
     random.seed(seed)
-    args, train_loader, val_loader, model = build(a, world, rank, dev, model_factory)
+    args, train_loader, val_loader, model = build(a, world, rank, dev, model_factory, preset)
     if rank == 0:
         log_hparams(args)
         print(f"Training with {sum(p.numel() for p in model.parameters())} number of parameters.")
@@ -176,7 +189,7 @@ def main(argv=None, model_factory=None):
                                   weight_decay=args.weight_decay)
     schedule = LRSchedule(warmup_epochs=.3, num_iters_per_epoch=len(train_loader), tot_num_epochs=args.tot_num_epochs)
     scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer=optimizer, lr_lambda=schedule)
-    out_dir = set_up_logging_directory("ncaltech101", "detection", a.output_directory, exp_name=a.exp_name)
+    out_dir = set_up_logging_directory(preset, "detection", a.output_directory, exp_name=a.exp_name)
     ckpt = Checkpointer(output_directory=out_dir, model=model, optimizer=optimizer, scheduler=scheduler, ema=ema, args=args)
     ckpt.mAP_max = float("-inf")            # the fallback metric (negative validation loss) is below the reference's 0
     start_epoch = 0

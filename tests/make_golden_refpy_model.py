@@ -38,10 +38,16 @@ TRAIN_CASES = [
     ("train_s_b2", 240, 180, 2, 2500, "edges", 21, {}),
     ("train_l_ncaltech_b3", 240, 180, 3, 1500, "edges", 22, dict(net_stem_width=1.0, yolo_stem_width=1.0, num_scales=1,
                                                                 dataset="ncaltech101")),
+    # train_dsec.py with --use_image: image features sampled into the graph detached, CNN-head logits added detached,
+    # a second get_losses on the image branch's own outputs against the earlier frame's boxes (dagr.py:241-268)
+    ("train_s_img18_b2", 240, 180, 2, 2000, "edges", 23, dict(use_image=True, img_net="resnet18")),
 ]
 TRAIN_GRAD_KEYS = ["backbone.conv_block1.conv_block1.conv.weight", "backbone.conv_block1.conv_block2.lin.mlp.weight",
                    "backbone.layer3.conv_block1.norm.module.weight", "backbone.layer5.conv_block2.conv.lin.weight",
-                   "head.stem1.conv.weight", "head.cls_pred1.bias", "head.reg_pred1.weight", "head.obj_pred2.bias"]
+                   "head.stem1.conv.weight", "head.cls_pred1.bias", "head.reg_pred1.weight", "head.obj_pred2.bias",
+                   "backbone.net.module.conv1.weight", "backbone.net.module.layer3.0.conv1.weight",
+                   "backbone.net.feature_dconv.0.weight", "head.cnn_head.stems.1.conv.weight",
+                   "head.cnn_head.cls_preds.0.bias", "head.cnn_head.reg_preds.1.weight"]
 
 
 def main():
@@ -103,6 +109,12 @@ def main():
                                 width=torch.tensor([W] * B), height=torch.tensor([H] * B),
                                 time_window=torch.tensor([1000000] * B), num_graphs=B,
                                 bbox=torch.from_numpy(bbox), bbox_batch=torch.from_numpy(bbox_batch))
+        if getattr(args, "use_image", False):
+            data.image = torch.randint(0, 256, (B, 3, H, W), generator=torch.Generator().manual_seed(seed)).float() / 255.0
+            bbox0 = bbox.copy()
+            bbox0[:, :2] -= 3.0                 # the earlier frame's boxes: same tracks, shifted
+            data.bbox0, data.bbox0_batch = torch.from_numpy(bbox0), torch.from_numpy(bbox_batch)
+            out[f"{name}_bbox0"] = bbox0
         losses = ref(data)
         losses["total_loss"].backward()
         grads = {k: v.grad for k, v in ref.named_parameters() if v.grad is not None}
@@ -115,7 +127,11 @@ def main():
                     f"{name}_grad_keys": np.array(picked),
                     f"{name}_n_grads": np.array(len(grads))})
         for k in picked:
-            out[f"{name}_grad:{k}"] = grads[k].numpy()
+            g = grads[k].numpy()
+            if g.size > 20000:        # big image-branch tensors: a strided sample and the norm keep the fixture small
+                out[f"{name}_gradnorm:{k}"] = np.array(np.sqrt((g.astype(np.float64) ** 2).sum()))
+                g = g.reshape(-1)[::g.size // 4096]
+            out[f"{name}_grad:{k}"] = g
 
     # ---- EV_TGN over consecutive calls: reset=True, reset=False (nodes attach to the running graph), reset=True
     import dagr.model.layers.ev_tgn as rtgn

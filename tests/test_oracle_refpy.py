@@ -293,6 +293,7 @@ def test_in_repo_restatements_of_third_party_primitives():
     ("train_s_b2", 240, 180, 2, 21, {}),
     ("train_l_ncaltech_b3", 240, 180, 3, 22, dict(net_stem_width=1.0, yolo_stem_width=1.0, num_scales=1,
                                                   dataset="ncaltech101")),
+    ("train_s_img18_b2", 240, 180, 2, 23, dict(use_image=True, img_net="resnet18")),
 ])
 def test_training_forward_and_gradients_match_the_reference_code(name, W, H, B, seed, over):
     """oracle.train.training_losses + torch autograd (what the GPU training tests compare the HIP path with) vs the
@@ -311,8 +312,17 @@ def test_training_forward_and_gradients_match_the_reference_code(name, W, H, B, 
     bbox, bbox_batch = torch.from_numpy(GM[f"{name}_bbox"]), torch.from_numpy(GM[f"{name}_bbox_batch"])
     # the mirror's target formatting == the reference's convert_to_training_format (run inside the golden forward)
     assert torch.equal(convert_to_training_format(bbox, bbox_batch, B), otr.convert_to_training_format(bbox, bbox_batch, B))
+    extra = {}
+    if over.get("use_image"):
+        # the image branch = the mirror's torch modules (HookModule over the ResNet, CNNHead) in training mode, their
+        # parameters re-bound to the leaf tensors of sd so that the gradients land there
+        img = torch.randint(0, 256, (B, 3, H, W), generator=torch.Generator().manual_seed(seed)).float() / 255.0
+        model.train()
+        image_feat, cnn_out = _image_branch_functional(model, sd, img, om.NetConstants(args, H, W), args.num_scales)
+        extra = dict(image_feat=image_feat, cnn_out=cnn_out, bbox0=torch.from_numpy(GM[f"{name}_bbox0"]),
+                     bbox0_batch=bbox_batch)
     out = otr.training_losses(sd, args, H, W, GM[f"{name}_x"], GM[f"{name}_y"], GM[f"{name}_t"], GM[f"{name}_p"],
-                              GM[f"{name}_b"], B, bbox, bbox_batch)
+                              GM[f"{name}_b"], B, bbox, bbox_batch, **extra)
     want = GM[f"{name}_losses"]          # total, iou, conf, cls, l1, num_fg
     got = [float(out[0]), float(out[1]), float(out[2]), float(out[3]), float(out[4]), float(out[5])]
     assert np.allclose(got, want, rtol=2e-6, atol=1e-6), (got, want.tolist())
@@ -322,4 +332,21 @@ def test_training_forward_and_gradients_match_the_reference_code(name, W, H, B, 
     for k in GM[f"{name}_grad_keys"]:
         g_ref = torch.from_numpy(GM[f"{name}_grad:{k}"])
         g = sd[str(k)].grad
-        assert float((g - g_ref).abs().max()) <= 2e-5 * max(1e-6, float(g_ref.abs().max())), k
+        tol = 2e-5
+        if f"{name}_gradnorm:{k}" in GM:       # strided sample + norm of a big tensor
+            assert float(g.double().norm()) == pytest.approx(float(GM[f"{name}_gradnorm:{k}"]), rel=1e-4), k
+            g = g.reshape(-1)[::g.numel() // 4096]
+            tol = 2e-4                          # conv weight gradients: long fp32 reductions, thread-order dependent
+        assert float((g - g_ref).abs().max()) <= tol * max(1e-6, float(g_ref.abs().max())), k
+
+
+def _image_branch_functional(model, sd, img, nc, num_scales):
+    """``Net.forward``'s image part (net.py:109-110) and ``GNNHead.forward``'s CNN head (dagr.py:197-206) evaluated with
+    the parameters taken from ``sd`` (``torch.func.functional_call``), so that autograd reaches those leaf tensors."""
+    from torch.func import functional_call
+    net, head = model.backbone.net, model.head.cnn_head
+    pn = {k[len("backbone.net."):]: v for k, v in sd.items() if k.startswith("backbone.net.")}
+    ph = {k[len("head.cnn_head."):]: v for k, v in sd.items() if k.startswith("head.cnn_head.")}
+    image_feat, outs = functional_call(net, pn, (img,))
+    resized = [torch.nn.functional.interpolate(f, o) for f, o in zip(outs[-num_scales:], nc.output_sizes)]
+    return image_feat, functional_call(head, ph, (resized,))

@@ -188,3 +188,39 @@ def test_train_script_on_the_hip_layers_then_evaluate_the_checkpoint(tmp_path):
     with torch.no_grad():
         detections, targets = ema.ema(format_data(batch.cuda()))
     assert len(detections) == 4 and len(targets) == 4 and all(torch.isfinite(d["boxes"]).all() for d in detections)
+
+
+def test_training_with_the_image_branch_matches_the_oracle():
+    """``--use_image`` training (train_dsec.py; dagr.py:197-222,241-268): ResNet-18 features sampled into the graph detached,
+    CNN-head logits added detached, the image branch trained by its own ``get_losses`` against the earlier frame's boxes.
+    HIP layers + PyTorch-ROCm image branch vs the oracle (pinned to the reference's training branch, train_s_img18_b2)."""
+    from oracle import train as otr
+    from tests.test_oracle_refpy import _image_branch_functional
+    W, H, B, seed = 240, 180, 2, 5
+    args, model, sd, batch, ev, b = _training_case(W, H, B, 2000, seed, use_image=True, img_net="resnet18")
+    img = torch.randint(0, 256, (B, 3, H, W), generator=torch.Generator().manual_seed(seed), dtype=torch.uint8)
+    batch.image = img
+    batch.bbox0 = batch.bbox.clone()
+    batch.bbox0[:, :2] -= 3.0
+    batch.bbox0_batch = batch.bbox_batch.clone()
+    from dagr_amd.model.networks.dagr import DAGR
+    cpu_model = DAGR(args, height=H, width=W).train()          # module structure for functional_call; parameters come from sd
+    image_feat, cnn_out = _image_branch_functional(cpu_model, sd, img.float() / 255.0, om.NetConstants(args, H, W),
+                                                   args.num_scales)
+    ref = otr.training_losses(sd, args, H, W, ev[0], ev[1], ev[2], ev[3], b, B, batch.bbox, batch.bbox_batch,
+                              image_feat=image_feat, cnn_out=cnn_out, bbox0=batch.bbox0, bbox0_batch=batch.bbox0_batch)
+    ref[0].backward()
+    out = model(format_data(batch.cuda()))
+    for k, r in zip(("total_loss", "iou_loss", "conf_loss", "cls_loss"), ref[:4]):
+        assert abs(float(out[k]) - float(r)) <= 1e-3 * max(1.0, abs(float(r))), (k, float(out[k]), float(r))
+    out["total_loss"].backward()
+    params = dict(model.named_parameters())
+    worst, checked, image_checked = (0.0, ""), 0, 0
+    for k, v in sd.items():
+        if v.requires_grad and v.grad is not None and float(v.grad.abs().max()) > 0:
+            assert params[k].grad is not None, f"no gradient reached {k}"
+            worst = max(worst, (_rel(params[k].grad, v.grad), k))
+            checked += 1
+            image_checked += k.startswith("backbone.net.") or "cnn_head" in k
+    assert checked >= 150 and image_checked >= 60, (checked, image_checked)
+    assert worst[0] < 5e-3, worst

@@ -50,6 +50,8 @@ def oracle_kernels(monkeypatch):
     monkeypatch.setattr(_ops, "conv_on_data", conv_on_data)
     monkeypatch.setattr(_ops, "voxel_pool", voxel_pool)
     monkeypatch.setattr(_ops, "to_dense", lambda x, pos, pooling, batch, batch_size: oo.to_dense(x, pos, pooling, batch, batch_size))
+    monkeypatch.setattr(_ops, "sample_features",
+                        lambda data, feat, width, height: om.sample_features(data.pos, data.batch, feat, width, height))
 
 
 @pytest.mark.parametrize("over", [{}, dict(num_scales=1, dataset="ncaltech101")], ids=["two_scales", "ncaltech_one_scale"])
@@ -123,3 +125,48 @@ def test_exact_codes_recover_the_pixel_offsets_at_every_level():
         assert torch.equal((code >> 16) - _ops.EXACT_R, d[:, 1].int())
         pseudo = d[:, 0].float() / den_x + 0.5                      # what the kernels evaluate
         assert float((pseudo - attr[:, 0]).abs().max()) < 2e-6
+
+
+def test_training_forward_wiring_with_the_image_branch(oracle_kernels):
+    """``--use_image`` training wiring on CPU (train_dsec.py): detached feature sampling, detached CNN-head logits in the
+    hybrid sum, the image branch's own loss against ``bbox0``, the element-wise sum of the two loss tuples."""
+    from tests.test_oracle_refpy import _image_branch_functional
+    from dagr_amd.model.networks.dagr import DAGR
+    from dagr_amd.utils.buffers import format_data
+    W, H, B, seed = 240, 180, 2, 9
+    torch.manual_seed(seed)
+    args = om.default_args(batch_size=B, use_image=True, img_net="resnet18")
+    model = randomize_(DAGR(args, height=H, width=W), seed=seed).train()
+    sd = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() and "running" not in k
+              else v.detach().clone()) for k, v in model.state_dict().items()}
+    samples, raw = [], []
+    img = torch.randint(0, 256, (B, 3, H, W), generator=torch.Generator().manual_seed(seed), dtype=torch.uint8)
+    for s_ in range(B):
+        x, y, t, p = syn.edges_window(1200, W, H, seed=90 + s_)
+        raw.append((x, y, t, p))
+        boxes = torch.tensor([[30.0 + 40 * s_, 30.0, 80.0, 60.0, float(s_ % 2), 1, 0]])
+        samples.append(Data(x=torch.from_numpy(p.reshape(-1, 1)), pos=torch.from_numpy(np.stack([x, y], -1)),
+                            t=torch.from_numpy(t), width=W, height=H, time_window=1000000, bbox=boxes,
+                            bbox0=boxes - torch.tensor([[3.0, 3.0, 0, 0, 0, 0, 0]]), image=img[s_:s_ + 1], sequence=f"s{s_}"))
+    batch = Batch.from_data_list(samples, follow_batch=["bbox", "bbox0"])
+    ev = [np.concatenate([r[k] for r in raw]) for k in range(4)]
+    b = np.concatenate([np.full(len(r[0]), i, np.int64) for i, r in enumerate(raw)])
+    ref_model = DAGR(args, height=H, width=W).train()
+    image_feat, cnn_out = _image_branch_functional(ref_model, sd, img.float() / 255.0, om.NetConstants(args, H, W),
+                                                   args.num_scales)
+    ref = otr.training_losses(sd, args, H, W, ev[0], ev[1], ev[2], ev[3], b, B, batch.bbox, batch.bbox_batch,
+                              image_feat=image_feat, cnn_out=cnn_out, bbox0=batch.bbox0, bbox0_batch=batch.bbox0_batch)
+    ref[0].backward()
+    out = model(format_data(batch))
+    got = [float(out[k]) for k in ("total_loss", "iou_loss", "conf_loss", "cls_loss", "l1_loss", "num_fg")]
+    assert np.allclose(got, [float(v) for v in ref], rtol=1e-5, atol=1e-6), (got, [float(v) for v in ref])
+    out["total_loss"].backward()
+    params = dict(model.named_parameters())
+    n_img = 0
+    for k, v in sd.items():
+        if v.requires_grad and v.grad is not None:
+            g = params[k].grad
+            assert g is not None, k
+            assert float((g - v.grad).abs().max()) <= 2e-4 * max(1e-6, float(v.grad.abs().max())), k
+            n_img += k.startswith("backbone.net.") or "cnn_head" in k
+    assert n_img >= 60
