@@ -59,7 +59,7 @@ def detections_to_records(det, t):
 
 class DetectionBuffer:
     """Collects detections / ground truth of a test run on the host (buffers.py:100-122).  ``compute`` hands them to the
-    COCO evaluation (``utils/coco_eval.py`` over pycocotools in the reference) when that package exists."""
+    COCO-protocol evaluation of ``utils/coco_eval.py`` (pycocotools / detectron2 in the reference; restated in numpy here)."""
 
     def __init__(self, height, width, classes):
         self.height, self.width, self.classes = height, width, classes
@@ -79,12 +79,8 @@ class DetectionBuffer:
         return by_sequence(self.detections), by_sequence(self.ground_truth)
 
     def compute(self):
-        try:
-            import pycocotools  # noqa: F401
-        except ImportError as e:
-            raise RuntimeError("mAP needs pycocotools (src/dagr/utils/coco_eval.py:64-94), which this image lacks: run "
-                               "with no_eval=True and evaluate the saved detection records elsewhere") from e
-        from .coco_eval import evaluate_detection   # only importable with pycocotools
+        """mAP & co over everything collected since the last call (buffers.py:113-122)."""
+        from .coco_eval import evaluate_detection
         out = evaluate_detection(self.ground_truth, self.detections, height=self.height, width=self.width,
                                  classes=self.classes)
         self.detections, self.ground_truth = [], []

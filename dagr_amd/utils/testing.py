@@ -4,8 +4,8 @@ same signature and return convention, so ``scripts/run_test.py:61`` / ``run_test
 Per batch: ``data.cuda()`` -> ``format_data`` -> ``model(data)`` -> (optionally) collect the detections with their
 sequence / timestamp, feed the mAP buffer.  Differences that follow from this stack: the per-window work is one
 device pipeline with a single synchronisation (the survivor counts of the NMS), visualisation (wandb image logging) is
-not part of the hot path and is skipped, and the COCO evaluation needs ``pycocotools`` (absent here: ``no_eval=True``
-is the mode that runs; with it present the buffer delegates to it)."""
+not part of the hot path and is skipped, and the COCO evaluation is the numpy restatement in ``utils/coco_eval.py``
+(pycocotools / detectron2 are absent); ``no_eval=True`` skips it (datasets without boxes)."""
 import torch
 
 from .buffers import DetectionBuffer, format_data

@@ -5,7 +5,8 @@ checkpoint into ``ema.ema`` (strict) -> ``cache_luts`` -> ``run_test_with_visual
 Under ``torch.distributed.run`` (one process per GPU) the window batches are sharded over the ranks and the detections
 gathered once at the end (RCCL).  The DSEC reader's dependencies are absent here, so the dataset is the benchmark's
 synthetic event stream with the DSEC sample contract (``dagr/data/synthetic_data.py``); without ``--checkpoint`` the model
-keeps seeded random weights; mAP needs pycocotools, so the run is ``no_eval`` and writes detection records instead.
+keeps seeded random weights.  The synthetic windows carry no boxes, so that run is ``no_eval`` and writes detection records;
+with ``--dataset_directory`` (DSEC) the detections are also scored (COCO-protocol mAP, ``dagr/utils/coco_eval.py``).
 
   python scripts/run_test.py --config dagr-s --windows 64 --batch_size 8 --output_directory /tmp/out
   python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 scripts/run_test.py ...
@@ -31,8 +32,12 @@ def main(argv=None, model_factory=None):
     if rank == 0:
         log_hparams(args)
     t0 = time.perf_counter()
+    labelled = a.dataset_directory is not None
     with torch.no_grad():
-        _, detections = run_test_with_visualization(loader, net, dataset="synthetic", compile_detections=True, no_eval=True)
+        metrics, detections = run_test_with_visualization(loader, net, dataset="dsec" if labelled else "synthetic",
+                                                          compile_detections=True, no_eval=not labelled)
+    if labelled and rank == 0:
+        print("metrics of this rank's windows:", metrics)
     files = C.gather_and_save(C.detection_rows(detections, dev), out_dir, rank)
     if rank == 0:
         print(f"{len(ds) // a.batch_size * a.batch_size} windows on {world} GPU(s) in {time.perf_counter() - t0:.2f} s "

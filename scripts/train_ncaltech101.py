@@ -12,8 +12,8 @@ backward pass; BatchNorm statistics stay per replica (the reference has no SyncB
 (the learning-rate rule above refers to it).
 
 The N-Caltech101 reader needs h5py (absent here): with ``--dataset_directory`` it is used, without it the run is on
-``SyntheticObjects`` (labelled synthetic rectangles, 240 x 180).  mAP needs pycocotools; without it the validation pass
-reports the mean validation loss instead and the best-checkpoint logic keys on its negative.
+``SyntheticObjects`` (labelled synthetic rectangles, 240 x 180).  The validation pass computes the COCO-protocol mAP
+(``dagr/utils/coco_eval.py``) of ``ema.ema``'s detections and keeps the best checkpoint, as the reference does.
 
   python scripts/train_ncaltech101.py --epochs 3 --samples 256 --batch_size 16
   python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 scripts/train_ncaltech101.py --batch_size 64
@@ -92,24 +92,26 @@ def train_epoch(loader, net, module, ema, scheduler, optimizer, clip, dev, log, 
 
 
 @torch.no_grad()
-def validate(loader, net, dev, dry_run_steps=-1):
-    """``run_test`` of the training script (:76-99): detections of ``ema.ema`` into the mAP buffer when pycocotools
-    exists; otherwise the mean training-mode loss of the validation batches (batch statistics, no parameter update)."""
+def validate(loader, net, dev, dry_run_steps=-1, detections=True):
+    """``run_test`` of the training script (:76-99): ``ema.ema`` in eval mode through the window engine, detections and
+    targets into the mAP buffer; every rank evaluates its slice of the validation batches and the buffers are merged on
+    all ranks before ``compute``.  ``detections=False`` (stand-in models without an eval branch): the mean training-mode
+    loss of the validation batches instead, reported as a negative "mAP" so that the best-checkpoint logic still works."""
     from dagr.utils.buffers import DetectionBuffer
-    try:
-        import pycocotools  # noqa: F401
-        have_coco = True
-    except ImportError:
-        have_coco = False
-    if have_coco:
+    if detections:
         net.eval()
         buf = DetectionBuffer(height=loader.dataset.height, width=loader.dataset.width, classes=loader.dataset.classes)
         for i, data in enumerate(loader):
             data = format_data(data.to(dev))
-            detections, targets = net(data)
-            buf.update(detections, targets, "ncaltech101", data.height[0], data.width[0])
+            dets, targets = net(data)
+            buf.update(dets, targets, "ncaltech101", data.height[0], data.width[0])
             if 0 < dry_run_steps == i:
                 break
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            parts = [None] * torch.distributed.get_world_size()
+            torch.distributed.all_gather_object(parts, (buf.detections, buf.ground_truth))
+            buf.detections = [d for p in parts for d in p[0]]
+            buf.ground_truth = [g for p in parts for g in p[1]]
         return buf.compute()
     was = net.training
     net.train()
@@ -191,7 +193,8 @@ def main(argv=None, model_factory=None, preset="ncaltech101"):
     scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer=optimizer, lr_lambda=schedule)
     out_dir = set_up_logging_directory(preset, "detection", a.output_directory, exp_name=a.exp_name)
     ckpt = Checkpointer(output_directory=out_dir, model=model, optimizer=optimizer, scheduler=scheduler, ema=ema, args=args)
-    ckpt.mAP_max = float("-inf")            # the fallback metric (negative validation loss) is below the reference's 0
+    if model_factory is not None:
+        ckpt.mAP_max = float("-inf")        # stand-in models report a negative validation loss in place of mAP
     start_epoch = 0
     if a.resume_checkpoint is not None:
         start_epoch = ckpt.restore_checkpoint(a.resume_checkpoint, best=False)
@@ -210,7 +213,7 @@ def main(argv=None, model_factory=None, preset="ncaltech101"):
             break
         if epoch % 3 > 0:
             continue
-        metrics = validate(val_loader, ema.ema if model_factory is None else model, dev)
+        metrics = validate(val_loader, ema.ema if model_factory is None else model, dev, detections=model_factory is None)
         if rank == 0:
             print(f"epoch {epoch}: validation {metrics}")
             ckpt.process(metrics, epoch)
