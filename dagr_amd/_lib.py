@@ -108,6 +108,7 @@ SIGNATURES = {
                                               c_i64, c_i32, c_void_p]),
     "dagr_downsample_events": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_i32, c_i32, c_void_p,
                                               c_void_p, c_void_p]),
+    "dagr_debug_postprocess_clocks": (ctypes.c_int, [c_void_p]),
     "dagr_debug_calibrate": (ctypes.c_int, [c_i32, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p]),
     "dagr_spline_conv_fused_lds_bytes": (c_size_t, [c_i32, c_i32]),
     "dagr_spline_conv_fused": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32,

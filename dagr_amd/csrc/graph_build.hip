@@ -573,7 +573,12 @@ __global__ __launch_bounds__(kBlock) void k_search_tiled(const int32_t *__restri
         }
         if (l == 0) { deg[n] = total; edges_acc += total; }
     }
-    if (l == 0 && edges_acc) atomicAdd(reinterpret_cast<unsigned long long *>(status + 2), (unsigned long long)edges_acc);
+    {   // one atomic per wave instead of one per lane group (same single-counter drain as in k_search_rows)
+        unsigned long long v = (l == 0) ? (unsigned long long)edges_acc : 0ull;
+        v += __shfl_down(v, 32, 64);
+        v += __shfl_down(v, 16, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(reinterpret_cast<unsigned long long *>(status + 2), v);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -615,6 +620,7 @@ __global__ __launch_bounds__(kBlock, 7) void k_search_rows(const int32_t *__rest
     // has 160 KiB per CU and runs 6 workgroups of this kernel.
     extern __shared__ int v_key_dyn[];
     __shared__ int def_buf[kBlock / 64][64];
+    __shared__ unsigned long long blk_edges;   // the block's edge count: ONE global atomic per workgroup at the end
     int wcnt = 0;    // entries of this wave's deferral buffer (uniform over the wave's active lanes)
     const int side = 2 * r + 1;
     const int S = side * side;
@@ -623,6 +629,7 @@ __global__ __launch_bounds__(kBlock, 7) void k_search_rows(const int32_t *__rest
         spiral_offset(s, sx, sy);
         sp_rank[(sy + r) * 16 + (sx + r)] = (unsigned char)s;
     }
+    if (threadIdx.x == 0) blk_edges = 0ull;
     __syncthreads();
     const int l = threadIdx.x & 15;
     const int grp = threadIdx.x >> 4;
@@ -806,7 +813,13 @@ __global__ __launch_bounds__(kBlock, 7) void k_search_rows(const int32_t *__rest
             if (lane64 < wcnt) node_list[base + lane64] = def_buf[threadIdx.x >> 6][lane64];
         }
     }
-    if (l == 0 && edges_acc) atomicAdd(reinterpret_cast<unsigned long long *>(status + 2), (unsigned long long)edges_acc);
+    // A persistent grid ends all of its ~25 k lane groups at about the same time: one global atomic per group on this
+    // single counter drained at ~350 M/s, i.e. ~70 us after the last neighbourhood was written (most of the kernel at
+    // 25 k events, a quarter of it at 800 k).  Reduced in LDS first.
+    if (l == 0 && edges_acc) atomicAdd(&blk_edges, (unsigned long long)edges_acc);
+    __syncthreads();
+    if (threadIdx.x == 0 && blk_edges)
+        atomicAdd(reinterpret_cast<unsigned long long *>(status + 2), blk_edges);
 }
 
 // ---------------------------------------------------------------------------------------------

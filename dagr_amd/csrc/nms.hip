@@ -12,6 +12,10 @@ namespace dagr {
 namespace {
 constexpr int kMaxAnchors = 1024;
 constexpr int kMaskAnchors = 256, kMaskWords = kMaskAnchors / 64;
+// phase clocks of k_postprocess, image 0 (constant 100 MHz counter): written on every launch, read by
+// dagr_debug_postprocess_clocks -- builder instrumentation, a handful of scalar stores
+__device__ long long g_pp_clk[8];
+#define PP_CLK(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_pp_clk[k] = wall_clock64(); } while (0)
 
 // Greedy suppression over the score-sorted candidates (s_keep = candidate flags in, survivor flags out): box i, if still
 // alive when its turn comes, removes every later box j with IoU(i, j) > thr.  The chain over i is inherently sequential,
@@ -28,6 +32,48 @@ __device__ __forceinline__ bool iou_above(const float4 bi, float area_i, const f
     return inter / (area_i + area_j - inter) > thr;
 }
 
+// Descending sort of (key, index) pairs with ties broken by ascending index, in LDS.  Up to 256 candidates: rank sort --
+// every element counts the elements that precede it (175 broadcast reads per thread) and drops itself at that position:
+// two barriers instead of the 36 of a 256-wide bitonic network, which were most of k_postprocess (54 us per launch).
+// Larger inputs keep the bitonic network.  s_idx must hold i at position i on entry (pads: 0x7fffffff, key -inf).
+__device__ void sort_desc(int A, int Apad, float *s_key, int *s_idx, float *s_key2) {
+    if (A <= kMaskAnchors) {
+        float ki = 0.f;
+        int rank = 0;
+        const int i = threadIdx.x;
+        if (i < A) {
+            ki = s_key[i];
+            for (int j = 0; j < A; j++) {
+                const float kj = s_key[j];
+                rank += ((kj > ki) || (kj == ki && j < i)) ? 1 : 0;
+            }
+        }
+        __syncthreads();
+        if (i < A) { s_key2[rank] = ki; s_idx[rank] = i; }
+        __syncthreads();
+        if (i < A) s_key[i] = s_key2[i];
+        __syncthreads();
+        return;
+    }
+    for (int k = 2; k <= Apad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < Apad; i += (int)blockDim.x) {
+                const int q = i ^ j;
+                if (q > i) {
+                    const float ka = s_key[i], kb = s_key[q];
+                    const int ia = s_idx[i], ib = s_idx[q];
+                    const bool a_first = (ka > kb) || (ka == kb && ia < ib);   // a should precede b
+                    const bool up = (i & k) == 0;
+                    if (up ? !a_first : a_first) {
+                        s_key[i] = kb; s_key[q] = ka; s_idx[i] = ib; s_idx[q] = ia;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 __device__ void greedy_suppress(int A, const float4 *s_box, int *s_keep, float thr,
                                 unsigned long long (*s_mask)[kMaskWords]) {
     if (A > kMaskAnchors) {      // generic path: one barrier per candidate
@@ -35,15 +81,15 @@ __device__ void greedy_suppress(int A, const float4 *s_box, int *s_keep, float t
             if (s_keep[i]) {   // uniform: read after the barrier below
                 const float4 bi = s_box[i];
                 const float area_i = (bi.z - bi.x) * (bi.w - bi.y);
-                for (int j = i + 1 + threadIdx.x; j < A; j += kBlock)
+                for (int j = i + 1 + threadIdx.x; j < A; j += (int)blockDim.x)
                     if (s_keep[j] && iou_above(bi, area_i, s_box[j], thr)) s_keep[j] = 0;
             }
             __syncthreads();
         }
         return;
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = wave; i < A; i += kBlock / 64) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    for (int i = wave; i < A; i += n_waves) {
         const float4 bi = s_box[i];
         const float area_i = (bi.z - bi.x) * (bi.w - bi.y);
         const bool vi = s_keep[i] != 0;
@@ -56,26 +102,40 @@ __device__ void greedy_suppress(int A, const float4 *s_box, int *s_keep, float t
         }
     }
     __syncthreads();
+    PP_CLK(6);
     if (wave == 0) {
+        // The chain.  Everything here is wave-uniform: the removed-set lives in scalar registers, a block of 64 rows is
+        // pulled from LDS once (lane l holds row 64 blk + l) and row `bit` is then broadcast with readlane -- no LDS
+        // round trip inside the dependent loop.
         unsigned long long removed[kMaskWords] = {0ull, 0ull, 0ull, 0ull};
-        unsigned long long cur[kMaskWords], nxt[kMaskWords];
-#pragma unroll
-        for (int w = 0; w < kMaskWords; w++) cur[w] = s_mask[0][w];
 #pragma unroll
         for (int blk = 0; blk < kMaskWords; blk++) {
-            for (int bit = 0; bit < 64; bit++) {
-                const int i = blk * 64 + bit;
-                if (i >= A) break;
-                const int in = min(i + 1, A - 1);
+            if (blk * 64 < A) {
+                const int row = blk * 64 + lane;
+                unsigned long long mine[kMaskWords];
 #pragma unroll
-                for (int w = 0; w < kMaskWords; w++) nxt[w] = s_mask[in][w];     // prefetch: independent of the chain
-                const bool alive = s_keep[i] != 0 && ((removed[blk] >> bit) & 1ull) == 0ull;
-                if (alive) {
+                for (int w = 0; w < kMaskWords; w++) mine[w] = row < A ? s_mask[row][w] : 0ull;
+                // only candidates whose row has a bit set can remove anything: walk those (few when boxes barely overlap,
+                // all of them around a crowded object)
+                bool any = false;
 #pragma unroll
-                    for (int w = 0; w < kMaskWords; w++) removed[w] |= cur[w];
+                for (int w = 0; w < kMaskWords; w++) any = any || mine[w] != 0ull;
+                unsigned long long todo = __ballot(row < A && s_keep[row] != 0 && any);
+                while (todo) {
+                    const int bit = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1ull;
+                    const bool alive = ((removed[blk] >> bit) & 1ull) == 0ull;
+                    if (alive) {
+#pragma unroll
+                        for (int w = 0; w < kMaskWords; w++) {
+                            if (w >= blk) {      // a row only carries bits of later candidates: words below its own are 0
+                                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(mine[w] & 0xffffffffull), bit);
+                                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(mine[w] >> 32), bit);
+                                removed[w] |= ((unsigned long long)hi << 32) | lo;
+                            }
+                        }
+                    }
                 }
-#pragma unroll
-                for (int w = 0; w < kMaskWords; w++) cur[w] = nxt[w];
             }
         }
 #pragma unroll
@@ -97,6 +157,7 @@ __global__ __launch_bounds__(kBlock) void k_nms(const float *__restrict__ boxes,
     __shared__ float4 s_box[kMaxAnchors];
     __shared__ int s_keep[kMaxAnchors];
     __shared__ unsigned long long s_mask[kMaskAnchors][kMaskWords];
+    __shared__ float s_key2[kMaskAnchors];
     __shared__ int s_count;
     const int b = blockIdx.x;
     const float *bx = boxes + (size_t)b * A * 4;
@@ -106,24 +167,7 @@ __global__ __launch_bounds__(kBlock) void k_nms(const float *__restrict__ boxes,
         s_idx[i] = i < A ? i : 0x7fffffff;
     }
     __syncthreads();
-    // bitonic sort, descending by score, ascending by index on ties
-    for (int k = 2; k <= Apad; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < Apad; i += kBlock) {
-                const int p = i ^ j;
-                if (p > i) {
-                    const float ka = s_key[i], kb = s_key[p];
-                    const int ia = s_idx[i], ib = s_idx[p];
-                    const bool a_first = (ka > kb) || (ka == kb && ia < ib);   // a should precede b
-                    const bool up = (i & k) == 0;
-                    if (up ? !a_first : a_first) {
-                        s_key[i] = kb; s_key[p] = ka; s_idx[i] = ib; s_idx[p] = ia;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    }
+    sort_desc(A, Apad, s_key, s_idx, s_key2);      // descending by score, ascending by index on ties
     for (int i = threadIdx.x; i < A; i += kBlock) {
         const int a = s_idx[i];
         const bool ok = s_key[i] > -INFINITY;
@@ -151,7 +195,8 @@ __global__ __launch_bounds__(kBlock) void k_nms(const float *__restrict__ boxes,
 // rows [cx, cy, w, h, obj, cls...] -> xyxy (x1 = cx - w/2, x2 = w + x1: the reference's in-place op order), class
 // max / argmax, score = obj * class_conf, confidence mask (score * class_conf >= thr), class-offset greedy NMS, and
 // the survivors written front-compacted in descending-score order as rows (x1, y1, x2, y2, score, label).
-__global__ __launch_bounds__(kBlock) void k_postprocess(const float *__restrict__ pred, int A, int Apad, int ncls,
+constexpr int kPostThreads = 1024;   // 16 waves: four per SIMD, so the pairwise-IoU phase hides its VALU latencies
+__global__ __launch_bounds__(kPostThreads) void k_postprocess(const float *__restrict__ pred, int A, int Apad, int ncls,
                                                        float conf_thr, float nms_thr, float class_offset,
                                                        float *__restrict__ det, int32_t *__restrict__ n_keep) {
     __shared__ float s_key[kMaxAnchors];
@@ -162,11 +207,13 @@ __global__ __launch_bounds__(kBlock) void k_postprocess(const float *__restrict_
     __shared__ float4 s_box[kMaxAnchors];     // class-offset boxes, score order
     __shared__ int s_keep[kMaxAnchors];
     __shared__ unsigned long long s_mask[kMaskAnchors][kMaskWords];
-    __shared__ int s_scan[4];
+    __shared__ float s_key2[kMaskAnchors];
+    __shared__ int s_scan[kPostThreads / 64];
     const int b = blockIdx.x;
     const int ld = 5 + ncls;
     const float *p = pred + (size_t)b * A * ld;
-    for (int i = threadIdx.x; i < Apad; i += kBlock) {
+    PP_CLK(0);
+    for (int i = threadIdx.x; i < Apad; i += kPostThreads) {
         bool ok = false;
         float sc = -INFINITY;
         if (i < A) {
@@ -186,24 +233,10 @@ __global__ __launch_bounds__(kBlock) void k_postprocess(const float *__restrict_
         s_idx[i] = i < A ? i : 0x7fffffff;
     }
     __syncthreads();
-    for (int k = 2; k <= Apad; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < Apad; i += kBlock) {
-                const int q = i ^ j;
-                if (q > i) {
-                    const float ka = s_key[i], kb = s_key[q];
-                    const int ia = s_idx[i], ib = s_idx[q];
-                    const bool a_first = (ka > kb) || (ka == kb && ia < ib);
-                    const bool up = (i & k) == 0;
-                    if (up ? !a_first : a_first) {
-                        s_key[i] = kb; s_key[q] = ka; s_idx[i] = ib; s_idx[q] = ia;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    }
-    for (int i = threadIdx.x; i < A; i += kBlock) {
+    PP_CLK(1);
+    sort_desc(A, Apad, s_key, s_idx, s_key2);
+    PP_CLK(2);
+    for (int i = threadIdx.x; i < A; i += kPostThreads) {
         const bool ok = s_key[i] > -INFINITY;
         float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ok) {
@@ -216,7 +249,9 @@ __global__ __launch_bounds__(kBlock) void k_postprocess(const float *__restrict_
         s_keep[i] = ok ? 1 : 0;
     }
     __syncthreads();
+    PP_CLK(3);
     greedy_suppress(A, s_box, s_keep, nms_thr, s_mask);
+    PP_CLK(4);
     // front-compaction: thread t owns the 4 consecutive sorted positions 4t .. 4t+3
     int mine[4], cnt = 0;
 #pragma unroll
@@ -240,6 +275,7 @@ __global__ __launch_bounds__(kBlock) void k_postprocess(const float *__restrict_
         }
     }
     if (threadIdx.x == 0) n_keep[b] = total;
+    PP_CLK(5);
 }
 // collect_outputs + decode_outputs of the eval head (model/networks/dagr.py:283-312) for up to two scales in one launch:
 // dense maps [B, 5+C, Hs, Ws] (reg 4 | obj 1 | cls C, raw logits) -> out[B, A, 5+C] with A = sum Hs*Ws, anchors of a scale
@@ -295,9 +331,15 @@ extern "C" int dagr_postprocess(const float *pred, int32_t B, int32_t A, int32_t
     }
     int Apad = 1;
     while (Apad < A) Apad <<= 1;
-    k_postprocess<<<B, kBlock, 0, (hipStream_t)stream>>>(pred, A, Apad, num_classes, conf_threshold, iou_threshold,
+    k_postprocess<<<B, kPostThreads, 0, (hipStream_t)stream>>>(pred, A, Apad, num_classes, conf_threshold, iou_threshold,
                                                          class_offset, det, n_keep);
     DAGR_CHECK_LAUNCH();
+    return DAGR_OK;
+}
+
+extern "C" int dagr_debug_postprocess_clocks(long long *out8) {
+    DAGR_CHECK_ARG(out8, "NULL pointer");
+    DAGR_CHECK_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_pp_clk), 8 * sizeof(long long)));
     return DAGR_OK;
 }
 

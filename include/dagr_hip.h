@@ -356,6 +356,9 @@ int dagr_nms_batched(const float *boxes, const float *scores, const int32_t *cls
                      int32_t B, int32_t A, float iou_threshold, float class_offset,
                      int32_t *order_out, int32_t *keep_out, int32_t *n_keep, void *stream);
 
+/* builder instrumentation: the 100-MHz phase clocks image 0 of the last dagr_postprocess launch wrote
+ * (0 start, 1 scored, 2 sorted, 3 boxes staged, 6 suppression bits built, 4 chain done, 5 end). */
+int dagr_debug_postprocess_clocks(long long *out8);
 /* collect_outputs + decode_outputs of the eval head (model/networks/dagr.py:283-312; grid/stride cache of
  * model/utils.py:119-134) for one or two scales in one launch: dense logit maps [B, channels = 5+C, Hs, Ws] (reg | obj |
  * cls) -> out[B, A, channels], A = H0*W0 (+ H1*W1), xy = (logit + cell) * stride, wh = exp(logit) * stride, the rest
