@@ -600,8 +600,9 @@ __global__ __launch_bounds__(kBlock) void k_search_tiled(const int32_t *__restri
 // (LIST_IN re-sweeps a deferral list; kept for experiments.)
 constexpr int kRowCap = 320;
 
-template <int CAP, bool LIST_IN>
-__global__ __launch_bounds__(kBlock, 7) void k_search_rows(const int32_t *__restrict__ m_ptr, int W, int H, int K, int r,
+// ROUNDS x 16 candidates are requested before the first is examined; WAVES per SIMD = the register budget (512 / WAVES)
+template <int CAP, bool LIST_IN, int ROUNDS = 4, int WAVES = 7>
+__global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__restrict__ m_ptr, int W, int H, int K, int r,
                                                        float delta_t, const int32_t *__restrict__ slot_xyb,
                                                        const int32_t *__restrict__ start,
                                                        const int2 *__restrict__ slot_it,
@@ -717,11 +718,11 @@ __global__ __launch_bounds__(kBlock, 7) void k_search_rows(const int32_t *__rest
         __builtin_amdgcn_wave_barrier();
         // 2. candidates, 16 per round, 4 rounds of loads in flight
         int V = 0;
-        for (int c0 = 0; c0 < C; c0 += 64) {
-            int2 it[4];
-            int cxv[4], sv[4], relv[4], rrv[4];
+        for (int c0 = 0; c0 < C; c0 += 16 * ROUNDS) {
+            int2 it[ROUNDS];
+            int cxv[ROUNDS], sv[ROUNDS], relv[ROUNDS], rrv[ROUNDS];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < ROUNDS; q++) {
                 const int ci = c0 + 16 * q + l;
                 it[q] = make_int2(0, 0);
                 cxv[q] = 0; sv[q] = 0; relv[q] = 0; rrv[q] = 0;
@@ -739,7 +740,7 @@ __global__ __launch_bounds__(kBlock, 7) void k_search_rows(const int32_t *__rest
                 }
             }
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < ROUNDS; q++) {
                 const int ci = c0 + 16 * q + l;
                 bool valid = false;
                 int key = 0;
@@ -1003,12 +1004,24 @@ int dagr_graph_build_window(const dagr_graph_desc *desc, void *workspace, const 
         // is dead after k_scatter; counter in status[5]) to the position-centric tiled kernel
         // (the deferral list lives in ev_rank, dead after k_scatter; its counter is status[5])
         constexpr size_t rows_lds = (size_t)(kBlock / 16) * kRowCap * 4;
-        static const unsigned res_rows = persistent_grid(k_search_rows<kRowCap, false>, kBlock, rows_lds, 1 << 30);
         static const unsigned res_tiled = persistent_grid(k_search_tiled, kBlock, 0, 1 << 30);
-        const unsigned gR = round_grid8(std::min<int64_t>(ceil_div(N * 16, kBlock), res_rows));
-        k_search_rows<kRowCap, false><<<gR, kBlock, rows_lds, stream>>>(
-            ws.start + ws.P, W, H, desc->max_neighbors, desc->radius, (float)desc->delta_t_us, ws.slot_xyb, ws.start,
-            ws.slot_it, nbr_src, nbr_code, deg, ws.status, ws.ev_rank, ws.status + 5, nullptr, nullptr);
+        // builder knob DAGR_ROWS_VARIANT = 10 * rounds + waves per SIMD (16 candidates per round); default 47
+        static const int variant = [] { const char *e = getenv("DAGR_ROWS_VARIANT"); return e ? atoi(e) : 47; }();
+        auto launch_rows = [&](auto kern) {
+            static thread_local unsigned res_rows = 0;
+            if (!res_rows) res_rows = persistent_grid(kern, kBlock, rows_lds, 1 << 30);
+            const unsigned gR = round_grid8(std::min<int64_t>(ceil_div(N * 16, kBlock), res_rows));
+            kern<<<gR, kBlock, rows_lds, stream>>>(
+                ws.start + ws.P, W, H, desc->max_neighbors, desc->radius, (float)desc->delta_t_us, ws.slot_xyb, ws.start,
+                ws.slot_it, nbr_src, nbr_code, deg, ws.status, ws.ev_rank, ws.status + 5, nullptr, nullptr);
+        };
+        switch (variant) {
+            case 57: launch_rows(k_search_rows<kRowCap, false, 5, 7>); break;
+            case 46: launch_rows(k_search_rows<kRowCap, false, 4, 6>); break;
+            case 66: launch_rows(k_search_rows<kRowCap, false, 6, 6>); break;
+            case 85: launch_rows(k_search_rows<kRowCap, false, 8, 5>); break;
+            default: launch_rows(k_search_rows<kRowCap, false, 4, 7>); break;
+        }
         DAGR_CHECK_LAUNCH();
         const unsigned gT = round_grid8(std::min<int64_t>(ceil_div(N * 16, kBlock), res_tiled));
         k_search_tiled<<<gT, kBlock, 0, stream>>>(ws.start + ws.P, W, H, desc->max_neighbors, desc->queue_size,

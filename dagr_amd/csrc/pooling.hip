@@ -675,6 +675,7 @@ __global__ __launch_bounds__(1024) void k_pool_scan(PoolWs ws, int32_t *__restri
     constexpr int PER = 16;
     __shared__ int w_occ[16], w_cnt[16];
     __shared__ int carry[2];
+    __shared__ __align__(16) unsigned char st_occ[1024 * PER], st_cnt[1024 * PER];
     const int n = ws.T + 1;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     if (threadIdx.x == 0) { carry[0] = 0; carry[1] = 0; }
@@ -682,33 +683,44 @@ __global__ __launch_bounds__(1024) void k_pool_scan(PoolWs ws, int32_t *__restri
     for (int base = 0; base < n; base += 1024 * PER) {
         const int i0 = base + threadIdx.x * PER;
         int occ[PER], cnt[PER];
-        if (i0 + PER <= n) {       // (the tables are padded: whole int4 rounds stay inside the allocation)
+        // Load phase, coalesced: thread t takes elements base + 1024 j + t (one 4-KiB row of each table per step, the
+        // clearing stores ride on the same addresses) and parks them as bytes in LDS -- a flag is 0/1, a row size or bitmap
+        // population is <= 64; the scan below then reads its 16 CONSECUTIVE slots as one 16-byte LDS word per table.
+        // (Reading 16 consecutive slots per thread straight from memory touched 64 cache lines per load instruction:
+        // 35 us for the 20 k slots of a B = 8 level-0 table.)
+        {
+            int ov[PER];
+            unsigned long long mv[PER];
+            int cv[PER];
+            // all 16 (x2) loads of a thread are issued before anything waits on them: one memory round trip per round
 #pragma unroll
-            for (int k = 0; k < PER; k += 4) {
-                const int4 a = *reinterpret_cast<const int4 *>(ws.occupied + i0 + k);
-                occ[k] = a.x; occ[k + 1] = a.y; occ[k + 2] = a.z; occ[k + 3] = a.w;
-                *reinterpret_cast<int4 *>(ws.occupied + i0 + k) = make_int4(0, 0, 0, 0);
-                if (!MASKS) {
-                    const int4 c = *reinterpret_cast<const int4 *>(ws.rowcnt + i0 + k);
-                    cnt[k] = c.x; cnt[k + 1] = c.y; cnt[k + 2] = c.z; cnt[k + 3] = c.w;
-                    *reinterpret_cast<int4 *>(ws.rowcnt + i0 + k) = make_int4(0, 0, 0, 0);
+            for (int j = 0; j < PER; j++) {
+                const int e = base + j * 1024 + (int)threadIdx.x;
+                ov[j] = (e < n) ? ws.occupied[e] : 0;
+                if (MASKS) mv[j] = (e < ws.T) ? ws.nbmask[e] : 0ull;
+                else cv[j] = (e < n) ? ws.rowcnt[e] : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < PER; j++) {
+                const int e = base + j * 1024 + (int)threadIdx.x;
+                if (e < n) {
+                    ws.occupied[e] = 0;
+                    if (!MASKS) ws.rowcnt[e] = 0;
                 }
+                const int c = MASKS ? __popcll(mv[j]) : cv[j];
+                st_occ[j * 1024 + threadIdx.x] = (unsigned char)ov[j];
+                st_cnt[j * 1024 + threadIdx.x] = (unsigned char)min(c, 255);
             }
-            if (MASKS) {
-#pragma unroll
-                for (int k = 0; k < PER; k++) cnt[k] = (i0 + k < ws.T) ? __popcll(ws.nbmask[i0 + k]) : 0;
-            }
-        } else {
+        }
+        __syncthreads();
+        {
+            const uint4 po = *reinterpret_cast<const uint4 *>(st_occ + threadIdx.x * PER);
+            const uint4 pc = *reinterpret_cast<const uint4 *>(st_cnt + threadIdx.x * PER);
+            const unsigned wo[4] = {po.x, po.y, po.z, po.w}, wc[4] = {pc.x, pc.y, pc.z, pc.w};
 #pragma unroll
             for (int k = 0; k < PER; k++) {
-                const bool in = i0 + k < n;
-                occ[k] = in ? ws.occupied[i0 + k] : 0;
-                if (MASKS) cnt[k] = (i0 + k < ws.T) ? __popcll(ws.nbmask[i0 + k]) : 0;
-                else cnt[k] = in ? ws.rowcnt[i0 + k] : 0;
-                if (in) {
-                    ws.occupied[i0 + k] = 0;
-                    if (!MASKS) ws.rowcnt[i0 + k] = 0;
-                }
+                occ[k] = (wo[k >> 2] >> (8 * (k & 3))) & 0xff;
+                cnt[k] = (wc[k >> 2] >> (8 * (k & 3))) & 0xff;
             }
         }
         int s_occ = 0, s_cnt = 0;
