@@ -32,7 +32,7 @@ def convert_to_training_format(bbox, batch, batch_size):
 
 
 def training_losses(sd, args, height, width, x, y, t, p, b, batch_size, bbox, bbox_batch, image_feat=None, cnn_out=None,
-                    bbox0=None, bbox0_batch=None):
+                    bbox0=None, bbox0_batch=None, exact_pos_mean=False):
     """The 6-tuple of ``get_losses`` (total, 5*iou, obj, cls, l1 = 0, matched anchors / ground truths) for one batch of
     windows; ``sd`` may hold leaf tensors that require grad.
 
@@ -40,7 +40,11 @@ def training_losses(sd, args, height, width, x, y, t, p, b, batch_size, bbox, bb
     DETACHED, net.py:118,129,...), ``cnn_out`` = the CNN head's raw maps on the resized image outputs (dict of lists
     ``cls_output`` / ``reg_output`` / ``obj_output``; they enter the hybrid sum detached, and train on their own through a
     second ``get_losses`` against the boxes of the EARLIER frame, ``bbox0``); the two loss tuples are added element-wise
-    for the first five entries, the sixth is the image branch's."""
+    for the first five entries, the sixth is the image branch's.
+
+    ``exact_pos_mean``: pooled positions from the correctly rounded mean (``oracle.ops.pooling``): the form the GPU
+    comparisons use -- a cluster mean that lands within 1e-4 px of a pixel boundary floors differently under fp32
+    sequential summation, which moves ONE pooled node by a pixel and with it ~1 % of a mid-level weight gradient."""
     nc = om.NetConstants(args, height, width)
     detached = None
     if cnn_out is not None:
@@ -48,7 +52,7 @@ def training_losses(sd, args, height, width, x, y, t, p, b, batch_size, bbox, bb
         image_feat = [f.detach() for f in image_feat]
     with ops.batch_statistics():
         _, raw = om.forward_events(sd, args, height, width, x, y, t, p, b, batch_size, use_lut=False,
-                                   image_feat=image_feat, cnn_out=detached)
+                                   image_feat=image_feat, cnn_out=detached, exact_pos_mean=exact_pos_mean)
     maps = [torch.cat([reg_o, obj_o, cls_o], 1) for (cls_o, reg_o, obj_o) in raw]      # collect_outputs, dagr.py:293-294
     labels = convert_to_training_format(bbox, bbox_batch, batch_size)
     n_cls = maps[0].shape[1] - 5

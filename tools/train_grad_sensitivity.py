@@ -1,0 +1,73 @@
+#!/usr/bin/env python
+"""tools/train_grad_sensitivity.py -- how ill-conditioned are the training gradients?  CPU only: the oracle's gradients
+(oracle/train.py) with the weights perturbed by relative gaussian noise of a given size, against the unperturbed run, on
+cases of tools/train_parity_sweep.py.  Discrete switches (max-pool arg-max near ties, ReLU at ~0, SimOTA costs) make
+single tensors move by per cents under perturbations of a few 1e-6 -- the size of the rounding differences between two
+correct fp32 implementations -- while the loss moves by 1e-7.  Puts the sweep's outliers (<= 1.2e-2 on one tensor, 1e-5
+typical) in proportion.  usage: python tools/train_grad_sensitivity.py [noise=3e-6]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import model as om, train as otr  # noqa: E402
+from dagr_amd.data import Batch, Data  # noqa: E402
+from dagr_amd.model.networks.dagr import DAGR  # noqa: E402
+from dagr_amd.utils import synthetic as syn  # noqa: E402
+from dagr_amd.utils.testing_weights import randomize_  # noqa: E402
+
+NOISE = float(sys.argv[1]) if len(sys.argv) > 1 else 3e-6
+CASES = [(346, 260, 3, 4699, 704, dict(net_stem_width=1.0, yolo_stem_width=1.0, num_scales=1, dataset="ncaltech101")),
+         (240, 180, 2, 1707, 710, dict(net_stem_width=0.25, yolo_stem_width=0.25)),
+         (240, 180, 2, 3656, 700, dict(num_scales=1, dataset="ncaltech101"))]
+
+
+def case(W, H, B, n, seed, **over):          # == tests/test_training_gpu.py:_training_case, CPU side only
+    torch.manual_seed(seed)
+    args = om.default_args(batch_size=B, **over)
+    model = randomize_(DAGR(args, height=H, width=W), seed=seed)
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    samples, raw = [], []
+    rng = np.random.default_rng(seed)
+    for s in range(B):
+        x, y, t, p = syn.edges_window(n, W, H, seed=seed * 10 + s)
+        raw.append((x, y, t, p))
+        nb = 1 + s % 2
+        boxes = np.stack([rng.uniform(5, W / 2, nb), rng.uniform(5, H / 2, nb), rng.uniform(20, W / 3, nb),
+                          rng.uniform(20, H / 3, nb), rng.integers(0, 2, nb), np.ones(nb), np.zeros(nb)], 1)
+        samples.append(Data(x=torch.from_numpy(p.reshape(-1, 1)), pos=torch.from_numpy(np.stack([x, y], -1)),
+                            t=torch.from_numpy(t), width=W, height=H, time_window=1000000,
+                            bbox=torch.from_numpy(boxes.astype(np.float32)), sequence=f"s{s}"))
+    batch = Batch.from_data_list(samples, follow_batch=["bbox"])
+    ev = [np.concatenate([r[k] for r in raw]) for k in range(4)]
+    b = np.concatenate([np.full(len(r[0]), i, np.int64) for i, r in enumerate(raw)])
+    return args, sd0, batch, ev, b
+
+
+def grads(args, sd0, batch, ev, b, W, H, B, noise, gen):
+    sd = {}
+    for k, v in sd0.items():
+        if v.is_floating_point() and "running" not in k:
+            w = v.clone()
+            if noise:
+                w = w * (1 + noise * torch.randn(w.shape, generator=gen))
+            sd[k] = w.requires_grad_(True)
+        else:
+            sd[k] = v.clone()
+    out = otr.training_losses(sd, args, H, W, ev[0], ev[1], ev[2], ev[3], b, B, batch.bbox, batch.bbox_batch)
+    out[0].backward()
+    return float(out[0].detach()), {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
+
+
+for W, H, B, n, seed, over in CASES:
+    args, sd0, batch, ev, b = case(W, H, B, n, seed, **over)
+    l0, g0 = grads(args, sd0, batch, ev, b, W, H, B, 0, None)
+    l1, g1 = grads(args, sd0, batch, ev, b, W, H, B, NOISE, torch.Generator().manual_seed(1))
+    rel = {k: float((g1[k] - g0[k]).abs().max()) / max(1e-12, float(g0[k].abs().max())) for k in g0
+           if float(g0[k].abs().max()) > 0}
+    worst = max(rel, key=rel.get)
+    print(f"seed {seed}: loss {l0:.6f} -> {l1:.6f}; gradient change under {NOISE:g} relative weight noise: median "
+          f"{np.median(list(rel.values())):.1e}, worst {rel[worst]:.1e} ({worst})", flush=True)

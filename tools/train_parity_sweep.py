@@ -1,0 +1,59 @@
+#!/usr/bin/env python
+"""One-off randomized training-parity sweep on the GPU box: HIP training forward + backward vs the CPU oracle
+(tests/test_training_gpu.py helpers) over sensor sizes, batch sizes, event counts, model widths, head scales and seeds
+beyond the fixed cases of the test-suite.  usage: python tools/train_parity_sweep.py [n_cases] [first_seed]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+
+import test_training_gpu as T
+from oracle import train as otr
+from dagr_amd.utils.buffers import format_data
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 500
+rng = np.random.default_rng(seed0)
+geoms = [(240, 180), (320, 215), (346, 260)]
+t0 = time.time()
+bad = 0
+for k in range(n_cases):
+    W, H = geoms[int(rng.integers(0, len(geoms)))]
+    B = int(rng.integers(1, 5))
+    n = int(rng.integers(800, 5000))
+    over = {}
+    kind = int(rng.integers(0, 4))
+    if kind == 1:
+        over = dict(num_scales=1, dataset="ncaltech101")
+    elif kind == 2:
+        over = dict(net_stem_width=1.0, yolo_stem_width=1.0, num_scales=1, dataset="ncaltech101")
+    elif kind == 3:
+        over = dict(net_stem_width=0.25, yolo_stem_width=0.25)
+    seed = seed0 + k
+    args, model, sd, batch, ev, b = T._training_case(W, H, B, n, seed, **over)
+    ref = otr.training_losses(sd, args, H, W, ev[0], ev[1], ev[2], ev[3], b, B, batch.bbox, batch.bbox_batch)
+    ref[0].backward()
+    out = model(format_data(batch.cuda()))
+    out["total_loss"].backward()
+    dl = abs(float(out["total_loss"]) - float(ref[0])) / max(1.0, abs(float(ref[0])))
+    params = dict(model.named_parameters())
+    worst, cnt = (0.0, ""), 0
+    for name, v in sd.items():
+        if v.requires_grad and v.grad is not None and float(v.grad.abs().max()) > 0:
+            worst = max(worst, (T._rel(params[name].grad, v.grad), name))
+            cnt += 1
+    # typical agreement is ~1e-5; single tensors can move by per cents when a max-pool arg-max / ReLU / SimOTA switch
+    # sits within rounding distance (tools/train_grad_sensitivity.py: the ORACLE's own gradients move by up to 18 % under
+    # 3e-6 relative weight noise on these cases) -- flagged, and bounded at 5e-2
+    ok = dl < 5e-4 and worst[0] < 5e-2 and out["num_fg"] == ref[5]
+    if ok and worst[0] >= 2e-3:
+        print(f"   (case {k}: one tensor beyond 2e-3 -- a discrete switch within rounding distance)")
+    bad += not ok
+    print(f"case {k}: {W}x{H} B={B} n={n}/sample kind={kind} seed={seed}: loss rel {dl:.1e}, worst grad {worst[0]:.1e} "
+          f"({worst[1]}), {cnt} tensors: {'ok' if ok else 'MISMATCH'} ({time.time() - t0:.0f} s)", flush=True)
+print("sweep ok" if not bad else f"sweep: {bad} mismatching cases")
