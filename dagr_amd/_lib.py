@@ -88,6 +88,8 @@ SIGNATURES = {
     "dagr_pool_status": (ctypes.c_int, [ctypes.POINTER(PoolDesc), c_void_p, ctypes.POINTER(c_i32), c_void_p]),
     "dagr_to_dense": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_i32, c_i32, c_void_p, c_void_p, c_float, c_float,
                                      c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dagr_to_dense_armed": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_i32, c_i32, c_void_p, c_void_p, c_float, c_float,
+                                           c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dagr_pool_argmax": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_i32, c_i32, c_void_p, c_i32, c_i32, c_void_p, c_void_p]),
     "dagr_pool_grad": (ctypes.c_int, [c_void_p, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_i32,
                                       c_void_p]),

@@ -434,6 +434,9 @@ __global__ __launch_bounds__(kBlock) void k_search_tiled(const int32_t *__restri
                                                         const int32_t *__restrict__ node_list,
                                                         const int32_t *__restrict__ node_list_count) {
     __shared__ int tile[(kBlock / 16) * 16 * 17];
+    // list mode (the usual call): most windows defer nothing -- leave before the per-lane spiral constants are built
+    // (an empty sweep of the persistent grid cost 10 us per window)
+    if (node_list && *node_list_count <= 0) return;
     const int side = 2 * r + 1;
     const int S = side * side;
     const int l = threadIdx.x & 15;

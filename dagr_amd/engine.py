@@ -439,7 +439,7 @@ class WindowEngine:
                 stem=torch.zeros((T, self.n_reg), dtype=torch.float32, device=dev),
                 cr=torch.zeros((T, 2 * self.n_reg), dtype=torch.float32, device=dev),
                 pred=torch.zeros((T, 5 + self.num_classes), dtype=torch.float32, device=dev),
-                winner=torch.zeros((self.B * Hc * Wc,), dtype=torch.int32, device=dev),
+                winner=torch.full((self.B * Hc * Wc,), -1, dtype=torch.int32, device=dev),   # armed: dagr_to_dense_armed
                 dense=torch.zeros((self.B, 5 + self.num_classes, Hc, Wc), dtype=torch.float32, device=dev)))
         self.status = torch.zeros((4,), dtype=torch.int32, device=dev)
         # a head whose table domain is not its input level's (num_scales = 1: head "1" on out4 with the pool3
@@ -758,7 +758,7 @@ class WindowEngine:
                            dom, stream, code, scratch)
         Hc, Wc = self.out_sizes[i]
         vox = self.head_vox[i]
-        _lib.check(L.dagr_to_dense(P(lvl.counts), lvl.T, P(pred), npred, npred, P(lvl.pos), P(lvl.batch),
+        _lib.check(L.dagr_to_dense_armed(P(lvl.counts), lvl.T, P(pred), npred, npred, P(lvl.pos), P(lvl.batch),
                                    float(vox[0]), float(vox[1]), self.B, Hc, Wc, P(hb["winner"]), P(hb["dense"]),
                                    P(self.status), stream), "to_dense")
         return hb["dense"]

@@ -298,6 +298,11 @@ int dagr_pool_status(const dagr_pool_desc *desc, void *pool_ws, int32_t *flags_h
 int dagr_to_dense(const int32_t *n_ptr, int32_t n_max, const float *x, int32_t ldx, int32_t channels,
                   const float *pos, const int32_t *batch, float vx, float vy, int32_t batch_size,
                   int32_t Hc, int32_t Wc, int32_t *winner_scratch, float *dense, int32_t *status, void *stream);
+/* same result, two launches instead of three: winner_armed must hold -1 in every entry on entry (fill it once after
+ * allocation) and holds -1 again on return -- for callers that keep the scratch between windows (the engine). */
+int dagr_to_dense_armed(const int32_t *n_ptr, int32_t n_max, const float *x, int32_t ldx, int32_t channels,
+                        const float *pos, const int32_t *batch, float vx, float vy, int32_t batch_size,
+                        int32_t Hc, int32_t Wc, int32_t *winner_armed, float *dense, int32_t *status, void *stream);
 
 /* ------------------------------------------------------------------------ *
  * training path (scripts/train_ncaltech101.py:41-74): backward halves the reference gets from
