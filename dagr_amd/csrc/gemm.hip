@@ -217,9 +217,16 @@ __global__ __launch_bounds__(kGemmThreads) void k_conv_fused(
                 for (int c0 = 0; c0 < cin; c0 += 64) {
                     const int ch = c0 + lane;
                     const bool ch_ok = ch < cin;
+                    // A remainder of a few channels beyond this chunk (every pooled level carries C + 2 = 66 / 130 inputs:
+                    // the features and pos_xy) rides along on the first lanes instead of costing a second walk over the
+                    // edges with two active lanes -- same per-channel arithmetic and order, half the dependent chain.
+                    const int rem = cin - (c0 + 64);
+                    const bool ride = rem > 0 && rem <= 8;       // wave-uniform
+                    const int ch2 = c0 + 64 + lane;
+                    const bool ch2_ok = ride && lane < rem;
                     constexpr int UA = 8;
                     for (int j = 0; j < cnt; j += UA) {
-                        float v[UA];
+                        float v[UA], v2[UA];
                         int cd[UA];
 #pragma unroll
                         for (int u = 0; u < UA; u++) {   // UA gathers in flight
@@ -227,6 +234,7 @@ __global__ __launch_bounds__(kGemmThreads) void k_conv_fused(
                             const int src = __builtin_amdgcn_readlane(my_src, jj);
                             cd[u] = __builtin_amdgcn_readlane(my_cd, jj);
                             v[u] = ch_ok ? x[(size_t)src * ldx + ch] : 0.0f;
+                            v2[u] = ch2_ok ? x[(size_t)src * ldx + ch2] : 0.0f;
                         }
 #pragma unroll
                         for (int u = 0; u < UA; u++) {
@@ -245,9 +253,17 @@ __global__ __launch_bounds__(kGemmThreads) void k_conv_fused(
                                 *a10 = o10 + b10 * v[u];
                                 *a01 = o01 + b01 * v[u];
                                 *a11 = o11 + b11 * v[u];
+                                if (ch2_ok) {
+                                    const float p00 = a00[64], p10 = a10[64], p01 = a01[64], p11 = a11[64];
+                                    a00[64] = p00 + b00 * v2[u];
+                                    a10[64] = p10 + b10 * v2[u];
+                                    a01[64] = p01 + b01 * v2[u];
+                                    a11[64] = p11 + b11 * v2[u];
+                                }
                             }
                         }
                     }
+                    if (ride) break;
                 }
             }
         }
@@ -305,13 +321,24 @@ __global__ __launch_bounds__(kGemmThreads) void k_conv_fused(
                 }
                 g += 2 * U;
             }
-            for (g = gbeg + nfull * U; g < gend; g++) {   // < U left-over groups
-                const float4 bt = wq[(size_t)g * 64];
-                const float *ap = a_rd + 16 * g;
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[0], bt.x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4], bt.y, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[8], bt.z, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[12], bt.w, acc1, 0, 0, 0);
+            {   // < U left-over groups: all of their operands are requested before the first is used (on the small
+                // levels K / 16 splits into 7 groups per wave: one full batch + 3 left-overs, which used to be three
+                // dependent load -> MFMA round trips)
+                const int g0 = gbeg + nfull * U, rem = gend - g0;
+                float4 bt[U - 1];
+#pragma unroll
+                for (int r = 0; r < U - 1; r++)
+                    bt[r] = r < rem ? wq[(size_t)(g0 + r) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int r = 0; r < U - 1; r++) {
+                    if (r < rem) {
+                        const float *ap = a_rd + 16 * (g0 + r);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[0], bt[r].x, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4], bt[r].y, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[8], bt[r].z, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[12], bt[r].w, acc1, 0, 0, 0);
+                    }
+                }
             }
         }
         const f32x4 acc = {acc0[0] + acc1[0], acc0[1] + acc1[1], acc0[2] + acc1[2], acc0[3] + acc1[3]};
