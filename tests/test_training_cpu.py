@@ -313,3 +313,39 @@ def test_product_loss_equals_the_literal_oracle_restatement(seed):
     mine[0].backward()
     for a, b in zip(my_maps, ref_maps):
         assert torch.allclose(a.grad, b.grad, rtol=1e-4, atol=1e-6)
+
+
+def test_train_dsec_script_preset_on_cpu(tmp_path):
+    """scripts/train_dsec.py (the DSEC preset of the training script): two head scales, flip / zoom / translate
+    augmentations on events + frames + both box sets, ``--use_image`` samples (synthetic frames, bbox0) through the loader,
+    the loop, the validation pass and the checkpointer -- with a stand-in model (the HIP layers need a GPU)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "scripts"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    import train_dsec
+    seen = {}
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.l = torch.nn.Linear(2, 1)
+
+        def forward(self, data):
+            assert tuple(data.image.shape[1:]) == (3, 215, 320) and data.image.dtype == torch.float32
+            assert float(data.image.max()) <= 1.0
+            assert data.bbox.shape[0] == data.bbox0.shape[0] and hasattr(data, "bbox0_batch")
+            assert int(data.pos[:, 0].max() * 320 + 0.5) < 320 and data.pos.shape[1] == 3
+            seen["n"] = seen.get("n", 0) + 1
+            return {"total_loss": (self.l(data.pos[:, :2]).mean() - 0.3) ** 2, "num_fg": 1.0}
+
+    def factory(args, ds):
+        assert args.dataset == "dsec" and args.num_scales == 2 and args.use_image and args.aug_zoom == 1.5
+        assert (ds.height, ds.width) == (215, 320)
+        return M()
+    out, log = train_dsec.main(["--epochs", "1", "--samples", "8", "--val_samples", "4", "--batch_size", "4", "--n_nodes", "500",
+                                "--use_image", "--config", "dagr-s", "--output_directory", str(tmp_path)], model_factory=factory)
+    assert len(log) == 2 and seen["n"] == 3                      # two training batches + one validation batch
+    assert sorted(p.name.split("_")[0] for p in out.glob("*.pth")) == ["best", "last"]
+    assert out.parts[-3:] == ("dsec", "detection", "train")
