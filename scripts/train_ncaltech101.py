@@ -19,6 +19,7 @@ The N-Caltech101 reader needs h5py (absent here): with ``--dataset_directory`` i
   python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 scripts/train_ncaltech101.py --batch_size 64
 """
 import argparse
+import os
 import random
 import time
 from pathlib import Path
@@ -185,7 +186,9 @@ def main(argv=None, model_factory=None, preset="ncaltech101"):
         log_hparams(args)
         print(f"Training with {sum(p.numel() for p in model.parameters())} number of parameters.")
     ema = ModelEMA(model)
-    net = parallel.data_parallel(model, dev) if world > 1 else model
+    # (DAGR_FORCE_DDP=1 wraps a single process too: exercises the reducer on one GPU)
+    ddp = world > 1 or (os.environ.get("DAGR_FORCE_DDP") == "1" and torch.distributed.is_initialized())
+    net = parallel.data_parallel(model, dev) if ddp else model
     lr = float(args.l_r * np.sqrt(a.batch_size) / np.sqrt(64))                    # :132-133, nominal batch 64
     optimizer = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=lr,
                                   weight_decay=args.weight_decay)
