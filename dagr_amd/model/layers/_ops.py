@@ -43,6 +43,11 @@ def graph_csr(data):
     return cached[:3]
 
 
+def _in_csr_order(edge_attr, perm):
+    """Edge attributes in the CSR's edge order (perm None: the graph was built in that order)."""
+    return edge_attr if perm is None else edge_attr[perm]
+
+
 def spline_conv(conv, x, rowptr, col, code, norm=None, skip=None, xskip=None, relu=False):
     """out = act(BN(sum_j x_j . What(code_j) + x . root (+ bias)) (+ BN_skip(xskip . Wskip))) on a CSR graph."""
     from ...engine import _pack_generic
@@ -104,12 +109,12 @@ def conv_on_data(conv, data, norm=None, skip=None, xskip=None, relu=False):
         if not (norm is None and skip is None and not relu):
             raise RuntimeError("fused conv + BN epilogues are eval-mode only")
         d = conv.lut_domain
-        code, den_x, den_y = exact_codes(data.edge_attr[perm], data.edge_attr_max, d["width"], d["height"]) \
+        code, den_x, den_y = exact_codes(_in_csr_order(data.edge_attr, perm), data.edge_attr_max, d["width"], d["height"]) \
             if col.shape[0] else (col, 1.0, 1.0)
         from .autograd import SplineConvFn
         return SplineConvFn.apply(data.x, conv.weight, conv.lin.weight, conv.bias, rowptr, col, code, EXACT_R, EXACT_R,
                                   den_x, den_y)
-    code = lut_codes(data.edge_attr[perm], conv.lut_domain) if col.shape[0] else col
+    code = lut_codes(_in_csr_order(data.edge_attr, perm), conv.lut_domain) if col.shape[0] else col
     if norm is None and skip is None and not relu and torch.is_grad_enabled() and \
             (data.x.requires_grad or conv.weight.requires_grad):
         from .autograd import spline_conv_autograd       # eval-mode (LUT-domain) conv with gradients

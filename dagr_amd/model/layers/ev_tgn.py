@@ -6,6 +6,8 @@ batch's (width, height, time_window, num_graphs), resets it on ``reset=True`` ca
 attach to the running graph.  ``DAGR.forward`` on whole ``reset=True`` windows does not go through it: the engine asks
 ``window_builder()`` for the fused single-window builder (csrc/graph_build.hip), which produces the same edge set as
 fixed-stride neighbour lists without the FIFO volume."""
+import os
+
 import torch
 
 from ...graph.ev_graph import SlidingWindowGraph, WindowGraphBuilder
@@ -50,9 +52,32 @@ class EV_TGN(torch.nn.Module):
                                            delta_t_us, time_window=time_window, max_events=max_events, device=device)
         return self._builder
 
+    def _training_graph(self, events):
+        """Training windows are always independent (``reset=True``, train_ncaltech101.py:56): their graph comes from the
+        single-window builder (csrc/graph_build.hip) instead of the FIFO volume -- same edge set, emitted grouped by
+        destination event together with its row pointer, so the convolutions' CSR needs no sort either."""
+        width, height = _get_value_as_int(events, "width"), _get_value_as_int(events, "height")
+        tw = _get_value_as_int(events, "time_window")
+        key = (width, height, tw, int(events.num_graphs), str(events.pos.device))
+        if getattr(self, "_train_key", None) != key:
+            self._train_builder = WindowGraphBuilder(width, height, events.num_graphs, self.max_neighbors,
+                                                     self.max_queue_size, *self._geometry(width, tw), time_window=tw,
+                                                     max_events=max(1 << 16, int(events.pos.shape[0])),
+                                                     device=events.pos.device)
+            self._train_key = key
+        b = self._train_builder
+        nbr_src, _, deg = b.build(events.pos.float().contiguous(), events.batch.contiguous())
+        ei, rowptr = b.edge_index(nbr_src, deg)
+        events.edge_index = ei
+        # CSR by destination for model/layers/_ops.graph_csr (perm None: the edges already are in CSR order)
+        events._dagr_csr = (rowptr, ei[0].int().contiguous(), None, (int(events.pos.shape[0]), ei.data_ptr(), int(ei.shape[1])))
+        return events
+
     def forward(self, events, reset=True):
         if getattr(events, "batch", None) is None:
             events.batch = torch.zeros(events.pos.shape[0], dtype=torch.long, device=events.pos.device)
+        if self.training and reset and events.pos.is_cuda and os.environ.get("DAGR_TRAIN_FAST_GRAPH", "1") != "0":
+            return self._training_graph(events)
         if self.graph_creators is None:
             self.init_graph_creator(events)
         elif reset:
