@@ -34,7 +34,13 @@ def spline_basis(pseudo, kernel_size=KERNEL_SIZE, is_open_spline=1, degree=DEGRE
     S=(degree+1)^D combinations s, per dimension d: k_mod = (s / (degree+1)^d) % (degree+1),
     v = pseudo[e,d] * (kernel_size - degree*is_open_spline), frac = v - floor(v),
     basis *= 1 - frac - k_mod + 2*frac*k_mod, index += ((int(floor(v)) + k_mod) % kernel_size) * offset,
-    offset *= kernel_size (dimension 0 fastest)."""
+    offset *= kernel_size (dimension 0 fastest).
+
+    Domain note: the published kernel takes the index from ``(int64_t) v`` (truncation toward zero) and the fraction from
+    ``v - floor(v)``; the two only part ways for v < 0, i.e. pseudo-coordinates below 0, which PyG documents as outside
+    the operator's domain.  This model never leaves [0, 1]: level 0 clamps its attributes (net.py:123) and the pooled
+    levels' Cartesian maxima (2 x the voxel size) bound the coarse offsets -- on the golden and sweep workloads the
+    attributes lie in [0.17, 0.87].  The restatement below uses floor for both."""
     E, D = pseudo.shape
     S = (degree + 1) ** D
     basis = torch.ones((E, S), dtype=pseudo.dtype)
