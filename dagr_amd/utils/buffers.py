@@ -57,6 +57,41 @@ def detections_to_records(det, t):
     return rec
 
 
+def bbox_t_to_ndarray(bbox, t):
+    """The reference's name for ``detections_to_records`` (buffers.py:46-66)."""
+    return detections_to_records(bbox, t)
+
+
+def compile(detections, sequences, timestamps):        # noqa: A001  (the reference's module-level name, buffers.py:69-80)
+    """Per-sequence concatenation of the per-image record arrays."""
+    import numpy as np
+    out = {}
+    for det, seq, t in zip(detections, sequences, timestamps):
+        out.setdefault(seq, []).append(detections_to_records(det, t))
+    return {k: np.concatenate(v) for k, v in out.items() if len(v) > 0}
+
+
+class DictBuffer:
+    """Running mean of dictionaries with the same keys (buffers.py:124-146; the FLOP script's accumulator)."""
+
+    def __init__(self):
+        self.running_mean = None
+        self.n = 0
+
+    def update(self, dictionary):
+        if self.running_mean is None:
+            self.running_mean = {k: 0 for k in dictionary}
+        self.running_mean = {k: self.n / (self.n + 1) * self.running_mean[k] + dictionary[k] / (self.n + 1)
+                             for k in dictionary}
+        self.n += 1
+
+    def save(self, path):
+        torch.save(self.running_mean, path)
+
+    def compute(self):
+        return self.running_mean
+
+
 class DetectionBuffer:
     """Collects detections / ground truth of a test run on the host (buffers.py:100-122).  ``compute`` hands them to the
     COCO-protocol evaluation of ``utils/coco_eval.py`` (pycocotools / detectron2 in the reference; restated in numpy here)."""

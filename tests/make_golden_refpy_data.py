@@ -275,6 +275,52 @@ def main():
         out.update({f"ds{c}_out_{k}": v for k, v in res.items()})
         out[f"ds{c}_change_map"] = cm.copy()
 
+    # ---- record writers: utils/buffers.py bbox_t_to_ndarray / compile / DictBuffer, run_test_interframe.py to_npy / save_detections
+    rbuf = import_ref("dagr.utils.buffers")
+    g = np.random.default_rng(17)
+    dets, seqs, stamps = [], [], []
+    for i in range(7):
+        n = int(g.integers(0, 6))
+        x1y1 = g.uniform(0, 200, (n, 2)).astype(np.float32)
+        boxes = np.concatenate([x1y1, x1y1 + g.uniform(5, 90, (n, 2)).astype(np.float32)], 1)
+        dets.append(dict(boxes=torch.from_numpy(boxes), labels=torch.from_numpy(g.integers(0, 2, n)),
+                         scores=torch.from_numpy(g.uniform(0, 1, n).astype(np.float32))))
+        seqs.append(["zurich_city_12_a", "thun_01_a"][i % 2])
+        stamps.append(int(50_000_000 + 50_000 * (6 - i)))           # decreasing: the writers must sort by time
+    for i, d in enumerate(dets):
+        for k, v in d.items():
+            out[f"rec_in{i}_{k}"] = v.numpy()
+    out["rec_seqs"], out["rec_stamps"] = np.array(seqs), np.array(stamps)
+    out["rec_single"] = rbuf.bbox_t_to_ndarray(dets[1], stamps[1])
+    out["rec_single_gt"] = rbuf.bbox_t_to_ndarray({k: v for k, v in dets[1].items() if k != "scores"}, stamps[1])
+    comp = rbuf.compile(dets, seqs, stamps)
+    for k, v in comp.items():
+        out[f"rec_compiled_{k}"] = v
+    db = rbuf.DictBuffer()
+    for i in range(4):
+        db.update({"a": float(i), "b": float(i * i)})
+    out["dictbuffer"] = np.array([db.compute()["a"], db.compute()["b"]])
+    _mod("wandb")
+    spec = importlib.util.spec_from_file_location("ref_interframe", "/root/reference/scripts/run_test_interframe.py")
+    rif = importlib.util.module_from_spec(spec)
+    rif.__dict__["__name__"] = "ref_interframe"
+    for _ in range(40):
+        try:
+            spec.loader.exec_module(rif)
+            break
+        except ModuleNotFoundError as e:
+            _mod(e.name)
+    rif.tqdm = types.SimpleNamespace(tqdm=lambda it, **k: it)
+    rif.np = np                                   # the script imports numpy inside its __main__ block
+    import tempfile as _tf
+    from pathlib import Path as _P
+    with _tf.TemporaryDirectory() as tmp:
+        flat = [dict(boxes=d["boxes"].numpy(), labels=d["labels"].numpy(), scores=d["scores"].numpy(), sequence=s_, t=t_)
+                for d, s_, t_ in zip(dets, seqs, stamps)]
+        rif.save_detections(_P(tmp), flat)
+        for f in sorted(_P(tmp).glob("*.npy")):
+            out[f"rec_saved_{f.stem}"] = np.load(f)
+
     # the script's own main loop (:139-167) over a 230 123-event recording in chunks of 100 000: every full chunk with
     # p -> {-1, +1}, the trailing partial chunk as it is read (p in {0, 1}); then the writer's casts and ms_to_idx.
     # Input re-drawn from the seed by the test; outputs stored as digests + a few probes.

@@ -204,3 +204,50 @@ def test_downsample_script_stream_matches_the_reference_main_loop(tmp_path):
                      "--input_width", "64", "--output_height", "24", "--output_width", "32"], downsampler=cpu)
     assert counts["t"] == int(G["stream_count"])
     _check_stream_output(dst)
+
+
+def _rec_inputs():
+    dets = []
+    for i in range(7):
+        dets.append({k: torch.from_numpy(G[f"rec_in{i}_{k}"]) for k in ("boxes", "labels", "scores")})
+    return dets, [str(s) for s in G["rec_seqs"]], [int(t) for t in G["rec_stamps"]]
+
+
+def test_record_writers_match_the_reference_functions(tmp_path):
+    """``bbox_t_to_ndarray`` / ``compile`` / ``DictBuffer`` (utils/buffers.py:46-80,124-146) and the per-sequence,
+    time-sorted ``detections_<sequence>.npy`` files of run_test_interframe.py:21-45 -- the repository's record helpers
+    and the scripts' ``gather_and_save`` against the reference's own functions."""
+    import sys
+    from dagr_amd.utils import buffers as B
+    dets, seqs, stamps = _rec_inputs()
+    got = B.bbox_t_to_ndarray(dets[1], stamps[1])
+    assert got.dtype == G["rec_single"].dtype and np.array_equal(got, G["rec_single"])
+    gt = B.bbox_t_to_ndarray({k: v for k, v in dets[1].items() if k != "scores"}, stamps[1])
+    assert gt.dtype == G["rec_single_gt"].dtype and np.array_equal(gt, G["rec_single_gt"])
+    comp = B.compile(dets, seqs, stamps)
+    assert sorted(comp) == sorted(set(seqs))
+    for k, v in comp.items():
+        assert np.array_equal(v, G[f"rec_compiled_{k}"]), k
+    db = B.DictBuffer()
+    for i in range(4):
+        db.update({"a": float(i), "b": float(i * i)})
+    assert np.allclose([db.compute()["a"], db.compute()["b"]], G["dictbuffer"], rtol=1e-15)
+    # the scripts' writer: rows (sequence number, t, x1, y1, x2, y2, score, label) -> detections_<prefix><seq>.npy
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import _common as C
+    names = {"zurich_city_12_a": "12", "thun_01_a": "1"}          # detection_rows keeps the digits of the sequence name
+    flat = [dict(boxes=d["boxes"].numpy(), labels=d["labels"].numpy(), scores=d["scores"].numpy(), sequence=names[s], t=t)
+            for d, s, t in zip(dets, seqs, stamps)]
+    files = C.gather_and_save(C.detection_rows(flat, torch.device("cpu")), tmp_path, 0, prefix="seq")
+    assert sorted(files) == ["detections_seq001.npy", "detections_seq012.npy"]
+    for fname, ref in (("detections_seq012.npy", "rec_saved_detections_zurich_city_12_a"),
+                       ("detections_seq001.npy", "rec_saved_detections_thun_01_a")):
+        mine, want = np.load(tmp_path / fname), G[ref]
+        assert mine.dtype == want.dtype and len(mine) == len(want)
+        assert np.array_equal(mine["t"], want["t"]) and bool((np.diff(mine["t"].astype(np.int64)) >= 0).all())
+        # within one timestamp the reference's argsort is not stable: compare as sets of records per timestamp
+        for t in np.unique(want["t"]):
+            a, b = mine[mine["t"] == t], want[want["t"] == t]
+            key = lambda r: np.lexsort((r["class_confidence"], r["x"]))
+            for f in ("x", "y", "w", "h", "class_id", "class_confidence"):
+                assert np.allclose(a[key(a)][f], b[key(b)][f], rtol=1e-6, atol=1e-4), (fname, f)
