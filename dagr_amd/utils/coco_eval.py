@@ -109,11 +109,10 @@ def _accumulate(per_image):
     return precision
 
 
-def evaluate_detection(gt_boxes_list, dt_boxes_list, classes=("car", "pedestrian"), height=240, width=304,
-                       time_tol=50000):
-    """gt / dt: one dict per image, ``boxes`` [n, 4] (x1, y1, x2, y2), ``labels`` [n], detections also ``scores`` [n]."""
+def evaluated_images(gt_boxes_list, dt_boxes_list):
+    """What the reference's ``_convert_to_coco_format`` (:15-60) hands to COCO: one entry per image WITH ground truth, in
+    input order -- (gt boxes xywh, gt classes, detection boxes xywh, detection classes, scores)."""
     images = []
-    n_det = 0
     for gt, dt in zip(gt_boxes_list, dt_boxes_list):
         g_box = _xywh(gt)
         if len(g_box) == 0:
@@ -121,8 +120,14 @@ def evaluate_detection(gt_boxes_list, dt_boxes_list, classes=("car", "pedestrian
         d_box = _xywh(dt)
         d_score = _arr(dt["scores"], np.float32).astype(np.float64) if "scores" in dt else np.ones(len(d_box))
         images.append((g_box, _arr(gt["labels"], np.int64), d_box, _arr(dt["labels"], np.int64), d_score))
-        n_det += len(d_box)
-    if n_det == 0:
+    return images
+
+
+def evaluate_detection(gt_boxes_list, dt_boxes_list, classes=("car", "pedestrian"), height=240, width=304,
+                       time_tol=50000):
+    """gt / dt: one dict per image, ``boxes`` [n, 4] (x1, y1, x2, y2), ``labels`` [n], detections also ``scores`` [n]."""
+    images = evaluated_images(gt_boxes_list, dt_boxes_list)
+    if sum(len(im[2]) for im in images) == 0:
         return {k: 0 for k in OUT_KEYS}
     prec = -np.ones((len(IOU_THRS), len(REC_THRS), len(classes), len(AREA_RNG)))
     for c in range(len(classes)):

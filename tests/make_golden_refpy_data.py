@@ -321,6 +321,23 @@ def main():
         for f in sorted(_P(tmp).glob("*.npy")):
             out[f"rec_saved_{f.stem}"] = np.load(f)
 
+    # ---- utils/coco_eval.py: the reference's own half of the metric -- which images / boxes / ids reach COCO
+    _mod("pycocotools"); _mod("pycocotools.coco"); _mod("detectron2"); _mod("detectron2.evaluation")
+    _mod("detectron2.evaluation.fast_eval_api")
+    rco = import_ref("dagr.utils.coco_eval")
+    gts = []
+    for i, d in enumerate(dets):                       # ground truth: a perturbed subset of the detections, two images empty
+        keep = slice(0, 0) if i in (2, 5) else slice(0, max(1, len(d["boxes"]) - 1))
+        gts.append(dict(boxes=d["boxes"][keep] + 1.5, labels=d["labels"][keep]))
+    (dataset, results), n_img = rco._convert_to_coco_format(gts, dets, classes=("car", "pedestrian"), height=215, width=320)
+    out["coco_n_images"] = np.array(n_img)
+    out["coco_ann"] = np.array([[a["image_id"], a["category_id"], *a["bbox"], a["area"]] for a in dataset["annotations"]],
+                               dtype=np.float64).reshape(-1, 7)
+    out["coco_res"] = np.array([[r["image_id"], r["category_id"], *r["bbox"], r["score"]] for r in results],
+                               dtype=np.float64).reshape(-1, 7)
+    for i, gdict in enumerate(gts):
+        out[f"coco_gt{i}_boxes"], out[f"coco_gt{i}_labels"] = gdict["boxes"].numpy(), gdict["labels"].numpy()
+
     # the script's own main loop (:139-167) over a 230 123-event recording in chunks of 100 000: every full chunk with
     # p -> {-1, +1}, the trailing partial chunk as it is read (p in {0, 1}); then the writer's casts and ms_to_idx.
     # Input re-drawn from the seed by the test; outputs stored as digests + a few probes.

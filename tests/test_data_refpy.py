@@ -251,3 +251,23 @@ def test_record_writers_match_the_reference_functions(tmp_path):
             key = lambda r: np.lexsort((r["class_confidence"], r["x"]))
             for f in ("x", "y", "w", "h", "class_id", "class_confidence"):
                 assert np.allclose(a[key(a)][f], b[key(b)][f], rtol=1e-6, atol=1e-4), (fname, f)
+
+
+def test_metric_inputs_match_what_the_reference_hands_to_coco():
+    """The reference's own half of ``evaluate_detection`` (utils/coco_eval.py:15-60,96-144,175-233): which images are
+    evaluated (those with ground truth), their boxes as (x, y, w, h) through float32, category = class + 1, the scores --
+    ``coco_eval.evaluated_images`` against the annotation / result lists the reference builds for pycocotools."""
+    from dagr_amd.utils.coco_eval import evaluated_images
+    dets, _, _ = _rec_inputs()
+    gts = [dict(boxes=torch.from_numpy(G[f"coco_gt{i}_boxes"]), labels=torch.from_numpy(G[f"coco_gt{i}_labels"]))
+           for i in range(7)]
+    images = evaluated_images(gts, dets)
+    assert len(images) == int(G["coco_n_images"]) == 5                      # two of the seven images carry no box
+    ann, res = G["coco_ann"], G["coco_res"]
+    for k, (g_box, g_cls, d_box, d_cls, d_score) in enumerate(images):
+        a = ann[ann[:, 0] == k + 1]
+        r = res[res[:, 0] == k + 1]
+        assert np.array_equal(a[:, 2:6], g_box) and np.array_equal(a[:, 1], g_cls + 1)
+        assert np.allclose(a[:, 6], g_box[:, 2] * g_box[:, 3], rtol=1e-6)   # area: float32 product there, float64 here
+        assert np.array_equal(r[:, 2:6], d_box) and np.array_equal(r[:, 1], d_cls + 1)
+        assert np.array_equal(r[:, 6], d_score)
