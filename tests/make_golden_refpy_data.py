@@ -321,6 +321,26 @@ def main():
         for f in sorted(_P(tmp).glob("*.npy")):
             out[f"rec_saved_{f.stem}"] = np.load(f)
 
+    # ---- utils/logging.py Checkpointer: which file a directory of checkpoints resolves to, and the saved dict's keys
+    rlog = import_ref("dagr.utils.logging")
+    with _tf.TemporaryDirectory() as tmp:
+        tmp = _P(tmp)
+        lin = torch.nn.Linear(2, 2)
+        opt = torch.optim.SGD(lin.parameters(), lr=0.1)
+        sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda i: 1.0)
+        ema = types.SimpleNamespace(ema=torch.nn.Linear(2, 2), updates=7)
+        ck = rlog.Checkpointer(output_directory=tmp, model=lin, optimizer=opt, scheduler=sched, ema=ema, args={"x": 1})
+        picks = {"empty": str(ck.search_for_checkpoint(tmp))}
+        for name in ("best_model_mAP_0.125", "best_model_mAP_0.5", "best_model_mAP_0.25"):
+            ck.checkpoint(3, name=name)
+        picks["best_only_last"] = ck.search_for_checkpoint(tmp, best=False).name
+        ck.checkpoint(9, name="last_model")
+        picks["last"] = ck.search_for_checkpoint(tmp, best=False).name
+        picks["best"] = ck.search_for_checkpoint(tmp, best=True).name
+        out["ckpt_picks"] = np.array([picks[k] for k in ("empty", "best_only_last", "last", "best")])
+        out["ckpt_keys"] = np.array(sorted(torch.load(tmp / "last_model.pth", weights_only=False)))
+        out["ckpt_restored_epoch"] = np.array(ck.restore_checkpoint(tmp, best=False))
+
     # ---- utils/coco_eval.py: the reference's own half of the metric -- which images / boxes / ids reach COCO
     _mod("pycocotools"); _mod("pycocotools.coco"); _mod("detectron2"); _mod("detectron2.evaluation")
     _mod("detectron2.evaluation.fast_eval_api")

@@ -271,3 +271,25 @@ def test_metric_inputs_match_what_the_reference_hands_to_coco():
         assert np.allclose(a[:, 6], g_box[:, 2] * g_box[:, 3], rtol=1e-6)   # area: float32 product there, float64 here
         assert np.array_equal(r[:, 2:6], d_box) and np.array_equal(r[:, 1], d_cls + 1)
         assert np.array_equal(r[:, 6], d_score)
+
+
+def test_checkpointer_resolves_directories_like_the_reference(tmp_path):
+    """``Checkpointer.search_for_checkpoint`` / ``checkpoint`` / ``restore_checkpoint`` (utils/logging.py:25-88): last model
+    preferred unless the best is asked for, best = highest mAP in the file name, the saved dictionary's keys."""
+    import types as _types
+    from dagr_amd.utils.logging import Checkpointer
+    lin = torch.nn.Linear(2, 2)
+    opt = torch.optim.SGD(lin.parameters(), lr=0.1)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda i: 1.0)
+    ema = _types.SimpleNamespace(ema=torch.nn.Linear(2, 2), updates=7)
+    ck = Checkpointer(output_directory=tmp_path, model=lin, optimizer=opt, scheduler=sched, ema=ema, args={"x": 1})
+    picks = [str(ck.search_for_checkpoint(tmp_path))]
+    for name in ("best_model_mAP_0.125", "best_model_mAP_0.5", "best_model_mAP_0.25"):
+        ck.checkpoint(3, name=name)
+    picks.append(ck.search_for_checkpoint(tmp_path, best=False).name)
+    ck.checkpoint(9, name="last_model")
+    picks.append(ck.search_for_checkpoint(tmp_path, best=False).name)
+    picks.append(ck.search_for_checkpoint(tmp_path, best=True).name)
+    assert picks == [str(v) for v in G["ckpt_picks"]]
+    assert sorted(torch.load(tmp_path / "last_model.pth", weights_only=False)) == [str(v) for v in G["ckpt_keys"]]
+    assert ck.restore_checkpoint(tmp_path, best=False) == int(G["ckpt_restored_epoch"])
