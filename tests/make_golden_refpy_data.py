@@ -12,7 +12,11 @@ resize for cv2, identity decorators for numba).  Pins, in tests/golden/ref_py_da
   * ``data/augment``: the training chain ``Augmentations(args).transform_training`` under fixed torch seeds (events +
     boxes; frames need cv2), and the integrate-and-fire ``_subsample``
   * ``data/ncaltech101_data.NCaltech101``: class list, box decoding, event tail + time shift, on stand-in files
-  * ``scripts/downsample_events.py``: ``downsample_events`` over two chunks with the carried change map
+  * ``scripts/downsample_events.py``: ``downsample_events`` over two chunks with the carried change map, and the script's
+    main loop over a 230 k-event recording (digests)
+  * ``utils/buffers.py`` record helpers + ``DictBuffer``, ``scripts/run_test_interframe.py`` ``save_detections``
+  * ``utils/logging.py`` ``Checkpointer``; ``utils/coco_eval.py`` ``_convert_to_coco_format`` (what reaches pycocotools)
+  * ``data/dsec_utils._load_events`` over an h5py-shaped in-memory file
 
 tests/test_data_refpy.py holds this repository's data layer (and oracle/downsample.py) to them."""
 import argparse
