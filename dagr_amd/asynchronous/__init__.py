@@ -11,3 +11,23 @@ engine, so the running window is kept on the device and re-evaluated as a whole 
 (bit-identical to one ``reset=True`` call on the concatenated events) without the per-layer caches."""
 from . import asy_tools  # noqa: F401
 from .streaming import StreamingWindow  # noqa: F401
+
+
+def make_model_asynchronous(module, log_flops=False):
+    """Entry point of the reference's conversion (``asynchronous/__init__.py:41-110``; used as
+    ``model = make_model_asynchronous(model, log_flops=True)`` followed by ``model.forward(events_initial, reset=True)``
+    and ``model.forward(events_new, reset=False)``, evaluate_flops.py:113-118).  ``DAGR.forward(reset=False)`` is native
+    here, so there is nothing to convert: the model is returned as it is.  The reference's per-layer FLOP log counts the
+    operations of ITS incremental update scheme, which this stack does not run (the window is re-evaluated): asking for
+    it is an error rather than a made-up number."""
+    if log_flops:
+        raise NotImplementedError("log_flops counts the reference's per-layer incremental updates (asynchronous/flops); "
+                                  "this stack re-evaluates the running window -- see DESIGN.md section 7")
+    if not hasattr(module, "forward"):
+        raise TypeError("module must be a torch.nn.Module")
+    return module
+
+
+def make_model_synchronous(module):
+    """``asynchronous/__init__.py:30-39``: back to the synchronous forward -- the same object here."""
+    return module

@@ -54,3 +54,15 @@ def test_state_dict_roundtrip_strict():
     b.load_state_dict(a.state_dict(), strict=True)
     for (k1, v1), (k2, v2) in zip(a.state_dict().items(), b.state_dict().items()):
         assert k1 == k2 and torch.equal(v1, v2)
+
+
+def test_asynchronous_entry_points_resolve():
+    """``dagr.asynchronous.make_model_asynchronous / make_model_synchronous`` (asynchronous/__init__.py:30-110) exist under
+    the reference's import path; conversion is the identity here (``reset=False`` is native), the FLOP log is refused."""
+    import pytest
+    import torch
+    from dagr.asynchronous import make_model_asynchronous, make_model_synchronous
+    m = torch.nn.Linear(1, 1)
+    assert make_model_synchronous(make_model_asynchronous(m)) is m
+    with pytest.raises(NotImplementedError):
+        make_model_asynchronous(m, log_flops=True)
