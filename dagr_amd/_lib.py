@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdagr_hip.so")
+# builder knob: DAGR_HIP_LIB=<path> loads an experimental build of the same library (A/B runs of kernel variants)
+LIB_PATH = os.environ.get("DAGR_HIP_LIB") or os.path.join(_HERE, "lib", "libdagr_hip.so")
 
 c_void_p = ctypes.c_void_p
 c_i32 = ctypes.c_int32

@@ -617,6 +617,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
                                                        const int32_t *__restrict__ node_in_count) {
     constexpr int G = kBlock / 16;
     __shared__ unsigned char sp_rank[256];      // spiral index of offset (dy + r) * 16 + (dx + r)
+    __shared__ unsigned short sp_dec[256];      // spiral index -> offset code (dx + r) * side + (dy + r) | (dy + r) << 12
     __shared__ int row_lo[G][16], row_base[G][17];
     // candidate keys, (spiral rank << 20) | (0xFFFFF - position in its row range): the source slot follows from the key.
     // Dynamic LDS on purpose: with the size visible the compiler's occupancy estimate (made against 64 KiB) drops to 4
@@ -632,6 +633,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
         int sx, sy;
         spiral_offset(s, sx, sy);
         sp_rank[(sy + r) * 16 + (sx + r)] = (unsigned char)s;
+        sp_dec[s] = (unsigned short)(((sx + r) * side + (sy + r)) | ((sy + r) << 12));
     }
     if (threadIdx.x == 0) blk_edges = 0ull;
     __syncthreads();
@@ -714,12 +716,18 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
                 }
             }
         }
+        // the wave's largest candidate count among the neighbourhoods searched here (a lane group that has left the loop
+        // contributes whatever its registers hold: Cw >= C of every active group either way, it only bounds skipping)
+        int Cw = defer ? 0 : C;
+        Cw = max(Cw, __shfl_xor(Cw, 16, 64));
+        Cw = max(Cw, __shfl_xor(Cw, 32, 64));
         if (defer) continue;
         row_lo[grp][l] = lo_cur;
         row_base[grp][l] = incl - len_cur;
         if (l == 15) row_base[grp][16] = C;
         __builtin_amdgcn_wave_barrier();
-        // 2. candidates, 16 per round, 4 rounds of loads in flight
+        // 2. candidates, 16 per round, 4 rounds of loads in flight.  Rounds that no lane group of the wave needs are
+        //    skipped (wave-uniform): with ~73 candidates per neighbourhood a fixed batch of 4 ran 8 rounds for 5.
         int V = 0;
         for (int c0 = 0; c0 < C; c0 += 16 * ROUNDS) {
             int2 it[ROUNDS];
@@ -729,6 +737,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
                 const int ci = c0 + 16 * q + l;
                 it[q] = make_int2(0, 0);
                 cxv[q] = 0; sv[q] = 0; relv[q] = 0; rrv[q] = 0;
+                if (c0 + 16 * q >= Cw) break;      // wave-uniform
                 if (ci < C) {
                     int rr = 0;
                     if (row_base[grp][rr + 8] <= ci) rr += 8;
@@ -747,6 +756,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
                 const int ci = c0 + 16 * q + l;
                 bool valid = false;
                 int key = 0;
+                if (c0 + 16 * q >= Cw) break;      // wave-uniform
                 if (ci < C) {
                     // visible in the FIFO; older than the destination (ev_graph.cu:64); dt <= delta (:69)
                     valid = (cxv[q] < 0) && it[q].x < e && !((float)(t - it[q].y) > delta_t);
@@ -796,10 +806,9 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
             int rk = 0;
             for (int j = 0; j < V; j++) rk += (v_keys[j] < mk) ? 1 : 0;
             if (rk < K - 1) {
-                int sx, sy;
-                spiral_offset(mk >> 20, sx, sy);
-                nbr_src[row + 1 + rk] = row_lo[grp][sy + r] + (0xFFFFF - (mk & 0xFFFFF));   // row range start + position
-                nbr_code[row + 1 + rk] = (int16_t)((sx + r) * side + (sy + r));
+                const int dec = sp_dec[mk >> 20];
+                nbr_src[row + 1 + rk] = row_lo[grp][dec >> 12] + (0xFFFFF - (mk & 0xFFFFF));   // row range start + position
+                nbr_code[row + 1 + rk] = (int16_t)(dec & 0xfff);
             }
         }
         const int total = 1 + min(V, K - 1);
