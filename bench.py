@@ -4,7 +4,8 @@
 One "step" = one pass of the hot path (format_data'd events -> graph build -> SplineConv stack + voxel pooling ->
 decoded detection-head outputs [B,175,5+C] -> device-side confidence mask + NMS) over one batch of B synthetic 50 ms
 event windows already resident in HBM.  `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches
-it under torch.distributed.run (one rank per GPU); windows are independent so ranks share nothing on the data path
+it under torch.distributed.run (one rank per GPU) -- run by hand without that environment, `--gpus N` starts the N
+ranks itself and refuses to run on fewer devices; windows are independent so ranks share nothing on the data path
 (weak scaling) and RCCL is used once, to gather the run's detections (variable length).  Prints ONE JSON line on rank 0:
 
   value / ms_per_step   BASELINE config 2 on the synthetic 640x480 stream (dagr-s + resnet50 image branch), K steps
@@ -12,11 +13,16 @@ it under torch.distributed.run (one rank per GPU); windows are independent so ra
   latency_ms            per-window latency (HIP events, one window batch at a time, 20 warm-up + 100 timed windows):
                         median / p95 for B in {1, 8}, N in {25k..400k} events per window, S-uniform and S-edges
   roofline / stages     dominant kernel of the event path and per-stage timings (HIP events on the kernels' stream)
-  cpu_baseline          the CPU oracle (a port of the reference's op sequence) on the host cores, median of 10 windows
+  cpu_baseline          the CPU oracle (a port of the reference's op sequence) on the host cores: the SAME step (B windows)
+  image_branch          the dense ResNet-50 branch's time, GFLOP and rate against the fp32 matrix peak (library code)
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -50,11 +56,40 @@ def parse():
                     help="independent engine instances (own buffers + stream) that consecutive window batches "
                          "rotate through; windows share no state, so batch i's latency-bound tail overlaps the level 0 "
                          "of batches i+1, i+2")
-    ap.add_argument("--cpu-windows", type=int, default=10)
+    ap.add_argument("--cpu-steps", type=int, default=1, help="steps (of B windows) the CPU baseline leg times")
     ap.add_argument("--latency-windows", type=int, default=100)
     ap.add_argument("--latency-warmup", type=int, default=20)
     ap.add_argument("--latency-n", type=str, default="25000,50000,100000,200000,400000")
+    ap.add_argument("--dry-run-gloo", action="store_true",
+                    help="no device: the launch logic, rendezvous, barrier-bracketed timed region, detection gather and "
+                         "per-rank report over gloo on CPU with a stand-in rig (value is null)")
     return ap.parse_args()
+
+
+def source_stamp():
+    """sha256 over the kernel sources + build flags: PMC traffic measured on another build is refused as stale."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "dagr_amd", "csrc", "*"))) + [os.path.join(ROOT, "Makefile")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher's environment: start N ranks of this same command line under
+    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1) and return their exit code."""
+    if not a.dry_run_gloo:
+        n_dev = torch.cuda.device_count()
+        if n_dev < a.gpus:
+            raise SystemExit(f"bench.py: {a.gpus} ranks requested, {n_dev} device(s) visible -- refusing to run fewer "
+                             f"ranks than asked for")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def make_model(W, H, B, use_image=False, img_net="resnet50"):
@@ -126,36 +161,80 @@ def time_gpu(fn, iters, warm=3):
     return ev0.elapsed_time(ev1) / iters  # ms
 
 
-def cpu_baseline(model_cpu, model_sd, W, H, n_events, n_windows, stream, use_image, img_net):
-    """The oracle (op-for-op CPU restatement, `port`) on a bounded sample: B=1 windows of the same synthetic stream,
-    median per-window time over `n_windows`.  Graph build: single-threaded C; conv/pool (and, with the image branch, the
-    same torch ResNet/CNN-head modules) on all host threads."""
+def cpu_baseline(model_cpu, model_sd, W, H, B, n_events, n_steps, stream, use_image, img_net):
+    """The oracle (op-for-op CPU restatement, `port`) on a bounded sample of THE SAME step the GPU line times: B windows
+    of the same synthetic stream per step.  Graph build: the C restatement of the reference kernels, one thread per
+    sample (windows share no state); conv / pool (and, with the image branch, the same torch ResNet / CNN-head modules)
+    on all host threads."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import graph as og
     from oracle import model as om
     from dagr_amd.utils import synthetic as syn
     gen = syn.uniform_window if stream == "uniform" else syn.edges_window
-    a = om.default_args(batch_size=1, use_image=use_image, img_net=img_net)
+    a = om.default_args(batch_size=B, use_image=use_image, img_net=img_net)
     nc = om.NetConstants(a, H, W)
-    times = []
-    with torch.no_grad():
-        for w in range(n_windows):
-            x, y, t, p = gen(n_events, W, H, seed=1234 + w)
-            b = np.zeros(len(x), np.int64)
+    r, dt = og.graph_params(a.radius, W, 1000000)
+    times, t_graph = [], []
+    with torch.no_grad(), ThreadPoolExecutor(max_workers=min(B, os.cpu_count() or 1)) as pool:
+        for w in range(n_steps):
+            x, y, t, p, b = syn.batch_windows(gen, n_events, B, W, H, seed=1234 + 10 * w)
             t0 = time.perf_counter()
             image_feat = cnn_out = None
             if use_image:
-                img = torch.rand((1, 3, H, W), generator=torch.Generator().manual_seed(w))
+                img = torch.randint(0, 256, (B, 3, H, W), dtype=torch.uint8,
+                                    generator=torch.Generator().manual_seed(w)).float() / 255     # format_data: uint8 / 255
                 feats, outs = model_cpu.backbone.net(img)
                 resized = [torch.nn.functional.interpolate(f, o) for f, o in zip(outs[-a.num_scales:], nc.output_sizes)]
                 cnn_out = model_cpu.head.cnn_head(resized)
                 image_feat = feats
-            om.forward_events(model_sd, a, H, W, x, y, t, p, b, 1, image_feat=image_feat, cnn_out=cnn_out)
+            tg = time.perf_counter()
+            dpos = og.denormalize_pos(syn.format_data_np(x, y, t, W, H), W, H, 1000000)
+            lo = [int(np.searchsorted(b, s)) for s in range(B + 1)]
+
+            def one(s):
+                sl = slice(lo[s], lo[s + 1])
+                return og.build_window_graph(dpos[sl, 0], dpos[sl, 1], dpos[sl, 2], np.zeros(lo[s + 1] - lo[s], np.int32),
+                                             W, H, 1, r, dt, K=a.max_neighbors, Q=128) + lo[s]
+            ei = np.concatenate(list(pool.map(one, range(B))), axis=1)
+            t_graph.append(time.perf_counter() - tg)
+            om.forward_events(model_sd, a, H, W, x, y, t, p, b, B, image_feat=image_feat, cnn_out=cnn_out,
+                              edge_index=torch.from_numpy(ei))
             times.append(time.perf_counter() - t0)
     med = float(np.median(times))
     what = f"dagr-s + {img_net} image branch" if use_image else "events-only dagr-s"
-    return dict(value=n_events / med, unit="events/s", cores=torch.get_num_threads(), kind="port",
-                window_ms_median=round(1e3 * med, 1), window_ms_p95=round(1e3 * float(np.percentile(times, 95)), 1),
-                sample=f"median of {n_windows} windows x {n_events} events, {W}x{H}, B=1, {what}, oracle/model.py "
-                       f"(torch-CPU fp32 + C graph builder), {sum(times):.1f} s of CPU work")
+    return dict(value=B * n_events / med, unit="events/s", cores=torch.get_num_threads(), kind="port",
+                step_ms_median=round(1e3 * med, 1), graph_ms_median=round(1e3 * float(np.median(t_graph)), 1),
+                graph_threads=min(B, os.cpu_count() or 1),
+                sample=f"median of {n_steps} steps of B={B} windows x {n_events} events, {W}x{H}, {what} -- the step the "
+                       f"GPU line times; oracle/model.py (torch-CPU fp32 on {torch.get_num_threads()} threads + C graph "
+                       f"builder, one thread per sample), {sum(times):.1f} s of CPU work")
+
+
+class DryRunRig:
+    """--dry-run-gloo stand-in for the model (CPU, no library): deterministic per-(rank, step) detections -- image b of
+    step i on rank r keeps (r + i + b) % 4 rows -- so that launch, rendezvous, timed region, gather and report run
+    exactly as on GPUs."""
+    B, A = 3, 8
+
+    class _Engine:
+        def check_status(self):
+            pass
+
+    def __init__(self, rank):
+        self.rank, self.dev = rank, torch.device("cpu")
+        self.engines = [self._Engine()]
+        self.streams = []
+
+    def step(self, i, slots):
+        det = torch.zeros((self.B, self.A, 6))
+        n = torch.tensor([(self.rank + i + b) % 4 for b in range(self.B)], dtype=torch.int32)
+        for b in range(self.B):
+            for k in range(int(n[b])):
+                det[b, k] = torch.tensor([1.0 * k, 2.0, 3.0 + k, 4.0, 0.5, float(self.rank)])
+        return det, n
+
+    def drain(self):
+        pass
 
 
 class Rig:
@@ -185,8 +264,8 @@ class Rig:
             batch = torch.from_numpy(b).to(self.dev)
             image = None
             if self.use_image:  # format_data'd frames (uint8/255, utils/buffers.py:37-38), resident like the events
-                image = torch.rand((self.B, 3, self.H, self.W),
-                                   generator=torch.Generator().manual_seed(77 + s + seed - 1234)).to(self.dev)
+                image = (torch.randint(0, 256, (self.B, 3, self.H, self.W), dtype=torch.uint8,
+                                       generator=torch.Generator().manual_seed(77 + s + seed - 1234)).float() / 255).to(self.dev)
             slots.append((pos, feat, batch, image))
         return slots
 
@@ -249,8 +328,11 @@ def timed_run(rig, slots, steps, warmup, dist, world, rank):
         dist.barrier()
     _sync()
     elapsed = time.perf_counter() - t0
-    per_rank = None
+    per_rank, ranks_seen = None, 1
     if dist is not None:
+        ones = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(ones)                               # every rank of the job took part in the collectives
+        ranks_seen = int(ones.item())
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -259,7 +341,7 @@ def timed_run(rig, slots, steps, warmup, dist, world, rank):
         dist.all_gather(every, mine)
         per_rank = [[float(v) for v in t.tolist()] for t in every]
     rig.engines[0].check_status()
-    return dict(elapsed=elapsed, t_compute=t_compute, t_gather=t_gather, per_rank=per_rank,
+    return dict(elapsed=elapsed, t_compute=t_compute, t_gather=t_gather, per_rank=per_rank, ranks_seen=ranks_seen,
                 n_detections=int(allrows.shape[0]))
 
 
@@ -278,6 +360,8 @@ def stage_timings(rig, slots, n_events_step):
     if use_image:
         stages["image_branch"] = time_gpu(lambda: eng.stage_image(image), 5, warm=1)
     stages["graph"] = time_gpu(lambda: eng.stage_graph(pos, batch), iters)
+    # the neighbour search alone (k_search_rows + the sweep of its deferral list), on the pixel index just built
+    stages["graph_search"] = time_gpu(lambda: eng.graph.search_again(eng._nbr), iters)
     eng.stage_l0_input(feat)
     stages["l0_input"] = time_gpu(lambda: eng.stage_l0_input(feat), iters)
     stages["l0_conv1"] = time_gpu(eng.stage_l0_conv1, iters)
@@ -296,30 +380,62 @@ def stage_timings(rig, slots, n_events_step):
     kernels = {k: dict(ms=round(v, 4), alg_MB=round(ab[k] / 1e6, 2) if k in ab else None,
                        alg_GBs=round(ab[k] / 1e9 / (v / 1e3), 1) if k in ab else None)
                for k, v in stages.items()}
-    dom = max(("l0_conv1", "l0_conv2"), key=lambda k: stages[k])  # single-launch stages
+    # the dominant kernel of the event path: the longest single-kernel stage among ALL of them (the other stages are
+    # sequences of short launches, reported as stages)
+    N_ = n_events_step
+    ab["graph_search"] = 4 * (2 * r + 1) ** 2 * N_ + 12 * ne + 4 * (N_ + 1)     # 8(d): FIFO probes + timestamps + edges
+    comp = compulsory_bytes(N_, eng.graph.K, use_image)
+    # what this design's search cannot avoid moving once: the per-pixel offsets, {id, t} + x|y|b per event, its lists
+    comp["graph_search"] = 4 * rig.W * rig.H * rig.B + 12 * N_ + 6 * ne + 4 * N_
+    kernels["graph_search"] = dict(ms=round(stages["graph_search"], 4), alg_MB=round(ab["graph_search"] / 1e6, 2),
+                                   alg_GBs=round(ab["graph_search"] / 1e9 / (stages["graph_search"] / 1e3), 1))
+    dom = max(("graph_search", "l0_conv1", "l0_conv2"), key=lambda k: stages[k])
     achieved = ab[dom] / 1e9 / (stages[dom] / 1e3)
-    kname = eng.l0_kernel_names()[dom]
+    kname = dict(eng.l0_kernel_names(), graph_search="k_search_rows<320, false, 4, 7>")[dom]
     # HBM bytes per launch: PMC counters cannot be read from inside this process; the number is the one the
-    # rocprofv3 --pmc passes of this same command produced (tools/pmc.sh -> profiles/r*_traffic.json, committed)
+    # rocprofv3 --pmc passes of this same command produced (tools/pmc.sh -> profiles/r*_traffic.json, committed) --
+    # accepted only if that file was measured on this build of the kernels (source stamp), else null
     traffic, src = None, None
-    for tj in ("r2_traffic.json", "r1_traffic.json"):
-        path = os.path.join(ROOT, "profiles", tj)
-        if n_events_step == 800000 and (rig.W, rig.H) == (640, 480) and os.path.exists(path):
-            cfg = json.load(open(path))["configs"]["use_image" if use_image else "events_only"]
-            if kname in cfg:
-                traffic, src = cfg[kname].get("traffic_bytes"), "profiles/" + tj
-                break
-    floor = compulsory_bytes(n_events_step, eng.graph.K, use_image)[dom]
+    stamp = source_stamp()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        tj = json.load(open(path))
+        if n_events_step != 800000 or (rig.W, rig.H) != (640, 480):
+            break
+        if tj.get("source_stamp") != stamp:
+            src = f"stale: {os.path.basename(path)} was measured on another build of the kernels"
+            continue
+        cfg = tj["configs"]["use_image" if use_image else "events_only"]
+        if kname in cfg:
+            traffic, src = cfg[kname].get("traffic_bytes"), "profiles/" + os.path.basename(path)
+            break
+    floor = comp[dom]
     floor_us = floor / (HBM_ACHIEVABLE_GBS * 1e3)
-    roofline = dict(kernel=kname, bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+    roofline = dict(kernel=kname, stage=dom, bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=src,
                     frac_traffic=(round(traffic / 1e9 / (stages[dom] / 1e3) / HBM_PEAK_GBS, 4) if traffic else None),
                     compulsory_bytes=int(floor), floor_us=round(floor_us, 1),
                     x_over_floor=round(stages[dom] * 1e3 / floor_us, 1),
-                    alg_bytes_per_launch=int(ab[dom]), launch_ms=round(stages[dom], 4))
-    total = sum(v for k, v in stages.items() if k != "tail_head_graph")
+                    alg_bytes_per_launch=int(ab[dom]), launch_ms=round(stages[dom], 4), source_stamp=stamp,
+                    candidates={k: dict(ms=round(stages[k], 4), frac=round(ab[k] / 1e9 / (stages[k] / 1e3) / HBM_PEAK_GBS, 4),
+                                        x_over_floor=round(stages[k] * 1e3 / (comp[k] / (HBM_ACHIEVABLE_GBS * 1e3)), 1))
+                                for k in ("graph_search", "l0_conv1", "l0_conv2")})
+    image_branch = None
+    if use_image:
+        # the dense image branch is library code (MIOpen / hipBLASLt fp32): its share and its rate against the fp32 matrix peak
+        from torch.utils.flop_counter import FlopCounterMode
+        with FlopCounterMode(display=False) as fc:
+            feats_, outs_ = rig.model.backbone.net(image)
+            rig.model.head.cnn_head([torch.nn.functional.interpolate(f, o) for f, o in
+                                     zip(outs_[-eng.num_scales:], eng.out_sizes)])
+        gflop = fc.get_total_flops() / 1e9
+        image_branch = dict(ms=round(stages["image_branch"], 4), gflop=round(gflop, 1),
+                            tflops=round(gflop / stages["image_branch"], 1),
+                            frac_of_157=round(gflop / stages["image_branch"] / 157.3, 3),
+                            note="ResNet-50 HookModule + CNNHead on PyTorch-ROCm (MIOpen / hipBLASLt fp32), FLOPs counted "
+                                 "on the plain modules; not hand-written code")
+    total = sum(v for k, v in stages.items() if k not in ("tail_head_graph", "graph_search"))
     return dict(roofline=roofline, stages=kernels, edges_per_step=int(ne), levels=levels, radius=r,
-                batch_latency_ms=round(total, 4))
+                batch_latency_ms=round(total, 4), image_branch=image_branch)
 
 
 def latency_sweep(W, H, use_image, img_net, dev, Ns, n_warm, n_timed):
@@ -362,12 +478,38 @@ def latency_sweep(W, H, use_image, img_net, dev, Ns, n_warm, n_timed):
     return out
 
 
+def dry_run(a, world, rank):
+    """--dry-run-gloo: every step of a multi-rank run except the model, on CPU."""
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    run = timed_run(DryRunRig(rank), None, a.steps, a.warmup, dist, world, rank)
+    if rank == 0:
+        print(json.dumps({"metric": "events_per_sec", "value": None, "unit": "events/s", "n_gpus": world, "world": world,
+                          "ranks_seen": run["ranks_seen"], "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": round(1e3 * run["elapsed"] / a.steps, 4), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "dry-run (gloo, no device)",
+                          "config": {"workload": "control flow only: DryRunRig"},
+                          "gather": {"detections": run["n_detections"]},
+                          "per_rank": [dict(compute_ms=round(1e3 * c, 3), gather_ms=round(1e3 * g, 3))
+                                       for c, g in run["per_rank"]]}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch_ranks(a))            # N ranks of this command line, one per GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
+    if a.dry_run_gloo:
+        return dry_run(a, world, rank)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} has no device ({torch.cuda.device_count()} visible, local rank {local_rank})")
     torch.backends.cudnn.benchmark = True   # MIOpen picks its fastest fp32 conv kernels for the image branch
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -404,7 +546,7 @@ def main():
         st = stage_timings(rig, slots, n_events_step)
         result = {
             "metric": "events_per_sec", "value": round(value, 1), "unit": "events/s", "n_gpus": world,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
+            "world": world, "ranks_seen": run["ranks_seen"], "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("dagr-s + --use_image --img_net " + a.img_net if use_image else "dagr-s events-only")
                                    + f", {W}x{H} synthetic S-{a.stream}, B={B} windows/step x {NPW} events (50 ms "
@@ -420,6 +562,10 @@ def main():
                        "compute_ms_rank0": round(1e3 * run["t_compute"], 3)},
             "roofline": st["roofline"], "stages": st["stages"],
         }
+        if st["image_branch"] is not None:
+            ib = dict(st["image_branch"])
+            ib["share_of_step"] = round(ib["ms"] / ms_per_step, 3)     # one engine's isolated stage time over the step time
+            result["image_branch"] = ib
         if run["per_rank"] is not None:
             result["per_rank"] = [dict(events_per_s=round(n_events_step * a.steps / c, 1), gather_ms=round(1e3 * g, 3))
                                   for c, g in run["per_rank"]]
@@ -434,7 +580,7 @@ def main():
     sd_cpu = rig.sd_cpu
     model_cpu = None
     if want_cpu and use_image:
-        _, model_cpu = make_model(W, H, 1, use_image=True, img_net=a.img_net)
+        _, model_cpu = make_model(W, H, B, use_image=True, img_net=a.img_net)
         model_cpu.load_state_dict(sd_cpu)
     del slots, ev_slots, rig, ev_rig
     torch.cuda.empty_cache()
@@ -450,7 +596,7 @@ def main():
                                                       a.latency_windows)
         result["latency_ms"] = lat
     if want_cpu:
-        result["cpu_baseline"] = cpu_baseline(model_cpu, sd_cpu, W, H, NPW, a.cpu_windows, a.stream, use_image,
+        result["cpu_baseline"] = cpu_baseline(model_cpu, sd_cpu, W, H, B, NPW, a.cpu_steps, a.stream, use_image,
                                               a.img_net)
     if rank == 0:
         print(json.dumps(result), flush=True)

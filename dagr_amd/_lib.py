@@ -51,6 +51,8 @@ SIGNATURES = {
     "dagr_graph_workspace_init": (ctypes.c_int, [ctypes.POINTER(GraphDesc), c_void_p, c_size_t, c_void_p]),
     "dagr_graph_build_window": (ctypes.c_int, [ctypes.POINTER(GraphDesc), c_void_p, c_void_p, c_i32, c_void_p,
                                                c_i32, c_i64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dagr_graph_search_window": (ctypes.c_int, [ctypes.POINTER(GraphDesc), c_void_p, c_i64, c_void_p, c_void_p, c_void_p,
+                                                c_void_p]),
     "dagr_graph_status": (ctypes.c_int, [ctypes.POINTER(GraphDesc), c_void_p, ctypes.POINTER(c_i64),
                                          ctypes.POINTER(c_i32), c_void_p]),
     "dagr_scan_scratch_elems": (c_size_t, [c_i64]),

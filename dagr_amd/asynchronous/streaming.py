@@ -11,14 +11,27 @@ class StreamingWindow:
     def __init__(self):
         self.pos = self.x = self.batch = None
         self.image = None
+        self._seed = None
 
     def reset(self):
         self.pos = self.x = self.batch = self.image = None
+        self._seed = None
 
     def __len__(self):
+        if self._seed is not None:
+            return int(self._seed.pos.shape[0])
         return 0 if self.pos is None else int(self.pos.shape[0])
 
+    def seed(self, data):
+        """The batch of a plain ``reset=True`` call: only remembered -- the conversions of ``push`` are paid by the first
+        ``reset=False`` call that continues from it, not by every window of an evaluation run."""
+        self.reset()
+        self._seed = data
+
     def push(self, data):
+        if self._seed is not None:
+            first, self._seed = self._seed, None
+            self.push(first)
         batch = data.batch if getattr(data, "batch", None) is not None else \
             torch.zeros(data.pos.shape[0], dtype=torch.int64, device=data.pos.device)
         pos, x, batch = data.pos.float(), data.x.float().view(-1, 1), batch.long()

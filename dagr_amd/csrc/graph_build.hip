@@ -968,6 +968,48 @@ int dagr_graph_workspace_init(const dagr_graph_desc *desc, void *workspace, size
     return DAGR_OK;
 }
 
+static int launch_search(const dagr_graph_desc *desc, const GraphWs &ws, int64_t N, int32_t *nbr_src, int16_t *nbr_code,
+                         int32_t *deg, hipStream_t stream) {
+    const int W = desc->width, H = desc->height;
+    const unsigned gS = (unsigned)ceil_div(N * 16, kBlock);
+    if (2 * desc->radius + 2 <= 16) {
+        // fast path: candidate-centric row kernel; dense neighbourhoods are deferred (list in ev_rank, which
+        // is dead after k_scatter; counter in status[5]) to the position-centric tiled kernel
+        // (the deferral list lives in ev_rank, dead after k_scatter; its counter is status[5])
+        constexpr size_t rows_lds = (size_t)(kBlock / 16) * kRowCap * 4;
+        static const unsigned res_tiled = persistent_grid(k_search_tiled, kBlock, 0, 1 << 30);
+        // builder knob DAGR_ROWS_VARIANT = 10 * rounds + waves per SIMD (16 candidates per round); default 47
+        static const int variant = [] { const char *e = getenv("DAGR_ROWS_VARIANT"); return e ? atoi(e) : 47; }();
+        auto launch_rows = [&](auto kern) {
+            static thread_local unsigned res_rows = 0;
+            if (!res_rows) res_rows = persistent_grid(kern, kBlock, rows_lds, 1 << 30);
+            const unsigned gR = round_grid8(std::min<int64_t>(ceil_div(N * 16, kBlock), res_rows));
+            kern<<<gR, kBlock, rows_lds, stream>>>(
+                ws.start + ws.P, W, H, desc->max_neighbors, desc->radius, (float)desc->delta_t_us, ws.slot_xyb, ws.start,
+                ws.slot_it, nbr_src, nbr_code, deg, ws.status, ws.ev_rank, ws.status + 5, nullptr, nullptr);
+        };
+        switch (variant) {
+            case 57: launch_rows(k_search_rows<kRowCap, false, 5, 7>); break;
+            case 46: launch_rows(k_search_rows<kRowCap, false, 4, 6>); break;
+            case 66: launch_rows(k_search_rows<kRowCap, false, 6, 6>); break;
+            case 85: launch_rows(k_search_rows<kRowCap, false, 8, 5>); break;
+            default: launch_rows(k_search_rows<kRowCap, false, 4, 7>); break;
+        }
+        DAGR_CHECK_LAUNCH();
+        const unsigned gT = round_grid8(std::min<int64_t>(ceil_div(N * 16, kBlock), res_tiled));
+        k_search_tiled<<<gT, kBlock, 0, stream>>>(ws.start + ws.P, W, H, desc->max_neighbors, desc->queue_size,
+                                                  desc->radius, (float)desc->delta_t_us, ws.slot_xyb, ws.start,
+                                                  ws.slot_it, nbr_src, nbr_code, deg, ws.status, ws.ev_rank,
+                                                  ws.status + 5);
+    } else {
+        k_search<<<gS, kBlock, 0, stream>>>(ws.start + ws.P, W, H, desc->max_neighbors, desc->queue_size, desc->radius,
+                                            (float)desc->delta_t_us, ws.slot_xyb, ws.start, ws.slot_it, nbr_src,
+                                            nbr_code, deg, ws.status);
+    }
+    DAGR_CHECK_LAUNCH();
+    return DAGR_OK;
+}
+
 int dagr_graph_build_window(const dagr_graph_desc *desc, void *workspace, const void *pos, int32_t pos_is_int32,
                             const void *batch, int32_t batch_is_int64, int64_t N, int32_t *nbr_src, int16_t *nbr_code, int32_t *deg,
                             void *stream_) {
@@ -1010,43 +1052,24 @@ int dagr_graph_build_window(const dagr_graph_desc *desc, void *workspace, const 
                                             ws.slot_tmp, ws.slot_it,
                                             ws.long_list, long_cap, ws.status);
     DAGR_CHECK_LAUNCH();
-    const unsigned gS = (unsigned)ceil_div(N * 16, kBlock);
-    if (2 * desc->radius + 2 <= 16) {
-        // fast path: candidate-centric row kernel; dense neighbourhoods are deferred (list in ev_rank, which
-        // is dead after k_scatter; counter in status[5]) to the position-centric tiled kernel
-        // (the deferral list lives in ev_rank, dead after k_scatter; its counter is status[5])
-        constexpr size_t rows_lds = (size_t)(kBlock / 16) * kRowCap * 4;
-        static const unsigned res_tiled = persistent_grid(k_search_tiled, kBlock, 0, 1 << 30);
-        // builder knob DAGR_ROWS_VARIANT = 10 * rounds + waves per SIMD (16 candidates per round); default 47
-        static const int variant = [] { const char *e = getenv("DAGR_ROWS_VARIANT"); return e ? atoi(e) : 47; }();
-        auto launch_rows = [&](auto kern) {
-            static thread_local unsigned res_rows = 0;
-            if (!res_rows) res_rows = persistent_grid(kern, kBlock, rows_lds, 1 << 30);
-            const unsigned gR = round_grid8(std::min<int64_t>(ceil_div(N * 16, kBlock), res_rows));
-            kern<<<gR, kBlock, rows_lds, stream>>>(
-                ws.start + ws.P, W, H, desc->max_neighbors, desc->radius, (float)desc->delta_t_us, ws.slot_xyb, ws.start,
-                ws.slot_it, nbr_src, nbr_code, deg, ws.status, ws.ev_rank, ws.status + 5, nullptr, nullptr);
-        };
-        switch (variant) {
-            case 57: launch_rows(k_search_rows<kRowCap, false, 5, 7>); break;
-            case 46: launch_rows(k_search_rows<kRowCap, false, 4, 6>); break;
-            case 66: launch_rows(k_search_rows<kRowCap, false, 6, 6>); break;
-            case 85: launch_rows(k_search_rows<kRowCap, false, 8, 5>); break;
-            default: launch_rows(k_search_rows<kRowCap, false, 4, 7>); break;
-        }
-        DAGR_CHECK_LAUNCH();
-        const unsigned gT = round_grid8(std::min<int64_t>(ceil_div(N * 16, kBlock), res_tiled));
-        k_search_tiled<<<gT, kBlock, 0, stream>>>(ws.start + ws.P, W, H, desc->max_neighbors, desc->queue_size,
-                                                  desc->radius, (float)desc->delta_t_us, ws.slot_xyb, ws.start,
-                                                  ws.slot_it, nbr_src, nbr_code, deg, ws.status, ws.ev_rank,
-                                                  ws.status + 5);
-    } else {
-        k_search<<<gS, kBlock, 0, stream>>>(ws.start + ws.P, W, H, desc->max_neighbors, desc->queue_size, desc->radius,
-                                            (float)desc->delta_t_us, ws.slot_xyb, ws.start, ws.slot_it, nbr_src,
-                                            nbr_code, deg, ws.status);
-    }
-    DAGR_CHECK_LAUNCH();
-    return DAGR_OK;
+    return launch_search(desc, ws, N, nbr_src, nbr_code, deg, stream);
+}
+
+int dagr_graph_search_window(const dagr_graph_desc *desc, void *workspace, int64_t N, int32_t *nbr_src, int16_t *nbr_code,
+                             int32_t *deg, void *stream_) {
+    int rc = validate(desc);
+    if (rc != DAGR_OK) return rc;
+    DAGR_CHECK_ARG(workspace != nullptr, "workspace is NULL");
+    DAGR_CHECK_ARG(N >= 0 && N <= desc->max_events, "N exceeds desc.max_events");
+    if (N == 0) return DAGR_OK;
+    DAGR_CHECK_ARG(nbr_src && nbr_code && deg, "NULL pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    GraphWs ws;
+    carve(*desc, (char *)workspace, &ws);
+    // edge counter (status[2..3]) and deferral list length (status[5]) start over; the pixel index stays
+    DAGR_CHECK_HIP(hipMemsetAsync(ws.status + 2, 0, 2 * 4, stream));
+    DAGR_CHECK_HIP(hipMemsetAsync(ws.status + 5, 0, 4, stream));
+    return launch_search(desc, ws, N, nbr_src, nbr_code, deg, stream);
 }
 
 int dagr_graph_status(const dagr_graph_desc *desc, void *workspace, int64_t *num_edges, int32_t *flags,

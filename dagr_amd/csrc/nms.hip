@@ -12,6 +12,7 @@ namespace dagr {
 namespace {
 constexpr int kMaxAnchors = 1024;
 constexpr int kMaskAnchors = 256, kMaskWords = kMaskAnchors / 64;
+static_assert(kBlock >= kMaskAnchors, "the rank sort gives one thread to every key");
 // phase clocks of k_postprocess, image 0 (constant 100 MHz counter): written on every launch, read by
 // dagr_debug_postprocess_clocks -- builder instrumentation, a handful of scalar stores
 __device__ long long g_pp_clk[8];
@@ -163,7 +164,8 @@ __global__ __launch_bounds__(kBlock) void k_nms(const float *__restrict__ boxes,
     const float *bx = boxes + (size_t)b * A * 4;
     for (int i = threadIdx.x; i < Apad; i += kBlock) {
         const bool ok = i < A && valid[(size_t)b * A + i];
-        s_key[i] = ok ? scores[(size_t)b * A + i] : -INFINITY;
+        const float sc = ok ? scores[(size_t)b * A + i] : -INFINITY;
+        s_key[i] = sc == sc ? sc : -INFINITY;       // a NaN key has no rank (the sort needs a total order): never kept
         s_idx[i] = i < A ? i : 0x7fffffff;
     }
     __syncthreads();

@@ -24,6 +24,10 @@ class SyntheticWindows:
     def set_num_us(self, num_us):            # dsec_data.py:114-115
         self.num_us = int(num_us)
 
+    def sequence_names(self):
+        """Names of the synthetic recordings (``windows_per_sequence`` consecutive windows each)."""
+        return [f"synthetic{q:03d}" for q in range((self.n + self.per_seq - 1) // self.per_seq)]
+
     def __len__(self):
         return self.n
 

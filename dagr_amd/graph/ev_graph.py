@@ -79,6 +79,13 @@ class WindowGraphBuilder:
                    "graph_build_window")
         return nbr_src, nbr_code, deg
 
+    def search_again(self, out):
+        """The neighbour search alone on the pixel index of the last ``build`` (measurement: bench.py)."""
+        nbr_src, nbr_code, deg = out
+        _lib.check(_lib.lib().dagr_graph_search_window(ctypes.byref(self.desc), _lib.ptr(self.workspace), int(deg.shape[0]),
+                                                       _lib.ptr(nbr_src), _lib.ptr(nbr_code), _lib.ptr(deg),
+                                                       _lib.cur_stream(self.device)), "graph_search_window")
+
     def status(self):
         """(num_edges, flags) of the last build; synchronises the current stream."""
         ne, fl = ctypes.c_int64(0), ctypes.c_int32(0)

@@ -198,22 +198,37 @@ class DAGR(torch.nn.Module):
         """Cheap fingerprint of everything the engine snapshots (packed, BN-folded weights; the folded copy of the
         image branch): in-place edits bump ``_version``, ``.to()`` / ``load_state_dict`` on sub-modules
         (``init_subnetwork``) change storage or version."""
-        ver, first = 0, None
-        for t in list(self.parameters()) + list(self.buffers()):
+        # the tensor list is walked once per engine (module traversal is the expensive part of this check, and it
+        # sits on the single-window latency path); `.to()` / `load_state_dict` / `train()` drop the engine themselves
+        ts = self._stamp_tensors
+        if ts is None:
+            ts = self._stamp_tensors = list(self.parameters()) + list(self.buffers())
+        ver = 0
+        for t in ts:
             ver += t._version
-            if first is None:
-                first = (t.data_ptr(), str(t.device))
-        return ver, first
+        return ver, (ts[0].data_ptr(), str(ts[0].device)) if ts else None
 
     def invalidate_engine(self):
         """Drop the device-side plan; the next forward re-packs the weights."""
         self._engine = None
+        self._stamp_tensors = None
+
+    def _apply(self, fn, *a, **kw):          # .to() / .cuda() / .float(): parameters are replaced
+        self._engine = None
+        self._stamp_tensors = None
+        return super()._apply(fn, *a, **kw)
+
+    def train(self, mode=True):
+        if mode:
+            self._stamp_tensors = None
+        return super().train(mode)
 
     def engine(self):
         stamp = self._weights_stamp()
         if self._engine is None or self._engine_stamp != stamp:
             from ...engine import WindowEngine
             self._engine = None
+            self._stamp_tensors = None
             self._engine = WindowEngine(self)
             self._engine_stamp = self._weights_stamp()
         return self._engine
@@ -221,6 +236,7 @@ class DAGR(torch.nn.Module):
     def load_state_dict(self, *a, **kw):
         r = super().load_state_dict(*a, **kw)
         self._engine = None
+        self._stamp_tensors = None
         return r
 
     # -- dagr.py:74-103 (eval branch) ----------------------------------------------------------
@@ -246,7 +262,7 @@ class DAGR(torch.nn.Module):
             pos, feat, batch = self._window.tensors()
             outputs = eng.forward_raw(pos, feat, batch, image=self._window.image)
         else:
-            self._window.push(x)             # a later reset=False call continues from this window
+            self._window.seed(x)             # a later reset=False call continues from this window (converted then)
             outputs = eng.forward_data(x)
         detections = postprocess_network_output(outputs, self.backbone.num_classes, self.conf_threshold,
                                                 self.nms_threshold, filtering=filtering, height=self.height,

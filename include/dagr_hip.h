@@ -124,6 +124,12 @@ int dagr_graph_build_window(const dagr_graph_desc *desc, void *workspace,
                             const void *batch, int32_t batch_is_int64, int64_t N,
                             int32_t *nbr_src, int16_t *nbr_code, int32_t *deg, void *stream);
 
+/* The neighbour search alone, again, on the pixel index the last dagr_graph_build_window left in `workspace` (same N):
+ * rewrites nbr_src / nbr_code / deg and the edge count.  For measurement (bench.py times the search kernels on their own
+ * stream with HIP events); a product caller has no use for it. */
+int dagr_graph_search_window(const dagr_graph_desc *desc, void *workspace, int64_t N,
+                             int32_t *nbr_src, int16_t *nbr_code, int32_t *deg, void *stream);
+
 /* Device-side status words written by the last build on this workspace.
  * Synchronises `stream`.  flags bit0: event outside [0,W)x[0,H)x[0,B); bit1: internal list overflow.
  * num_edges = sum(deg). */

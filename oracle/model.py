@@ -274,7 +274,7 @@ def head_forward(sd, args, nc, outs, batch_size, use_lut=True, cnn_out=None, tra
 
 
 def forward_events(sd, args, height, width, x, y, t, p, b, batch_size, use_lut=True, trace=None,
-                   time_window=1000000, image_feat=None, cnn_out=None, exact_pos_mean=False):
+                   time_window=1000000, image_feat=None, cnn_out=None, exact_pos_mean=False, edge_index=None):
     """Whole hot path for one window batch from raw events (int arrays): format_data
     (utils/buffers.py:33-44) -> EV_TGN (layers/ev_tgn.py:39-58) -> Net -> GNNHead eval."""
     nc = NetConstants(args, height, width)
@@ -283,11 +283,14 @@ def forward_events(sd, args, height, width, x, y, t, p, b, batch_size, use_lut=T
                                      t.astype(np.float32) / np.float32(time_window)], -1).astype(np.float32))
     feat = torch.from_numpy(p.astype(np.float32)).view(-1, 1)
     batch = torch.from_numpy(b.astype(np.int64))
-    r, dt = og.graph_params(args.radius, width, time_window)
-    dpos = og.denormalize_pos(pos.numpy(), width, height, time_window)
-    ei = og.build_window_graph(dpos[:, 0], dpos[:, 1], dpos[:, 2], b.astype(np.int32), width, height, batch_size,
-                               r, dt, K=args.max_neighbors, Q=128)
-    ei = torch.from_numpy(ei)
+    if edge_index is None:
+        r, dt = og.graph_params(args.radius, width, time_window)
+        dpos = og.denormalize_pos(pos.numpy(), width, height, time_window)
+        ei = og.build_window_graph(dpos[:, 0], dpos[:, 1], dpos[:, 2], b.astype(np.int32), width, height, batch_size,
+                                   r, dt, K=args.max_neighbors, Q=128)
+        ei = torch.from_numpy(ei)
+    else:       # the caller built the graph (bench.py's CPU leg: the same C builder, one thread per sample)
+        ei = edge_index
     if trace is not None:
         trace["edge_index"] = ei.clone()
     outs = net_forward(sd, args, nc, pos, feat, batch, ei, use_lut=use_lut, image_feat=image_feat, trace=trace,

@@ -35,6 +35,7 @@ def flags(description, extra=None):
                    help="DSEC root (run_test.py:45: DSEC(root, 'test', transform_testing, ...)); needs dsec-det + h5py + "
                         "hdf5plugin.  Default: the synthetic event stream with the DSEC sample contract")
     p.add_argument("--split", default="test")
+    p.add_argument("--no_eval", action="store_true", help="utils/args.py:62: no ground truth is loaded / scored")
     p.add_argument("--use_image", action="store_true")
     p.add_argument("--img_net", default="resnet50")
     if extra:
@@ -61,11 +62,13 @@ def dataset_and_loader(a, world, rank):
     """The dataset and THIS rank's loader: batch k holds windows [k*B, (k+1)*B) (drop_last=True, run_test.py:48) and
     goes to rank k mod G -- independent windows, no collective on the data path."""
     if getattr(a, "dataset_directory", None) is not None:
-        # run_test.py:45-46 / run_test_interframe.py:66-67: the DSEC test split, boxes >= 30 px diagonal, no size floor on
-        # height; the interframe script additionally restricts itself to perfect tracks
+        # run_test.py:43 / run_test_interframe.py:66-68: the DSEC test split, boxes of at least 15 px diagonal and 10 px
+        # height; run_test.py scores every frame pair (no_eval left at its default False), the interframe script restricts
+        # itself to perfect tracks and passes --no_eval through
         from dagr.data.dsec_data import DSEC
+        interframe = hasattr(a, "num_interframe_steps")
         ds = DSEC(a.dataset_directory, a.split, Augmentations.transform_testing, debug=False, min_bbox_diag=15,
-                  min_bbox_height=10, only_perfect_tracks=bool(getattr(a, "num_interframe_steps", 0)), no_eval=True)
+                  min_bbox_height=10, only_perfect_tracks=interframe, no_eval=bool(a.no_eval) if interframe else False)
     else:
         ds = SyntheticWindows(a.windows, a.events_per_window, a.width, a.height, a.stream, a.use_image,
                               transform=Augmentations.transform_testing)
@@ -91,23 +94,33 @@ def build_model(a, ds, dev):
     return args, ema.ema
 
 
-def detection_rows(detections, device):
+def sequence_names(ds):
+    """Every sequence name of the dataset, sorted: the table all ranks share, so that a sequence travels through the
+    gather as its index and comes out as its own name (``save_detections`` writes one ``detections_{sequence}.npy`` per
+    sequence string, run_test_interframe.py:34-45)."""
+    if hasattr(ds, "sequence_names"):
+        return sorted(ds.sequence_names())
+    return sorted(folder.name for folder in ds.dataset.subsequence_directories)      # DSEC (dsec_data.py:144-150)
+
+
+def detection_rows(detections, device, names):
     """Per-window detection dicts ({boxes, scores, labels, sequence, t, [window]}) -> float rows
-    (sequence number, t, x1, y1, x2, y2, score, label) for the gather."""
+    (index of the sequence in `names`, t, x1, y1, x2, y2, score, label) for the gather."""
+    index = {n: i for i, n in enumerate(names)}
     rows = []
     for d in detections:
         n = len(d["boxes"])
         if n:
-            seq = float(int("".join(c for c in str(d["sequence"]) if c.isdigit()) or 0))
+            seq = float(index[str(d["sequence"])])
             rows.append(np.concatenate([np.full((n, 1), seq), np.full((n, 1), float(d["t"])), d["boxes"],
                                         d["scores"].reshape(-1, 1), d["labels"].reshape(-1, 1).astype(np.float64)], 1))
     arr = np.concatenate(rows, 0) if rows else np.zeros((0, 8))
     return torch.from_numpy(arr).to(torch.float64).to(device)
 
 
-def gather_and_save(rows, output_directory, rank, prefix="synthetic"):
-    """One gather of the run's detections (variable length), then rank 0 writes ``detections_<sequence>.npy`` with the
-    record layout of run_test_interframe.py:21-45, sorted by time."""
+def gather_and_save(rows, output_directory, rank, names):
+    """One gather of the run's detections (variable length), then rank 0 writes ``detections_{sequence}.npy`` per sequence
+    name with the record layout of run_test_interframe.py:21-45, sorted by time."""
     allrows = parallel.gather_detections(rows).cpu().numpy()
     if rank != 0:
         return None
@@ -117,7 +130,7 @@ def gather_and_save(rows, output_directory, rank, prefix="synthetic"):
         r = allrows[allrows[:, 0] == seq]
         r = r[np.argsort(r[:, 1], kind="stable")]
         rec = detections_to_records(dict(boxes=r[:, 2:6], scores=r[:, 6], labels=r[:, 7]), r[:, 1].astype(np.uint64))
-        path = output_directory / f"detections_{prefix}{int(seq):03d}.npy"
+        path = output_directory / f"detections_{names[int(seq)]}.npy"
         np.save(path, rec)
         files[path.name] = len(rec)
     return files

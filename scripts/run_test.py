@@ -32,13 +32,14 @@ def main(argv=None, model_factory=None):
     if rank == 0:
         log_hparams(args)
     t0 = time.perf_counter()
-    labelled = a.dataset_directory is not None
+    labelled = a.dataset_directory is not None and not a.no_eval
     with torch.no_grad():
         metrics, detections = run_test_with_visualization(loader, net, dataset="dsec" if labelled else "synthetic",
                                                           compile_detections=True, no_eval=not labelled)
     if labelled and rank == 0:
         print("metrics of this rank's windows:", metrics)
-    files = C.gather_and_save(C.detection_rows(detections, dev), out_dir, rank)
+    names = C.sequence_names(ds)
+    files = C.gather_and_save(C.detection_rows(detections, dev, names), out_dir, rank, names)
     if rank == 0:
         print(f"{len(ds) // a.batch_size * a.batch_size} windows on {world} GPU(s) in {time.perf_counter() - t0:.2f} s "
               f"(incl. synthetic data generation on the host) -> {out_dir}: {files}")

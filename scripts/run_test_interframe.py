@@ -30,10 +30,14 @@ def main(argv=None, model_factory=None):
     with torch.no_grad():
         for n_us in np.linspace(0, 50000, a.num_interframe_steps):
             loader.dataset.set_num_us(int(n_us))
-            _, one_offset = run_test_with_visualization(loader, net, dataset="synthetic", compile_detections=True,
-                                                        no_eval=True)
+            labelled = a.dataset_directory is not None and not a.no_eval
+            metrics, one_offset = run_test_with_visualization(loader, net, dataset="dsec" if labelled else "synthetic",
+                                                              compile_detections=True, no_eval=not labelled)
+            if metrics is not None and rank == 0:
+                print(f"Time Window: {int(n_us)} us \t mAP of this rank's windows: {metrics.get('mAP')}")
             detections.extend(one_offset)
-    files = C.gather_and_save(C.detection_rows(detections, dev), out_dir, rank)
+    names = C.sequence_names(ds)
+    files = C.gather_and_save(C.detection_rows(detections, dev, names), out_dir, rank, names)
     if rank == 0:
         print(f"{a.num_interframe_steps} offsets x {len(ds) // a.batch_size * a.batch_size} windows on {world} GPU(s) in "
               f"{time.perf_counter() - t0:.2f} s -> {out_dir}: {files}")

@@ -5,6 +5,7 @@ N-GPU launch cannot fail on plumbing.  The stand-in replaces the model only; `ti
 import json
 import os
 import socket
+import subprocess
 import sys
 
 import torch
@@ -13,6 +14,10 @@ import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+
+_FakeRig = bench.DryRunRig     # the stand-in `python bench.py --dry-run-gloo` runs
 
 
 def _free_port():
@@ -23,36 +28,10 @@ def _free_port():
     return p
 
 
-class _FakeEngine:
-    def check_status(self):
-        pass
-
-
-class _FakeRig:
-    """Deterministic per-(rank, step) detections: image b of step i on rank r keeps (r + i + b) % 4 rows."""
-    B, A = 3, 8
-
-    def __init__(self, rank):
-        self.rank, self.dev = rank, torch.device("cpu")
-        self.engines = [_FakeEngine()]
-        self.streams = []
-
-    def step(self, i, slots):
-        det = torch.zeros((self.B, self.A, 6))
-        n = torch.tensor([(self.rank + i + b) % 4 for b in range(self.B)], dtype=torch.int32)
-        for b in range(self.B):
-            for k in range(int(n[b])):
-                det[b, k] = torch.tensor([1.0 * k, 2.0, 3.0 + k, 4.0, 0.5, float(self.rank)])
-        return det, n
-
-    def drain(self):
-        pass
-
 
 def _worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    import bench
     run = bench.timed_run(_FakeRig(rank), None, steps=5, warmup=2, dist=dist, world=world, rank=rank)
     json.dump(run, open(os.path.join(out_dir, f"rank{rank}.json"), "w"))
     dist.barrier()
@@ -72,7 +51,6 @@ def test_timed_run_control_flow_world2(tmp_path):
 
 
 def test_detections_rows_cut_and_window_ids():
-    import bench
     rig = _FakeRig(1)
     res = [rig.step(i, None) for i in range(4)]
     rows = bench.detections_rows(res, rank=1, B=rig.B)
@@ -83,3 +61,34 @@ def test_detections_rows_cut_and_window_ids():
     for i in range(4):
         for b in range(3):
             assert int((wid == 12 + i * 3 + b).sum()) == (1 + i + b) % 4
+
+
+def _bench(*flags):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True,
+                          env=env, timeout=600)
+
+
+def test_gpus_flag_launches_the_ranks_itself():
+    """`python bench.py --gpus 2` without a launcher's environment starts two ranks (torch.distributed.run on
+    127.0.0.1) of the same command line: rendezvous, timed region, gather and the per-rank report all run (gloo)."""
+    p = _bench("--gpus", "2", "--dry-run-gloo", "--steps", "4", "--warmup", "1")
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["world"] == 2 and line["ranks_seen"] == 2
+    assert len(line["per_rank"]) == 2 and line["steps"] == 4
+    assert line["gather"]["detections"] == sum((r + i + b) % 4 for r in range(2) for i in range(4) for b in range(3))
+
+
+def test_gpus_flag_refuses_fewer_devices_than_ranks():
+    """No silent single-rank run: on a box with fewer devices than --gpus (here: none) the command fails loudly."""
+    p = _bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--no-latency", "--no-cpu-baseline")
+    assert p.returncode != 0
+    assert "2 ranks requested" in p.stderr and "device(s) visible" in p.stderr
+
+
+def test_world_size_must_match_gpus_flag():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], capture_output=True, text=True,
+                       env=env, timeout=120)
+    assert p.returncode != 0 and "--gpus 1 but the launcher started 2" in p.stderr

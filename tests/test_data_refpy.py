@@ -232,16 +232,20 @@ def test_record_writers_match_the_reference_functions(tmp_path):
     for i in range(4):
         db.update({"a": float(i), "b": float(i * i)})
     assert np.allclose([db.compute()["a"], db.compute()["b"]], G["dictbuffer"], rtol=1e-15)
-    # the scripts' writer: rows (sequence number, t, x1, y1, x2, y2, score, label) -> detections_<prefix><seq>.npy
+    # the scripts' writer: rows (index of the sequence name, t, x1, y1, x2, y2, score, label) -> detections_{sequence}.npy,
+    # one file per sequence STRING as the reference's save_detections writes them -- names that share their digits
+    # (interlaken_00_a / interlaken_00_b on the DSEC test split) stay apart
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
     import _common as C
-    names = {"zurich_city_12_a": "12", "thun_01_a": "1"}          # detection_rows keeps the digits of the sequence name
-    flat = [dict(boxes=d["boxes"].numpy(), labels=d["labels"].numpy(), scores=d["scores"].numpy(), sequence=names[s], t=t)
+    names = sorted(set(seqs) | {"thun_01_b", "interlaken_01_a"})
+    flat = [dict(boxes=d["boxes"].numpy(), labels=d["labels"].numpy(), scores=d["scores"].numpy(), sequence=s, t=t)
             for d, s, t in zip(dets, seqs, stamps)]
-    files = C.gather_and_save(C.detection_rows(flat, torch.device("cpu")), tmp_path, 0, prefix="seq")
-    assert sorted(files) == ["detections_seq001.npy", "detections_seq012.npy"]
-    for fname, ref in (("detections_seq012.npy", "rec_saved_detections_zurich_city_12_a"),
-                       ("detections_seq001.npy", "rec_saved_detections_thun_01_a")):
+    twin = dict(flat[-1], sequence="thun_01_b")                       # same digits as thun_01_a, another recording
+    files = C.gather_and_save(C.detection_rows(flat + [twin], torch.device("cpu"), names), tmp_path, 0, names)
+    assert sorted(files) == sorted(f"detections_{s}.npy" for s in set(seqs) | {"thun_01_b"})
+    assert files["detections_thun_01_b.npy"] == len(twin["boxes"])
+    for fname, ref in (("detections_zurich_city_12_a.npy", "rec_saved_detections_zurich_city_12_a"),
+                       ("detections_thun_01_a.npy", "rec_saved_detections_thun_01_a")):
         mine, want = np.load(tmp_path / fname), G[ref]
         assert mine.dtype == want.dtype and len(mine) == len(want)
         assert np.array_equal(mine["t"], want["t"]) and bool((np.diff(mine["t"].astype(np.int64)) >= 0).all())

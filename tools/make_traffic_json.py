@@ -18,7 +18,11 @@ def load(path):
     return d
 
 
-out = {"_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (plus --kernel-trace only) over `bench.py --steps 3 "
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (source_stamp: the line's roofline.traffic is refused when the kernels have changed since)
+
+out = {"source_stamp": bench.source_stamp(),
+       "_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (plus --kernel-trace only) over `bench.py --steps 3 "
                 "--warmup 1 --engines 1` (tools/pmc.sh); KB per dispatch averaged over the dispatches of the run; traffic_bytes = "
                 "(2*FETCH_SIZE + WRITE_SIZE)*1024 as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE reports 1/2 of coalesced reads). "
                 "Calibration on this library's patterns (profiles/r1_pmc_calibration.csv, round 1): coalesced 4 B and 16 B/lane streams 0.50x, 64-byte "
