@@ -75,24 +75,35 @@ __global__ __launch_bounds__(kBlock) void k_tap_aggregate(
 
 
 // ---------------------------------------------------------------------------------------------
-// Backward of the tap aggregation (training path, first slice): A[n] = [sum_edges basis * x[src] per tap | x[n] | ..]
-// is linear in x, so with gA = dL/dA (from the GEMM's backward, a plain library GEMM) the input gradient is its
-// transpose: gx[src] += sum_{taps of the edge} basis * gA[dst][tap], plus the root copy gx[n] += gA[n][25 cin + .].
-// One wave per destination node, lanes stride the channels; float atomics (order-dependent rounding, as torch_scatter's
-// own backward has it).  gx must be zero-initialised by the caller.
+// Backward of the tap aggregation (training path): A[n] = [sum_edges basis * x[src] per tap | x[n] | ..] is linear in x,
+// so with gA = dL/dA (from the GEMM's backward, a plain library GEMM) the input gradient is its transpose:
+// gx[src] += sum_{taps of the edge} basis * gA[dst][tap], plus the root copy gx[n] += gA[n][25 cin + .].
+// One wave per destination node, lanes stride the channels.  The scatter is DETERMINISTIC: contributions are added as
+// 64-bit fixed-point integers (integer addition is associative, so the order in which the atomics land does not
+// matter), scaled by 2^50 / max|gA| -- every contribution is a convex combination of gA entries, so |term| <= max|gA|,
+// a node has far fewer than 2^12 out-edges, and the resolution max|gA| * 2^-50 is 2^-26 of an fp32 ulp at the
+// tensor's own scale.  k_fixed_to_float turns the sums into fp32.  acc must be zero-initialised by the caller.
+constexpr double kFixedOne = 1125899906842624.0;     // 2^50
+
 __global__ __launch_bounds__(kBlock) void k_tap_scatter_grad(const int32_t *__restrict__ n_nodes_ptr, int n_nodes_max,
                                                             const int32_t *__restrict__ rowptr,
                                                             const int32_t *__restrict__ col,
                                                             const int32_t *__restrict__ code,
                                                             const float *__restrict__ gA, int lda, int cin, int rx,
-                                                            int ry, float den_x, float den_y, float *__restrict__ gx,
-                                                            int ldg) {
+                                                            int ry, float den_x, float den_y,
+                                                            const float *__restrict__ amax,
+                                                            long long *__restrict__ acc) {
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * kAggWaves + (threadIdx.x >> 6);
     const int n_nodes = n_nodes_ptr ? min(*n_nodes_ptr, n_nodes_max) : n_nodes_max;
     if (n >= n_nodes) return;
+    const float m = *amax;
+    const double scale = m > 0.0f ? kFixedOne / (double)m : 0.0;
+    auto add = [&](size_t at, float v) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(acc + at), (unsigned long long)__double2ll_rn((double)v * scale));
+    };
     const float *row = gA + (size_t)n * lda;
-    for (int i = lane; i < cin; i += 64) atomicAdd(gx + (size_t)n * ldg + i, row[25 * cin + i]);
+    for (int i = lane; i < cin; i += 64) add((size_t)n * cin + i, row[25 * cin + i]);
     const int e0 = rowptr[n], e1 = rowptr[n + 1];
     for (int e = e0; e < e1; e++) {
         const int src = col[e];
@@ -105,8 +116,19 @@ __global__ __launch_bounds__(kBlock) void k_tap_scatter_grad(const int32_t *__re
         const float *a01 = row + (ax.k0 + 5 * ay.k1) * cin;
         const float *a11 = row + (ax.k1 + 5 * ay.k1) * cin;
         for (int i = lane; i < cin; i += 64)
-            atomicAdd(gx + (size_t)src * ldg + i, b00 * a00[i] + b10 * a10[i] + b01 * a01[i] + b11 * a11[i]);
+            add((size_t)src * cin + i, b00 * a00[i] + b10 * a10[i] + b01 * a01[i] + b11 * a11[i]);
     }
+}
+
+__global__ __launch_bounds__(kBlock) void k_fixed_to_float(const int32_t *__restrict__ n_nodes_ptr, int n_nodes_max, int cin,
+                                                          const float *__restrict__ amax,
+                                                          const long long *__restrict__ acc, float *__restrict__ gx,
+                                                          int ldg) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int n_nodes = n_nodes_ptr ? min(*n_nodes_ptr, n_nodes_max) : n_nodes_max;
+    if (i >= (int64_t)n_nodes * cin) return;
+    const int n = (int)(i / cin), c = (int)(i - (int64_t)n * cin);
+    gx[(size_t)n * ldg + c] = (float)((double)acc[i] * ((double)*amax / kFixedOne));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -928,14 +950,18 @@ int dagr_spline_tap_aggregate(const int32_t *n_nodes_ptr, int32_t n_nodes_max, c
 
 int dagr_spline_tap_scatter_grad(const int32_t *n_nodes_ptr, int32_t n_nodes_max, const int32_t *rowptr,
                                  const int32_t *col, const int32_t *code, const float *grad_A, int32_t lda, int32_t cin,
-                                 int32_t rx, int32_t ry, float den_x, float den_y, float *grad_x, int32_t ldg,
-                                 void *stream) {
+                                 int32_t rx, int32_t ry, float den_x, float den_y, const float *grad_A_absmax,
+                                 int64_t *acc, float *grad_x, int32_t ldg, void *stream) {
     DAGR_CHECK_ARG(n_nodes_max >= 0, "n_nodes_max < 0");
     if (n_nodes_max == 0) return DAGR_OK;
-    DAGR_CHECK_ARG(rowptr && col && code && grad_A && grad_x, "NULL pointer");
+    DAGR_CHECK_ARG(rowptr && col && code && grad_A && grad_x && grad_A_absmax && acc, "NULL pointer");
     DAGR_CHECK_ARG(cin >= 1 && lda >= 26 * cin && ldg >= cin, "bad strides");
     k_tap_scatter_grad<<<(unsigned)ceil_div(n_nodes_max, kAggWaves), kBlock, 0, (hipStream_t)stream>>>(
-        n_nodes_ptr, n_nodes_max, rowptr, col, code, grad_A, lda, cin, rx, ry, den_x, den_y, grad_x, ldg);
+        n_nodes_ptr, n_nodes_max, rowptr, col, code, grad_A, lda, cin, rx, ry, den_x, den_y, grad_A_absmax,
+        (long long *)acc);
+    DAGR_CHECK_LAUNCH();
+    k_fixed_to_float<<<(unsigned)ceil_div((int64_t)n_nodes_max * cin, kBlock), kBlock, 0, (hipStream_t)stream>>>(
+        n_nodes_ptr, n_nodes_max, cin, grad_A_absmax, (const long long *)acc, grad_x, ldg);
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;
 }

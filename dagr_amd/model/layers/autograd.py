@@ -5,7 +5,7 @@
 ``dagr_spline_tap_aggregate`` (linear in x) and ``Wm = [W[25, cin, cout] flattened | root^T]``:
   * forward: tap aggregation (HIP) + one GEMM (hipBLASLt through torch);
   * backward: ``grad_Wm = A^T . g`` and ``grad_A = g . Wm^T`` are plain library GEMMs, ``grad_x`` is the transposed
-    aggregation (``dagr_spline_tap_scatter_grad``), ``grad_bias = sum g``.
+    aggregation (``dagr_spline_tap_scatter_grad``: deterministic fixed-point scatter), ``grad_bias = sum g``.
 ``PoolFeatFn`` / ``ToDenseFn`` attach the backward of the voxel pooling's feature aggregation (torch_scatter's
 ``scatter_max`` / ``scatter_mean`` autograd, pooling.py:74-77) and of ``to_dense`` (an ``index_put``, spline_conv.py:80-107)
 to the forward entry points the eval path already uses; both backwards are gathers (csrc/train_ops.hip).  BatchNorm in
@@ -53,9 +53,12 @@ class SplineConvFn(torch.autograd.Function):
         gA[:, :K] = g @ Wm.t()
         gx = torch.zeros((n, cin), dtype=torch.float32, device=g.device)
         if n:
+            # deterministic scatter: 64-bit fixed-point sums scaled by max |gA| (a device scalar, no host sync)
+            amax = gA.abs().max().reshape(1).contiguous()
+            acc = torch.zeros((n, cin), dtype=torch.int64, device=g.device)
             _lib.check(L.dagr_spline_tap_scatter_grad(P(counts), n, P(rowptr), P(col), P(code), P(gA), lda, cin, rx, ry,
-                                                      den_x, den_y, P(gx), cin, _lib.cur_stream(g.device)),
-                       "tap_scatter_grad")
+                                                      den_x, den_y, P(amax), P(acc), P(gx), cin,
+                                                      _lib.cur_stream(g.device)), "tap_scatter_grad")
         gb = g.sum(0) if has_bias else None
         return gx, gW, groot, gb, None, None, None, None, None, None, None
 

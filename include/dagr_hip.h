@@ -204,13 +204,15 @@ int dagr_spline_tap_aggregate(const int32_t *n_nodes_ptr, int32_t n_nodes_max, c
                               int32_t cin, const float *xskip, int32_t ldskip, int32_t cskip,
                               int32_t rx, int32_t ry, float den_x, float den_y,
                               float *A, int32_t lda, void *stream);
-/* backward of step 1 w.r.t. x (training path, first slice): grad_x[src] += basis * grad_A[dst][tap] over the edges and
- * grad_x[n] += grad_A[n][25 cin ..] (root copy); grad_x must be zeroed by the caller; float atomics.  The weight
- * gradient of the contraction is a plain GEMM (A^T . grad_out) on the A matrix of dagr_spline_tap_aggregate. */
+/* backward of step 1 w.r.t. x (training path): grad_x[src] = sum over its out-edges of basis * grad_A[dst][tap], plus
+ * grad_A[n][25 cin ..] (root copy).  Deterministic: the scatter adds 64-bit fixed-point integers (scale 2^50 /
+ * *grad_A_absmax, a device scalar >= max |grad_A|; acc int64[n_nodes_max * cin], zeroed by the caller), so the result
+ * does not depend on the order in which the atomics land; grad_x is overwritten.  The weight gradient of the
+ * contraction is a plain GEMM (A^T . grad_out) on the A matrix of dagr_spline_tap_aggregate. */
 int dagr_spline_tap_scatter_grad(const int32_t *n_nodes_ptr, int32_t n_nodes_max, const int32_t *rowptr,
                                  const int32_t *col, const int32_t *code, const float *grad_A, int32_t lda, int32_t cin,
-                                 int32_t rx, int32_t ry, float den_x, float den_y, float *grad_x, int32_t ldg,
-                                 void *stream);
+                                 int32_t rx, int32_t ry, float den_x, float den_y, const float *grad_A_absmax,
+                                 int64_t *acc, float *grad_x, int32_t ldg, void *stream);
 /* fused steps 1+2 for K = 26*cin + cskip small enough to keep 16 aggregated rows in LDS
  * (dagr_spline_conv_fused_lds_bytes(cin, cskip) <= 160 KiB): no A matrix in HBM, one launch.
  * Wq = the [K, N] matrix of dagr_gemm_bias_act re-packed on the host into MFMA operand order:

@@ -138,15 +138,30 @@ def test_training_loss_and_gradients_match_the_oracle(case):
         errs.append((_rel(gh, v.grad), k))
         checked += 1
     assert checked >= 60
-    # every tensor within 2e-3 on these seeds in practice (typically 1e-5).  The bar leaves room for ONE discrete switch
-    # (arg-max near tie, ReLU at ~0) going the other way under the run-to-run order of the float atomics: the oracle's own
-    # gradients move by per cents on single tensors under 3e-6 weight noise (tools/train_grad_sensitivity.py)
+    # every tensor within 2e-3 of its own scale (typically 1e-5); the backward is deterministic (fixed-point scatter in
+    # dagr_spline_tap_scatter_grad, gathers everywhere else), so this does not depend on the run
     errs.sort()
-    assert errs[int(0.9 * len(errs))][0] < 2e-3, errs[-5:]
-    assert errs[-1][0] < 5e-2, errs[-3:]
+    assert errs[-1][0] < 2e-3, errs[-5:]
     # batch statistics moved the running buffers (momentum 0.1), as nn.BatchNorm1d does in the reference
     bn = model.backbone.conv_block1.conv_block1.norm.module
     assert int(bn.num_batches_tracked) == 1 and float(bn.running_mean.abs().sum()) > 0
+
+
+def test_training_backward_is_deterministic():
+    """Two forward + backward passes over the same batch give bit-identical losses and gradients: the SplineConv input
+    gradient is a fixed-point scatter (integer atomics: order-free), pooling / to_dense backwards are gathers."""
+    W, H, B = 240, 180, 2
+    args, model, _, batch, _, _ = _training_case(W, H, B, 3000, seed=6)
+    snaps = []
+    for _ in range(2):
+        model.zero_grad(set_to_none=True)
+        out = model(format_data(batch.clone().cuda()))
+        out["total_loss"].backward()
+        snaps.append((float(out["total_loss"]), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+    assert snaps[0][0] == snaps[1][0]
+    assert snaps[0][1].keys() == snaps[1][1].keys() and len(snaps[0][1]) >= 60
+    for k in snaps[0][1]:
+        assert torch.equal(snaps[0][1][k], snaps[1][1][k]), k
 
 
 def test_a_few_optimizer_steps_reduce_the_loss():

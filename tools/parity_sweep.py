@@ -25,7 +25,9 @@ for k in range(n_cases):
     gen = syn.uniform_window if rng.integers(0, 2) else syn.edges_window
     n = int(rng.integers(1500, 9000))
     seed = seed0 + k
-    kind = int(rng.integers(0, 10))      # 0-1: image fusion (resnet18), 2: dagr-l widths, 3: one head scale, else dagr-s
+    # 0-1: image fusion (resnet18), 2: dagr-l widths, 3: one head scale, 10: dagr-m, 11: dagr-n, 12: dagr-m + image,
+    # else dagr-s
+    kind = int(rng.integers(0, 13))
     over = {}
     image = None
     if kind <= 1:
@@ -34,13 +36,17 @@ for k in range(n_cases):
         over = dict(net_stem_width=1.0, yolo_stem_width=1.0)
     elif kind == 3:
         over = dict(num_scales=1, dataset="ncaltech101")
+    elif kind in (10, 12):
+        over = dict(net_stem_width=0.75, yolo_stem_width=0.75, **(dict(use_image=True, img_net="resnet18") if kind == 12 else {}))
+    elif kind == 11:
+        over = dict(net_stem_width=0.25, yolo_stem_width=0.25)
     dense = int(rng.integers(0, 8))
     if dense <= 1:
         n = int(rng.integers(15000, 40000))      # dense: > 128 candidates per neighbourhood, FIFO pressure
     elif dense == 2:
         n = int(rng.integers(60000, 130000))     # very dense: position-centric search, voxels beyond the per-wave cap
     args, model, sd = T._setup(W, H, B, seed=seed, **over)
-    if kind <= 1:
+    if kind <= 1 or kind == 12:
         import torch
         image = torch.rand((B, 3, H, W), generator=torch.Generator().manual_seed(seed)).cuda()
     import torch
@@ -50,7 +56,7 @@ for k in range(n_cases):
             T._compare_one_scale(args, model, sd, W, H, B, *ev)
         else:
             out = T._compare(args, model, sd, W, H, B, *ev, image=image).clone()
-            if kind > 3:      # latency mode (graph replay + head overlap) must reproduce the launch-by-launch outputs
+            if kind > 3 and image is None:      # latency mode (graph replay + head overlap) must reproduce the launch-by-launch outputs
                 eng = model.engine().set_low_latency(True)
                 dev = out.device
                 inp = (torch.from_numpy(ev[5]).to(dev), torch.from_numpy(ev[3].astype(np.float32)).view(-1, 1).to(dev),

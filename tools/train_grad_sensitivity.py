@@ -22,7 +22,11 @@ from dagr_amd.utils.testing_weights import randomize_  # noqa: E402
 NOISE = float(sys.argv[1]) if len(sys.argv) > 1 else 3e-6
 CASES = [(346, 260, 3, 4699, 704, dict(net_stem_width=1.0, yolo_stem_width=1.0, num_scales=1, dataset="ncaltech101")),
          (240, 180, 2, 1707, 710, dict(net_stem_width=0.25, yolo_stem_width=0.25)),
-         (240, 180, 2, 3656, 700, dict(num_scales=1, dataset="ncaltech101"))]
+         (240, 180, 2, 3656, 700, dict(num_scales=1, dataset="ncaltech101")),
+         # round 3, sweep seed 500: the one case above 2e-3 (2.9e-3 on backbone.layer3.conv_block1.conv.weight)
+         (240, 180, 1, 4741, 509, dict(num_scales=1, dataset="ncaltech101"))]
+if len(sys.argv) > 2:
+    CASES = [c for c in CASES if c[4] == int(sys.argv[2])]
 
 
 def case(W, H, B, n, seed, **over):          # == tests/test_training_gpu.py:_training_case, CPU side only
@@ -69,5 +73,7 @@ for W, H, B, n, seed, over in CASES:
     rel = {k: float((g1[k] - g0[k]).abs().max()) / max(1e-12, float(g0[k].abs().max())) for k in g0
            if float(g0[k].abs().max()) > 0}
     worst = max(rel, key=rel.get)
+    if len(sys.argv) > 3:
+        print(f"   {sys.argv[3]}: {rel.get(sys.argv[3])}")
     print(f"seed {seed}: loss {l0:.6f} -> {l1:.6f}; gradient change under {NOISE:g} relative weight noise: median "
           f"{np.median(list(rel.values())):.1e}, worst {rel[worst]:.1e} ({worst})", flush=True)

@@ -47,12 +47,21 @@ for k in range(n_cases):
         if v.requires_grad and v.grad is not None and float(v.grad.abs().max()) > 0:
             worst = max(worst, (T._rel(params[name].grad, v.grad), name))
             cnt += 1
-    # typical agreement is ~1e-5; single tensors can move by per cents when a max-pool arg-max / ReLU / SimOTA switch
-    # sits within rounding distance (tools/train_grad_sensitivity.py: the ORACLE's own gradients move by up to 18 % under
-    # 3e-6 relative weight noise on these cases) -- flagged, and bounded at 5e-2
-    ok = dl < 5e-4 and worst[0] < 5e-2 and out["num_fg"] == ref[5]
-    if ok and worst[0] >= 2e-3:
-        print(f"   (case {k}: one tensor beyond 2e-3 -- a discrete switch within rounding distance)")
+    # typical agreement is ~1e-5; the bar is 2e-3 of every tensor's own scale (the backward is deterministic).  A tensor
+    # beyond it is put to the oracle itself: its gradient is recomputed with the weights perturbed by 1e-6 relative noise
+    # (one fp32 rounding); if the ORACLE's own gradient of that tensor moves by as much, the case sits on a discrete
+    # switch (a max-pool arg-max / ReLU within rounding distance) and the difference is the problem's, not the kernels'
+    ok = dl < 5e-4 and worst[0] < 2e-3 and out["num_fg"] == ref[5]
+    if not ok and dl < 5e-4 and out["num_fg"] == ref[5] and worst[0] < 5e-2:
+        gen = torch.Generator().manual_seed(1)
+        sd2 = {kk: ((v.detach() * (1 + 1e-6 * torch.randn(v.shape, generator=gen))).requires_grad_(True)
+                    if v.requires_grad else v.detach().clone()) for kk, v in sd.items()}
+        ref2 = otr.training_losses(sd2, args, H, W, ev[0], ev[1], ev[2], ev[3], b, B, batch.bbox, batch.bbox_batch)
+        ref2[0].backward()
+        own = T._rel(sd2[worst[1]].grad, sd[worst[1]].grad)
+        print(f"   case {k}: {worst[1]} differs by {worst[0]:.1e}; the oracle's own gradient of that tensor moves by "
+              f"{own:.1e} under 1e-6 relative weight noise -> {'a discrete switch within rounding distance' if own >= 0.5 * worst[0] else 'NOT explained'}")
+        ok = own >= 0.5 * worst[0]
     bad += not ok
     print(f"case {k}: {W}x{H} B={B} n={n}/sample kind={kind} seed={seed}: loss rel {dl:.1e}, worst grad {worst[0]:.1e} "
           f"({worst[1]}), {cnt} tensors: {'ok' if ok else 'MISMATCH'} ({time.time() - t0:.0f} s)", flush=True)
