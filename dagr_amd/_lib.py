@@ -115,6 +115,19 @@ SIGNATURES = {
     "dagr_downsample_events": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_i32, c_i32, c_void_p,
                                               c_void_p, c_void_p]),
     "dagr_debug_postprocess_clocks": (ctypes.c_int, [c_void_p]),
+    "dagr_spline_conv_l0_tiles_rows": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_float,
+                                                      c_float, c_i64, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                      c_i32, c_void_p, c_i32, c_void_p, c_void_p, c_i32, c_void_p, c_i32,
+                                                      c_void_p]),
+    "dagr_async_graph_append": (ctypes.c_int, [ctypes.POINTER(GraphDesc), c_void_p, c_i64, c_i64, c_void_p, c_void_p,
+                                               c_void_p, c_i64, c_void_p, c_i32, c_void_p, c_i32, c_i64, c_void_p, c_void_p,
+                                               c_void_p, c_void_p, c_void_p]),
+    "dagr_async_input_rows": (ctypes.c_int, [c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_void_p, c_void_p,
+                                             c_i32, c_i32, c_i32, c_void_p]),
+    "dagr_pool_l0_stream": (ctypes.c_int, [ctypes.POINTER(PoolDesc), c_void_p, c_i32, ctypes.POINTER(GraphDesc), c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_void_p, c_i64, c_i64, c_i64,
+                                           c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_void_p]),
     "dagr_debug_calibrate": (ctypes.c_int, [c_i32, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p]),
     "dagr_spline_conv_fused_lds_bytes": (c_size_t, [c_i32, c_i32]),
     "dagr_spline_conv_fused": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32,

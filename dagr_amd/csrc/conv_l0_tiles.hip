@@ -63,7 +63,7 @@ constexpr int kTileWaves = 4;   // waves per workgroup (each owns its tiles; the
 
 template <int CM, int CE, int CS, int TX, int TY>
 __global__ __launch_bounds__(kTileWaves * 64, 2) void k_conv_l0_tiles(
-    int N, int rx, int ry, float den_x, float den_y, int win_x, int win_y, const int32_t *__restrict__ nbr_src,
+    int n_first, int N, int rx, int ry, float den_x, float den_y, int win_x, int win_y, const int32_t *__restrict__ nbr_src,
     const int16_t *__restrict__ nbr_code, const int32_t *__restrict__ deg, const float *__restrict__ x, int ldx,
     const float *__restrict__ xskip, int ldskip, const float *__restrict__ wpack, const float *__restrict__ shift,
     int relu, float *__restrict__ out, int ldo) {
@@ -100,8 +100,10 @@ __global__ __launch_bounds__(kTileWaves * 64, 2) void k_conv_l0_tiles(
     const int xcd = blockIdx.x % nx, lb = blockIdx.x / nx, bpx = G / nx;
     const int chunk = ((N + nx - 1) / nx + 15) / 16 * 16;
     const int per_block = ((chunk + bpx - 1) / bpx + 15) / 16 * 16;
-    const int n_begin = xcd * chunk + lb * per_block;
-    const int n_end = min(min(N, (xcd + 1) * chunk), n_begin + per_block);
+    // nodes [n_first, n_first + N): the whole level, or the rows an asynchronous update appended (a node's result does
+    // not depend on the tile it shares with its neighbours in memory)
+    const int n_begin = n_first + xcd * chunk + lb * per_block;
+    const int n_end = min(n_first + min(N, (xcd + 1) * chunk), n_begin + per_block);
 
     // Software pipeline over this wave's tiles.  Per tile the dependent chain is {degree, neighbour row} -> source rows ->
     // FMAs; with ~200 registers per lane only two waves share a SIMD, so the chain is shortened instead of hidden: the
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(kTileWaves * 64, 2) void k_conv_l0_tiles(
 }
 
 template <int CM, int CE, int CS, int TX, int TY>
-int launch_tiles(int64_t N, int rx, int ry, float den_x, float den_y, int win_x, int win_y, const int32_t *nbr_src,
+int launch_tiles(int64_t n_first, int64_t N, int rx, int ry, float den_x, float den_y, int win_x, int win_y, const int32_t *nbr_src,
                  const int16_t *nbr_code, const int32_t *deg, const float *x, int ldx, const float *xskip, int ldskip,
                  const float *wpack, const float *shift, int relu, float *out, int ldo, hipStream_t stream) {
     using S = L0Steps<CM, CE, CS, TX, TY>;
@@ -265,7 +267,7 @@ int launch_tiles(int64_t N, int rx, int ry, float den_x, float den_y, int win_x,
     }
     const int64_t tiles = ceil_div(N, 16);
     const unsigned grid = round_grid8(persistent_grid(kern, kTileWaves * 64, lds_bytes, ceil_div(tiles, kTileWaves)));
-    kern<<<grid, kTileWaves * 64, lds_bytes, stream>>>((int)N, rx, ry, den_x, den_y, win_x, win_y, nbr_src, nbr_code, deg,
+    kern<<<grid, kTileWaves * 64, lds_bytes, stream>>>((int)n_first, (int)N, rx, ry, den_x, den_y, win_x, win_y, nbr_src, nbr_code, deg,
                                                        x, ldx, xskip, ldskip, wpack, shift, relu, out, ldo);
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;
@@ -276,13 +278,30 @@ int launch_tiles(int64_t N, int rx, int ry, float den_x, float den_y, int win_x,
 
 using namespace dagr;
 
+extern "C" int dagr_spline_conv_l0_tiles_rows(int32_t cmain, int32_t cextra, int32_t cskip, int32_t win_x, int32_t tx,
+                                              int32_t win_y, int32_t ty, int32_t rx, int32_t ry, float den_x, float den_y,
+                                              int64_t first_node, int64_t N, int32_t K, const int32_t *nbr_src,
+                                              const int16_t *nbr_code, const int32_t *deg, const float *x, int32_t ldx,
+                                              const float *xskip, int32_t ldskip, const float *wpack, const float *shift,
+                                              int32_t relu, float *out, int32_t ldo, void *stream_);
+
 extern "C" int dagr_spline_conv_l0_tiles(int32_t cmain, int32_t cextra, int32_t cskip, int32_t win_x, int32_t tx,
                                          int32_t win_y, int32_t ty, int32_t rx, int32_t ry, float den_x, float den_y,
                                          int64_t N, int32_t K, const int32_t *nbr_src, const int16_t *nbr_code,
                                          const int32_t *deg, const float *x, int32_t ldx, const float *xskip,
                                          int32_t ldskip, const float *wpack, const float *shift, int32_t relu,
                                          float *out, int32_t ldo, void *stream_) {
-    DAGR_CHECK_ARG(N >= 0, "N < 0");
+    return dagr_spline_conv_l0_tiles_rows(cmain, cextra, cskip, win_x, tx, win_y, ty, rx, ry, den_x, den_y, 0, N, K, nbr_src,
+                                          nbr_code, deg, x, ldx, xskip, ldskip, wpack, shift, relu, out, ldo, stream_);
+}
+
+extern "C" int dagr_spline_conv_l0_tiles_rows(int32_t cmain, int32_t cextra, int32_t cskip, int32_t win_x, int32_t tx,
+                                              int32_t win_y, int32_t ty, int32_t rx, int32_t ry, float den_x, float den_y,
+                                              int64_t first_node, int64_t N, int32_t K, const int32_t *nbr_src,
+                                              const int16_t *nbr_code, const int32_t *deg, const float *x, int32_t ldx,
+                                              const float *xskip, int32_t ldskip, const float *wpack, const float *shift,
+                                              int32_t relu, float *out, int32_t ldo, void *stream_) {
+    DAGR_CHECK_ARG(N >= 0 && first_node >= 0 && first_node + N < (1ll << 31), "bad node range");
     if (N == 0) return DAGR_OK;
     DAGR_CHECK_ARG(nbr_src && nbr_code && deg && x && wpack && shift && out, "NULL pointer");
     DAGR_CHECK_ARG(K == 16, "the tiled level-0 conv walks 16-entry neighbour lists");
@@ -295,7 +314,7 @@ extern "C" int dagr_spline_conv_l0_tiles(int32_t cmain, int32_t cextra, int32_t 
     hipStream_t stream = (hipStream_t)stream_;
 #define DAGR_TILES(CM_, CE_, CS_, TX_, TY_)                                                                        \
     if (cmain == CM_ && cextra == CE_ && cskip == CS_ && tx == TX_ && ty == TY_)                                   \
-        return launch_tiles<CM_, CE_, CS_, TX_, TY_>(N, rx, ry, den_x, den_y, win_x, win_y, nbr_src, nbr_code, deg, x, \
+        return launch_tiles<CM_, CE_, CS_, TX_, TY_>(first_node, N, rx, ry, den_x, den_y, win_x, win_y, nbr_src, nbr_code, deg, x, \
                                                     ldx, xskip, ldskip, wpack, shift, relu, out, ldo, stream);
 #define DAGR_TILES_WIN(TX_, TY_)                                                                   \
     DAGR_TILES(0, 3, 0, TX_, TY_)    /* events-only conv_block1.conv_block1: 3 -> 16 (net.py:75) */  \

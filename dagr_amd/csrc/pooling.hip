@@ -669,7 +669,9 @@ __global__ __launch_bounds__(kBlock) void k_recode(const int32_t *__restrict__ n
 // (-> CSR row pointers of the relabelled clusters) of the T + 1 table slots together, 16 consecutive slots per thread
 // and 16 Ki slots per round; clears both inputs, closes the epoch.  Row sizes: the insert counters (pooled levels) or
 // the population of the cell bitmaps (level 0).
-template <bool MASKS>
+// KEEP (asynchronous updates, dagr_pool_l0_stream): the accumulators stay as they are -- nothing is cleared and the epoch
+// stays open, so that later micro-batches keep adding to the same voxels.
+template <bool MASKS, bool KEEP = false>
 __global__ __launch_bounds__(1024) void k_pool_scan(PoolWs ws, int32_t *__restrict__ n_out,
                                                    int32_t *__restrict__ rowptr_out, int32_t *__restrict__ e_out) {
     constexpr int PER = 16;
@@ -703,7 +705,7 @@ __global__ __launch_bounds__(1024) void k_pool_scan(PoolWs ws, int32_t *__restri
 #pragma unroll
             for (int j = 0; j < PER; j++) {
                 const int e = base + j * 1024 + (int)threadIdx.x;
-                if (e < n) {
+                if (e < n && !KEEP) {
                     ws.occupied[e] = 0;
                     if (!MASKS) ws.rowcnt[e] = 0;
                 }
@@ -755,7 +757,7 @@ __global__ __launch_bounds__(1024) void k_pool_scan(PoolWs ws, int32_t *__restri
         *n_out = nc;
         *e_out = ne;
         ws.status[3] = 0;
-        ws.status[4] ^= 1;      // the next call fills the other accumulator pair; launch (C) reads the one just filled
+        if (!KEEP) ws.status[4] ^= 1;   // the next call fills the other accumulator pair; launch (C) reads the one just filled
     }
 }
 
@@ -764,7 +766,7 @@ __global__ __launch_bounds__(1024) void k_pool_scan(PoolWs ws, int32_t *__restri
 // source set -- 64 hashed raw ids (pooled levels) or the two cell bitmaps (level 0) -- into its sorted CSR row with the
 // LUT coordinate of every edge, and re-arms what the slot owns: its feature accumulators, perm, its set, and the
 // position/count accumulators of the OTHER pair (the one the previous call left behind).
-template <bool MASKS>
+template <bool MASKS, bool KEEP = false>
 __global__ __launch_bounds__(kBlock) void k_pool_emit(dagr_pool_desc d, PoolWs ws, const int32_t *__restrict__ batch32,
                                                      const int64_t *__restrict__ batch64, float *__restrict__ x_out,
                                                      int ldo, int xoff, float *__restrict__ pos_out,
@@ -774,10 +776,12 @@ __global__ __launch_bounds__(kBlock) void k_pool_emit(dagr_pool_desc d, PoolWs w
     const int lane = threadIdx.x & 63;
     const int raw = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     if (raw >= ws.T) return;
-    const int pair = ws_pair(ws) ^ 1;          // the scan has closed the epoch
+    const int pair = KEEP ? ws_pair(ws) : ws_pair(ws) ^ 1;     // the scan has closed the epoch (KEEP: it stays open)
     const int cnt = ws_cnt(ws, pair)[raw];
-    if (lane == 0) ws_cnt(ws, pair ^ 1)[raw] = 0;
-    if (lane < 3) ws_possum(ws, pair ^ 1)[(size_t)raw * 3 + lane] = 0ll;
+    if (!KEEP) {
+        if (lane == 0) ws_cnt(ws, pair ^ 1)[raw] = 0;
+        if (lane < 3) ws_possum(ws, pair ^ 1)[(size_t)raw * 3 + lane] = 0ll;
+    }
     if (cnt == 0) return;                      // empty slot: nothing was accumulated, no set entries
     const int C = d.channels;
     const int c = ws.newid[raw];
@@ -787,26 +791,32 @@ __global__ __launch_bounds__(kBlock) void k_pool_emit(dagr_pool_desc d, PoolWs w
         if (d.aggr == 0) v = dec_f((int)(*acc));
         else v = (float)(((double)(*acc) / kFeatScale) / (double)cnt);
         x_out[(size_t)c * ldo + xoff + ch] = v;
-        *acc = 0ll;
-        if (d.aggr == 0) *reinterpret_cast<int *>(acc) = kEncMin;
+        if (!KEEP) {
+            *acc = 0ll;
+            if (d.aggr == 0) *reinterpret_cast<int *>(acc) = kEncMin;
+        }
     }
     float p[3];
     cluster_pos(ws, pair, raw, cnt, d, p);
     if (lane == 0) {
         pos_out[3 * c] = p[0]; pos_out[3 * c + 1] = p[1]; pos_out[3 * c + 2] = p[2];
         const int pm = ws.perm[raw];
-        batch_out[c] = batch32 ? batch32[pm] : (int)batch64[pm];
+        // the sample of the member with the largest index (consecutive_cluster's perm); with resident accumulators
+        // (KEEP) the slot holds (sample + 1) << 26 | event id, so that "largest" does not depend on the order in which
+        // the samples' events arrived: a cluster shared by a sample's t == 1.0 nodes and the next sample's nodes
+        // (QUIRK-1) takes the next sample, as it does in a window, where samples are concatenated in order
+        batch_out[c] = KEEP ? (pm >> 26) - 1 : (batch32 ? batch32[pm] : (int)batch64[pm]);
         if (d.append_pos) {       // net.py:137-138, see k_pool_finalize
             x_out[(size_t)c * ldo + xoff + C] = p[0];
             x_out[(size_t)c * ldo + xoff + C + 1] = p[1];
         }
-        ws.perm[raw] = -1;
+        if (!KEEP) ws.perm[raw] = -1;
     }
     // the slot's sources in ascending raw id (= ascending new id), one per lane
     int v = -1, rank = 0;
     if (MASKS) {
         const unsigned long long m = ws.nbmask[raw];
-        if (lane == 0) ws.nbmask[raw] = 0ull;
+        if (lane == 0 && !KEEP) ws.nbmask[raw] = 0ull;
         // bit j of `ord` = j-th candidate in ascending id: the 25 cells of the plane below, then the 25 of this plane
         const unsigned long long ord = ((m >> 32) & 0x1ffffffull) | ((m & 0x1ffffffull) << 25);
         if (lane < 50 && ((ord >> lane) & 1ull)) {
@@ -837,6 +847,93 @@ __global__ __launch_bounds__(kBlock) void k_pool_emit(dagr_pool_desc d, PoolWs w
     if (ix < 0 || ix > 2 * d.rx || iy < 0 || iy > 2 * d.ry) atomicOr(ws.status, 8);
     col[o] = ws.newid[v];
     code[o] = (ix & 0xffff) | (iy << 16);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Asynchronous updates: level-0 rows appended to a resident window (async_update.hip) join the accumulators of their
+// voxels.  16 lanes per new node: lanes over channels (features) and over its <= 16 in-edges (the source-cell bitmaps);
+// same quantities as pool_l0_cell, by atomics (a micro-batch is small).  The new node's pixel comes from its own
+// position (denormalised as the graph builder does it); its sources' pixels from the offset codes of its row.
+__global__ __launch_bounds__(kBlock) void k_pool_l0_add_rows(dagr_pool_desc d, int W, int H, int first_row, int n_rows,
+                                                            const int32_t *__restrict__ xlo,
+                                                            const int32_t *__restrict__ ylo,
+                                                            const float *__restrict__ x, int ldx,
+                                                            const float *__restrict__ pos,
+                                                            const int32_t *__restrict__ batch_events, PoolWs ws,
+                                                            const int16_t *__restrict__ nbr_code,
+                                                            const int32_t *__restrict__ nbr_src,
+                                                            const int32_t *__restrict__ deg, int K, int r) {
+    const int l = threadIdx.x & 15;
+    const int i = (blockIdx.x * kBlock + threadIdx.x) >> 4;
+    if (i >= n_rows) return;
+    const int s = first_row + i;          // an appended event's node row is its event id
+    const float px = pos[3 * (size_t)s], py = pos[3 * (size_t)s + 1], pt = pos[3 * (size_t)s + 2];
+    const int b = batch_events[s];
+    bool ok;
+    const int raw = cluster_raw(px, py, pt, b, d, ok);      // a t == 1.0 node lands one sample plane up (QUIRK-1)
+    if (!ok) {
+        if (l == 0) atomicOr(&ws.status[0], 1);
+        return;
+    }
+    const bool leak = pt >= 1.0f;
+    const int cells = d.gx * d.gy;
+    const int C = d.channels;
+    const int pair = ws_pair(ws);
+    for (int ch = l; ch < C; ch += 16) {
+        const float v = x[(size_t)s * ldx + ch];
+        if (d.aggr == 0) atomicMax(reinterpret_cast<int *>(ws.xacc + (size_t)raw * C + ch), enc_f(v));
+        else atomicAdd(reinterpret_cast<unsigned long long *>(ws.xacc + (size_t)raw * C + ch),
+                       (unsigned long long)(long long)llrint((double)v * kFeatScale));
+    }
+    if (l == 0) {
+        ws.occupied[raw] = 1;
+        atomicAdd(&ws_cnt(ws, pair)[raw], 1);
+        atomicMax(&ws.perm[raw], ((b + 1) << 26) | s);
+        atomicAdd(reinterpret_cast<unsigned long long *>(ws_possum(ws, pair) + (size_t)raw * 3 + 0),
+                  (unsigned long long)(long long)llrint((double)px * kPosScale));
+        atomicAdd(reinterpret_cast<unsigned long long *>(ws_possum(ws, pair) + (size_t)raw * 3 + 1),
+                  (unsigned long long)(long long)llrint((double)py * kPosScale));
+        atomicAdd(reinterpret_cast<unsigned long long *>(ws_possum(ws, pair) + (size_t)raw * 3 + 2),
+                  (unsigned long long)(long long)llrint((double)pt * kPosScale));
+    }
+    if (nbr_code && l < deg[s]) {
+        const int xpix = (int)((float)W * px + 1e-3f), ypix = (int)((float)H * py + 1e-3f);   // ev_tgn.py:11-16
+        const int cx = (raw % cells) % d.gx, cy = (raw % cells) / d.gx;
+        const int side = 2 * r + 1;
+        const int code = nbr_code[(size_t)s * K + l];
+        const int ox = code / side, oy = code - ox * side;
+        const int xs = xpix + ox - r, ys = ypix + oy - r;
+        int dcx = 0, dcy = 0;          // source cell = cx - 2 + #(lower bounds of cells cx-1 .. cx+2 that are <= xs)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int qx = cx - 1 + q, qy = cy - 1 + q;
+            const int bxq = qx <= 0 ? INT_MIN : (qx >= d.gx ? INT_MAX : xlo[qx]);
+            const int byq = qy <= 0 ? INT_MIN : (qy >= d.gy ? INT_MAX : ylo[qy]);
+            dcx += xs >= bxq;
+            dcy += ys >= byq;
+        }
+        const int bit = dcy * 5 + dcx;
+        if (!leak) {
+            if (bit != 12) atomicOr(&ws.nbmask[raw], 1ull << bit);                 // own cell = self loops
+        } else {
+            // raw already is the slot one plane up: sources that are t == 1.0 nodes themselves sit in its own plane
+            // (bits 0..24; own cell = self loops), the others in the plane below (bits 32..56, any of the 25 cells)
+            const int src = nbr_src[(size_t)s * K + l];
+            if (pos[3 * (size_t)src + 2] >= 1.0f) {
+                if (bit != 12) atomicOr(&ws.nbmask[raw], 1ull << bit);
+            } else {
+                atomicOr(&ws.nbmask[raw], 1ull << (32 + bit));
+            }
+        }
+    }
+}
+
+// resident accumulators: perm (largest member event id, as the window kernels leave it) -> (sample + 1) << 26 | id
+__global__ __launch_bounds__(kBlock) void k_pool_perm_keys(int T, const int32_t *__restrict__ batch_events, PoolWs ws) {
+    const int raw = blockIdx.x * kBlock + threadIdx.x;
+    if (raw >= T) return;
+    const int pm = ws.perm[raw];
+    if (pm >= 0) ws.perm[raw] = ((batch_events[pm] + 1) << 26) | pm;
 }
 
 }  // namespace
@@ -992,6 +1089,75 @@ int dagr_pool_l0(const dagr_pool_desc *desc, void *pool_ws, const dagr_graph_des
     }
     return pool_tail(desc, ws, b32, b64, x_out, ldo, xoff, pos_out, batch_out, n_out, rowptr_out, col_out, code_out,
                      e_out, e_cap, stream);
+}
+
+int dagr_pool_l0_stream(const dagr_pool_desc *desc, void *pool_ws, int32_t rebuild, const dagr_graph_desc *gdesc,
+                        void *graph_ws, const int32_t *xlo, const int32_t *ylo, const float *x, int32_t ldx, const float *pos,
+                        const int32_t *batch_events, int64_t n_window, int64_t first_row, int64_t n_rows,
+                        const int32_t *nbr_src, const int16_t *nbr_code, const int32_t *deg, float *x_out, int32_t ldo,
+                        int32_t xoff, float *pos_out, int32_t *batch_out, int32_t *n_out, int32_t *rowptr_out,
+                        int32_t *col_out, int32_t *code_out, int32_t *e_out, int32_t e_cap, void *stream_) {
+    int rc = validate_pool(desc);
+    if (rc != DAGR_OK) return rc;
+    DAGR_CHECK_ARG(pool_ws && gdesc && graph_ws, "NULL workspace/desc");
+    DAGR_CHECK_ARG(desc->channels <= 16 * kMaxChunks, "too many channels for the level-0 pooling kernel");
+    DAGR_CHECK_ARG(desc->batch_size == gdesc->batch_size, "batch_size mismatch");
+    DAGR_CHECK_ARG(n_out && rowptr_out && e_out && xlo && ylo && x && pos && batch_events && nbr_src && nbr_code && deg,
+                   "NULL pointer");
+    DAGR_CHECK_ARG(n_window >= 0 && first_row >= n_window && n_rows >= 0 && first_row + n_rows < (1 << 26) &&
+                       desc->batch_size < 30, "bad row ranges");
+    hipStream_t stream = (hipStream_t)stream_;
+    PoolWs ws;
+    pool_carve(*desc, (char *)pool_ws, &ws);
+    const int T = desc->gx * desc->gy * (desc->batch_size + 1);
+    const int K = gdesc->max_neighbors;
+    const int cell_w = (int)floorf(desc->vx * (float)gdesc->width), cell_h = (int)floorf(desc->vy * (float)gdesc->height);
+    DAGR_CHECK_ARG(K <= 16 && gdesc->radius <= 2 * std::min(cell_w, cell_h) && gdesc->width <= 4096,
+                   "asynchronous pooling keeps its coarse edges as cell bitmaps: the search radius must span at most two cells");
+    if (rebuild) {
+        // the accumulators of the resident window, from scratch (this workspace is the asynchronous mode's own)
+        rc = dagr_pool_workspace_init(desc, pool_ws, pool_carve(*desc, nullptr, nullptr), stream_);
+        if (rc != DAGR_OK) return rc;
+        if (n_window > 0) {
+            const int32_t *start; const int2 *slot_it;
+            graph_ws_views(gdesc, graph_ws, &start, &slot_it);
+            const int ncell = desc->gx * desc->gy * desc->batch_size;
+            const int nchk = (desc->channels + 15) / 16;
+#define DAGR_POOL_L0_A(MC, AG)                                                                                        \
+    k_pool_l0_cells<MC, AG><<<(unsigned)ceil_div(ncell, kBlock / 64), kBlock, 0, stream>>>(                           \
+        *desc, gdesc->width, gdesc->height, xlo, ylo, start, slot_it, x, ldx, pos, ws, nbr_code, nbr_src, deg,        \
+        graph_ws_slot_xyb(gdesc, graph_ws), K, gdesc->radius);                                                        \
+    k_pool_l0_overflow<MC, AG><<<(unsigned)(2 * device_cu_count()), kBlock, 0, stream>>>(                             \
+        *desc, gdesc->width, gdesc->height, xlo, ylo, start, slot_it, x, ldx, pos, ws, nbr_code, nbr_src, deg,        \
+        graph_ws_slot_xyb(gdesc, graph_ws), K, gdesc->radius)
+#define DAGR_POOL_L0(MC)                                                                                              \
+    do {                                                                                                              \
+        if (desc->aggr == 0) { DAGR_POOL_L0_A(MC, 0); }                                                               \
+        else { DAGR_POOL_L0_A(MC, 1); }                                                                               \
+    } while (0)
+            if (nchk <= 1) DAGR_POOL_L0(1);
+            else if (nchk <= 2) DAGR_POOL_L0(2);
+            else if (nchk <= 5) DAGR_POOL_L0(5);
+            else DAGR_POOL_L0(kMaxChunks);
+#undef DAGR_POOL_L0
+#undef DAGR_POOL_L0_A
+            DAGR_CHECK_LAUNCH();
+            k_pool_perm_keys<<<(unsigned)ceil_div(T, kBlock), kBlock, 0, stream>>>(T, batch_events, ws);
+            DAGR_CHECK_LAUNCH();
+        }
+    }
+    if (n_rows > 0) {
+        k_pool_l0_add_rows<<<(unsigned)ceil_div(n_rows * 16, kBlock), kBlock, 0, stream>>>(
+            *desc, gdesc->width, gdesc->height, (int)first_row, (int)n_rows, xlo, ylo, x, ldx, pos, batch_events, ws, nbr_code,
+            nbr_src, deg, K, gdesc->radius);
+        DAGR_CHECK_LAUNCH();
+    }
+    k_pool_scan<true, true><<<1, 1024, 0, stream>>>(ws, n_out, rowptr_out, e_out);
+    DAGR_CHECK_LAUNCH();
+    k_pool_emit<true, true><<<(unsigned)ceil_div(T, kBlock / 64), kBlock, 0, stream>>>(
+        *desc, ws, batch_events, nullptr, x_out, ldo, xoff, pos_out, batch_out, rowptr_out, col_out, code_out, e_cap);
+    DAGR_CHECK_LAUNCH();
+    return DAGR_OK;
 }
 
 int dagr_pool_csr(const dagr_pool_desc *desc, void *pool_ws, const int32_t *n_ptr, int32_t n_max, const float *x,

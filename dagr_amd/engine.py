@@ -301,6 +301,9 @@ class WindowEngine:
         self.set_low_latency(os.environ.get("DAGR_LOW_LATENCY", "1") != "0")
         self._head_stream = self._head_join = self._graph = self._graph_out = None
         self._graph_warm = 0
+        self._async_on = False
+        self._app = None
+        self._n_rows = 0
         self._prepare(bb, head)
         self.max_events = 0
         self._alloc_events(int(max_events))
@@ -482,6 +485,131 @@ class WindowEngine:
         self.cluster0 = torch.zeros((n,), dtype=torch.int32, device=dev)
         self.pos_n = torch.zeros((n, 3), dtype=torch.float32, device=dev)     # node (slot) order
         self.batch_n = torch.zeros((n,), dtype=torch.int32, device=dev)
+        self.rows_cap = n
+        self._async_on = False
+        self._app = None
+
+    # ---------------------------------------------------------------------- asynchronous operation
+    _ROW_ARRAYS = ("nbr_src", "nbr_code", "deg", "h1", "hp0", "x0buf", "cluster0", "pos_n", "batch_n")
+
+    def _grow_rows(self, rows):
+        """More level-0 rows WITHOUT losing the resident window (the asynchronous state lives in these arrays)."""
+        if rows <= self.rows_cap:
+            return
+        cap = max(rows, self.rows_cap + self.rows_cap // 2)
+        for name in self._ROW_ARRAYS:
+            old = getattr(self, name)
+            new = torch.zeros((cap,) + tuple(old.shape[1:]), dtype=old.dtype, device=old.device)
+            new[:old.shape[0]] = old
+            setattr(self, name, new)
+        if self._app is not None:
+            for name in ("next", "xytb", "batch_ev"):
+                old = self._app[name]
+                new = torch.zeros((cap,) + tuple(old.shape[1:]), dtype=old.dtype, device=old.device)
+                new[:old.shape[0]] = old
+                self._app[name] = new
+        self.rows_cap = cap
+
+    def async_begin(self):
+        """Turn the resident window (the last ``forward_raw``) into the state of an asynchronous run: per-pixel chains for
+        the events to come (empty), the sample index by event id, and pool1's accumulators resident in their own
+        workspace (dagr_pool_l0_stream).  Called by the first ``forward_append`` after a window."""
+        L, P = self.L, _lib.ptr
+        dev = self.device
+        n0 = self._N
+        if n0 == 0:
+            raise RuntimeError("asynchronous update without a window: call forward_raw (reset=True) first")
+        self._grow_rows(n0 + max(4096, n0 // 4))
+        npix = self.B * self.H * self.W
+        if self._app is None or self._app["head"].shape[0] != npix:
+            nbytes = L.dagr_pool_workspace_bytes(ctypes.byref(self.pool_desc[0]))
+            self._app = dict(head=torch.empty((npix,), dtype=torch.int32, device=dev),
+                             next=torch.zeros((self.rows_cap,), dtype=torch.int32, device=dev),
+                             xytb=torch.zeros((self.rows_cap, 4), dtype=torch.int32, device=dev),
+                             batch_ev=torch.zeros((self.rows_cap,), dtype=torch.int32, device=dev),
+                             status=torch.zeros((4,), dtype=torch.int32, device=dev),
+                             pool_ws=torch.empty(nbytes, dtype=torch.uint8, device=dev))
+        a = self._app
+        for name in ("next", "xytb", "batch_ev"):
+            if a[name].shape[0] < self.rows_cap:
+                a[name] = torch.zeros((self.rows_cap,) + tuple(a[name].shape[1:]), dtype=a[name].dtype, device=dev)
+        a["head"].fill_(-1)
+        a["status"].zero_()
+        a["batch_ev"][:n0] = self._batch.to(torch.int32)
+        self._n_rows = n0
+        self._async_on = True
+        self._pool1_stream(rebuild=True, first=n0, n=0)
+
+    def _pool1_stream(self, rebuild, first, n):
+        L, P = self.L, _lib.ptr
+        g, a, l1, d = self.graph, self._app, self.levels[0], self.pool_desc[0]
+        _lib.check(L.dagr_pool_l0_stream(ctypes.byref(d), P(a["pool_ws"]), 1 if rebuild else 0, ctypes.byref(g.desc),
+                                         P(g.workspace), P(self.xlo), P(self.ylo), P(self.hp0), self.hp0.shape[1],
+                                         P(self.pos_n), P(a["batch_ev"]), self._N, first, n, P(self.nbr_src),
+                                         P(self.nbr_code), P(self.deg), P(l1.x), l1.x.shape[1], 0, P(l1.pos), P(l1.batch),
+                                         P(l1.counts), P(l1.rowptr), P(l1.col), P(l1.code),
+                                         ctypes.c_void_p(l1.counts.data_ptr() + 4), l1.e_cap,
+                                         _lib.cur_stream(self.device)), "pool_l0_stream")
+
+    def _conv_l0_rows(self, pack, first, n, x, ldx, xskip, ldskip, out, ldo):
+        L, P = self.L, _lib.ptr
+        cin, cskip, w, s = pack
+        d0 = self.dom[0]
+        wx, tx, wy, ty = self.win0
+        cm = 16 if cin >= 16 else 0
+        _lib.check(L.dagr_spline_conv_l0_tiles_rows(cm, cin - cm, cskip, wx, tx, wy, ty, d0["rx"], d0["ry"], d0["den_x"],
+                                                    d0["den_y"], first, n, self.graph.K, P(self.nbr_src), P(self.nbr_code),
+                                                    P(self.deg), x, ldx, xskip, ldskip, P(w), P(s), 1, out, ldo,
+                                                    _lib.cur_stream(self.device)), "conv_l0_tiles_rows")
+
+    def forward_append(self, pos, feat, batch):
+        """``reset=False``: the n events of a micro-batch attach to the resident window (EV_TGN.forward, ev_tgn.py:45-56).
+        Edges point from older to newer events, so the window's level-0 rows stand; the update
+          1. links the events into their pixels' chains and searches their in-edges (dagr_async_graph_append),
+          2. computes conv_block1 on the n new rows only (dagr_spline_conv_l0_tiles_rows),
+          3. adds the rows to pool1's resident accumulators and re-emits level 1 (dagr_pool_l0_stream),
+          4. runs the fixed-size part (levels 1-4, heads, decode) as a window does.
+        Output = what ``forward_raw`` gives on all events so far, bit for bit (same kernels per row; order-free
+        accumulators).  pos fp32[n,3] normalised as format_data does, feat fp32[n,1], batch int32/int64[n]."""
+        if not self.l0_tiles:
+            raise NotImplementedError("asynchronous updates run on the tiled level-0 conv (16 neighbours, 3x3/3x5 tap window)")
+        L, P = self.L, _lib.ptr
+        if not self._async_on:
+            self.async_begin()
+        n = int(pos.shape[0])
+        a = self._app
+        first = self._n_rows
+        stream = _lib.cur_stream(self.device)
+        if n:
+            self._grow_rows(first + n)
+            a = self._app
+            pos = pos.float().contiguous()
+            feat = feat.float().reshape(-1).contiguous()
+            batch = batch.contiguous()
+            b64 = 1 if batch.dtype == torch.int64 else 0
+            g = self.graph
+            _lib.check(L.dagr_async_graph_append(ctypes.byref(g.desc), P(g.workspace), self._N, first, P(a["head"]),
+                                                 P(a["next"]), P(a["xytb"]), a["next"].shape[0], P(pos), 0, P(batch), b64,
+                                                 n, P(self.nbr_src), P(self.nbr_code), P(self.deg), P(a["status"]), stream),
+                       "async_graph_append")
+            _lib.check(L.dagr_async_input_rows(n, first, P(pos), P(feat), P(batch), b64, P(self.pos_n), P(self.batch_n),
+                                               P(self.x0buf), self.x0_ld, self.x0_feat_col, self.x0_pos_col, stream),
+                       "async_input_rows")
+            a["batch_ev"][first:first + n] = batch.to(torch.int32)
+            rows = slice(first, first + n)
+            if self.use_image:
+                self._sample(None, n, self.pos_n[rows], self.batch_n[rows], 0, self._img_feats[0], self.x0buf[rows],
+                             self.x0_img_col)
+            self._conv_l0_rows(self.l0_conv1, first, n, P(self.x0buf), self.x0_ld, None, 0, P(self.h1), 16)
+            self._conv_l0_rows(self.l0_conv2, first, n, P(self.h1), 16, P(self.x0buf), self.x0_ld, P(self.hp0),
+                               self.hp0.shape[1])
+            if self.use_image:
+                self._sample(None, n, self.pos_n[rows], self.batch_n[rows], 0, self._img_feats[1], self.hp0[rows], 16)
+            self._n_rows = first + n
+        self._pool1_stream(rebuild=False, first=first, n=n)
+        if self.tail_graph and not self.use_image:
+            return self._replay_tail()
+        return self._decode(self._tail_and_head())
 
     # ------------------------------------------------------------------------------- kernels
     def _conv_generic(self, lvl, pack, x, ldx, xskip, ldskip, out, ldo, dom, stream, code=None, scratch=None):
@@ -521,6 +649,8 @@ class WindowEngine:
         self._pos, self._batch = pos, batch
         self._nbr = (self.nbr_src[:N], self.nbr_code[:N], self.deg[:N])
         self.graph.build(pos, batch, out=self._nbr)
+        self._n_rows = N              # a new window: the asynchronous state of the previous one is gone
+        self._async_on = False
 
     def _sample(self, n_ptr, n_max, pos, batch, b64, fmap, out, coff):
         """sample_features (net.py:193-221) of one channels-last feature map into out[:, coff:coff+C]."""
@@ -907,6 +1037,14 @@ class WindowEngine:
                                                _lib.cur_stream(self.device)), "pool_status")
             if f.value:
                 raise RuntimeError(f"pool{k + 1} flagged {f.value:#x}")
+        if self._async_on:
+            if int(self._app["status"][0]):
+                raise RuntimeError("asynchronous update: event outside the sensor / batch range")
+            f = ctypes.c_int32(0)
+            _lib.check(self.L.dagr_pool_status(ctypes.byref(self.pool_desc[0]), _lib.ptr(self._app["pool_ws"]),
+                                               ctypes.byref(f), _lib.cur_stream(self.device)), "pool_status")
+            if f.value:
+                raise RuntimeError(f"pool1 (asynchronous accumulators) flagged {f.value:#x}")
         st = self.status.tolist()
         if st[0]:
             raise RuntimeError("to_dense: node outside the output map")

@@ -125,6 +125,17 @@ class GNNHead(YOLOXHeadParams):
         return outputs
 
 
+def _concat_window(batches):
+    """All events of the running window ordered by sample, arrival order inside a sample: the layout one reset=True call
+    on the same events has (collation concatenates sample after sample)."""
+    pos = torch.cat([d.pos.float() for d in batches])
+    feat = torch.cat([d.x.float().view(-1, 1) for d in batches])
+    batch = torch.cat([(d.batch if getattr(d, "batch", None) is not None else
+                        torch.zeros(d.pos.shape[0], dtype=torch.int64, device=d.pos.device)).long() for d in batches])
+    order = torch.argsort(batch, stable=True)
+    return pos[order].contiguous(), feat[order].contiguous(), batch[order].contiguous()
+
+
 class DAGR(torch.nn.Module):
     def __init__(self, args, height, width):
         super().__init__()
@@ -140,8 +151,8 @@ class DAGR(torch.nn.Module):
                             pretrain_cnn=args.pretrain_cnn, args=args)
         self._engine = None
         self._engine_stamp = None
-        self._window = None          # events since the last reset=True call (DAGR.forward(reset=False))
-        self._streaming = False
+        self._window = None          # the batches since the last reset=True call (DAGR.forward(reset=False))
+        self.asynchronous = True     # reset=False calls update incrementally (asynchronous.make_model_synchronous: off)
         if bool(args.no_events) and not bool(args.use_image):
             raise ValueError("--no_events returns the image branch's detections (dagr.py:283-284): it needs --use_image")
         if bool(getattr(args, "keep_temporal_ordering", False)):
@@ -244,26 +255,28 @@ class DAGR(torch.nn.Module):
         if self.training:
             return self.forward_training(x)
         eng = self.engine()
-        if self._window is None:
-            from ...asynchronous import StreamingWindow
-            self._window = StreamingWindow()
-        if reset:
-            self._window.reset()
-            self._streaming = False
-        if not reset or self._streaming:
-            # dagr.py:90 `x.reset = reset` -> ev_tgn.py:45-56: the new events attach to the running graph.  The running
-            # window lives on the device and is re-evaluated as a whole (dagr_amd/asynchronous/__init__.py): the
-            # outputs equal one reset=True call on all events so far, which is what the reference's asynchronous
-            # model guarantees for its incremental update (evaluate_flops.py:139-147).
-            self._streaming = True
         eng.check_batch(x)
-        if self._streaming:
-            self._window.push(x)
-            pos, feat, batch = self._window.tensors()
-            outputs = eng.forward_raw(pos, feat, batch, image=self._window.image)
-        else:
-            self._window.seed(x)             # a later reset=False call continues from this window (converted then)
+        if reset:
+            self._window = None                  # a new window: the running one is gone
+        if reset or self._window is None:
+            # a window of its own (every evaluation script's call), or the first call of an asynchronous run
             outputs = eng.forward_data(x)
+            self._window = [x]                   # only remembered: a later reset=False call continues from it
+        elif self.asynchronous:
+            # dagr.py:90 `x.reset = reset` -> ev_tgn.py:45-56: the new events attach to the running graph.  Incremental:
+            # only their level-0 rows are computed, pool1's resident accumulators are extended, the fixed-size part of
+            # the network runs as for a window (engine.forward_append).  Equal to one reset=True call on all events so
+            # far -- the guarantee the reference's asynchronous model gives for its update (evaluate_flops.py:139-147).
+            batch = x.batch if getattr(x, "batch", None) is not None else \
+                torch.zeros(x.pos.shape[0], dtype=torch.int64, device=x.pos.device)
+            outputs = eng.forward_append(x.pos, x.x, batch)
+            self._window.append(x)
+        else:
+            # make_model_synchronous: the whole running window again (the reference's synchronous forward on all events)
+            self._window.append(x)
+            pos, feat, batch = _concat_window(self._window)
+            outputs = eng.forward_raw(pos, feat, batch, image=getattr(self._window[0], "image", None))
+            eng._async_on = False
         detections = postprocess_network_output(outputs, self.backbone.num_classes, self.conf_threshold,
                                                 self.nms_threshold, filtering=filtering, height=self.height,
                                                 width=self.width)

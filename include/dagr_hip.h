@@ -196,6 +196,14 @@ int dagr_spline_conv_l0_tiles(int32_t cmain, int32_t cextra, int32_t cskip, int3
                               const int32_t *nbr_src, const int16_t *nbr_code, const int32_t *deg, const float *x,
                               int32_t ldx, const float *xskip, int32_t ldskip, const float *wpack, const float *shift,
                               int32_t relu, float *out, int32_t ldo, void *stream);
+/* the same on the nodes [first_node, first_node + N) only (all arrays are the full level's: an asynchronous update
+ * computes the rows it appended; a node's result does not depend on which nodes share its tile) */
+int dagr_spline_conv_l0_tiles_rows(int32_t cmain, int32_t cextra, int32_t cskip, int32_t win_x, int32_t tx, int32_t win_y,
+                                   int32_t ty, int32_t rx, int32_t ry, float den_x, float den_y, int64_t first_node,
+                                   int64_t N, int32_t K, const int32_t *nbr_src, const int16_t *nbr_code,
+                                   const int32_t *deg, const float *x, int32_t ldx, const float *xskip, int32_t ldskip,
+                                   const float *wpack, const float *shift, int32_t relu, float *out, int32_t ldo,
+                                   void *stream);
 /* generic step 1: A[n] = [sum_j basis*x_j per tap (25*cin) | x[n] (cin) | xskip[n] (cskip)] over a
  * CSR-by-destination graph; code[e] = ix | iy<<16.  n_nodes_ptr (device, may be NULL) bounds the
  * rows actually processed (<= n_nodes_max) without a host sync. */
@@ -280,6 +288,40 @@ int dagr_pool_l0(const dagr_pool_desc *desc, void *pool_ws, const dagr_graph_des
                  int32_t *cluster_scratch /*[N]*/, float *x_out, int32_t ldo, int32_t xoff, float *pos_out,
                  int32_t *batch_out, int32_t *n_out, int32_t *rowptr_out, int32_t *col_out, int32_t *code_out,
                  int32_t *e_out, int32_t e_cap, void *stream);
+/* ------------------------------------------------------------------------ *
+ * Asynchronous operation (reset=False): a micro-batch of events joins the resident window
+ *   replaces, for the events-to-level-1 part, the reference's incremental update
+ *     EV_TGN.forward(reset=False) -> AsyncGraph.forward            model/layers/ev_tgn.py:45-56, graph/ev_graph.py:63-103
+ *     insert_in_queue_cuda_kernel / fill_edges_cuda_kernel (min_index > 0)   graph/ev_graph.cu:15-80,169-212
+ *     asynchronous conv on the new nodes (graph_new_nodes branch)  asynchronous/conv.py:107-125,196-207
+ *     asynchronous pooling, new-node branch (cluster caches)       asynchronous/max_pool.py:126-158
+ *   Edges point from older to newer events: the rows of the window's events never change, an update appends rows.
+ *   State owned by the caller (device): app_head int32[B*H*W] (-1 = empty), app_next int32[capacity],
+ *   app_xytb int32[capacity][4]; event ids continue the window's (first_id = n_static + number appended so far); an
+ *   appended event's node row is its id.  status int32[>=1]: bit 0 = event outside the sensor (self loop only).
+ * ------------------------------------------------------------------------ */
+int dagr_async_graph_append(const dagr_graph_desc *desc, void *graph_ws, int64_t n_static, int64_t first_id,
+                            int32_t *app_head, int32_t *app_next, int32_t *app_xytb, int64_t capacity,
+                            const void *pos /* fp32 normalised or int32 [n,3] */, int32_t pos_is_int32,
+                            const void *batch, int32_t batch_is_int64, int64_t n_new,
+                            int32_t *nbr_src, int16_t *nbr_code, int32_t *deg /* the level's full arrays */,
+                            int32_t *status, void *stream);
+/* node-ordered level-0 inputs of the new rows (cf. dagr_graph_gather_inputs): rows [first_row, first_row + n_new) */
+int dagr_async_input_rows(int64_t n_new, int64_t first_row, const float *pos, const float *feat, const void *batch,
+                          int32_t batch_is_int64, float *pos_nodes, int32_t *batch_nodes, float *x0, int32_t ldx0,
+                          int32_t col_feat, int32_t col_pos, void *stream);
+/* pool1 with RESIDENT accumulators (its own workspace, dagr_pool_workspace_bytes): rebuild != 0 recomputes them from the
+ * window (nodes [0, n_window) through the builder's pixel index); rows [first_row, first_row + n_rows) -- appended
+ * nodes, first_row >= n_window -- are added; then level 1 is emitted exactly as dagr_pool_l0 emits it, and the
+ * accumulators stay.  batch_events: sample index by EVENT id (window events in event order, then the appended ones).
+ * Needs the cell-bitmap form of the coarse edges (search radius <= two cells). */
+int dagr_pool_l0_stream(const dagr_pool_desc *desc, void *pool_ws, int32_t rebuild, const dagr_graph_desc *gdesc,
+                        void *graph_ws, const int32_t *xlo, const int32_t *ylo, const float *x, int32_t ldx, const float *pos,
+                        const int32_t *batch_events, int64_t n_window, int64_t first_row, int64_t n_rows,
+                        const int32_t *nbr_src, const int16_t *nbr_code, const int32_t *deg, float *x_out, int32_t ldo,
+                        int32_t xoff, float *pos_out, int32_t *batch_out, int32_t *n_out, int32_t *rowptr_out,
+                        int32_t *col_out, int32_t *code_out, int32_t *e_out, int32_t e_cap, void *stream);
+
 /* coarser levels: input graph in CSR; n_ptr (device) = number of valid input nodes (<= n_max) */
 int dagr_pool_csr(const dagr_pool_desc *desc, void *pool_ws, const int32_t *n_ptr, int32_t n_max, const float *x,
                   int32_t ldx, const float *pos, const int32_t *batch, const int32_t *rowptr, const int32_t *col,

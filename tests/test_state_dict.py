@@ -58,11 +58,13 @@ def test_state_dict_roundtrip_strict():
 
 def test_asynchronous_entry_points_resolve():
     """``dagr.asynchronous.make_model_asynchronous / make_model_synchronous`` (asynchronous/__init__.py:30-110) exist under
-    the reference's import path; conversion is the identity here (``reset=False`` is native), the FLOP log is refused."""
+    the reference's import path and return the module they were given; they switch ``reset=False`` calls between the
+    incremental update and the re-evaluation of the running window; the reference's FLOP log is refused."""
     import pytest
     import torch
     from dagr.asynchronous import make_model_asynchronous, make_model_synchronous
     m = torch.nn.Linear(1, 1)
-    assert make_model_synchronous(make_model_asynchronous(m)) is m
+    assert make_model_asynchronous(m) is m and m.asynchronous is True
+    assert make_model_synchronous(m) is m and m.asynchronous is False
     with pytest.raises(NotImplementedError):
         make_model_asynchronous(m, log_flops=True)
