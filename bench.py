@@ -12,6 +12,7 @@ ranks itself and refuses to run on fewer devices; windows are independent so ran
   events_only           the same K steps on the events-only model (config 1 shape): the hand-written path alone
   latency_ms            per-window latency (HIP events, one window batch at a time, 20 warm-up + 100 timed windows):
                         median / p95 for B in {1, 8}, N in {25k..400k} events per window, S-uniform and S-edges
+  async_update          f3: microseconds per reset=False update (1 / 10 / 100 events onto a 25 k-event window) vs re-evaluation
   roofline / stages     dominant kernel of the event path and per-stage timings (HIP events on the kernels' stream)
   cpu_baseline          the CPU oracle (a port of the reference's op sequence) on the host cores: the SAME step (B windows)
   image_branch          the dense ResNet-50 branch's time, GFLOP and rate against the fp32 matrix peak (library code)
@@ -496,6 +497,54 @@ def dry_run(a, world, rank):
     dist.destroy_process_group()
 
 
+def async_update_leg(W, H, dev, n_window=25000, sizes=(1, 10, 100), n_updates=100, n_warm=10):
+    """f3: microseconds per asynchronous update -- a micro-batch of m events attaching to a resident 25 k-event window
+    (B = 1, events-only, latency mode), p50 / p95 over `n_updates` consecutive updates, HIP events on the engine's stream,
+    device idle at the start of each update; beside it the re-evaluation of the whole window (what reset=False cost before
+    the incremental update existed)."""
+    from dagr_amd.utils import synthetic as syn
+    from dagr_amd.model.utils import postprocess_device
+    rig = Rig(W, H, 1, False, "resnet50", 1, dev, low_latency=True)
+    eng = rig.engines[0]
+    n_extra = max(sizes) * (n_updates + n_warm)
+    x, y, t, p = syn.uniform_window(n_window + n_extra, W, H, seed=4234)
+    pos = torch.from_numpy(syn.format_data_np(x, y, t, W, H)).to(dev)
+    feat = torch.from_numpy(p.astype(np.float32)).view(-1, 1).to(dev)
+    batch = torch.zeros(len(x), dtype=torch.int64, device=dev)
+
+    def timed(fn, n):
+        ms = []
+        for i in range(n):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            fn(i)
+            e1.record()
+            torch.cuda.synchronize()
+            ms.append(e0.elapsed_time(e1))
+        return np.array(ms)
+
+    def post(o):
+        return postprocess_device(o, rig.num_classes, 0.001, 0.65, H, W)
+    out = {"window_events": n_window, "protocol": f"{n_warm} warm-up + {n_updates} timed updates per micro-batch size, one at "
+                                                   "a time, HIP events around update + post-processing"}
+    full = timed(lambda i: post(eng.forward_raw(pos[:n_window], feat[:n_window], batch[:n_window])), 30)[10:]
+    out["reevaluate_window_us"] = dict(p50=round(1e3 * float(np.median(full)), 1), p95=round(1e3 * float(np.percentile(full, 95)), 1))
+    for m in sizes:
+        eng.forward_raw(pos[:n_window], feat[:n_window], batch[:n_window])
+
+        def upd(i, m=m):
+            lo = n_window + i * m
+            post(eng.forward_append(pos[lo:lo + m], feat[lo:lo + m], batch[lo:lo + m]))
+        us = 1e3 * timed(upd, n_warm + n_updates)[n_warm:]
+        eng.check_status()
+        out[f"update_{m}_events_us"] = dict(p50=round(float(np.median(us)), 1), p95=round(float(np.percentile(us, 95)), 1),
+                                            events_per_s=round(m / (float(np.median(us)) * 1e-6), 1))
+    del rig
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -595,6 +644,7 @@ def main():
             lat["image_" + a.img_net] = latency_sweep(W, H, True, a.img_net, dev, Ns, a.latency_warmup,
                                                       a.latency_windows)
         result["latency_ms"] = lat
+        result["async_update"] = async_update_leg(W, H, dev)
     if want_cpu:
         result["cpu_baseline"] = cpu_baseline(model_cpu, sd_cpu, W, H, B, NPW, a.cpu_steps, a.stream, use_image,
                                               a.img_net)

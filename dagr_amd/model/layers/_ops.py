@@ -178,6 +178,15 @@ def voxel_pool(pool, data):
     src = col_out[:ne].long()
     order = torch.argsort(src * max(nc, 1) + dst, stable=True)    # edge_index.unique(dim=-1): by source, then destination
     ei = torch.stack([src[order], dst[order]])
+    if getattr(pool, "keep_temporal_ordering", False) and ne > 0:
+        # pooling.py:69-72: coarse edges only towards clusters whose newest member is strictly newer than the source's.
+        # scratch holds every node's raw voxel id; clusters are the occupied voxels in ascending id order.
+        raw = scratch.long()
+        ok = raw >= 0
+        _, inv = torch.unique(raw[ok], return_inverse=True)
+        t_max = torch.full((nc,), float("-inf"), dtype=torch.float32, device=dev)
+        t_max.scatter_reduce_(0, inv, data.pos[ok][:, -1].float(), "amax")
+        ei = ei[:, t_max[ei[1]] > t_max[ei[0]]]
     out = data.__class__()
     out.__dict__.update({k: v for k, v in data.__dict__.items() if not k.startswith("_dagr")})
     out.x, out.pos, out.batch, out.edge_index = x_out[:nc], pos_out[:nc], batch_out[:nc].long(), ei

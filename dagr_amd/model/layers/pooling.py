@@ -8,9 +8,12 @@ class Pooling(torch.nn.Module):
                  dim=2, self_loop=False, in_channels=-1):
         super().__init__()
         assert aggr in ["mean", "max"]
-        assert not keep_temporal_ordering and not self_loop and in_channels <= 0, \
-            "only the default Pooling options used by Net (net.py:78-97) are implemented"
+        assert not self_loop and in_channels <= 0, \
+            "only the Pooling options reachable from Net (net.py:78-97) are implemented"
         self.aggr = aggr
+        # --keep_temporal_ordering (pooling.py:69-72): honoured by this module's forward; the window engine's fused
+        # pooling does not filter edges, so DAGR.forward takes the module path when the flag is set
+        self.keep_temporal_ordering = bool(keep_temporal_ordering)
         self.register_buffer("voxel_size", torch.cat([size, torch.Tensor([1])]), persistent=False)
         self.transform = transform
         self.dim = dim

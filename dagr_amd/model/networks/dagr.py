@@ -155,8 +155,9 @@ class DAGR(torch.nn.Module):
         self.asynchronous = True     # reset=False calls update incrementally (asynchronous.make_model_synchronous: off)
         if bool(args.no_events) and not bool(args.use_image):
             raise ValueError("--no_events returns the image branch's detections (dagr.py:283-284): it needs --use_image")
-        if bool(getattr(args, "keep_temporal_ordering", False)):
-            raise NotImplementedError("--keep_temporal_ordering (pooling.py:69-72) is not implemented by the HIP pooling")
+        # --keep_temporal_ordering (pooling.py:69-72): the coarse-edge filter lives in the Pooling modules; the window
+        # engine's fused pooling does not apply it, so eval forwards of such a model run module by module
+        self.module_path_only = bool(getattr(args, "keep_temporal_ordering", False))
         if "img_net_checkpoint" in vars(args):
             from ..utils import init_subnetwork
             state_dict = torch.load(args.img_net_checkpoint)
@@ -254,6 +255,17 @@ class DAGR(torch.nn.Module):
     def forward(self, x, reset=True, return_targets=True, filtering=True):
         if self.training:
             return self.forward_training(x)
+        if self.module_path_only:
+            if not reset:
+                raise NotImplementedError("reset=False with --keep_temporal_ordering: the module path evaluates whole windows")
+            outputs = self.forward_modules(x, reset=True)
+            detections = postprocess_network_output(outputs, self.backbone.num_classes, self.conf_threshold,
+                                                    self.nms_threshold, filtering=filtering, height=self.height,
+                                                    width=self.width)
+            ret = [detections]
+            if return_targets and hasattr(x, "bbox"):
+                ret.append(convert_to_evaluation_format(x))
+            return ret
         eng = self.engine()
         eng.check_batch(x)
         if reset:

@@ -198,7 +198,8 @@ def net_forward(sd, args, nc, pos, feat, batch, edge_index, use_lut=True, image_
     for k in range(4):
         if image_feat is not None:
             g.x = torch.cat((g.x, sample_features(g.pos, g.batch, image_feat[k + 1], W, H)), dim=1)
-        res = ops.pooling(nc.pools[k], g.x, g.pos, g.batch, g.edge_index, exact_mean=exact_pos_mean)
+        res = ops.pooling(nc.pools[k], g.x, g.pos, g.batch, g.edge_index, exact_mean=exact_pos_mean,
+                          keep_temporal_ordering=bool(getattr(args, "keep_temporal_ordering", False)))
         if res is not None:  # pooling.py:52-53 returns the input untouched on an empty graph
             g = Graph(*res)
         rec(f"pool{k + 1}", g)

@@ -270,9 +270,10 @@ class PoolingParams:
         self.cart_max = cart_max
 
 
-def pooling(pp, x, pos, batch, edge_index, exact_mean=False):
-    """``Pooling.forward`` (``pooling.py:51-97``), self_loop=False, keep_temporal_ordering=False,
-    bn=None.  Returns (x, pos, batch, edge_index, edge_attr[E,3]).
+def pooling(pp, x, pos, batch, edge_index, exact_mean=False, keep_temporal_ordering=False):
+    """``Pooling.forward`` (``pooling.py:51-97``), self_loop=False, bn=None.  Returns (x, pos, batch, edge_index,
+    edge_attr[E,3]).  ``keep_temporal_ordering`` (pooling.py:69-72): a coarse edge survives only if the destination
+    cluster's newest member is strictly newer than the source cluster's.
 
     ``exact_mean``: the cluster position is a mean that is then FLOORED to the pixel grid (pooling.py:47-49,86), so its
     last bits decide an integer.  The reference sums it with float atomics on the GPU (torch_scatter: order unspecified),
@@ -292,6 +293,10 @@ def pooling(pp, x, pos, batch, edge_index, exact_mean=False):
     if ei.shape[1] > 0:
         ei = ei.unique(dim=-1)
     new_batch = batch[perm]
+    if keep_temporal_ordering:
+        t_max = scatter_max(pos[:, -1:], cluster, n)[:, 0]
+        if ei.shape[1] > 0:
+            ei = ei[:, t_max[ei[1]] > t_max[ei[0]]]
     new_pos = scatter_mean(pos.double(), cluster, n).float() if exact_mean else scatter_mean(pos, cluster, n)
     if pp.aggr == "max":
         new_x = scatter_max(x, cluster, n)

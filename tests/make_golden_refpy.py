@@ -195,7 +195,9 @@ def main():
     rpool.Batch = _Batch
     rpool.grid_cluster = lambda pos, size, start, end: oo.grid_cluster(pos, size, start, end)
     rpool.torch_scatter = types.SimpleNamespace(
-        scatter_max=lambda src, index, dim=0: (oo.scatter_max(src, index, int(index.max()) + 1), None))
+        scatter_max=lambda src, index, dim=0: (
+            oo.scatter_max(src.reshape(src.shape[0], -1), index, int(index.max()) + 1).reshape((-1,) + tuple(src.shape[1:])),
+            None))
     rpool.pool_pos = lambda cluster, pos: oo.scatter_mean(pos, cluster, int(cluster.max()) + 1)
     rpool._avg_pool_x = lambda cluster, x: oo.scatter_mean(x, cluster, int(cluster.max()) + 1)
     W, H, B, N, E = 320, 215, 2, 900, 5000
@@ -213,6 +215,22 @@ def main():
         out.update({f"pool{k}_size": ps[0], f"pool{k}_x": x, f"pool{k}_pos": pos, f"pool{k}_batch": batch,
                     f"pool{k}_ei": ei, f"pool{k}_out_x": r.x, f"pool{k}_out_pos": r.pos, f"pool{k}_out_batch": r.batch,
                     f"pool{k}_out_ei": r.edge_index})
+
+    # ---- Pooling.forward with keep_temporal_ordering=True (pooling.py:69-72): coarse edges only towards clusters whose newest
+    # member is newer than the source cluster's (its own generator: the entries above stay as they were)
+    g2 = torch.Generator().manual_seed(2024)
+    pl = rpool.Pooling(ps[1], width=W, height=H, batch_size=B, transform=None, aggr="max", keep_temporal_ordering=True)
+    pos = torch.stack([torch.randint(0, W, (N,), generator=g2).float() / W, torch.randint(0, H, (N,), generator=g2).float() / H,
+                       torch.rand(N, generator=g2)], 1)
+    pos[5:9, 2] = pos[5, 2]                                     # equal newest timestamps in places: `>` is strict
+    batch = torch.sort(torch.randint(0, B, (N,), generator=g2)).values
+    x = torch.randn((N, 4), generator=g2)
+    ei = torch.randint(0, N, (2, E), generator=g2)
+    d = types.SimpleNamespace(x=x.clone(), pos=pos.clone(), batch=batch.clone(), edge_index=ei.clone(),
+                              height=torch.tensor([H]), width=torch.tensor([W]))
+    r = pl.forward(d)
+    out.update({"poolt_size": ps[1], "poolt_x": x, "poolt_pos": pos, "poolt_batch": batch, "poolt_ei": ei,
+                "poolt_out_x": r.x, "poolt_out_pos": r.pos, "poolt_out_batch": r.batch, "poolt_out_ei": r.edge_index})
 
     # ---- AsyncGraph / SlidingWindowGraph host logic (kernels from the oracle's C emulation)
     from oracle import graph as og

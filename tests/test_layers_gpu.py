@@ -128,3 +128,27 @@ def test_module_by_module_forward_equals_engine_and_oracle(over):
     if not over:
         out_o, _ = om.forward_events(sd, args, H, W, *ev, B, exact_pos_mean=True)
         assert _err(un(out_mod), un(out_o.cuda())) < TOL
+
+
+def test_keep_temporal_ordering_runs_module_by_module_and_matches_the_oracle():
+    """``--keep_temporal_ordering`` (pooling.py:69-72): a coarse edge survives only if the destination cluster's newest member
+    is strictly newer than the source cluster's.  The filter lives in the Pooling modules (the oracle's restatement of it is
+    pinned to the reference's code by tests/test_oracle_refpy.py); ``DAGR.forward`` of such a model evaluates module by
+    module instead of through the window engine, whose fused pooling does not filter."""
+    W, H, B = 320, 215, 2
+    args, model, sd = _model(W, H, B, seed=8, keep_temporal_ordering=True)
+    assert model.module_path_only and all(p.keep_temporal_ordering for p in
+                                           (model.backbone.pool1, model.backbone.pool2, model.backbone.pool3, model.backbone.pool4))
+    data, ev = _batch(W, H, B, 2500, seed=37)
+    with torch.no_grad():
+        out_mod = model.forward_modules(copy.copy(data), reset=True)
+        det, = model(copy.copy(data), return_targets=False)
+    grid, stride = model.engine().grid_cache, model.engine().stride_cache
+    un = lambda o: torch.cat([o[..., :2] / stride - grid, torch.log(o[..., 2:4] / stride), o[..., 4:]], -1)
+    out_o, _ = om.forward_events(sd, args, H, W, *ev, B, exact_pos_mean=True)
+    assert _err(un(out_mod), un(out_o.cuda())) < TOL
+    plain = copy.copy(args)
+    plain.keep_temporal_ordering = False
+    out_plain, _ = om.forward_events(sd, plain, H, W, *ev, B, exact_pos_mean=True)
+    assert float((out_plain - out_o).abs().max()) > 1e-3            # the filter changes the result
+    assert len(det) == B and all(set(d) >= {"boxes", "scores", "labels"} for d in det)

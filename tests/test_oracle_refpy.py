@@ -145,6 +145,18 @@ def test_pooling_forward_glue(k, aggr):
     assert ei.shape[1] > 500 and x.shape[0] > 50
 
 
+def test_pooling_forward_keep_temporal_ordering():
+    """pooling.py:69-72 (``--keep_temporal_ordering``) executed from the reference: only coarse edges towards clusters whose
+    newest member is strictly newer than the source cluster's survive."""
+    pp = oo.PoolingParams(T("poolt_size"), 320, 215, 2, cart_max=1.0, aggr="max")
+    x, pos, batch, ei, _ = oo.pooling(pp, T("poolt_x"), T("poolt_pos"), T("poolt_batch"), T("poolt_ei"),
+                                      keep_temporal_ordering=True)
+    assert torch.equal(x, T("poolt_out_x")) and torch.equal(pos, T("poolt_out_pos"))
+    assert torch.equal(batch, T("poolt_out_batch")) and torch.equal(ei, T("poolt_out_ei"))
+    plain = oo.pooling(pp, T("poolt_x"), T("poolt_pos"), T("poolt_batch"), T("poolt_ei"))[3]
+    assert 100 < ei.shape[1] < plain.shape[1]
+
+
 def test_sliding_window_graph_host_state_machine():
     """AsyncGraph / SlidingWindowGraph (graph/ev_graph.py:18-166) and graph/utils.py, run from the reference over five
     consecutive windows (400, 1, 350, 0, 300 events: batched insert, single-event insert, empty window) with
