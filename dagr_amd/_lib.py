@@ -121,9 +121,8 @@ SIGNATURES = {
                                                       c_void_p]),
     "dagr_async_graph_append": (ctypes.c_int, [ctypes.POINTER(GraphDesc), c_void_p, c_i64, c_i64, c_void_p, c_void_p,
                                                c_void_p, c_i64, c_void_p, c_i32, c_void_p, c_i32, c_i64, c_void_p, c_void_p,
-                                               c_void_p, c_void_p, c_void_p]),
-    "dagr_async_input_rows": (ctypes.c_int, [c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_void_p, c_void_p,
-                                             c_i32, c_i32, c_i32, c_void_p]),
+                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32,
+                                               c_i32, c_i32, c_void_p]),
     "dagr_pool_l0_stream": (ctypes.c_int, [ctypes.POINTER(PoolDesc), c_void_p, c_i32, ctypes.POINTER(GraphDesc), c_void_p,
                                            c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_void_p, c_i64, c_i64, c_i64,
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_void_p,

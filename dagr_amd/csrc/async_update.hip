@@ -59,7 +59,11 @@ __global__ __launch_bounds__(kChunk) void k_async_insert(const void *__restrict_
                                                         int n, int first_id, int n_static, int W, int H, int B,
                                                         float fW, float fH, float fT, int32_t *__restrict__ app_head,
                                                         int32_t *__restrict__ app_next, int4 *__restrict__ app_xytb,
-                                                        int32_t *__restrict__ status) {
+                                                        int32_t *__restrict__ status,
+                                                        // level-0 inputs of the new rows (row = event id), NULL = not wanted
+                                                        const float *__restrict__ feat, float *__restrict__ pos_n,
+                                                        int32_t *__restrict__ batch_n, int32_t *__restrict__ batch_ev,
+                                                        float *__restrict__ x0, int ldx0, int col_feat, int col_pos) {
     __shared__ int key[kChunk];
     const int i = threadIdx.x;
     int p = -1, x = 0, y = 0, t = 0, b = 0;
@@ -77,6 +81,18 @@ __global__ __launch_bounds__(kChunk) void k_async_insert(const void *__restrict_
         if (x < 0 || x >= W || y < 0 || y >= H || b < 0 || b >= B) atomicOr(&status[0], 1);   // outside the sensor: dropped
         else p = x + W * (y + H * b);
         app_xytb[first_id - n_static + i] = make_int4(x, y, t, b);
+        if (!kIntPos && x0) {        // cf. dagr_graph_gather_inputs: pos, sample index, [polarity | pos_xy] columns
+            const float *pos = static_cast<const float *>(pos_);
+            const size_t row = (size_t)first_id + i;
+            const float px = pos[3 * (size_t)i], py = pos[3 * (size_t)i + 1];
+            pos_n[3 * row] = px; pos_n[3 * row + 1] = py; pos_n[3 * row + 2] = pos[3 * (size_t)i + 2];
+            batch_n[row] = b;
+            batch_ev[row] = b;
+            float *xr = x0 + row * ldx0;
+            xr[col_feat] = feat[i];
+            xr[col_pos] = px;
+            xr[col_pos + 1] = py;
+        }
     }
     key[i] = p;
     __syncthreads();
@@ -174,24 +190,6 @@ __global__ __launch_bounds__(kBlock) void k_async_fill(int n, int first_id, int 
     if (l == 0) deg[own] = min(total, K);
 }
 
-// level-0 inputs of the new rows: pos, sample index and the [polarity | pos_xy] columns of the feature row
-template <typename BatchT>
-__global__ __launch_bounds__(kBlock) void k_async_rows(int n, int first_row, const float *__restrict__ pos,
-                                                      const float *__restrict__ feat, const BatchT *__restrict__ batch,
-                                                      float *__restrict__ pos_n, int32_t *__restrict__ batch_n,
-                                                      float *__restrict__ x0, int ldx0, int col_feat, int col_pos) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const size_t row = (size_t)first_row + i;
-    const float px = pos[3 * (size_t)i], py = pos[3 * (size_t)i + 1], pt = pos[3 * (size_t)i + 2];
-    pos_n[3 * row] = px; pos_n[3 * row + 1] = py; pos_n[3 * row + 2] = pt;
-    batch_n[row] = (int)batch[i];
-    float *xr = x0 + row * ldx0;
-    xr[col_feat] = feat[i];
-    xr[col_pos] = px;
-    xr[col_pos + 1] = py;
-}
-
 }  // namespace
 }  // namespace dagr
 
@@ -203,13 +201,19 @@ int dagr_async_graph_append(const dagr_graph_desc *desc, void *graph_ws, int64_t
                             int32_t *app_head, int32_t *app_next, int32_t *app_xytb, int64_t capacity,
                             const void *pos, int32_t pos_is_int32, const void *batch, int32_t batch_is_int64,
                             int64_t n_new, int32_t *nbr_src, int16_t *nbr_code, int32_t *deg, int32_t *status,
-                            void *stream_) {
+                            const float *feat, float *pos_nodes, int32_t *batch_nodes, int32_t *batch_events, float *x0,
+                            int32_t ldx0, int32_t col_feat, int32_t col_pos, void *stream_) {
     DAGR_CHECK_ARG(desc && graph_ws, "NULL desc / workspace");
     DAGR_CHECK_ARG(n_new >= 0 && n_static >= 0 && first_id >= n_static, "bad event ranges");
     if (n_new == 0) return DAGR_OK;
     DAGR_CHECK_ARG(first_id - n_static + n_new <= capacity, "the appended-event arrays are full");
     DAGR_CHECK_ARG(app_head && app_next && app_xytb && pos && batch && nbr_src && nbr_code && deg && status, "NULL pointer");
     DAGR_CHECK_ARG(desc->max_neighbors <= 16 && desc->radius <= 31, "max_neighbors <= 16 expected");
+    if (x0) {
+        DAGR_CHECK_ARG(!pos_is_int32 && feat && pos_nodes && batch_nodes && batch_events && ldx0 >= col_pos + 2 &&
+                           col_pos >= 0 && col_feat >= 0 && col_feat < ldx0 && col_feat != col_pos && col_feat != col_pos + 1,
+                       "level-0 input rows: normalised fp32 pos and all row arrays are needed");
+    }
     hipStream_t stream = (hipStream_t)stream_;
     const int32_t *start;
     const int2 *slot_it;
@@ -221,7 +225,8 @@ int dagr_async_graph_append(const dagr_graph_desc *desc, void *graph_ws, int64_t
 #define DAGR_INS(BT, IP)                                                                                               \
     k_async_insert<BT, IP><<<1, kChunk, 0, stream>>>(                                                                  \
         (const char *)pos + (size_t)c0 * 12, (const BT *)batch + c0, n, fid, (int)n_static, W, H, B, (float)W, (float)H, \
-        (float)desc->time_window, app_head, app_next, (int4 *)app_xytb, status)
+        (float)desc->time_window, app_head, app_next, (int4 *)app_xytb, status, feat ? feat + c0 : nullptr, pos_nodes,     \
+        batch_nodes, batch_events, x0, ldx0, col_feat, col_pos)
         if (batch_is_int64) { if (pos_is_int32) DAGR_INS(int64_t, true); else DAGR_INS(int64_t, false); }
         else                { if (pos_is_int32) DAGR_INS(int32_t, true); else DAGR_INS(int32_t, false); }
 #undef DAGR_INS
@@ -231,24 +236,6 @@ int dagr_async_graph_append(const dagr_graph_desc *desc, void *graph_ws, int64_t
     k_async_fill<<<(unsigned)ceil_div(n_new * 16, kBlock), kBlock, 0, stream>>>(
         (int)n_new, (int)first_id, (int)n_static, W, H, desc->max_neighbors, desc->queue_size, desc->radius,
         (float)desc->delta_t_us, start, slot_it, app_head, app_next, (const int4 *)app_xytb, nbr_src, nbr_code, deg);
-    DAGR_CHECK_LAUNCH();
-    return DAGR_OK;
-}
-
-int dagr_async_input_rows(int64_t n_new, int64_t first_row, const float *pos, const float *feat, const void *batch,
-                          int32_t batch_is_int64, float *pos_nodes, int32_t *batch_nodes, float *x0, int32_t ldx0,
-                          int32_t col_feat, int32_t col_pos, void *stream) {
-    DAGR_CHECK_ARG(n_new >= 0 && first_row >= 0, "bad sizes");
-    if (n_new == 0) return DAGR_OK;
-    DAGR_CHECK_ARG(pos && feat && batch && pos_nodes && batch_nodes && x0 && ldx0 >= col_pos + 2 && col_pos >= 0 &&
-                       col_feat >= 0 && col_feat < ldx0 && col_feat != col_pos && col_feat != col_pos + 1, "bad arguments");
-    const unsigned g = (unsigned)ceil_div(n_new, kBlock);
-    if (batch_is_int64)
-        k_async_rows<int64_t><<<g, kBlock, 0, (hipStream_t)stream>>>((int)n_new, (int)first_row, pos, feat, (const int64_t *)batch,
-                                                                     pos_nodes, batch_nodes, x0, ldx0, col_feat, col_pos);
-    else
-        k_async_rows<int32_t><<<g, kBlock, 0, (hipStream_t)stream>>>((int)n_new, (int)first_row, pos, feat, (const int32_t *)batch,
-                                                                     pos_nodes, batch_nodes, x0, ldx0, col_feat, col_pos);
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;
 }

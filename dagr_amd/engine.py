@@ -590,12 +590,10 @@ class WindowEngine:
             g = self.graph
             _lib.check(L.dagr_async_graph_append(ctypes.byref(g.desc), P(g.workspace), self._N, first, P(a["head"]),
                                                  P(a["next"]), P(a["xytb"]), a["next"].shape[0], P(pos), 0, P(batch), b64,
-                                                 n, P(self.nbr_src), P(self.nbr_code), P(self.deg), P(a["status"]), stream),
+                                                 n, P(self.nbr_src), P(self.nbr_code), P(self.deg), P(a["status"]), P(feat),
+                                                 P(self.pos_n), P(self.batch_n), P(a["batch_ev"]), P(self.x0buf),
+                                                 self.x0_ld, self.x0_feat_col, self.x0_pos_col, stream),
                        "async_graph_append")
-            _lib.check(L.dagr_async_input_rows(n, first, P(pos), P(feat), P(batch), b64, P(self.pos_n), P(self.batch_n),
-                                               P(self.x0buf), self.x0_ld, self.x0_feat_col, self.x0_pos_col, stream),
-                       "async_input_rows")
-            a["batch_ev"][first:first + n] = batch.to(torch.int32)
             rows = slice(first, first + n)
             if self.use_image:
                 self._sample(None, n, self.pos_n[rows], self.batch_n[rows], 0, self._img_feats[0], self.x0buf[rows],

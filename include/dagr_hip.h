@@ -305,11 +305,11 @@ int dagr_async_graph_append(const dagr_graph_desc *desc, void *graph_ws, int64_t
                             const void *pos /* fp32 normalised or int32 [n,3] */, int32_t pos_is_int32,
                             const void *batch, int32_t batch_is_int64, int64_t n_new,
                             int32_t *nbr_src, int16_t *nbr_code, int32_t *deg /* the level's full arrays */,
-                            int32_t *status, void *stream);
-/* node-ordered level-0 inputs of the new rows (cf. dagr_graph_gather_inputs): rows [first_row, first_row + n_new) */
-int dagr_async_input_rows(int64_t n_new, int64_t first_row, const float *pos, const float *feat, const void *batch,
-                          int32_t batch_is_int64, float *pos_nodes, int32_t *batch_nodes, float *x0, int32_t ldx0,
-                          int32_t col_feat, int32_t col_pos, void *stream);
+                            int32_t *status,
+                            /* optional (x0 != NULL, fp32 pos): the node-ordered level-0 inputs of the new rows, as
+                             * dagr_graph_gather_inputs writes them for a window, and the sample index by event id */
+                            const float *feat, float *pos_nodes, int32_t *batch_nodes, int32_t *batch_events, float *x0,
+                            int32_t ldx0, int32_t col_feat, int32_t col_pos, void *stream);
 /* pool1 with RESIDENT accumulators (its own workspace, dagr_pool_workspace_bytes): rebuild != 0 recomputes them from the
  * window (nodes [0, n_window) through the builder's pixel index); rows [first_row, first_row + n_rows) -- appended
  * nodes, first_row >= n_window -- are added; then level 1 is emitted exactly as dagr_pool_l0 emits it, and the
