@@ -129,6 +129,7 @@ SIGNATURES = {
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_void_p]),
     "dagr_debug_calibrate": (ctypes.c_int, [c_i32, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p]),
     "dagr_spline_conv_fused_lds_bytes": (c_size_t, [c_i32, c_i32]),
+    "dagr_spline_conv_fused_passes": (c_i32, [c_i32, c_i32]),
     "dagr_spline_conv_fused": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32,
                                               c_void_p, c_i32, c_i32, c_i32, c_i32, c_float, c_float, c_void_p,
                                               c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p]),

@@ -13,7 +13,13 @@
 // dwords so that a lane's MFMA operand (i = lane&15, k = lane>>4) is a conflict-free read; the next
 // 32-wide K stage is prefetched into registers while the current one is multiplied.  M is bounded by a
 // device-side count: no host sync.  Summation order is fixed: results are run-to-run identical.
+#include <algorithm>
+
 #include "common.hpp"
+
+#ifndef DAGR_TRACE          // tools/microbench/conv_trace.hip defines it to time the stages of k_conv_fused
+#define DAGR_TRACE(i)
+#endif
 
 namespace dagr {
 namespace {
@@ -189,11 +195,13 @@ __global__ __launch_bounds__(kGemmThreads) void k_conv_fused(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: loop bounds below stay in SGPRs
     constexpr int U = 4;
+    DAGR_TRACE(0);
     // rowptr has n_max + 1 entries: read it before the device-side bound is known (one latency, not two)
     const int n_spec = min(m0 + wv, n_max - 1);
     const int e0 = rowptr[n_spec], e1s = rowptr[n_spec + 1];
     const int M = n_ptr ? min(*n_ptr, n_max) : n_max;
     if (m0 >= M) return;
+    DAGR_TRACE(1);
     // ---- phase A: wave wv aggregates node m0 + wv (edge order and arithmetic of k_tap_aggregate)
     {
         const int n = m0 + wv;
@@ -214,6 +222,7 @@ __global__ __launch_bounds__(kGemmThreads) void k_conv_fused(
                     my_src = col[e0 + base + lane];
                     my_cd = code[e0 + base + lane];
                 }
+                DAGR_TRACE(2);
                 for (int c0 = 0; c0 < cin; c0 += 64) {
                     const int ch = c0 + lane;
                     const bool ch_ok = ch < cin;
@@ -268,7 +277,9 @@ __global__ __launch_bounds__(kGemmThreads) void k_conv_fused(
             }
         }
     }
+    DAGR_TRACE(3);
     __syncthreads();
+    DAGR_TRACE(4);
     // ---- phase B: [16 x K] . [K x N].  Wave (ks, w): K quarter ks, 16-column tile w of a 64-column block.
     // No weight staging: every weight element is used by exactly one wave of the block, so the B operands
     // come straight from L2 in the host-packed MFMA operand order Wq[col tile][k group of 16][lane][4]
@@ -342,6 +353,7 @@ __global__ __launch_bounds__(kGemmThreads) void k_conv_fused(
             }
         }
         const f32x4 acc = {acc0[0] + acc1[0], acc0[1] + acc1[1], acc0[2] + acc1[2], acc0[3] + acc1[3]};
+        DAGR_TRACE(5);
         float *rd = red + ks * 16 * NBc;
 #pragma unroll
         for (int q = 0; q < 4; q++) rd[(kk * 4 + q) * NBc + w * 16 + nn] = acc[q];
@@ -358,7 +370,304 @@ __global__ __launch_bounds__(kGemmThreads) void k_conv_fused(
             }
         }
         __syncthreads();
+        DAGR_TRACE(6);
     }
+}
+
+// Tap range of a pass: K is cut at tap boundaries into P = ceil(25 / tp) passes of tp taps (tp * cin a multiple of 16,
+// so that a pass starts on a weight group); the pass that holds tap 24 also holds the root and skip columns.  tp >= 25:
+// the whole row in one pass (every level of dagr-s / dagr-n).  Wider rows (26 * cin + cskip > ~2270 floats: dagr-m's
+// levels, every head conv) used to go through HBM as a [T, K] matrix and a second launch.
+__global__ __launch_bounds__(kGemmThreads) void k_conv_fused_mp(
+    const int32_t *__restrict__ n_ptr, int n_max, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const int32_t *__restrict__ code, const float *__restrict__ x, int ldx, int cin, const float *__restrict__ xskip,
+    int ldskip, int cskip, int rx, int ry, float den_x, float den_y, const float *__restrict__ Wq,
+    const float *__restrict__ bias, float *__restrict__ C, int ldc, int N, int relu, int KP, int NC, int tp) {
+    extern __shared__ __align__(16) float fl[];
+    const int K = 26 * cin + cskip;
+    float *At = fl;                                  // [16][KP]: the pass's columns, zero behind them
+    float *red = fl + 16 * KP;                       // [KSPLIT][16][NB] split-K partials
+    const int m0 = blockIdx.x * 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: loop bounds below stay in SGPRs
+    constexpr int U = 4;
+    // rowptr has n_max + 1 entries: read it before the device-side bound is known (one latency, not two)
+    const int n_spec = min(m0 + wv, n_max - 1);
+    const int e0 = rowptr[n_spec], e1s = rowptr[n_spec + 1];
+    const int M = n_ptr ? min(*n_ptr, n_max) : n_max;
+    // Phase-B roles are fixed by the thread id, so the first weight batch of this wave and the bias of this thread's
+    // output column are requested now: they arrive while phase A runs (a small level is one latency chain per launch,
+    // and this takes the weight round trip and the bias round trip off it).
+    // NC = column tiles per workgroup: 4 (K split 4 ways) or, for levels with too few nodes to fill the chip, fewer
+    // (more workgroups per 16 nodes, K split 16 / NC ways).  loop_cols: one workgroup per 16 nodes walks all 64-column
+    // blocks over the same tile (single pass only); else blockIdx.y picks the block.
+    const int ksplit = 16 / NC, NBc = 16 * NC;
+    const int ks = wv / NC, w = wv % NC;
+    const int kk = lane >> 4, nn = lane & 15;
+    const int G = (K + 15) / 16;
+    const int P = (25 + tp - 1) / tp;
+    const int n_first = (int)blockIdx.y * NBc;
+    const int n_last = min(N, n_first + NBc);
+    // groups [g_lo, g_hi) of pass p, this wave's share [gbeg, gend) of them
+    auto pass_groups = [&](int p, int &g_lo, int &gbeg, int &gend) {
+        g_lo = (p * tp * cin) >> 4;
+        const int g_hi = (p == P - 1) ? G : ((p + 1) * tp * cin) >> 4;
+        const int Gq = (g_hi - g_lo + ksplit - 1) / ksplit;
+        gbeg = g_lo + ks * Gq;
+        gend = min(g_hi, gbeg + Gq);
+    };
+    float4 b0[U], b1[U];
+    {
+        int g_lo, gbeg, gend;
+        pass_groups(0, g_lo, gbeg, gend);
+        const float4 *wq = reinterpret_cast<const float4 *>(Wq) + ((size_t)(n_first / 16 + w) * G) * 64 + lane;
+        if (n_first + w * 16 < N && gend - gbeg >= U) {
+#pragma unroll
+            for (int u = 0; u < U; u++) b0[u] = wq[(size_t)(gbeg + u) * 64];
+        }
+    }
+    float bias_first = 0.0f;
+    if (bias && tid < 16 * NBc && n_first + tid % NBc < N) bias_first = bias[n_first + tid % NBc];
+    if (m0 >= M) return;
+    const int n = m0 + wv;
+    float *row = At + wv * KP;
+    const bool active = n < M;                       // wave-uniform
+    const int ne = active ? e1s - e0 : 0;
+    // every global load of the prologue is in flight before the first one is waited for: the first 64 edges, the
+    // node's own row and its skip row (<= 2 registers each; longer rows loop)
+    int first_src = 0, first_cd = 0;
+    if (lane < min(64, ne)) {
+        first_src = col[e0 + lane];
+        first_cd = code[e0 + lane];
+    }
+    float rv[2] = {0.0f, 0.0f}, sv[2] = {0.0f, 0.0f};
+    if (active) {
+        const float *xn = x + (size_t)n * ldx;
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+            if (lane + 64 * r < cin) rv[r] = xn[lane + 64 * r];
+        if (cskip > 0) {
+            const float *sn = xskip + (size_t)n * ldskip;
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+                if (lane + 64 * r < cskip) sv[r] = sn[lane + 64 * r];
+        }
+    }
+    // ---- phase A of pass p: wave wv aggregates the pass's taps of node m0 + wv (edge order and arithmetic of
+    // k_tap_aggregate) into its row of the tile
+    auto phase_a = [&](int p) {
+        const int k_lo = p * tp * cin;                                  // first column of the pass
+        const int k_taps = (min(25, (p + 1) * tp) - p * tp) * cin;       // its tap columns
+        for (int i = lane; i < KP; i += 64) row[i] = 0.0f;
+        if (!active) return;
+        if (p == P - 1) {
+            float *rt = row + (25 * cin - k_lo);
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                if (lane + 64 * r < cin) rt[lane + 64 * r] = rv[r];
+                if (lane + 64 * r < cskip) rt[cin + lane + 64 * r] = sv[r];
+            }
+            const float *xn = x + (size_t)n * ldx;
+            for (int i = lane + 128; i < cin; i += 64) rt[i] = xn[i];
+            if (cskip > 128) {
+                const float *sn = xskip + (size_t)n * ldskip;
+                for (int i = lane + 128; i < cskip; i += 64) rt[cin + i] = sn[i];
+            }
+        }
+        for (int base = 0; base < ne; base += 64) {
+            const int cnt = min(64, ne - base);
+            int my_src = first_src, my_cd = first_cd;
+            if (base > 0) {
+                my_src = 0; my_cd = 0;
+                if (lane < cnt) {
+                    my_src = col[e0 + base + lane];
+                    my_cd = code[e0 + base + lane];
+                }
+            }
+                    // The spline basis of an edge is the same for all channels: lane e evaluates edge e once (4 tap columns,
+            // packed 2 x 16 bits, and 4 weights -- same expressions as k_tap_aggregate), the channel lanes below
+            // pick them up with readlane.  Evaluating it per edge on all 64 lanes was most of this phase's issue time.
+            int o01, o23;
+            float w00, w10, w01, w11;
+            {
+                const AxisF ax = spline_axis_f(my_cd & 0xffff, rx, den_x);
+                const AxisF ay = spline_axis_f(my_cd >> 16, ry, den_y);
+                w00 = ax.b0 * ay.b0; w10 = ax.b1 * ay.b0; w01 = ax.b0 * ay.b1; w11 = ax.b1 * ay.b1;
+                o01 = ((ax.k0 + 5 * ay.k0) * cin) | (((ax.k1 + 5 * ay.k0) * cin) << 16);
+                o23 = ((ax.k0 + 5 * ay.k1) * cin) | (((ax.k1 + 5 * ay.k1) * cin) << 16);
+            }
+            for (int c0 = 0; c0 < cin; c0 += 64) {
+                const int ch = c0 + lane;
+                const bool ch_ok = ch < cin;
+                // A remainder of a few channels beyond this chunk (every pooled level carries C + 2 = 66 / 130 inputs:
+                // the features and pos_xy) rides along on the first lanes instead of costing a second walk over the
+                // edges with two active lanes -- same per-channel arithmetic and order, half the dependent chain.
+                const int rem = cin - (c0 + 64);
+                const bool ride = rem > 0 && rem <= 8;       // wave-uniform
+                const int ch2 = c0 + 64 + lane;
+                const bool ch2_ok = ride && lane < rem;
+                constexpr int UA = 8;
+                for (int j = 0; j < cnt; j += UA) {
+                    float v[UA], v2[UA];
+#pragma unroll
+                    for (int u = 0; u < UA; u++) {   // UA gathers in flight
+                        const int jj = min(j + u, cnt - 1);
+                        const int src = __builtin_amdgcn_readlane(my_src, jj);
+                        v[u] = ch_ok ? x[(size_t)src * ldx + ch] : 0.0f;
+                        v2[u] = ch2_ok ? x[(size_t)src * ldx + ch2] : 0.0f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < UA; u++) {
+                        if (j + u < cnt) {                   // wave-uniform
+                            const int p01 = __builtin_amdgcn_readlane(o01, j + u);
+                            const int p23 = __builtin_amdgcn_readlane(o23, j + u);
+                            const float bq[4] = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(w00), j + u)),
+                                                 __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w10), j + u)),
+                                                 __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w01), j + u)),
+                                                 __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w11), j + u))};
+                            // columns of the four taps inside this pass's tile; a tap of another pass is skipped (scalar)
+                            const int tq[4] = {(p01 & 0xffff) - k_lo, (p01 >> 16) - k_lo, (p23 & 0xffff) - k_lo,
+                                               (p23 >> 16) - k_lo};
+                            // the four taps of one edge are distinct (k0 != k1 on both axes): read all, then write
+                            float o[4], q[4];
+#pragma unroll
+                            for (int t = 0; t < 4; t++) {
+                                if ((unsigned)tq[t] < (unsigned)k_taps) {
+                                    if (ch_ok) o[t] = row[tq[t] + ch];
+                                    if (ch2_ok) q[t] = row[tq[t] + ch + 64];
+                                }
+                            }
+#pragma unroll
+                            for (int t = 0; t < 4; t++) {
+                                if ((unsigned)tq[t] < (unsigned)k_taps) {
+                                    if (ch_ok) row[tq[t] + ch] = o[t] + bq[t] * v[u];
+                                    if (ch2_ok) row[tq[t] + ch + 64] = q[t] + bq[t] * v2[u];
+                                }
+                            }
+                        }
+                    }
+                }
+                if (ride) break;
+            }
+        }
+    };
+    // ---- phase B: [16 x K] . [K x N].  Wave (ks, w): K share ks, 16-column tile w of the column block.
+    // No weight staging: every weight element is used by exactly one wave of the block, so the B operands
+    // come straight from L2 in the host-packed MFMA operand order Wq[col tile][k group of 16][lane][4]
+    // (element j of lane l = W[16 g + 4 j + (l >> 4)][16 c + (l & 15)]): one 1-KiB fully coalesced wave
+    // load feeds 4 MFMAs, U of them are in flight per wave, and the loop has no barrier.
+    phase_a(0);
+    __syncthreads();
+    for (int n0 = n_first; n0 < n_last; n0 += NBc) {
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        // the pass's share of the contraction for column block n0
+        auto contract = [&](int p, bool first_batch_loaded) {
+            if (n0 + w * 16 >= N) return;
+            int g_lo, gbeg, gend;
+            pass_groups(p, g_lo, gbeg, gend);
+            const int nfull = max(0, gend - gbeg) / U;              // wave-uniform (wv is scalar)
+            const float *a_rd = At + nn * KP + kk - 16 * g_lo;
+            const float4 *wq = reinterpret_cast<const float4 *>(Wq) + ((size_t)(n0 / 16 + w) * G) * 64 + lane;
+            auto load_b = [&](float4(&dst)[U], int g0) {
+#pragma unroll
+                for (int u = 0; u < U; u++) dst[u] = wq[(size_t)(g0 + u) * 64];
+            };
+            // U groups = 16 k-steps: all A operands are read from the tile first, then the MFMAs run back to back
+            auto mac = [&](const float4(&b)[U], int g0) {
+                float a[U][4];
+                const float *ap = a_rd + 16 * g0;
+#pragma unroll
+                for (int u = 0; u < U; u++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) a[u][j] = ap[16 * u + 4 * j];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][0], b[u].x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][1], b[u].y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][2], b[u].z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][3], b[u].w, acc1, 0, 0, 0);
+                }
+            };
+            int g = gbeg;
+            if (nfull > 0 && !first_batch_loaded) load_b(b0, g);   // the very first batch was requested at kernel entry
+            for (int it = 0; it < nfull; it += 2) {     // ping-pong: no register copies between batches
+                if (it + 1 < nfull) load_b(b1, g + U);
+                mac(b0, g);
+                if (it + 1 < nfull) {
+                    if (it + 2 < nfull) load_b(b0, g + 2 * U);
+                    mac(b1, g + U);
+                }
+                g += 2 * U;
+            }
+            {   // < U left-over groups: all of their operands are requested before the first is used (on the small
+                // levels K / 16 splits into 7 groups per wave: one full batch + 3 left-overs, which used to be three
+                // dependent load -> MFMA round trips)
+                const int g0 = gbeg + nfull * U, rem = gend - g0;
+                float4 bt[U - 1];
+#pragma unroll
+                for (int r = 0; r < U - 1; r++)
+                    bt[r] = r < rem ? wq[(size_t)(g0 + r) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int r = 0; r < U - 1; r++) {
+                    if (r < rem) {
+                        const float *ap = a_rd + 16 * (g0 + r);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[0], bt[r].x, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4], bt[r].y, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[8], bt[r].z, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[12], bt[r].w, acc1, 0, 0, 0);
+                    }
+                }
+            }
+        };
+        contract(0, n0 == n_first);
+        for (int p = 1; p < P; p++) {           // (one column block per workgroup: the tile is rebuilt per pass)
+            __syncthreads();
+            phase_a(p);
+            __syncthreads();
+            contract(p, false);
+        }
+        const f32x4 acc = {acc0[0] + acc1[0], acc0[1] + acc1[1], acc0[2] + acc1[2], acc0[3] + acc1[3]};
+            float *rd = red + ks * 16 * NBc;
+#pragma unroll
+        for (int q = 0; q < 4; q++) rd[(kk * 4 + q) * NBc + w * 16 + nn] = acc[q];
+        __syncthreads();
+        if (tid < 16 * NBc) {
+            const int idx = tid;
+            const int orow = m0 + idx / NBc, ocol = n0 + idx % NBc;
+            if (orow < M && ocol < N) {
+                float v = red[idx];
+                for (int s = 1; s < ksplit; s++) v += red[s * 16 * NBc + idx];   // fixed order
+                v += (n0 == n_first) ? bias_first : (bias ? bias[ocol] : 0.f);
+                if (relu) v = fmaxf(v, 0.f);
+                C[(size_t)orow * ldc + ocol] = v;
+            }
+        }
+        __syncthreads();
+        }
+}
+
+// Pass scheme of a fused conv: taps per pass and the tile's row stride; false when even one tap does not fit.
+bool fused_plan(int cin, int cskip, int *tp_out, int *kp_out) {
+    auto kp_of = [](int k) { return (k + 1 + 31) / 32 * 32 + 2; };   // >= k + 3 and = 2 (mod 32): bank = 2*row + k, conflict-free per half-wave
+    const size_t red_bytes = (size_t)KSPLIT * 16 * NB * 4;
+    auto fits = [&](int k) { return (size_t)16 * kp_of(k) * 4 + red_bytes <= 160 * 1024; };
+    const int K = 26 * cin + cskip;
+    if (fits(K)) { *tp_out = 25; *kp_out = kp_of(K); return true; }
+    int gcd = 16;
+    while (cin % gcd) gcd >>= 1;
+    const int m = 16 / gcd;                     // tp * cin is a multiple of 16
+    // fewest passes; among those the smallest tile
+    for (int P = 2; P <= 25; P++) {
+        int best_tp = 0, best_k = 0;
+        for (int tp = m; tp < 25; tp += m) {
+            if ((25 + tp - 1) / tp != P) continue;
+            const int last = 25 - (P - 1) * tp;
+            const int k = std::max(tp * cin, last * cin + cin + cskip);
+            if (fits(k) && (best_tp == 0 || k < best_k)) { best_tp = tp; best_k = k; }
+        }
+        if (best_tp) { *tp_out = best_tp; *kp_out = kp_of(best_k); return true; }
+    }
+    return false;
 }
 
 }  // namespace
@@ -375,32 +684,62 @@ extern "C" int dagr_spline_conv_fused(const int32_t *n_nodes_ptr, int32_t n_node
     DAGR_CHECK_ARG(rowptr && col && code && x && Wq && C, "NULL pointer");
     DAGR_CHECK_ARG(cskip == 0 || xskip, "xskip is NULL");
     DAGR_CHECK_ARG(((uintptr_t)Wq % 16) == 0, "packed weights must be 16-byte aligned");
-    const int K = 26 * cin + cskip;
-    const int KP = (K + 1 + 31) / 32 * 32 + 2;    // >= K + 3 and = 2 (mod 32): bank = 2*row + k, conflict-free per half-wave
-    const size_t lds_bytes = ((size_t)16 * KP + (size_t)KSPLIT * 16 * NB) * 4;
-    if (lds_bytes > 160 * 1024) {
-        set_error("dagr_spline_conv_fused: K too large for the LDS tile (use tap_aggregate + gemm)");
+    int tp = 25, KP = 0;
+    if (!fused_plan(cin, cskip, &tp, &KP)) {
+        set_error("dagr_spline_conv_fused: one tap of the input row does not fit the LDS tile (use tap_aggregate + gemm)");
         return DAGR_ERR_UNSUPPORTED;
     }
-    static thread_local size_t set_max = 0;
-    if (lds_bytes > set_max) {
-        DAGR_CHECK_HIP(hipFuncSetAttribute((const void *)k_conv_fused, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds_bytes));
-        set_max = lds_bytes;
+    const size_t lds_bytes = ((size_t)16 * KP + (size_t)KSPLIT * 16 * NB) * 4;
+    const bool mp = tp < 25;
+    static thread_local size_t set_max[2] = {0, 0};
+    if (lds_bytes > set_max[mp]) {
+        DAGR_CHECK_HIP(hipFuncSetAttribute(mp ? (const void *)k_conv_fused_mp : (const void *)k_conv_fused,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        set_max[mp] = lds_bytes;
     }
+    // Column tiles per workgroup (4, 2 or 1): the tile leaves room for one workgroup per CU, so the launch runs in
+    // ceil(workgroups / CUs) rounds.  A round costs the edge walk + prologue (~5 us, repeated by every workgroup of a
+    // node tile) plus ~1.5 us per column tile (measured, tools/microbench/conv_trace.hip); few nodes -> spread the
+    // columns over workgroups, but never into an extra round: 71 node tiles x 4 column workgroups ran 284 workgroups
+    // on 256 CUs, 18.5 us where 141 node tiles took 16.9.
     const int row_blocks = ceil_div(n_nodes_max, 16);
-    const int nc = (row_blocks * 2 <= device_cu_count()) ? 1 : 4;   // few nodes: spread the columns over workgroups
-    const dim3 grid((unsigned)row_blocks, nc == 1 ? (unsigned)ceil_div(N, 16) : 1u);
-    k_conv_fused<<<grid, kGemmThreads, lds_bytes, (hipStream_t)stream>>>(
-        n_nodes_ptr, n_nodes_max, rowptr, col, code, x, ldx, cin, xskip, ldskip, cskip, rx, ry, den_x, den_y, Wq, bias, C,
-        ldc, N, relu, KP, nc);
+    const int passes = tp >= 25 ? 1 : (25 + tp - 1) / tp;
+    int nc = 4, loop_cols = passes == 1 ? 1 : 0;
+    float best = 0.0f;
+    for (int c = 4; c >= 1; c >>= 1) {
+        // single pass, 4 tiles: one workgroup per node tile walks all 64-column blocks over its tile; else gridDim.y
+        // workgroups of c tiles each
+        const int loop = (c == 4 && passes == 1) ? 1 : 0;
+        const int wgs = loop ? row_blocks : row_blocks * (int)ceil_div(N, 16 * c);
+        const float tiles = loop ? 4.0f * (float)ceil_div(N, 64) : (float)c;
+        // n_nodes_max is a capacity: a level's table has one sample plane more than the batch fills (QUIRK-1), and
+        // workgroups past the device-side count leave at once -- count 9 in 10 as live
+        const float cost = (float)ceil_div((int64_t)wgs * 9 / 10, device_cu_count()) * (5.0f * (float)passes + 1.5f * tiles);
+        if (best == 0.0f || cost < best) { best = cost; nc = c; loop_cols = loop; }
+    }
+    const dim3 grid((unsigned)row_blocks, loop_cols ? 1u : (unsigned)ceil_div(N, 16 * nc));
+    if (mp)
+        k_conv_fused_mp<<<grid, kGemmThreads, lds_bytes, (hipStream_t)stream>>>(
+            n_nodes_ptr, n_nodes_max, rowptr, col, code, x, ldx, cin, xskip, ldskip, cskip, rx, ry, den_x, den_y, Wq, bias,
+            C, ldc, N, relu, KP, nc, tp);
+    else
+        k_conv_fused<<<grid, kGemmThreads, lds_bytes, (hipStream_t)stream>>>(
+            n_nodes_ptr, n_nodes_max, rowptr, col, code, x, ldx, cin, xskip, ldskip, cskip, rx, ry, den_x, den_y, Wq, bias,
+            C, ldc, N, relu, KP, nc);
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;
 }
 
 extern "C" size_t dagr_spline_conv_fused_lds_bytes(int32_t cin, int32_t cskip) {
     using namespace dagr;
-    const int K = 26 * cin + cskip;
-    const int KP = (K + 1 + 31) / 32 * 32 + 2;
+    int tp = 25, KP = 0;
+    if (!fused_plan(cin, cskip, &tp, &KP)) return (size_t)1 << 30;     // no pass scheme: callers compare against 160 KiB
     return ((size_t)16 * KP + (size_t)KSPLIT * 16 * NB) * 4;
+}
+
+extern "C" int32_t dagr_spline_conv_fused_passes(int32_t cin, int32_t cskip) {
+    using namespace dagr;
+    int tp = 25, KP = 0;
+    if (cin < 1 || cskip < 0 || !fused_plan(cin, cskip, &tp, &KP)) return 0;
+    return tp >= 25 ? 1 : (25 + tp - 1) / tp;
 }

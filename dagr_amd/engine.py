@@ -445,6 +445,7 @@ class WindowEngine:
                 winner=torch.full((self.B * Hc * Wc,), -1, dtype=torch.int32, device=dev),   # armed: dagr_to_dense_armed
                 dense=torch.zeros((self.B, 5 + self.num_classes, Hc, Wc), dtype=torch.float32, device=dev)))
         self.status = torch.zeros((4,), dtype=torch.int32, device=dev)
+        self.fused_passes_max_nodes = int(os.environ.get("DAGR_FUSED_PASSES_MAX_NODES", "1600"))
         # a head whose table domain is not its input level's (num_scales = 1: head "1" on out4 with the pool3
         # table) gets its own LUT coordinates (dagr_pool_recode)
         self.head_code = []
@@ -624,8 +625,10 @@ class WindowEngine:
                                                 dom["den_y"], P(pack.Wt), P(pack.bias), out, ldo, pack.N,
                                                 1 if pack.relu else 0, stream), "spline_conv_tiles")
             return
-        if self.fuse_convs and L.dagr_spline_conv_fused_lds_bytes(pack.cin, pack.cskip) <= 160 * 1024:
-            # tap aggregation + contraction in one launch (A tile lives in LDS)
+        passes = L.dagr_spline_conv_fused_passes(pack.cin, pack.cskip)
+        if self.fuse_convs and (passes == 1 or (passes > 1 and lvl.T <= self.fused_passes_max_nodes)):
+            # tap aggregation + contraction in one launch (A tile lives in LDS; rows wider than the tile in passes over
+            # the edges, which pays on small levels only: tools/microbench/head_ab.hip)
             _lib.check(L.dagr_spline_conv_fused(P(lvl.counts), lvl.T, P(lvl.rowptr), P(lvl.col), P(code), x, ldx,
                                                 pack.cin, xskip, ldskip, pack.cskip, dom["rx"], dom["ry"], dom["den_x"],
                                                 dom["den_y"], P(pack.Wq), P(pack.bias), out, ldo, pack.N,

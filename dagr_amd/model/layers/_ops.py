@@ -66,7 +66,8 @@ def spline_conv(conv, x, rowptr, col, code, norm=None, skip=None, xskip=None, re
     dom = conv.lut_domain
     stream = _lib.cur_stream(dev)
     xs, lds = (None, 0) if xskip is None else (xskip.float().contiguous(), xskip.shape[1])
-    if L.dagr_spline_conv_fused_lds_bytes(pack.cin, pack.cskip) <= 160 * 1024:
+    passes = L.dagr_spline_conv_fused_passes(pack.cin, pack.cskip)
+    if passes == 1 or (passes > 1 and n <= 1600):       # wide rows in passes: small graphs only (include/dagr_hip.h)
         _lib.check(L.dagr_spline_conv_fused(P(counts), n, P(rowptr), P(col), P(code), P(x), x.shape[1], pack.cin, P(xs),
                                             lds, pack.cskip, dom["rx"], dom["ry"], dom["den_x"], dom["den_y"], P(pack.Wq),
                                             P(pack.bias), P(out), pack.N, pack.N, 1 if relu else 0, stream),

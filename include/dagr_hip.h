@@ -221,12 +221,18 @@ int dagr_spline_tap_scatter_grad(const int32_t *n_nodes_ptr, int32_t n_nodes_max
                                  const int32_t *col, const int32_t *code, const float *grad_A, int32_t lda, int32_t cin,
                                  int32_t rx, int32_t ry, float den_x, float den_y, const float *grad_A_absmax,
                                  int64_t *acc, float *grad_x, int32_t ldg, void *stream);
-/* fused steps 1+2 for K = 26*cin + cskip small enough to keep 16 aggregated rows in LDS
- * (dagr_spline_conv_fused_lds_bytes(cin, cskip) <= 160 KiB): no A matrix in HBM, one launch.
+/* fused steps 1+2: 16 aggregated rows live in LDS, no A matrix in HBM, one launch.  K = 26*cin + cskip beyond the tile
+ * (~2270 floats) is cut at tap boundaries into passes over the same edges, the accumulators staying in registers;
+ * dagr_spline_conv_fused_lds_bytes(cin, cskip) = the tile of the scheme chosen, > 160 KiB when a single tap
+ * (cin floats, + cin + cskip in the last pass) does not fit.
  * Wq = the [K, N] matrix of dagr_gemm_bias_act re-packed on the host into MFMA operand order:
  *   Wq[c][g][l][j] = W[16 g + 4 j + (l >> 4)][16 c + (l & 15)],  c < ceil(N/16), g < ceil(K/16), l < 64, j < 4,
  * zero outside [K, N]; 16-byte aligned. */
 size_t dagr_spline_conv_fused_lds_bytes(int32_t cin, int32_t cskip);
+/* passes of the scheme (1 = the whole row in the tile; 0 = unsupported).  Every pass walks the edges again: measured on
+ * MI355X the multi-pass form beats tap_aggregate + gemm up to ~1.5 k node slots (one launch instead of two, no A
+ * matrix) and loses beyond (tools/microbench/head_ab.hip). */
+int32_t dagr_spline_conv_fused_passes(int32_t cin, int32_t cskip);
 int dagr_spline_conv_fused(const int32_t *n_nodes_ptr, int32_t n_nodes_max, const int32_t *rowptr,
                            const int32_t *col, const int32_t *code, const float *x, int32_t ldx, int32_t cin,
                            const float *xskip, int32_t ldskip, int32_t cskip, int32_t rx, int32_t ry,

@@ -51,14 +51,16 @@ def test_spiral_helper_matches_oracle():
 def test_argument_validation_of_the_conv_and_elementwise_entry_points():
     """These calls are rejected on the host before any device work, so they run without a GPU."""
     L = _lib.lib()
-    # fused pooled-level conv: the 16-node LDS tile bounds K = 26*cin + cskip
+    # fused pooled-level conv: the 16-node LDS tile holds K = 26*cin + cskip, or -- cut at tap boundaries -- one pass of it
     assert 0 < L.dagr_spline_conv_fused_lds_bytes(64, 64) <= 160 * 1024
     assert 0 < L.dagr_spline_conv_fused_lds_bytes(82, 0) <= 160 * 1024
-    assert L.dagr_spline_conv_fused_lds_bytes(130, 0) > 160 * 1024
+    assert 0 < L.dagr_spline_conv_fused_lds_bytes(130, 0) <= 160 * 1024       # two passes
+    assert 0 < L.dagr_spline_conv_fused_lds_bytes(256, 0) <= 160 * 1024       # four
+    assert L.dagr_spline_conv_fused_lds_bytes(2400, 0) > 160 * 1024           # a single tap is wider than the tile
     one = ctypes.c_void_p(16)     # non-NULL, 16-byte aligned, never dereferenced
-    rc = L.dagr_spline_conv_fused(None, 1, one, one, one, one, 130, 130, None, 0, 0, 7, 7, 14.0, 14.0, one, None, one,
+    rc = L.dagr_spline_conv_fused(None, 1, one, one, one, one, 2400, 2400, None, 0, 0, 7, 7, 14.0, 14.0, one, None, one,
                                   64, 64, 1, None)
-    assert rc != 0 and b"too large" in L.dagr_last_error()
+    assert rc != 0 and b"does not fit" in L.dagr_last_error()
     assert L.dagr_spline_conv_fused(None, 1, None, one, one, one, 64, 64, None, 0, 0, 7, 7, 14.0, 14.0, one, None, one,
                                     64, 64, 1, None) != 0
     assert b"NULL" in L.dagr_last_error()

@@ -1,7 +1,7 @@
 """Kernel-level parity of the pooled-level SplineConv entry points on random CSR graphs:
 dagr_spline_conv_fused and dagr_spline_tap_aggregate + dagr_gemm_bias_act against a float64 evaluation
 built on the oracle's torch_spline_conv basis (oracle/ops.py:spline_basis).  Tolerance 1e-4 relative to the
-output scale (fp32 accumulation over K <= 2200 terms)."""
+output scale (fp32 accumulation over K <= 6700 terms)."""
 import numpy as np
 import pytest
 import torch
@@ -46,6 +46,12 @@ CASES = [  # T, cin, cskip, N, max_deg, relu
     (5000, 82, 0, 64, 8, True),       # cin > 64 (two channel chunks), K = 2132
     (16, 3, 5, 7, 0, True),           # no edges at all
     (200, 64, 0, 200, 6, False),      # N > 128: four column blocks
+    # rows beyond the LDS tile: K cut at tap boundaries into passes (accumulators stay in registers across them)
+    (300, 128, 0, 256, 9, True),      # head conv pair of dagr-s (cls_conv | reg_conv): 2 passes of 13 / 12 + root
+    (1200, 130, 130, 64, 7, True),    # --use_image level >= 2: K = 3510, tap split must be a multiple of 8
+    (500, 98, 98, 64, 8, True),       # dagr-m level: K = 2646
+    (150, 256, 0, 7, 70, False),      # merged predictor of a 128-wide head: 4 passes, > 64 edges on a node
+    (64, 66, 2000, 64, 5, True),      # a skip row longer than 128 channels, root + skip alone in the last pass
 ]
 
 
@@ -115,13 +121,14 @@ def test_fused_and_unfused_match_float64(T, cin, cskip, N, max_deg, relu):
 def test_fused_rejects_oversized_k():
     from dagr_amd import _lib
     L = _lib.lib()
-    assert L.dagr_spline_conv_fused_lds_bytes(130, 0) > 160 * 1024
+    assert L.dagr_spline_conv_fused_lds_bytes(130, 0) <= 160 * 1024      # two passes
+    assert L.dagr_spline_conv_fused_lds_bytes(2400, 0) > 160 * 1024      # not even one tap fits the tile
     dev = torch.device("cuda:0")
     z = torch.zeros(64, dtype=torch.int32, device=dev)
     f = torch.zeros(4096, dtype=torch.float32, device=dev)
-    rc = L.dagr_spline_conv_fused(None, 1, _lib.ptr(z), _lib.ptr(z), _lib.ptr(z), _lib.ptr(f), 130, 130, None, 0, 0, 7, 7,
+    rc = L.dagr_spline_conv_fused(None, 1, _lib.ptr(z), _lib.ptr(z), _lib.ptr(z), _lib.ptr(f), 2400, 2400, None, 0, 0, 7, 7,
                                   14.0, 14.0, _lib.ptr(f), None, _lib.ptr(f), 64, 64, 1, _lib.cur_stream(dev))
-    assert rc != 0 and b"too large" in L.dagr_last_error()
+    assert rc != 0 and b"does not fit" in L.dagr_last_error()
 
 
 TILE_CASES = [  # T, cin, cskip, N, max_deg, relu
