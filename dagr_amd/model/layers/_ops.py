@@ -110,8 +110,14 @@ def conv_on_data(conv, data, norm=None, skip=None, xskip=None, relu=False):
         if not (norm is None and skip is None and not relu):
             raise RuntimeError("fused conv + BN epilogues are eval-mode only")
         d = conv.lut_domain
-        code, den_x, den_y = exact_codes(_in_csr_order(data.edge_attr, perm), data.edge_attr_max, d["width"], d["height"]) \
-            if col.shape[0] else (col, 1.0, 1.0)
+        # every conv on this graph sees the same codes (a level runs 2 convs on it, a head 3-6): cached with the CSR
+        key = (data.edge_attr.data_ptr(), col.data_ptr(), float(data.edge_attr_max), d["width"], d["height"])
+        cached = getattr(data, "_dagr_exact", None)
+        if cached is None or cached[0] != key:
+            cached = (key, exact_codes(_in_csr_order(data.edge_attr, perm), data.edge_attr_max, d["width"], d["height"])
+                      if col.shape[0] else (col, 1.0, 1.0))
+            data._dagr_exact = cached
+        code, den_x, den_y = cached[1]
         from .autograd import SplineConvFn
         return SplineConvFn.apply(data.x, conv.weight, conv.lin.weight, conv.bias, rowptr, col, code, EXACT_R, EXACT_R,
                                   den_x, den_y)

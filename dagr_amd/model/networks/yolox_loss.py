@@ -7,7 +7,8 @@ sites, ``dagr.py:238-282`` (``get_losses`` on the hybrid / image outputs), ``:29
 Pieces (all plain torch on <= 175 anchors per image -- host-side glue next to the HIP path, differentiable w.r.t. the maps):
   * ``output_and_grid``   : [B, 5+C, h, w] raw map -> [B, h*w, 5+C] with xy decoded ((xy + grid) * stride) and
                             wh = exp(wh) * stride, plus the cell grid
-  * ``simota_assign``     : SimOTA label assignment of one image (candidate anchors = centre inside a box OR inside the
+  * ``simota_assign``     : SimOTA label assignment of one image, ``simota_assign_batch`` the same for all images at
+                            once over the padded label rows (candidate anchors = centre inside a box OR inside the
                             2.5-stride square around its centre; cost = BCE(sqrt(cls*obj), one-hot) + 3 * -log(IoU) +
                             1e5 * [not in box AND centre]; dynamic k = clamp(sum of the 10 best IoUs, 1); conflicts go
                             to the cheapest ground truth)
@@ -99,39 +100,78 @@ def simota_assign(gt_boxes, gt_classes, boxes, cls_logits, obj_logits, centers, 
     return fg, matched_gt, matched_iou
 
 
+@torch.no_grad()
+def simota_assign_batch(labels, boxes, cls_logits, obj_logits, centers, strides, num_classes):
+    """``simota_assign`` for the whole batch at once over the padded label rows (labels [B, R, 5], a row is a ground truth
+    iff it sums to > 0): the same candidate sets, costs, ranks and conflict rule per image -- rows that are not ground
+    truths and anchors that are not candidates of their image are masked instead of cut out, so that nothing depends on
+    a per-image count and nothing synchronises with the host.  Returns (fg [B, A] bool, matched_gt [B, A] long row index
+    of the anchor's ground truth, matched_iou [B, A]); the last two are meaningful where fg."""
+    B, R, _ = labels.shape
+    A = boxes.shape[1]
+    dt = boxes.dtype
+    valid = labels.sum(dim=2) > 0                                                      # [B, R]
+    gt = labels[..., 1:5]
+    cx, cy = centers[:, 0].view(1, 1, A), centers[:, 1].view(1, 1, A)
+    gx, gy, gw, gh = (gt[..., k].unsqueeze(2) for k in range(4))
+    in_box = torch.stack([cx - (gx - gw / 2), cy - (gy - gh / 2), (gx + gw / 2) - cx, (gy + gh / 2) - cy], 3).min(3).values > 0
+    rad = CENTER_RADIUS * strides.view(1, 1, A)
+    in_ctr = torch.stack([cx - (gx - rad), cy - (gy - rad), (gx + rad) - cx, (gy + rad) - cy], 3).min(3).values > 0
+    v3 = valid.unsqueeze(2)
+    cand = ((in_box | in_ctr) & v3).any(1)                                             # [B, A]: candidates of the image
+    both = in_box & in_ctr
+    # IoU of every (row, anchor) pair, as pairwise_iou_cxcywh
+    a_lo, a_hi = (gt[..., :2] - gt[..., 2:] / 2).unsqueeze(2), (gt[..., :2] + gt[..., 2:] / 2).unsqueeze(2)
+    b_lo, b_hi = (boxes[..., :2] - boxes[..., 2:] / 2).unsqueeze(1), (boxes[..., :2] + boxes[..., 2:] / 2).unsqueeze(1)
+    lo, hi = torch.max(a_lo, b_lo), torch.min(a_hi, b_hi)
+    inter = (hi - lo).prod(dim=3) * (lo < hi).all(dim=3).to(dt)
+    ious = inter / (gt[..., 2:].prod(2).unsqueeze(2) + boxes[..., 2:].prod(2).unsqueeze(1) - inter)
+    joint = (cls_logits.float().sigmoid() * obj_logits.float().sigmoid()).sqrt()      # [B, A, C]
+    onehot = F.one_hot(labels[..., 0].long().clamp(0, num_classes - 1), num_classes).to(dt)
+    cls_cost = F.binary_cross_entropy(joint.unsqueeze(1).expand(-1, R, -1, -1), onehot.unsqueeze(2).expand(-1, -1, A, -1),
+                                      reduction="none").sum(-1)
+    cost = cls_cost + 3.0 * -torch.log(ious + 1e-8) + 100000.0 * (~both).to(dt)
+    live = v3 & cand.unsqueeze(1)                                                      # pairs that exist in the per-image form
+    cost = torch.where(live, cost, torch.full_like(cost, float("inf")))
+    ious = torch.where(live, ious, torch.zeros_like(ious))
+    dyn_k = torch.topk(ious, min(N_CANDIDATE_K, A), dim=2).values.sum(2).int().clamp(min=1)
+    rank = cost.argsort(dim=2, stable=True).argsort(dim=2, stable=True)
+    match = (rank < dyn_k.unsqueeze(2)) & live                                         # [B, R, A]
+    multi = match.sum(1) > 1                                                           # contested anchors: cheapest gt
+    best = F.one_hot(cost.argmin(dim=1), R).permute(0, 2, 1).bool()
+    match = torch.where(multi.unsqueeze(1), best, match)
+    fg = match.any(1)
+    matched_gt = match.to(torch.uint8).argmax(1)
+    matched_iou = (match.to(dt) * ious).sum(1)
+    return fg, matched_gt, matched_iou
+
+
 def detection_losses(labels, outputs, grids, strides, num_classes):
     """YOLOXHead.get_losses with use_l1 = False (dagr.py:168).  labels [B, 100, 5] = (class, cx, cy, w, h) rows, zero
     padded (``convert_to_training_format``); outputs [B, A, 5+C] from ``output_and_grid`` concatenated over the scales;
-    grids: list of [1, A_k, 2]; strides: per-scale stride."""
+    grids: list of [1, A_k, 2]; strides: per-scale stride.  One batched assignment, no host synchronisation (the counts
+    in the result are tensors)."""
     B, A, _ = outputs.shape
     dev, dt = outputs.device, outputs.dtype
     grid = torch.cat(grids, 1)[0]
     stride = torch.cat([torch.full((g.shape[1],), float(s), device=dev, dtype=dt) for g, s in zip(grids, strides)])
     centers = (grid + 0.5) * stride[:, None]
     box, obj, cls = outputs[..., :4], outputs[..., 4:5], outputs[..., 5:]
-    n_gt = (labels.sum(dim=2) > 0).sum(dim=1)
-    fg_all, reg_t, cls_t = [], [], []
-    num_fg, num_gts = 0.0, 0.0
-    for b in range(B):
-        G = int(n_gt[b])
-        num_gts += G
-        if G == 0:
-            fg_all.append(torch.zeros(A, dtype=torch.bool, device=dev))
-            continue
-        gt_boxes, gt_cls = labels[b, :G, 1:5], labels[b, :G, 0]
-        fg, m_gt, m_iou = simota_assign(gt_boxes, gt_cls, box[b].detach(), cls[b].detach(), obj[b].detach(), centers,
-                                        stride, num_classes)
-        num_fg += float(fg.sum())
-        fg_all.append(fg)
-        reg_t.append(gt_boxes[m_gt])
-        cls_t.append(F.one_hot(gt_cls[m_gt].long(), num_classes).to(dt) * m_iou[:, None])
-    fg_all = torch.stack(fg_all).view(-1)
-    reg_t = torch.cat(reg_t) if reg_t else outputs.new_zeros((0, 4))
-    cls_t = torch.cat(cls_t) if cls_t else outputs.new_zeros((0, num_classes))
-    num_fg = max(num_fg, 1.0)
-    loss_iou = iou_loss(box.reshape(-1, 4)[fg_all], reg_t).sum() / num_fg
-    loss_obj = F.binary_cross_entropy_with_logits(obj.reshape(-1, 1), fg_all.to(dt)[:, None], reduction="none").sum() / num_fg
-    loss_cls = F.binary_cross_entropy_with_logits(cls.reshape(-1, num_classes)[fg_all], cls_t, reduction="none").sum() / num_fg
+    num_gts = (labels.sum(dim=2) > 0).sum().to(dt)
+    fg, m_gt, m_iou = simota_assign_batch(labels.to(dt), box.detach(), cls.detach(), obj.detach(), centers, stride,
+                                          num_classes)
+    fgf = fg.to(dt)
+    # targets of every anchor (those of non-foreground anchors are multiplied away below); per-image order of the
+    # foreground anchors = row-major order of fg, as the per-image form concatenates them
+    rows = torch.gather(labels.to(dt), 1, m_gt.unsqueeze(2).expand(-1, -1, 5))         # [B, A, 5]
+    reg_t = rows[..., 1:5]
+    cls_t = F.one_hot(rows[..., 0].long().clamp(0, num_classes - 1), num_classes).to(dt) * m_iou.unsqueeze(2)
+    num_fg = fgf.sum().clamp(min=1.0)
+    sel = fg.view(-1)
+    loss_iou = iou_loss(box.reshape(-1, 4)[sel], reg_t.reshape(-1, 4)[sel]).sum() / num_fg
+    loss_obj = F.binary_cross_entropy_with_logits(obj.reshape(-1, 1), fgf.view(-1, 1), reduction="none").sum() / num_fg
+    loss_cls = F.binary_cross_entropy_with_logits(cls.reshape(-1, num_classes)[sel], cls_t.reshape(-1, num_classes)[sel],
+                                                  reduction="none").sum() / num_fg
     loss_l1 = 0.0
     total = REG_WEIGHT * loss_iou + loss_obj + loss_cls + loss_l1
-    return total, REG_WEIGHT * loss_iou, loss_obj, loss_cls, loss_l1, num_fg / max(num_gts, 1)
+    return total, REG_WEIGHT * loss_iou, loss_obj, loss_cls, loss_l1, num_fg / num_gts.clamp(min=1.0)

@@ -96,7 +96,7 @@ def shallow_copy(data):
     cached CSR of the graph is shared, the reference's ``adj_t`` is not carried over -- it is recomputed there)."""
     out = data.__class__()
     keep = ("edge_index", "edge_attr", "pos", "batch", "pooling", "num_image_channels", "skipped", "pooled", "width",
-            "height", "time_window", "edge_attr_max", "_dagr_csr")
+            "height", "time_window", "edge_attr_max", "_dagr_csr", "_dagr_exact")
     for k in keep:
         if k in data.__dict__:
             out.__dict__[k] = data.__dict__[k]
