@@ -207,6 +207,7 @@ __global__ __launch_bounds__(kGemmThreads) void k_conv_fused(
         const int n = m0 + wv;
         float *row = At + wv * KP;
         for (int i = lane; i < KP; i += 64) row[i] = 0.0f;
+        DAGR_TRACE(7);
         if (n < M) {
             const int ne = e1s - e0;
             const float *xn = x + (size_t)n * ldx;
@@ -215,6 +216,7 @@ __global__ __launch_bounds__(kGemmThreads) void k_conv_fused(
                 const float *sn = xskip + (size_t)n * ldskip;
                 for (int i = lane; i < cskip; i += 64) row[26 * cin + i] = sn[i];
             }
+            DAGR_TRACE(8);
             for (int base = 0; base < ne; base += 64) {
                 const int cnt = min(64, ne - base);
                 int my_src = 0, my_cd = 0;
@@ -245,6 +247,7 @@ __global__ __launch_bounds__(kGemmThreads) void k_conv_fused(
                             v[u] = ch_ok ? x[(size_t)src * ldx + ch] : 0.0f;
                             v2[u] = ch2_ok ? x[(size_t)src * ldx + ch2] : 0.0f;
                         }
+                        DAGR_TRACE(9);
 #pragma unroll
                         for (int u = 0; u < UA; u++) {
                             if (j + u < cnt && ch_ok) {
@@ -332,6 +335,7 @@ __global__ __launch_bounds__(kGemmThreads) void k_conv_fused(
                 }
                 g += 2 * U;
             }
+            DAGR_TRACE(10);
             {   // < U left-over groups: all of their operands are requested before the first is used (on the small
                 // levels K / 16 splits into 7 groups per wave: one full batch + 3 left-overs, which used to be three
                 // dependent load -> MFMA round trips)
@@ -358,6 +362,7 @@ __global__ __launch_bounds__(kGemmThreads) void k_conv_fused(
 #pragma unroll
         for (int q = 0; q < 4; q++) rd[(kk * 4 + q) * NBc + w * 16 + nn] = acc[q];
         __syncthreads();
+        DAGR_TRACE(11);
         if (tid < 16 * NBc) {
             const int idx = tid;
             const int orow = m0 + idx / NBc, ocol = n0 + idx % NBc;

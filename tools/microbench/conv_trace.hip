@@ -5,11 +5,11 @@
 //            -o tools/microbench/conv_trace[_t] tools/microbench/conv_trace.hip
 #include <hip/hip_runtime.h>
 #ifdef TRACE
-__device__ long long g_trace[16];
+__device__ long long g_trace[16][16];     // [wave][stage] of workgroup 0
 #define DAGR_TRACE(i)                                                                                  \
     do {                                                                                               \
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                    \
-        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_trace[i] = wall_clock64();       \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0) g_trace[threadIdx.x >> 6][i] = wall_clock64(); \
     } while (0)
 #endif
 #include "errors.hip"
@@ -77,19 +77,30 @@ int main(int argc, char **argv) {
         CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
         conv(1); k_stamp<<<1, 64, 0, s>>>(d_st); conv(2); k_stamp<<<1, 64, 0, s>>>(d_st + 1);
         CK(hipStreamEndCapture(s, &g2)); CK(hipGraphInstantiate(&ge2, g2, nullptr, nullptr, 0));
-        double acc[10] = {0};
+        // stage order along the kernel; per stage: wave 0, and the latest wave (the barrier waits for it)
+        const int order[] = {0, 1, 7, 8, 2, 9, 3, 4, 10, 5, 11, 6};
+        const char *names[] = {"entry", "rowptr", "zero", "root/skip", "col/code", "gathers", "phaseA end", "barrier", "mfma main",
+                               "mfma all", "red+barrier", "store+barrier"};
+        double w0[12] = {0}, wl[12] = {0}, first[12] = {0};
+        double exit_gap = 0;
         const int R = 10;
         for (int r = 0; r < R; r++) {
             CK(hipGraphLaunch(ge2, s)); CK(hipStreamSynchronize(s));
-            long long st[2], tr[16];
+            long long st[2], tr[16][16];
             CK(hipMemcpy(st, d_st, 16, hipMemcpyDeviceToHost));
             CK(hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_trace), sizeof(tr)));
-            acc[0] += (tr[0] - st[0]) * 0.01;
-            for (int i = 1; i <= 6; i++) acc[i] += (tr[i] - tr[i - 1]) * 0.01;
-            acc[7] += (st[1] - tr[6]) * 0.01;
+            for (int k = 0; k < 12; k++) {
+                long long mx = tr[0][order[k]], mn = tr[0][order[k]];
+                for (int w = 1; w < 16; w++) { mx = tr[w][order[k]] > mx ? tr[w][order[k]] : mx; mn = tr[w][order[k]] < mn ? tr[w][order[k]] : mn; }
+                w0[k] += (tr[0][order[k]] - st[0]) * 0.01; wl[k] += (mx - st[0]) * 0.01; first[k] += (mn - st[0]) * 0.01;
+            }
+            long long mx6 = tr[0][6];
+            for (int w = 1; w < 16; w++) mx6 = tr[w][6] > mx6 ? tr[w][6] : mx6;
+            exit_gap += (st[1] - mx6) * 0.01;
         }
-        printf("  | stamp->entry %.2f, rowptr %.2f, col/code %.2f, phaseA %.2f, barrier %.2f, weights+mfma %.2f, reduce+store %.2f, end->next stamp %.2f",
-               acc[0] / R, acc[1] / R, acc[2] / R, acc[3] / R, acc[4] / R, acc[5] / R, acc[6] / R, acc[7] / R);
+        printf("\n    us since the previous kernel's stamp (earliest wave / wave 0 / latest wave):");
+        for (int k = 0; k < 12; k++) printf("\n      %-14s %6.2f %6.2f %6.2f", names[k], first[k] / R, w0[k] / R, wl[k] / R);
+        printf("\n      last wave done -> next kernel's stamp %.2f", exit_gap / R);
 #endif
         printf("\n");
     }
