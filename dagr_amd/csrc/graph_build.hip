@@ -716,39 +716,35 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
                 }
             }
         }
-        // the wave's largest candidate count among the neighbourhoods searched here (a lane group that has left the loop
-        // contributes whatever its registers hold: Cw >= C of every active group either way, it only bounds skipping)
-        int Cw = defer ? 0 : C;
-        Cw = max(Cw, __shfl_xor(Cw, 16, 64));
-        Cw = max(Cw, __shfl_xor(Cw, 32, 64));
         if (defer) continue;
         row_lo[grp][l] = lo_cur;
         row_base[grp][l] = incl - len_cur;
         if (l == 15) row_base[grp][16] = C;
         __builtin_amdgcn_wave_barrier();
-        // 2. candidates, 16 per round, 4 rounds of loads in flight.  Rounds that no lane group of the wave needs are
-        //    skipped (wave-uniform): with ~73 candidates per neighbourhood a fixed batch of 4 ran 8 rounds for 5.
+        // 2. candidates, 16 per round, 4 rounds of loads in flight.  (Skipping the rounds no lane group of the wave needs
+        //    -- a wave-uniform break out of the batch -- was tried in round 3: same time, and the break cost 19 more
+        //    spilled registers, i.e. 2.6 x the kernel's HBM traffic in scratch.)
         int V = 0;
         for (int c0 = 0; c0 < C; c0 += 16 * ROUNDS) {
             int2 it[ROUNDS];
-            int cxv[ROUNDS], sv[ROUNDS], relv[ROUNDS], rrv[ROUNDS];
+            int cxv[ROUNDS], rpv[ROUNDS];     // rpv: position in its row range (20 bits) | row << 20 -- one register, not two:
+                                              // the kernel sits exactly at its 72-register budget (7 waves per SIMD)
 #pragma unroll
             for (int q = 0; q < ROUNDS; q++) {
                 const int ci = c0 + 16 * q + l;
                 it[q] = make_int2(0, 0);
-                cxv[q] = 0; sv[q] = 0; relv[q] = 0; rrv[q] = 0;
-                if (c0 + 16 * q >= Cw) break;      // wave-uniform
+                cxv[q] = 0; rpv[q] = 0;
                 if (ci < C) {
                     int rr = 0;
                     if (row_base[grp][rr + 8] <= ci) rr += 8;
                     if (row_base[grp][rr + 4] <= ci) rr += 4;
                     if (row_base[grp][rr + 2] <= ci) rr += 2;
                     if (row_base[grp][rr + 1] <= ci) rr += 1;
-                    relv[q] = ci - row_base[grp][rr];
-                    rrv[q] = rr;
-                    sv[q] = row_lo[grp][rr] + relv[q];
-                    it[q] = slot_it[sv[q]];
-                    cxv[q] = slot_xyb[sv[q]];
+                    const int rel = ci - row_base[grp][rr];
+                    rpv[q] = rel | (rr << 20);
+                    const int sv = row_lo[grp][rr] + rel;
+                    it[q] = slot_it[sv];
+                    cxv[q] = slot_xyb[sv];
                 }
             }
 #pragma unroll
@@ -756,14 +752,13 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
                 const int ci = c0 + 16 * q + l;
                 bool valid = false;
                 int key = 0;
-                if (c0 + 16 * q >= Cw) break;      // wave-uniform
                 if (ci < C) {
                     // visible in the FIFO; older than the destination (ev_graph.cu:64); dt <= delta (:69)
                     valid = (cxv[q] < 0) && it[q].x < e && !((float)(t - it[q].y) > delta_t);
                     const int dx = (cxv[q] & 4095) - x;
-                    const int rank = sp_rank[rrv[q] * 16 + (dx + r)];
+                    const int rank = sp_rank[(rpv[q] >> 20) * 16 + (dx + r)];
                     // spiral rank first, then newest first inside the pixel (larger slot = newer)
-                    key = (rank << 20) | (0xFFFFF - relv[q]);
+                    key = (rank << 20) | (0xFFFFF - (rpv[q] & 0xFFFFF));
                 }
                 const unsigned bits = (unsigned)(__ballot(valid) >> gshift) & 0xffffu;
                 if (valid) {
