@@ -95,15 +95,19 @@ __global__ __launch_bounds__(kTileWaves * 64, 2) void k_conv_l0_tiles(
     const float my_shift = shift[c];
     const float inv_sy = 1.0f / (float)(2 * ry + 1);
     const int sy = 2 * ry + 1;
-    // XCD-contiguous node ranges per workgroup, 16-node tiles dealt round-robin to its waves
+    // XCD x = blockIdx % 8 owns the x-th eighth of the nodes (one sample of a B = 8 batch); its workgroups sweep that range
+    // TOGETHER: workgroup lb takes the 64-node groups lb, lb + bpx, lb + 2 bpx ... (one 16-node tile per wave).  The source
+    // rows a tile gathers lie within +-r pixel rows of it, so the rows all workgroups of the XCD need at one time form a band
+    // of a few hundred KB that stays in the XCD's 4-MB L2.  (Contiguous strips per workgroup -- rounds 1-2 -- put 64 strips
+    // in flight per XCD, together the whole 8 MB of its rows: every source row came from HBM ~3 times, PMC.)
     const int G = gridDim.x, nx = (G % 8 == 0) ? 8 : 1;
     const int xcd = blockIdx.x % nx, lb = blockIdx.x / nx, bpx = G / nx;
     const int chunk = ((N + nx - 1) / nx + 15) / 16 * 16;
-    const int per_block = ((chunk + bpx - 1) / bpx + 15) / 16 * 16;
+    const int stride = 16 * kTileWaves * bpx;
     // nodes [n_first, n_first + N): the whole level, or the rows an asynchronous update appended (a node's result does
     // not depend on the tile it shares with its neighbours in memory)
-    const int n_begin = n_first + xcd * chunk + lb * per_block;
-    const int n_end = min(n_first + min(N, (xcd + 1) * chunk), n_begin + per_block);
+    const int n_begin = n_first + xcd * chunk + lb * 16 * kTileWaves;
+    const int n_end = n_first + min(N, (xcd + 1) * chunk);
 
     // Software pipeline over this wave's tiles.  Per tile the dependent chain is {degree, neighbour row} -> source rows ->
     // FMAs; with ~200 registers per lane only two waves share a SIMD, so the chain is shortened instead of hidden: the
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(kTileWaves * 64, 2) void k_conv_l0_tiles(
     int4 s_nx[4];
     int2 c_nx[4];
     if (n_begin + 16 * wv < n_end) load_meta(n_begin + 16 * wv, d_nx, s_nx, c_nx);
-    for (int n0 = n_begin + 16 * wv; n0 < n_end; n0 += 16 * kTileWaves) {
+    for (int n0 = n_begin + 16 * wv; n0 < n_end; n0 += stride) {
         const int n = n0 + c;
         const bool valid = n < n_end;
         const int nn = valid ? n : n0;                  // a row that exists, for the predicated-off lanes
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(kTileWaves * 64, 2) void k_conv_l0_tiles(
         if (CE) xre = (q < CE) ? x[(size_t)nn * ldx + CM + q] : 0.f;
         if (S::SKF) xs = *reinterpret_cast<const float4 *>(xskip + (size_t)nn * ldskip + 4 * q);
         if (S::SKE) xse = (q < S::SKE) ? xskip[(size_t)nn * ldskip + 16 * S::SKF + q] : 0.f;
-        load_meta(n0 + 16 * kTileWaves, d_nx, s_nx, c_nx);
+        load_meta(n0 + stride, d_nx, s_nx, c_nx);
 
         float acc[CM ? NT : 1][4];
         float acce[CE ? NT : 1];
