@@ -94,8 +94,12 @@ class RandomHFlip:
         return data
 
 
+REFERENCE_FRAME_CROP = True      # see _keep_window
+
+
 def _keep_window(data, lo, hi):
-    """Events inside [lo, hi] (inclusive, as augment.py:39-51 keeps them), frame blanked outside, boxes clamped."""
+    """Events inside [lo, hi] (inclusive, as augment.py:39-51 keeps them), frame cropped as the reference does it (below),
+    boxes clamped."""
     keep = ((data.pos >= lo) & (data.pos <= hi)).all(dim=1)
     for name in ("pos", "x", "t"):
         v = getattr(data, name, None)
@@ -104,10 +108,21 @@ def _keep_window(data, lo, hi):
     x0, y0, x1, y1 = int(lo[0]), int(lo[1]), int(hi[0]), int(hi[1])
     if hasattr(data, "image"):
         img = data.image.clone()
-        img[..., :y0, :] = 0
-        img[..., y1:, :] = 0
-        img[..., :, :x0] = 0
-        img[..., :, x1:] = 0
+        if REFERENCE_FRAME_CROP:
+            # augment.py:51-58 as written: the four assignments index the FIRST TWO dimensions of the [1, 3, H, W] frame
+            # (batch, channel), not rows and columns -- any window that does not start in row 0 blanks the whole frame,
+            # one that starts in column c > 0 of row 0 blanks the first min(c, 3) channels.  Kept: a model trained here
+            # sees the frames the reference's training loop shows it.  REFERENCE_FRAME_CROP = False blanks outside the
+            # window, which is what the function's name promises.
+            img[:y0, :] = 0
+            img[y1:, :] = 0
+            img[:, :x0] = 0
+            img[:, x1:] = 0
+        else:
+            img[..., :y0, :] = 0
+            img[..., y1:, :] = 0
+            img[..., :, :x0] = 0
+            img[..., :, x1:] = 0
         data.image = img
     for name, b in _each_box_field(data):
         b = b.clone()
@@ -175,14 +190,18 @@ class RandomZoom:
         pass
 
     def __call__(self, data):
-        z = float(torch.rand(1)) * (self.zoom[1] - self.zoom[0]) + self.zoom[0]
+        # the factor is a float32 tensor expression in the reference (augment.py:174): same roundings here
+        z = float(torch.rand(1) * (self.zoom[1] - self.zoom[0]) + self.zoom[0])
         W, H = int(data.width), int(data.height)
         cx, cy = W // 2, H // 2
         pos = data.pos.float()
         zx = ((pos[:, 0] - cx) * z + cx)
         zy = ((pos[:, 1] - cy) * z + cy)
         if self.subsample and z < 1:
-            p, keep = subsample_events(torch.stack([zx, zy], 1).numpy(), data.x.reshape(-1).numpy(), z)
+            # augment.py:178-182: the zoomed coordinates are int16 before the integrate-and-fire pass sees them (the
+            # bilinear weights collapse onto the truncated pixel; the other three pixels still get their threshold check)
+            p, keep = subsample_events(torch.stack([zx, zy], 1).to(torch.int16).numpy().astype(np.float32),
+                                       data.x.reshape(-1).numpy(), z)
             data.pos = torch.from_numpy(p[keep].astype("int16"))
             data.x = data.x[torch.from_numpy(keep)]
             if hasattr(data, "t") and torch.is_tensor(data.t):

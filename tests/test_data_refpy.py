@@ -297,3 +297,56 @@ def test_checkpointer_resolves_directories_like_the_reference(tmp_path):
     assert picks == [str(v) for v in G["ckpt_picks"]]
     assert sorted(torch.load(tmp_path / "last_model.pth", weights_only=False)) == [str(v) for v in G["ckpt_keys"]]
     assert ck.restore_checkpoint(tmp_path, best=False) == int(G["ckpt_restored_epoch"])
+
+
+def test_random_zoom_subsample_branch_matches_the_reference():
+    """RandomZoom(subsample=True) with zoom < 1 (augment.py:146-198; dead with the shipped configs): the zoomed
+    coordinates are int16 before the integrate-and-fire pass, as in the reference (tests/make_golden_refpy_zoom.py)."""
+    from dagr_amd.data.augment import RandomZoom
+    from dagr_amd.data.utils import to_data
+    Z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_py_zoom_subsample.npz"))
+    base = {k: Z[f"base_{k}"] for k in ("x", "y", "t", "p", "bbox")}
+    sizes = set()
+    for seed in range(4):
+        zoom = RandomZoom(zoom=[0.5, 0.9], subsample=True)
+        zoom.init(180, 240)
+        d = to_data(**{k: v.copy() for k, v in base.items()}, width=240, height=180, time_window=1000000)
+        torch.manual_seed(seed)
+        o = zoom(d)
+        for k in ("pos", "x", "t"):
+            assert np.array_equal(getattr(o, k).numpy(), Z[f"zoom{seed}_{k}"]), (seed, k)
+        assert np.allclose(o.bbox.numpy(), Z[f"zoom{seed}_bbox"], rtol=0, atol=1e-4), seed
+        sizes.add(len(o.pos))
+    assert len(sizes) == 4 and min(sizes) > 100
+
+
+def test_random_crop_with_a_frame_matches_the_reference():
+    """RandomCrop on a sample that carries a frame: events, boxes AND the frame as the reference's ``_crop_image``
+    (augment.py:51-58) leaves it -- it indexes the first two dimensions of the [1, 3, H, W] tensor, so every window that
+    does not start in row 0 blanks the whole frame (mirrored, see dagr_amd/data/augment.py:_keep_window)."""
+    from dagr_amd.data import augment as A
+    from dagr_amd.data.utils import to_data
+    Z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_py_zoom_subsample.npz"))
+    base = {k: Z[f"base_{k}"] for k in ("x", "y", "t", "p", "bbox")}
+    for seed in range(6):
+        crop = A.RandomCrop([0.75, 0.75], p=1.0)
+        crop.init(180, 240)
+        d = to_data(**{k: v.copy() for k, v in base.items()}, width=240, height=180, time_window=1000000)
+        d.image = torch.from_numpy(Z["crop_frame"].copy())
+        torch.manual_seed(seed)
+        o = crop(d)
+        for k in ("pos", "x", "t"):
+            assert np.array_equal(getattr(o, k).numpy(), Z[f"crop{seed}_{k}"]), (seed, k)
+        assert np.allclose(o.bbox.numpy(), Z[f"crop{seed}_bbox"], rtol=0, atol=1e-4), seed
+        assert np.array_equal(o.image.numpy().astype(np.int64).sum(axis=(0, 2, 3)), Z[f"crop{seed}_channel_sums"]), seed
+        assert np.array_equal(o.image.numpy()[..., ::12, ::12], Z[f"crop{seed}_grid"]), seed
+    # the spatial form stays available
+    A.REFERENCE_FRAME_CROP = False
+    try:
+        d = to_data(**{k: v.copy() for k, v in base.items()}, width=240, height=180, time_window=1000000)
+        d.image = torch.from_numpy(Z["crop_frame"].copy())
+        torch.manual_seed(0)
+        o = A.RandomCrop([0.75, 0.75], p=1.0)(d)
+        assert int(o.image.sum()) > 0
+    finally:
+        A.REFERENCE_FRAME_CROP = True
