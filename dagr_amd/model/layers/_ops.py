@@ -185,7 +185,9 @@ def voxel_pool(pool, data):
     src = col_out[:ne].long()
     order = torch.argsort(src * max(nc, 1) + dst, stable=True)    # edge_index.unique(dim=-1): by source, then destination
     ei = torch.stack([src[order], dst[order]])
+    filtered = False
     if getattr(pool, "keep_temporal_ordering", False) and ne > 0:
+        filtered = True
         # pooling.py:69-72: coarse edges only towards clusters whose newest member is strictly newer than the source's.
         # scratch holds every node's raw voxel id; clusters are the occupied voxels in ascending id order.
         raw = scratch.long()
@@ -197,18 +199,26 @@ def voxel_pool(pool, data):
     out = data.__class__()
     out.__dict__.update({k: v for k, v in data.__dict__.items() if not k.startswith("_dagr")})
     out.x, out.pos, out.batch, out.edge_index = x_out[:nc], pos_out[:nc], batch_out[:nc].long(), ei
+    if not filtered:
+        # the kernel's own CSR (rows = destinations, sources ascending = the order csr_by_destination would establish)
+        # rides along, so that the convs of the next level do not sort the edges back: perm maps a CSR edge to its
+        # position in edge_index
+        inv = torch.empty_like(order)
+        inv[order] = torch.arange(ne, device=dev)
+        out._dagr_csr = (rowptr_out[:nc + 1].contiguous(), col_out[:ne].contiguous(), inv, (nc, ei.data_ptr(), ne))
     if torch.is_grad_enabled() and data.x.requires_grad:
         # training path: attach the backward of the feature aggregation (torch_scatter's autograd in the reference).
         # scratch holds each node's raw voxel id; the output clusters are the occupied voxels in ascending id order.
         from types import SimpleNamespace
         from .autograd import PoolFeatFn
+        # consecutive id of a node's voxel = number of occupied voxels below it (no sort, no host synchronisation)
         raw = scratch.long()
         valid = raw >= 0
-        uniq, inv = torch.unique(raw[valid], return_inverse=True)
-        if uniq.numel() != nc:
-            raise RuntimeError(f"pooling: {uniq.numel()} occupied voxels but {nc} output clusters")
-        cluster = torch.full((n,), -1, **i32)
-        cluster[valid] = inv.int()
+        idx = raw.clamp(min=0)
+        occ = torch.zeros((T + 1,), **i32)
+        occ.scatter_reduce_(0, idx, valid.to(torch.int32), "amax")
+        newid = torch.cumsum(occ, 0, dtype=torch.int32) - occ
+        cluster = torch.where(valid, newid[idx], torch.full_like(newid[:1], -1)).contiguous()
         out.x = PoolFeatFn.apply(data.x, cluster, 0 if pool.aggr == "max" else 1, SimpleNamespace(pooled=x_out[:nc]))
     out.edge_attr = cartesian(out.pos, ei, pool.transform.max)
     out.edge_attr_max = pool.transform.max
