@@ -349,3 +349,61 @@ def test_train_dsec_script_preset_on_cpu(tmp_path):
     assert len(log) == 2 and seen["n"] == 3                      # two training batches + one validation batch
     assert sorted(p.name.split("_")[0] for p in out.glob("*.pth")) == ["best", "last"]
     assert out.parts[-3:] == ("dsec", "detection", "train")
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_batched_simota_equals_the_per_image_form(seed):
+    """``simota_assign_batch`` (one masked pass over the padded label rows, no host synchronisation) gives every image the
+    assignment ``simota_assign`` gives it alone: same foreground anchors, same matched ground truths, same IoUs."""
+    g = torch.Generator().manual_seed(7000 + seed)
+    B = int(torch.randint(1, 5, (1,), generator=g))
+    C = [2, 5, 100][seed % 3]
+    shapes, strides_ = ([(10, 14), (5, 7)], [22, 43]) if seed % 2 else ([(5, 7)], [43])
+    maps = [torch.randn(B, 5 + C, h, w, generator=g) * 1.5 for h, w in shapes]
+    labels = torch.zeros(B, 100, 5)
+    for b in range(B):
+        n = int(torch.randint(0, 9, (1,), generator=g)) if seed % 7 else 0          # images without ground truth too
+        for k in range(n):
+            cx, cy = torch.rand(2, generator=g) * torch.tensor([300.0, 200.0])
+            wh = 2 + torch.rand(2, generator=g) * (150 if seed % 5 else 10)        # tiny boxes: no candidate anchors
+            labels[b, k] = torch.tensor([float(torch.randint(0, C, (1,), generator=g)), cx, cy, wh[0], wh[1]])
+    outs, grids = zip(*(yl.output_and_grid(m, s) for m, s in zip(maps, strides_)))
+    out = torch.cat(outs, 1)
+    grid = torch.cat(grids, 1)[0]
+    stride = torch.cat([torch.full((gg.shape[1],), float(s)) for gg, s in zip(grids, strides_)])
+    centers = (grid + 0.5) * stride[:, None]
+    box, obj, cls = out[..., :4], out[..., 4:5], out[..., 5:]
+    fg, mg, mi = yl.simota_assign_batch(labels, box, cls, obj, centers, stride, C)
+    for b in range(B):
+        G = int((labels[b].sum(1) > 0).sum())
+        if G == 0:
+            assert not fg[b].any()
+            continue
+        f1, g1, i1 = yl.simota_assign(labels[b, :G, 1:5], labels[b, :G, 0], box[b], cls[b], obj[b], centers, stride, C)
+        assert torch.equal(f1, fg[b]) and torch.equal(g1, mg[b][fg[b]]) and torch.equal(i1, mi[b][fg[b]])
+
+
+def test_ema_update_is_the_per_entry_recurrence():
+    """ModelEMA.update (two multi-tensor launches over cached tensor lists) == avg = d * avg + (1 - d) * value per
+    floating-point state_dict entry (ema.py:33-45), also after the model was moved (its storage re-allocated)."""
+    from dagr_amd.model.networks.ema import ModelEMA
+    torch.manual_seed(3)
+    m = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.BatchNorm1d(7), torch.nn.Linear(7, 3))
+    e = ModelEMA(m)
+    ref = {k: v.clone() for k, v in e.ema.state_dict().items()}
+    opt = torch.optim.SGD(m.parameters(), lr=0.1)
+    for it in range(6):
+        m(torch.randn(4, 5)).sum().backward()
+        opt.step()
+        opt.zero_grad()
+        if it == 3:
+            m = m.double().float()          # new parameter storage: the cached lists must notice
+            opt = torch.optim.SGD(m.parameters(), lr=0.1)
+        e.update(m)
+        d = e.decay(e.updates)
+        for k, v in m.state_dict().items():
+            if ref[k].dtype.is_floating_point:
+                ref[k].mul_(d).add_(v.detach(), alpha=1 - d)
+    for k, v in e.ema.state_dict().items():
+        if v.dtype.is_floating_point:
+            assert torch.equal(ref[k], v), k
