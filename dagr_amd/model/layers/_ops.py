@@ -62,23 +62,23 @@ def spline_conv(conv, x, rowptr, col, code, norm=None, skip=None, xskip=None, re
     if n == 0:
         return out
     x = x.float().contiguous()
-    counts = torch.tensor([n, col.shape[0]], dtype=torch.int32, device=dev)
+    # the device-side node count of the kernels is optional: here it IS n (a device scalar would cost a host-to-device copy)
     dom = conv.lut_domain
     stream = _lib.cur_stream(dev)
     xs, lds = (None, 0) if xskip is None else (xskip.float().contiguous(), xskip.shape[1])
     passes = L.dagr_spline_conv_fused_passes(pack.cin, pack.cskip)
     if passes == 1 or (passes > 1 and n <= 1600):       # wide rows in passes: small graphs only (include/dagr_hip.h)
-        _lib.check(L.dagr_spline_conv_fused(P(counts), n, P(rowptr), P(col), P(code), P(x), x.shape[1], pack.cin, P(xs),
+        _lib.check(L.dagr_spline_conv_fused(None, n, P(rowptr), P(col), P(code), P(x), x.shape[1], pack.cin, P(xs),
                                             lds, pack.cskip, dom["rx"], dom["ry"], dom["den_x"], dom["den_y"], P(pack.Wq),
                                             P(pack.bias), P(out), pack.N, pack.N, 1 if relu else 0, stream),
                    "spline_conv_fused")
         return out
     lda = (pack.K + 3) // 4 * 4
     A = torch.empty((n, lda), dtype=torch.float32, device=dev)
-    _lib.check(L.dagr_spline_tap_aggregate(P(counts), n, P(rowptr), P(col), P(code), P(x), x.shape[1], pack.cin, P(xs), lds,
+    _lib.check(L.dagr_spline_tap_aggregate(None, n, P(rowptr), P(col), P(code), P(x), x.shape[1], pack.cin, P(xs), lds,
                                            pack.cskip, dom["rx"], dom["ry"], dom["den_x"], dom["den_y"], P(A), lda, stream),
                "tap_aggregate")
-    _lib.check(L.dagr_gemm_bias_act(P(counts), n, P(A), lda, P(pack.Wm), pack.ldw, P(pack.bias), P(out), pack.N, pack.K,
+    _lib.check(L.dagr_gemm_bias_act(None, n, P(A), lda, P(pack.Wm), pack.ldw, P(pack.bias), P(out), pack.N, pack.K,
                                     pack.N, 1 if relu else 0, stream), "gemm")
     return out
 
@@ -169,10 +169,9 @@ def voxel_pool(pool, data):
     rowptr_out = torch.zeros((T + 2,), **i32)
     e_cap = T * 64
     col_out, code_out = torch.zeros((e_cap,), **i32), torch.zeros((e_cap,), **i32)
-    n_ptr = torch.tensor([n], **i32)
     batch = (data.batch if data.batch is not None else torch.zeros(n, dtype=torch.int64, device=dev)).int().contiguous()
     scratch = torch.zeros((n,), **i32)
-    _lib.check(L.dagr_pool_csr(ctypes.byref(desc), P(ws), P(n_ptr), n, P(data.x.float().contiguous()), C,
+    _lib.check(L.dagr_pool_csr(ctypes.byref(desc), P(ws), None, n, P(data.x.float().contiguous()), C,
                                P(data.pos.float().contiguous()), P(batch), P(rowptr), P(col), P(scratch), P(x_out), C, 0,
                                P(pos_out), P(batch_out), P(counts), P(rowptr_out), P(col_out), P(code_out),
                                ctypes.c_void_p(counts.data_ptr() + 4), e_cap, stream), "pool_csr")
@@ -239,8 +238,7 @@ def to_dense(x, pos, pooling, batch, batch_size):
         return dense
     winner = torch.zeros((batch_size * Hc * Wc,), dtype=torch.int32, device=dev)
     status = torch.zeros((1,), dtype=torch.int32, device=dev)
-    n_ptr = torch.tensor([n], dtype=torch.int32, device=dev)
-    _lib.check(L.dagr_to_dense(P(n_ptr), n, P(x.float().contiguous()), C, C, P(pos.float().contiguous()),
+    _lib.check(L.dagr_to_dense(None, n, P(x.float().contiguous()), C, C, P(pos.float().contiguous()),
                                P(batch.int().contiguous()), float(pooling[0]), float(pooling[1]), batch_size, Hc, Wc,
                                P(winner), P(dense), P(status), _lib.cur_stream(dev)), "to_dense")
     return dense

@@ -26,15 +26,14 @@ class SplineConvFn(torch.autograd.Function):
         lda = K                 # dense rows: the matrix is read by library GEMMs only, and the aggregation writes every entry
         x = x.float().contiguous()
         A = torch.empty((n, lda), dtype=torch.float32, device=x.device)
-        counts = torch.tensor([n, col.shape[0]], dtype=torch.int32, device=x.device)
         if n:
-            _lib.check(L.dagr_spline_tap_aggregate(P(counts), n, P(rowptr), P(col), P(code), P(x), cin, cin, None, 0, 0, rx,
+            _lib.check(L.dagr_spline_tap_aggregate(None, n, P(rowptr), P(col), P(code), P(x), cin, cin, None, 0, 0, rx,
                                                    ry, den_x, den_y, P(A), lda, _lib.cur_stream(x.device)), "tap_aggregate")
         Wm = torch.cat([weight.reshape(25 * cin, cout), root.t()], 0)
         out = A[:, :K] @ Wm
         if bias is not None:
             out = out + bias
-        ctx.save_for_backward(A, Wm, rowptr, col, code, counts)
+        ctx.save_for_backward(A, Wm, rowptr, col, code)
         ctx.dom = (rx, ry, den_x, den_y)
         ctx.shape = (n, cin, cout, K, lda, bias is not None)
         return out
@@ -42,7 +41,7 @@ class SplineConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         L, P = _lib.lib(), _lib.ptr
-        A, Wm, rowptr, col, code, counts = ctx.saved_tensors
+        A, Wm, rowptr, col, code = ctx.saved_tensors
         n, cin, cout, K, lda, has_bias = ctx.shape
         rx, ry, den_x, den_y = ctx.dom
         g = g.float().contiguous()
@@ -56,7 +55,7 @@ class SplineConvFn(torch.autograd.Function):
             # reduction pass, no |gA| temporary)
             amax = torch.linalg.vector_norm(gA, ord=float("inf")).reshape(1).contiguous()
             acc = torch.zeros((n, cin), dtype=torch.int64, device=g.device)
-            _lib.check(L.dagr_spline_tap_scatter_grad(P(counts), n, P(rowptr), P(col), P(code), P(gA), lda, cin, rx, ry,
+            _lib.check(L.dagr_spline_tap_scatter_grad(None, n, P(rowptr), P(col), P(code), P(gA), lda, cin, rx, ry,
                                                       den_x, den_y, P(amax), P(acc), P(gx), cin,
                                                       _lib.cur_stream(g.device)), "tap_scatter_grad")
         gb = g.sum(0) if has_bias else None
@@ -126,8 +125,7 @@ class ToDenseFn(torch.autograd.Function):
         batch = batch.int().contiguous()
         if n:
             status = torch.zeros((1,), dtype=torch.int32, device=dev)
-            n_ptr = torch.tensor([n], dtype=torch.int32, device=dev)
-            _lib.check(L.dagr_to_dense(P(n_ptr), n, P(x.detach().float().contiguous()), C, C, P(pos), P(batch), vx, vy,
+            _lib.check(L.dagr_to_dense(None, n, P(x.detach().float().contiguous()), C, C, P(pos), P(batch), vx, vy,
                                        batch_size, Hc, Wc, P(winner), P(dense), P(status), _lib.cur_stream(dev)),
                        "to_dense")
         ctx.save_for_backward(pos, batch)
