@@ -29,19 +29,24 @@ namespace {
 // One wave per destination node; LDS accumulators [25][Cin] per wave; lanes stride the channels.
 // Row layout of A: [25*Cin taps | Cin root copy | Cskip skip-input copy], row stride lda.
 constexpr int kAggWaves = 4;
+// LPN = lanes per node: 64 (one wave per node, the pooled levels: 18 ... 258 input channels) or 16 (four nodes per wave,
+// rows of <= 16 channels: the event level of the training path, where 48 of 64 lanes used to idle).  A node's edges are
+// walked in the same order by either form: same sums, bit for bit.
+template <int LPN>
 __global__ __launch_bounds__(kBlock) void k_tap_aggregate(
     const int32_t *__restrict__ n_nodes_ptr, int n_nodes_max, const int32_t *__restrict__ rowptr,
     const int32_t *__restrict__ col, const int32_t *__restrict__ code, const float *__restrict__ x, int ldx,
     int cin, const float *__restrict__ xskip, int ldskip, int cskip, int rx, int ry, float den_x, float den_y,
     float *__restrict__ A, int lda) {
     extern __shared__ float lds[];
-    const int lane = threadIdx.x & 63;
-    const int wid = threadIdx.x >> 6;
-    const int n = blockIdx.x * kAggWaves + wid;
+    constexpr int NPW = 64 / LPN;                    // nodes per wave
+    const int lane = threadIdx.x & (LPN - 1);
+    const int slot = threadIdx.x / LPN;              // node slot inside the workgroup
+    const int n = blockIdx.x * (kAggWaves * NPW) + slot;
     const int n_nodes = n_nodes_ptr ? min(*n_nodes_ptr, n_nodes_max) : n_nodes_max;
     if (n >= n_nodes) return;
-    float *acc = lds + (size_t)wid * 25 * cin;
-    for (int i = lane; i < 25 * cin; i += 64) acc[i] = 0.0f;
+    float *acc = lds + (size_t)slot * 25 * cin;
+    for (int i = lane; i < 25 * cin; i += LPN) acc[i] = 0.0f;
     const int e0 = rowptr[n], e1 = rowptr[n + 1];
     for (int e = e0; e < e1; e++) {
         const int src = col[e];
@@ -55,7 +60,7 @@ __global__ __launch_bounds__(kBlock) void k_tap_aggregate(
         float *a01 = acc + (ax.k0 + 5 * ay.k1) * cin;
         float *a11 = acc + (ax.k1 + 5 * ay.k1) * cin;
         const float *xs = x + (size_t)src * ldx;
-        for (int i = lane; i < cin; i += 64) {
+        for (int i = lane; i < cin; i += LPN) {
             const float v = xs[i];
             a00[i] += b00 * v;
             a10[i] += b10 * v;
@@ -64,12 +69,12 @@ __global__ __launch_bounds__(kBlock) void k_tap_aggregate(
         }
     }
     float *row = A + (size_t)n * lda;
-    for (int i = lane; i < 25 * cin; i += 64) row[i] = acc[i];
+    for (int i = lane; i < 25 * cin; i += LPN) row[i] = acc[i];
     const float *xn = x + (size_t)n * ldx;
-    for (int i = lane; i < cin; i += 64) row[25 * cin + i] = xn[i];
+    for (int i = lane; i < cin; i += LPN) row[25 * cin + i] = xn[i];
     if (cskip > 0) {
         const float *sn = xskip + (size_t)n * ldskip;
-        for (int i = lane; i < cskip; i += 64) row[26 * cin + i] = sn[i];
+        for (int i = lane; i < cskip; i += LPN) row[26 * cin + i] = sn[i];
     }
 }
 
@@ -85,6 +90,7 @@ __global__ __launch_bounds__(kBlock) void k_tap_aggregate(
 // tensor's own scale.  k_fixed_to_float turns the sums into fp32.  acc must be zero-initialised by the caller.
 constexpr double kFixedOne = 1125899906842624.0;     // 2^50
 
+template <int LPN>      // lanes per node, as k_tap_aggregate
 __global__ __launch_bounds__(kBlock) void k_tap_scatter_grad(const int32_t *__restrict__ n_nodes_ptr, int n_nodes_max,
                                                             const int32_t *__restrict__ rowptr,
                                                             const int32_t *__restrict__ col,
@@ -93,8 +99,9 @@ __global__ __launch_bounds__(kBlock) void k_tap_scatter_grad(const int32_t *__re
                                                             int ry, float den_x, float den_y,
                                                             const float *__restrict__ amax,
                                                             long long *__restrict__ acc) {
-    const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * kAggWaves + (threadIdx.x >> 6);
+    constexpr int NPW = 64 / LPN;
+    const int lane = threadIdx.x & (LPN - 1);
+    const int n = blockIdx.x * (kAggWaves * NPW) + threadIdx.x / LPN;
     const int n_nodes = n_nodes_ptr ? min(*n_nodes_ptr, n_nodes_max) : n_nodes_max;
     if (n >= n_nodes) return;
     const float m = *amax;
@@ -103,7 +110,7 @@ __global__ __launch_bounds__(kBlock) void k_tap_scatter_grad(const int32_t *__re
         atomicAdd(reinterpret_cast<unsigned long long *>(acc + at), (unsigned long long)__double2ll_rn((double)v * scale));
     };
     const float *row = gA + (size_t)n * lda;
-    for (int i = lane; i < cin; i += 64) add((size_t)n * cin + i, row[25 * cin + i]);
+    for (int i = lane; i < cin; i += LPN) add((size_t)n * cin + i, row[25 * cin + i]);
     const int e0 = rowptr[n], e1 = rowptr[n + 1];
     for (int e = e0; e < e1; e++) {
         const int src = col[e];
@@ -115,7 +122,7 @@ __global__ __launch_bounds__(kBlock) void k_tap_scatter_grad(const int32_t *__re
         const float *a10 = row + (ax.k1 + 5 * ay.k0) * cin;
         const float *a01 = row + (ax.k0 + 5 * ay.k1) * cin;
         const float *a11 = row + (ax.k1 + 5 * ay.k1) * cin;
-        for (int i = lane; i < cin; i += 64)
+        for (int i = lane; i < cin; i += LPN)
             add((size_t)src * cin + i, b00 * a00[i] + b10 * a10[i] + b01 * a01[i] + b11 * a11[i]);
     }
 }
@@ -932,18 +939,25 @@ int dagr_spline_tap_aggregate(const int32_t *n_nodes_ptr, int32_t n_nodes_max, c
     if (n_nodes_max == 0) return DAGR_OK;
     DAGR_CHECK_ARG(rowptr && col && code && x && A, "NULL pointer");
     DAGR_CHECK_ARG(cin >= 1 && lda >= 26 * cin + cskip, "lda too small");
-    const size_t lds_bytes = (size_t)kAggWaves * 25 * cin * 4;
+    const bool narrow = cin <= 16;                    // four nodes per wave
+    const int nodes_per_block = kAggWaves * (narrow ? 4 : 1);
+    const size_t lds_bytes = (size_t)nodes_per_block * 25 * cin * 4;
     DAGR_CHECK_ARG(lds_bytes <= 160 * 1024, "cin too large for the LDS accumulators");
     {
-        static thread_local size_t set_max = 0;   // the attribute is a maximum: raise it only when needed
-        if (lds_bytes > set_max) {
-            DAGR_CHECK_HIP(hipFuncSetAttribute((const void *)k_tap_aggregate,
+        static thread_local size_t set_max[2] = {0, 0};   // the attribute is a maximum: raise it only when needed
+        if (lds_bytes > set_max[narrow]) {
+            DAGR_CHECK_HIP(hipFuncSetAttribute(narrow ? (const void *)k_tap_aggregate<16> : (const void *)k_tap_aggregate<64>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            set_max = lds_bytes;
+            set_max[narrow] = lds_bytes;
         }
     }
-    k_tap_aggregate<<<(unsigned)ceil_div(n_nodes_max, kAggWaves), kBlock, lds_bytes, (hipStream_t)stream>>>(
-        n_nodes_ptr, n_nodes_max, rowptr, col, code, x, ldx, cin, xskip, ldskip, cskip, rx, ry, den_x, den_y, A, lda);
+    const unsigned grid = (unsigned)ceil_div(n_nodes_max, nodes_per_block);
+    if (narrow)
+        k_tap_aggregate<16><<<grid, kBlock, lds_bytes, (hipStream_t)stream>>>(
+            n_nodes_ptr, n_nodes_max, rowptr, col, code, x, ldx, cin, xskip, ldskip, cskip, rx, ry, den_x, den_y, A, lda);
+    else
+        k_tap_aggregate<64><<<grid, kBlock, lds_bytes, (hipStream_t)stream>>>(
+            n_nodes_ptr, n_nodes_max, rowptr, col, code, x, ldx, cin, xskip, ldskip, cskip, rx, ry, den_x, den_y, A, lda);
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;
 }
@@ -956,9 +970,14 @@ int dagr_spline_tap_scatter_grad(const int32_t *n_nodes_ptr, int32_t n_nodes_max
     if (n_nodes_max == 0) return DAGR_OK;
     DAGR_CHECK_ARG(rowptr && col && code && grad_A && grad_x && grad_A_absmax && acc, "NULL pointer");
     DAGR_CHECK_ARG(cin >= 1 && lda >= 26 * cin && ldg >= cin, "bad strides");
-    k_tap_scatter_grad<<<(unsigned)ceil_div(n_nodes_max, kAggWaves), kBlock, 0, (hipStream_t)stream>>>(
-        n_nodes_ptr, n_nodes_max, rowptr, col, code, grad_A, lda, cin, rx, ry, den_x, den_y, grad_A_absmax,
-        (long long *)acc);
+    if (cin <= 16)
+        k_tap_scatter_grad<16><<<(unsigned)ceil_div(n_nodes_max, kAggWaves * 4), kBlock, 0, (hipStream_t)stream>>>(
+            n_nodes_ptr, n_nodes_max, rowptr, col, code, grad_A, lda, cin, rx, ry, den_x, den_y, grad_A_absmax,
+            (long long *)acc);
+    else
+        k_tap_scatter_grad<64><<<(unsigned)ceil_div(n_nodes_max, kAggWaves), kBlock, 0, (hipStream_t)stream>>>(
+            n_nodes_ptr, n_nodes_max, rowptr, col, code, grad_A, lda, cin, rx, ry, den_x, den_y, grad_A_absmax,
+            (long long *)acc);
     DAGR_CHECK_LAUNCH();
     k_fixed_to_float<<<(unsigned)ceil_div((int64_t)n_nodes_max * cin, kBlock), kBlock, 0, (hipStream_t)stream>>>(
         n_nodes_ptr, n_nodes_max, cin, grad_A_absmax, (const long long *)acc, grad_x, ldg);
