@@ -55,6 +55,7 @@ SIGNATURES = {
                                                 c_void_p]),
     "dagr_graph_status": (ctypes.c_int, [ctypes.POINTER(GraphDesc), c_void_p, ctypes.POINTER(c_i64),
                                          ctypes.POINTER(c_i32), c_void_p]),
+    "dagr_graph_counters": (ctypes.c_int, [ctypes.POINTER(GraphDesc), c_void_p, c_void_p, c_void_p]),
     "dagr_scan_scratch_elems": (c_size_t, [c_i64]),
     "dagr_graph_edge_index": (ctypes.c_int, [ctypes.POINTER(GraphDesc), c_void_p, c_void_p, c_void_p, c_i64, c_void_p,
                                              c_void_p, c_void_p, c_i64, c_void_p]),
@@ -90,6 +91,7 @@ SIGNATURES = {
     "dagr_pool_recode": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
                                         c_float, c_i32, c_i32, c_void_p, c_i32, c_void_p, c_void_p]),
     "dagr_pool_status": (ctypes.c_int, [ctypes.POINTER(PoolDesc), c_void_p, ctypes.POINTER(c_i32), c_void_p]),
+    "dagr_pool_counters": (ctypes.c_int, [ctypes.POINTER(PoolDesc), c_void_p, c_void_p, c_void_p]),
     "dagr_to_dense": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_i32, c_i32, c_void_p, c_void_p, c_float, c_float,
                                      c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dagr_to_dense_armed": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_i32, c_i32, c_void_p, c_void_p, c_float, c_float,
@@ -114,7 +116,6 @@ SIGNATURES = {
                                               c_i64, c_i32, c_void_p]),
     "dagr_downsample_events": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_i32, c_i32, c_void_p,
                                               c_void_p, c_void_p]),
-    "dagr_debug_postprocess_clocks": (ctypes.c_int, [c_void_p]),
     "dagr_spline_conv_l0_tiles_rows": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_float,
                                                       c_float, c_i64, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_void_p,
                                                       c_i32, c_void_p, c_i32, c_void_p, c_void_p, c_i32, c_void_p, c_i32,
@@ -127,15 +128,9 @@ SIGNATURES = {
                                            c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_void_p, c_i64, c_i64, c_i64,
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_void_p]),
-    "dagr_debug_calibrate": (ctypes.c_int, [c_i32, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p]),
     "dagr_spline_conv_fused_lds_bytes": (c_size_t, [c_i32, c_i32]),
     "dagr_spline_conv_fused_passes": (c_i32, [c_i32, c_i32]),
     "dagr_spline_conv_fused": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32,
-                                              c_void_p, c_i32, c_i32, c_i32, c_i32, c_float, c_float, c_void_p,
-                                              c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p]),
-    "dagr_spline_conv_tiles_pack_elems": (c_size_t, [c_i32, c_i32, c_i32]),
-    "dagr_spline_conv_tiles_pack": (ctypes.c_int, [c_void_p, c_i32, c_i32, c_i32, c_i32, c_void_p]),
-    "dagr_spline_conv_tiles": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32,
                                               c_void_p, c_i32, c_i32, c_i32, c_i32, c_float, c_float, c_void_p,
                                               c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p]),
     "dagr_add_relu": (ctypes.c_int, [c_void_p, c_void_p, c_i64, c_void_p]),

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(kChunk) void k_async_insert(const void *__restrict_
     if (p >= 0 && last) app_head[p] = first_id + i;
 }
 
-__global__ __launch_bounds__(kBlock) void k_async_fill(int n, int first_id, int n_static, int W, int H, int K, int Q, int r,
+__global__ __launch_bounds__(kBlock) void k_async_fill(int n, int first_id, int n_static, int W, int H, int B, int K, int Q, int r,
                                                       float delta_t, const int32_t *__restrict__ start,
                                                       const int2 *__restrict__ slot_it,
                                                       const int32_t *__restrict__ app_head,
@@ -134,7 +134,8 @@ __global__ __launch_bounds__(kBlock) void k_async_fill(int n, int first_id, int 
         nbr_src[row] = own;
         nbr_code[row] = (int16_t)(r * side + r);
     }
-    const bool inside = x >= 0 && x < W && y >= 0 && y < H;      // an event outside the sensor keeps only its self loop
+    // an event outside the sensor or the batch range (flagged by k_async_insert) keeps only its self loop
+    const bool inside = x >= 0 && x < W && y >= 0 && y < H && b >= 0 && b < B;
     for (int s0 = 0; s0 < S && total < K && inside; s0 += 16) {
         const int s = s0 + l;
         int v = 0, head = -1, a0 = 0, a1 = 0, code = 0;
@@ -234,7 +235,7 @@ int dagr_async_graph_append(const dagr_graph_desc *desc, void *graph_ws, int64_t
     }
     // the reference pushes the whole micro-batch into the queue before it searches (ev_graph.py:84-93): all chains first
     k_async_fill<<<(unsigned)ceil_div(n_new * 16, kBlock), kBlock, 0, stream>>>(
-        (int)n_new, (int)first_id, (int)n_static, W, H, desc->max_neighbors, desc->queue_size, desc->radius,
+        (int)n_new, (int)first_id, (int)n_static, W, H, desc->batch_size, desc->max_neighbors, desc->queue_size, desc->radius,
         (float)desc->delta_t_us, start, slot_it, app_head, app_next, (const int4 *)app_xytb, nbr_src, nbr_code, deg);
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;

@@ -1082,6 +1082,17 @@ int dagr_graph_status(const dagr_graph_desc *desc, void *workspace, int64_t *num
     return DAGR_OK;
 }
 
+int dagr_graph_counters(const dagr_graph_desc *desc, void *workspace, int32_t *out8_host, void *stream) {
+    int rc = validate(desc);
+    if (rc != DAGR_OK) return rc;
+    DAGR_CHECK_ARG(workspace != nullptr && out8_host != nullptr, "NULL pointer");
+    GraphWs ws;
+    carve(*desc, (char *)workspace, &ws);
+    DAGR_CHECK_HIP(hipMemcpyAsync(out8_host, ws.status, 32, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    DAGR_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return DAGR_OK;
+}
+
 size_t dagr_scan_scratch_elems(int64_t n) { return scan_scratch_elems(n); }
 
 int dagr_spiral_offsets(int32_t n, int32_t *dx_host, int32_t *dy_host) {

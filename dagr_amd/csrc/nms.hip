@@ -13,10 +13,6 @@ namespace {
 constexpr int kMaxAnchors = 1024;
 constexpr int kMaskAnchors = 256, kMaskWords = kMaskAnchors / 64;
 static_assert(kBlock >= kMaskAnchors, "the rank sort gives one thread to every key");
-// phase clocks of k_postprocess, image 0 (constant 100 MHz counter): written on every launch, read by
-// dagr_debug_postprocess_clocks -- builder instrumentation, a handful of scalar stores
-__device__ long long g_pp_clk[8];
-#define PP_CLK(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_pp_clk[k] = wall_clock64(); } while (0)
 
 // Greedy suppression over the score-sorted candidates (s_keep = candidate flags in, survivor flags out): box i, if still
 // alive when its turn comes, removes every later box j with IoU(i, j) > thr.  The chain over i is inherently sequential,
@@ -103,7 +99,6 @@ __device__ void greedy_suppress(int A, const float4 *s_box, int *s_keep, float t
         }
     }
     __syncthreads();
-    PP_CLK(6);
     if (wave == 0) {
         // The chain.  Everything here is wave-uniform: the removed-set lives in scalar registers, a block of 64 rows is
         // pulled from LDS once (lane l holds row 64 blk + l) and row `bit` is then broadcast with readlane -- no LDS
@@ -214,7 +209,6 @@ __global__ __launch_bounds__(kPostThreads) void k_postprocess(const float *__res
     const int b = blockIdx.x;
     const int ld = 5 + ncls;
     const float *p = pred + (size_t)b * A * ld;
-    PP_CLK(0);
     for (int i = threadIdx.x; i < Apad; i += kPostThreads) {
         bool ok = false;
         float sc = -INFINITY;
@@ -235,9 +229,7 @@ __global__ __launch_bounds__(kPostThreads) void k_postprocess(const float *__res
         s_idx[i] = i < A ? i : 0x7fffffff;
     }
     __syncthreads();
-    PP_CLK(1);
     sort_desc(A, Apad, s_key, s_idx, s_key2);
-    PP_CLK(2);
     for (int i = threadIdx.x; i < A; i += kPostThreads) {
         const bool ok = s_key[i] > -INFINITY;
         float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -251,9 +243,7 @@ __global__ __launch_bounds__(kPostThreads) void k_postprocess(const float *__res
         s_keep[i] = ok ? 1 : 0;
     }
     __syncthreads();
-    PP_CLK(3);
     greedy_suppress(A, s_box, s_keep, nms_thr, s_mask);
-    PP_CLK(4);
     // front-compaction: thread t owns the 4 consecutive sorted positions 4t .. 4t+3
     int mine[4], cnt = 0;
 #pragma unroll
@@ -277,7 +267,6 @@ __global__ __launch_bounds__(kPostThreads) void k_postprocess(const float *__res
         }
     }
     if (threadIdx.x == 0) n_keep[b] = total;
-    PP_CLK(5);
 }
 // collect_outputs + decode_outputs of the eval head (model/networks/dagr.py:283-312) for up to two scales in one launch:
 // dense maps [B, 5+C, Hs, Ws] (reg 4 | obj 1 | cls C, raw logits) -> out[B, A, 5+C] with A = sum Hs*Ws, anchors of a scale
@@ -336,12 +325,6 @@ extern "C" int dagr_postprocess(const float *pred, int32_t B, int32_t A, int32_t
     k_postprocess<<<B, kPostThreads, 0, (hipStream_t)stream>>>(pred, A, Apad, num_classes, conf_threshold, iou_threshold,
                                                          class_offset, det, n_keep);
     DAGR_CHECK_LAUNCH();
-    return DAGR_OK;
-}
-
-extern "C" int dagr_debug_postprocess_clocks(long long *out8) {
-    DAGR_CHECK_ARG(out8, "NULL pointer");
-    DAGR_CHECK_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_pp_clk), 8 * sizeof(long long)));
     return DAGR_OK;
 }
 

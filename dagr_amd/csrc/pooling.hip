@@ -35,9 +35,7 @@ namespace dagr {
 namespace {
 
 constexpr int kRowSlots = 64;           // coarse in-degree bound per cluster (flagged if exceeded)
-constexpr int kMaxChunks = 9;           // up to 144 feature channels at level 0
-constexpr int kCellCap = 256;           // members of a level-0 voxel walked by its own wave; the rest is split (k_pool_l0_overflow)
-constexpr int kOverWaves = 16;          // waves sharing the tail of an event-dense voxel
+constexpr int kMaxL0Channels = 512;     // feature channels of a level-0 pooling (LDS window: at least one voxel row)
 constexpr double kPosScale = 1099511627776.0;  // 2^40
 constexpr double kFeatScale = 4294967296.0;    // 2^32
 
@@ -51,11 +49,10 @@ struct PoolWs {
     long long *xacc;     // [T][C]: ordered-int max (low 32 bits) or fixed-point sum
     int32_t *rows;       // [T][64] source-cluster sets, -1 = empty (raw ids on the 3-launch path)
     int32_t *rowcnt;     // [T+1]
-    int32_t *status;     // [8]: 0 flags (sticky); 3 = #over_list (cleared by the scan / rearm); 4 = epoch
+    int32_t *status;     // [8]: 0 flags (sticky); 4 = epoch; 5 = level-0 nodes merged through the global path (sticky, cumulative)
     unsigned long long *nbmask;  // [T] level 0: 5x5 bitmaps of source cells, zero between calls: bits 0-24 cells of the
                                  // slot's own sample plane, bits 32-56 cells of the plane below (sources of the slot's
                                  // t == 1.0 members, QUIRK-1)
-    int32_t *over_list;  // [T] level 0: cells with more than kCellCap members (their tail is split over waves); count = status[3]
     int T;
 };
 
@@ -79,7 +76,6 @@ __host__ __device__ inline size_t pool_carve(const dagr_pool_desc &d, char *base
     w.rowcnt = (int32_t *)take((T + 32) * 4);
     w.status = (int32_t *)take(32);
     w.nbmask = (unsigned long long *)take((T + 9) * 8);
-    w.over_list = (int32_t *)take((T + 9) * 4);
     w.T = (int)T;
     if (ws) *ws = w;
     return off;
@@ -195,254 +191,275 @@ __global__ __launch_bounds__(kBlock) void k_pool_accumulate(dagr_pool_desc d, co
 }
 
 // ---------------------------------------------------------------------------------------------
-// level 0: one wave per source voxel (cx, cy, b).  The voxel's members are the slot runs of its pixel rows
-// (CSR-by-pixel): the row bounds are fetched by one lane per row in a single round, prefix-summed, and the
-// members are then walked as one flat list, 8 in flight (4 lane groups x 2, 16 lanes = 16 channels / 16
-// neighbour slots each) -- walking row by row instead costs two dependent HBM latencies per pixel row.
-template <int MC, int AGGR>   // accumulator chunks of 16 channels held in registers; 0 = max, 1 = mean
-__device__ __forceinline__ void pool_l0_cell(int cell, int i_first, int i_stride, int i_limit, bool list_overflow,
-                                             dagr_pool_desc d, int W, int H,
+// level 0, streaming form.  Nodes are CSR slots in (sample, y, x, time) order, so all voxels of one sample / voxel row
+// (a "band") own ONE contiguous run of slots, and their table ids are contiguous too (raw = cx + gx * (cy + gy * b)).
+// The kernel therefore never looks a member up: every workgroup streams a contiguous run of slots -- feature rows,
+// positions, ids, degrees and neighbour codes as fully coalesced reads -- and accumulates into an LDS window of VW
+// table slots that starts at the band of its first slot:
+//   phase B  one lane per node (64 nodes per wave step): voxel from two per-pixel LDS tables, count / largest id /
+//            64-bit fixed-point position sums as LDS atomics, the 5x5 source-cell bitmap from the node's neighbour codes;
+//   phase A  the step's 64 feature rows as one flat run of 16-byte pieces across the wave (lane f: node f / PPN, piece
+//            f % PPN), each piece merged by LDS atomics (ordered-int max / 64-bit fixed-point add).
+// Nodes outside the window (a run of a sparse window spans several bands) and t == 1.0 nodes (QUIRK-1: their cluster is
+// the same cell one sample plane up) go straight to the global accumulators; status[5] counts them (sticky).  At the end the
+// workgroup merges the voxels it touched into the global accumulators with one atomic per word: every reduction is
+// order-free (integer max / integer sums), so the result does not depend on how slots are cut into workgroups.
+// Before: one wave per voxel walking its members through a row table in LDS -- a chain of dependent loads per member,
+// 0.18 - 0.23 of HBM peak, and a second launch for the tails of event-dense voxels.
+struct PoolL0Lds {
+    int *acc;                    // [VW][C] ordered-int max, or [VW][C] u64 sums
+    int *cnt, *perm;             // [VW]
+    unsigned *nbm;               // [VW]
+    unsigned long long *ps;      // [VW][3]
+    unsigned short *xlut, *ylut; // [W], [H] voxel column / row of a pixel
+    short *sv;                   // [waves][64] window slot of the nodes of the wave's current step (-1: none)
+};
+
+template <int AGGR>
+__host__ __device__ inline size_t pool_l0_lds_bytes(int VW, int C, int W, int H) {
+    size_t b = (size_t)VW * C * (AGGR == 0 ? 4 : 8);
+    b += (size_t)VW * (4 + 4 + 4 + 24);
+    b += ((size_t)(W + H) * 2 + 7) / 8 * 8;
+    b += (kBlock / 64) * 64 * 2;
+    return b + 64;
+}
+
+template <int AGGR, int VEC>   // 0 = max, 1 = mean; VEC = floats per piece (4: rows are 16-byte aligned, 1: any layout)
+__global__ __launch_bounds__(kBlock) void k_pool_l0_slots(dagr_pool_desc d, int W, int H, int n_cap, int VW,
+                                                         const int32_t *__restrict__ n_ptr,
                                                          const int32_t *__restrict__ xlo,  // [gx+1] pixel bounds
                                                          const int32_t *__restrict__ ylo,  // [gy+1]
-                                                         const int32_t *__restrict__ start,
                                                          const int2 *__restrict__ slot_it,
+                                                         const int32_t *__restrict__ slot_xyb,
                                                          const float *__restrict__ x, int ldx,
                                                          const float *__restrict__ pos, PoolWs ws,
                                                          // coarse-edge fast path (NULL = off): neighbour offset codes
                                                          const int16_t *__restrict__ nbr_code,
                                                          const int32_t *__restrict__ nbr_src,
-                                                         const int32_t *__restrict__ deg,
-                                                         const int32_t *__restrict__ slot_xyb, int K, int r) {
-    __shared__ int s_a[kBlock / 64][64], s_off[kBlock / 64][65];
-    const int lane = threadIdx.x & 63, l = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
-    const int cx = cell % d.gx, cy = (cell / d.gx) % d.gy, b = cell / (d.gx * d.gy);
-    const int x0 = xlo[cx], x1 = xlo[cx + 1] - 1, y0 = ylo[cy], y1 = ylo[cy + 1] - 1;
+                                                         const int32_t *__restrict__ deg, int K, int r) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int n = min(*n_ptr, n_cap);
+    // every workgroup takes the same share of the nodes that are there (n comes from the device: the launch is sized
+    // for the capacity, so that a captured graph serves windows of any size)
+    const int per_block = max(256, (int)(((long long)n + gridDim.x - 1) / gridDim.x + 63) / 64 * 64);
+    const int s_begin = blockIdx.x * per_block;
+    if (s_begin >= n) return;
+    const int s_end = min(n, s_begin + per_block);
     const int C = d.channels;
-    const int nchk = (C + 15) >> 4;
-    float mx[AGGR == 0 ? MC : 1];
-    double sm[AGGR == 0 ? 1 : MC];
-#pragma unroll
-    for (int c = 0; c < MC; c++) {
-        if (AGGR == 0) mx[c] = -INFINITY;
-        else sm[c] = 0.0;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    PoolL0Lds L;
+    {
+        unsigned char *p = lds_raw;
+        L.acc = reinterpret_cast<int *>(p); p += (size_t)VW * C * (AGGR == 0 ? 4 : 8);
+        L.ps = reinterpret_cast<unsigned long long *>(p); p += (size_t)VW * 24;
+        L.cnt = reinterpret_cast<int *>(p); p += (size_t)VW * 4;
+        L.perm = reinterpret_cast<int *>(p); p += (size_t)VW * 4;
+        L.nbm = reinterpret_cast<unsigned *>(p); p += (size_t)VW * 4;
+        L.sv = reinterpret_cast<short *>(p); p += (kBlock / 64) * 64 * 2;
+        L.xlut = reinterpret_cast<unsigned short *>(p); p += (size_t)W * 2;
+        L.ylut = reinterpret_cast<unsigned short *>(p);
     }
-    long long ps0 = 0, ps1 = 0, ps2 = 0;
-    int cnt = 0, pmax = -1;
-    const int raw = cx + d.gx * (cy + d.gy * b);
+    for (int i = threadIdx.x; i < VW * C; i += kBlock) {
+        if (AGGR == 0) L.acc[i] = kEncMin;
+        else reinterpret_cast<unsigned long long *>(L.acc)[i] = 0ull;
+    }
+    for (int i = threadIdx.x; i < VW; i += kBlock) {
+        L.cnt[i] = 0; L.perm[i] = -1; L.nbm[i] = 0u;
+        L.ps[3 * i] = 0ull; L.ps[3 * i + 1] = 0ull; L.ps[3 * i + 2] = 0ull;
+    }
+    // pixel -> voxel column / row (cell c owns the pixels [lo[c], lo[c+1]): the host's fp32 division, tabulated)
+    for (int c = threadIdx.x; c < d.gx; c += kBlock)
+        for (int px = xlo[c]; px < min(xlo[c + 1], W); px++) L.xlut[px] = (unsigned short)c;
+    for (int c = threadIdx.x; c < d.gy; c += kBlock)
+        for (int py = ylo[c]; py < min(ylo[c + 1], H); py++) L.ylut[py] = (unsigned short)c;
+    __syncthreads();
+    const int cells = d.gx * d.gy;
+    int raw0;
+    {
+        const int c0 = slot_xyb[s_begin];
+        raw0 = d.gx * ((int)L.ylut[(c0 >> 12) & 4095] + d.gy * ((c0 >> 24) & 127));
+    }
     const int pair = ws_pair(ws);
     long long *w_possum = ws_possum(ws, pair);
     int32_t *w_cnt = ws_cnt(ws, pair);
-    // Coarse edges without a hash set: a source lies within r pixels of its destination, r <= 2 cells (checked by
-    // the caller), so the source cells of this voxel's in-edges form a 5x5 bitmap around it.  Lower pixel bounds
-    // of the cells cx-1 .. cx+2 (and rows): the source's cell = cx-2 + #(bounds <= its pixel).
-    int nbm = 0, nbm_up = 0, nbm_low = 0;   // this slot's sources; the slot above: sources in its own plane / in this one
-    int bx[4], by[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int qx = cx - 1 + i, qy = cy - 1 + i;
-        bx[i] = qx <= 0 ? INT_MIN : (qx >= d.gx ? INT_MAX : xlo[qx]);
-        by[i] = qy <= 0 ? INT_MIN : (qy >= d.gy ? INT_MAX : ylo[qy]);
-    }
     const int side = 2 * r + 1;
     const int side_magic = (65536 + side - 1) / side;   // code / side == (code * magic) >> 16 for code * side < 65536
-    const int cells = d.gx * d.gy;
-    const int ny = (x1 >= x0) ? y1 - y0 + 1 : 0;
-    for (int yb = 0; yb < ny; yb += 64) {
-        // row bounds of up to 64 pixel rows, one lane each; exclusive scan of the run lengths
-        int a = 0, len = 0;
-        if (yb + lane < ny) {
-            const int base = W * (y0 + yb + lane + H * b);
-            a = start[base + x0];
-            len = start[base + x1 + 1] - a;
-        }
-        int incl = len;
+    const int PPN = C / VEC;                            // pieces per node
+    // f / PPN == umulhi(f, ceil(2^32 / PPN)) for f * PPN < 2^32
+    const unsigned ppn_magic = PPN > 1 ? (unsigned)((0x100000000ull + (unsigned)PPN - 1) / (unsigned)PPN) : 0u;
+    int n_slow = 0;
+    for (int cs = s_begin + 64 * wv; cs < s_end; cs += 64 * (kBlock / 64)) {
+        // ---- phase B: one lane per node
+        const int s = cs + lane;
+        int vloc = -1;
+        if (s < s_end) {
+            const int c = slot_xyb[s];
+            const int xp = c & 4095, yp = (c >> 12) & 4095, b = (c >> 24) & 127;
+            const float px = pos[3 * (size_t)s], py = pos[3 * (size_t)s + 1], pt = pos[3 * (size_t)s + 2];
+            const int id = slot_it[s].x;       // event id: consecutive_cluster's `perm`
+            const int cx = L.xlut[xp], cy = L.ylut[yp];
+            const bool leak = pt >= 1.0f;
+            const int raw = cx + d.gx * (cy + d.gy * b);
+            const int rel = raw - raw0;
+            const bool inwin = !leak && rel >= 0 && rel < VW;
+            const unsigned long long q0 = (unsigned long long)(long long)llrint((double)px * kPosScale);
+            const unsigned long long q1 = (unsigned long long)(long long)llrint((double)py * kPosScale);
+            const unsigned long long q2 = (unsigned long long)(long long)llrint((double)pt * kPosScale);
+            // source cells of the node's in-edges: a source lies within r pixels of its destination, r <= 2 cells (checked
+            // by the caller), so they form a 5x5 bitmap around the node's voxel.  Lower pixel bounds of the cells
+            // cx-1 .. cx+2 (and rows): the source's cell = cx-2 + #(bounds <= its pixel).
+            unsigned nbm = 0, nbm_up = 0, nbm_low = 0;
+            if (nbr_code) {
+                int bx[4], by[4];
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int o = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += o;
-        }
-        const int total = __shfl(incl, 63, 64);
-        __builtin_amdgcn_wave_barrier();   // previous chunk's readers are done
-        s_a[wv][lane] = a;
-        s_off[wv][lane] = incl - len;
-        if (lane == 63) s_off[wv][64] = total;
-        __builtin_amdgcn_wave_barrier();
-        // 16 members in flight per wave (4 lane groups x 4): the walk is a chain of dependent loads (slot -> pos /
-        // neighbour codes / feature row), so its pace on event-dense voxels (S-edges: hundreds of members) is set by how
-        // many are outstanding
-        // a wave walks members [i_first, i_limit) in steps of i_stride: the voxel's own wave takes the first kCellCap, the
-        // tail of an event-dense voxel (S-edges: thousands of members) is listed and shared by kOverWaves waves
-        if (list_overflow && lane == 0 && total > i_limit) ws.over_list[atomicAdd(&ws.status[3], 1)] = cell;
-        const int i_end = min(total, i_limit);
-        for (int i0 = i_first; i0 < i_end; i0 += i_stride) {
-#pragma unroll
-            for (int h = 0; h < 4; h++) {
-                const int i = i0 + 4 * h + g;
-                if (i >= i_end) continue;
-                // row of member i: the last j with off[j] <= i (empty rows share their successor's offset)
-                int j = 0;
-#pragma unroll
-                for (int st = 32; st >= 1; st >>= 1)
-                    if (s_off[wv][j + st] <= i) j += st;
-                const int s = s_a[wv][j] + (i - s_off[wv][j]);
-                const int y = y0 + yb + j;
-                const int id = slot_it[s].x;   // event id: only for consecutive_cluster's `perm`
-                const float px = pos[3 * (size_t)s], py = pos[3 * (size_t)s + 1], pt = pos[3 * (size_t)s + 2];
-                const bool leak = pt >= 1.0f;
-                if (nbr_code && l < deg[s]) {
-                    const int code = nbr_code[(size_t)s * K + l];
-                    const int ox = (code * side_magic) >> 16, oy = code - ox * side;
-                    const int xs = (slot_xyb[s] & 4095) + ox - r, ys = y + oy - r;
-                    const int dcx = (xs >= bx[0]) + (xs >= bx[1]) + (xs >= bx[2]) + (xs >= bx[3]);   // 0..4, 2 = own cell
-                    const int dcy = (ys >= by[0]) + (ys >= by[1]) + (ys >= by[2]) + (ys >= by[3]);
-                    if (!leak) {
-                        nbm |= 1 << (dcy * 5 + dcx);
-                    } else {
-                        // QUIRK-1: a t == 1.0 node belongs to cluster raw + gx*gy (the same cell one sample plane up), so
-                        // its in-edges are that slot's: from this plane's cells, or -- sources that are t == 1.0 nodes
-                        // themselves -- from the slot's own plane
-                        const int src = nbr_src[(size_t)s * K + l];
-                        if (pos[3 * (size_t)src + 2] >= 1.0f) nbm_up |= 1 << (dcy * 5 + dcx);
-                        else nbm_low |= 1 << (dcy * 5 + dcx);
-                    }
+                for (int i = 0; i < 4; i++) {
+                    const int qx = cx - 1 + i, qy = cy - 1 + i;
+                    bx[i] = qx <= 0 ? INT_MIN : (qx >= d.gx ? INT_MAX : xlo[qx]);
+                    by[i] = qy <= 0 ? INT_MIN : (qy >= d.gy ? INT_MAX : ylo[qy]);
                 }
-                if (leak) {
-                    // QUIRK-1: t == 1.0 lands in the next sample's id range -> rare, atomics
-                    const int rl = raw + cells;
+                const int dg = min(deg[s], K);
+                int codes[16];
+                if (K == 16) {
+                    const int4 lo4 = *reinterpret_cast<const int4 *>(nbr_code + (size_t)s * 16);
+                    const int4 hi4 = *reinterpret_cast<const int4 *>(nbr_code + (size_t)s * 16 + 8);
+                    const int w8[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
 #pragma unroll
-                    for (int c = 0; c < MC; c++) {
-                        const int ch = c * 16 + l;
-                        if (c < nchk && ch < C) {
-                            const float v = x[(size_t)s * ldx + ch];
-                            if (AGGR == 0)
-                                atomicMax(reinterpret_cast<int *>(ws.xacc + (size_t)rl * C + ch), enc_f(v));
-                            else
-                                atomicAdd(reinterpret_cast<unsigned long long *>(ws.xacc + (size_t)rl * C + ch),
-                                          (unsigned long long)(long long)llrint((double)v * kFeatScale));
+                    for (int j = 0; j < 8; j++) { codes[2 * j] = (short)(w8[j] & 0xffff); codes[2 * j + 1] = w8[j] >> 16; }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; j++) codes[j] = j < dg ? (int)nbr_code[(size_t)s * K + j] : 0;
+                }
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    if (j < dg) {
+                        const int code = codes[j];
+                        const int ox = (code * side_magic) >> 16, oy = code - ox * side;
+                        const int xs = xp + ox - r, ys = yp + oy - r;
+                        const int dcx = (xs >= bx[0]) + (xs >= bx[1]) + (xs >= bx[2]) + (xs >= bx[3]);   // 0..4, 2 = own cell
+                        const int dcy = (ys >= by[0]) + (ys >= by[1]) + (ys >= by[2]) + (ys >= by[3]);
+                        const unsigned bit = 1u << (dcy * 5 + dcx);
+                        if (!leak) {
+                            nbm |= bit;
+                        } else {
+                            // QUIRK-1: a t == 1.0 node belongs to cluster raw + gx*gy (the same cell one sample plane up),
+                            // so its in-edges are that slot's: from this plane's cells, or -- sources that are t == 1.0
+                            // nodes themselves -- from the slot's own plane
+                            const int src = nbr_src[(size_t)s * K + j];
+                            if (pos[3 * (size_t)src + 2] >= 1.0f) nbm_up |= bit;
+                            else nbm_low |= bit;
                         }
                     }
-                    if (l == 0) {
-                        ws.occupied[rl] = 1;
-                        atomicAdd(&w_cnt[rl], 1);
-                        atomicMax(&ws.perm[rl], id);
-                        atomicAdd(reinterpret_cast<unsigned long long *>(w_possum + (size_t)rl * 3 + 0),
-                                  (unsigned long long)(long long)llrint((double)px * kPosScale));
-                        atomicAdd(reinterpret_cast<unsigned long long *>(w_possum + (size_t)rl * 3 + 1),
-                                  (unsigned long long)(long long)llrint((double)py * kPosScale));
-                        atomicAdd(reinterpret_cast<unsigned long long *>(w_possum + (size_t)rl * 3 + 2),
-                                  (unsigned long long)(long long)llrint((double)pt * kPosScale));
-                    }
-                    continue;
                 }
-#pragma unroll
-                for (int c = 0; c < MC; c++) {
-                    const int ch = c * 16 + l;
-                    if (c < nchk && ch < C) {
-                        const float v = x[(size_t)s * ldx + ch];
-                        if (AGGR == 0) mx[c] = fmaxf(mx[c], v);
-                        else sm[c] += (double)(long long)llrint((double)v * kFeatScale);
-                    }
+                nbm &= ~(1u << 12);      // own cell = self loops
+                nbm_up &= ~(1u << 12);
+            }
+            if (inwin) {
+                vloc = rel;
+                atomicAdd(&L.cnt[rel], 1);
+                atomicMax(&L.perm[rel], id);
+                atomicAdd(&L.ps[3 * rel], q0);
+                atomicAdd(&L.ps[3 * rel + 1], q1);
+                atomicAdd(&L.ps[3 * rel + 2], q2);
+                if (nbm) atomicOr(&L.nbm[rel], nbm);
+            } else {
+                // outside the window, or a t == 1.0 node: this lane merges its node into the global accumulators
+                const int rl = leak ? raw + cells : raw;
+                n_slow++;
+                for (int ch = 0; ch < C; ch++) {
+                    const float v = x[(size_t)s * ldx + ch];
+                    if (AGGR == 0)
+                        atomicMax(reinterpret_cast<int *>(ws.xacc + (size_t)rl * C + ch), enc_f(v));
+                    else
+                        atomicAdd(reinterpret_cast<unsigned long long *>(ws.xacc + (size_t)rl * C + ch),
+                                  (unsigned long long)(long long)llrint((double)v * kFeatScale));
                 }
-                ps0 += (long long)llrint((double)px * kPosScale);
-                ps1 += (long long)llrint((double)py * kPosScale);
-                ps2 += (long long)llrint((double)pt * kPosScale);
-                cnt++;
-                pmax = max(pmax, id);
+                ws.occupied[rl] = 1;
+                atomicAdd(&w_cnt[rl], 1);
+                atomicMax(&ws.perm[rl], id);
+                atomicAdd(reinterpret_cast<unsigned long long *>(w_possum + (size_t)rl * 3 + 0), q0);
+                atomicAdd(reinterpret_cast<unsigned long long *>(w_possum + (size_t)rl * 3 + 1), q1);
+                atomicAdd(reinterpret_cast<unsigned long long *>(w_possum + (size_t)rl * 3 + 2), q2);
+                if (!leak) {
+                    if (nbm) atomicOr(&ws.nbmask[rl], (unsigned long long)nbm);
+                } else if (nbm_up | nbm_low) {
+                    atomicOr(&ws.nbmask[rl], ((unsigned long long)nbm_low << 32) | nbm_up);
+                }
             }
         }
-    }
-    // combine the 4 event groups (lanes l, l+16, l+32, l+48 hold the same channel)
-#pragma unroll
-    for (int off = 16; off < 64; off <<= 1) {
-#pragma unroll
-        for (int c = 0; c < MC; c++) {
-            if (c < nchk) {
-                if (AGGR == 0) mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], off, 64));
-                else sm[c] += __shfl_xor(sm[c], off, 64);
-            }
-        }
-        ps0 += __shfl_xor(ps0, off, 64);
-        ps1 += __shfl_xor(ps1, off, 64);
-        ps2 += __shfl_xor(ps2, off, 64);
-        cnt += __shfl_xor(cnt, off, 64);
-        pmax = max(pmax, __shfl_xor(pmax, off, 64));
-    }
-    if (nbr_code) {
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            nbm |= __shfl_xor(nbm, off, 64);
-            nbm_up |= __shfl_xor(nbm_up, off, 64);
-            nbm_low |= __shfl_xor(nbm_low, off, 64);
-        }
-        nbm &= ~(1 << 12);      // own cell = self loops
-        nbm_up &= ~(1 << 12);
-        if (lane == 0 && nbm) atomicOr(&ws.nbmask[raw], (unsigned long long)(unsigned)nbm);
-        if (lane == 0 && (nbm_up | nbm_low))
-            atomicOr(&ws.nbmask[raw + cells], ((unsigned long long)(unsigned)nbm_low << 32) | (unsigned)nbm_up);
-    }
-    if (cnt > 0 && g == 0) {
-        // this wave is the only non-atomic writer of slot `raw`; leak events of sample b-1 may hit it
-        // concurrently with atomics, so merge with atomics as well (exactly-once per channel).
-#pragma unroll
-        for (int c = 0; c < MC; c++) {
-            const int ch = c * 16 + l;
-            if (c < nchk && ch < C) {
-                if (AGGR == 0)
-                    atomicMax(reinterpret_cast<int *>(ws.xacc + (size_t)raw * C + ch), enc_f(mx[c]));
-                else
-                    atomicAdd(reinterpret_cast<unsigned long long *>(ws.xacc + (size_t)raw * C + ch),
-                              (unsigned long long)(long long)sm[c]);
-            }
-        }
-        if (l == 0) {
-            ws.occupied[raw] = 1;
-            atomicAdd(&w_cnt[raw], cnt);
-            atomicMax(&ws.perm[raw], pmax);
-            atomicAdd(reinterpret_cast<unsigned long long *>(w_possum + (size_t)raw * 3 + 0), (unsigned long long)ps0);
-            atomicAdd(reinterpret_cast<unsigned long long *>(w_possum + (size_t)raw * 3 + 1), (unsigned long long)ps1);
-            atomicAdd(reinterpret_cast<unsigned long long *>(w_possum + (size_t)raw * 3 + 2), (unsigned long long)ps2);
-        }
-    }
-}
-
-
-template <int MC, int AGGR>
-__global__ __launch_bounds__(kBlock) void k_pool_l0_cells(dagr_pool_desc d, int W, int H, const int32_t *__restrict__ xlo,
-                                                         const int32_t *__restrict__ ylo,
-                                                         const int32_t *__restrict__ start,
-                                                         const int2 *__restrict__ slot_it, const float *__restrict__ x,
-                                                         int ldx, const float *__restrict__ pos, PoolWs ws,
-                                                         const int16_t *__restrict__ nbr_code,
-                                                         const int32_t *__restrict__ nbr_src,
-                                                         const int32_t *__restrict__ deg,
-                                                         const int32_t *__restrict__ slot_xyb, int K, int r) {
-    const int cell = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    if (cell >= d.gx * d.gy * d.batch_size) return;
-    pool_l0_cell<MC, AGGR>(cell, 0, 16, kCellCap, true, d, W, H, xlo, ylo, start, slot_it, x, ldx, pos, ws, nbr_code, nbr_src,
-                           deg, slot_xyb, K, r);
-}
-
-// tails of the listed event-dense voxels: kOverWaves waves per voxel, persistent over the list
-template <int MC, int AGGR>
-__global__ __launch_bounds__(kBlock) void k_pool_l0_overflow(dagr_pool_desc d, int W, int H,
-                                                            const int32_t *__restrict__ xlo,
-                                                            const int32_t *__restrict__ ylo,
-                                                            const int32_t *__restrict__ start,
-                                                            const int2 *__restrict__ slot_it,
-                                                            const float *__restrict__ x, int ldx,
-                                                            const float *__restrict__ pos, PoolWs ws,
-                                                            const int16_t *__restrict__ nbr_code,
-                                                            const int32_t *__restrict__ nbr_src,
-                                                            const int32_t *__restrict__ deg,
-                                                            const int32_t *__restrict__ slot_xyb, int K, int r) {
-    const int n_items = ws.status[3] * kOverWaves;
-    const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    const int n_waves = gridDim.x * (kBlock / 64);
-    for (int it = wave; it < n_items; it += n_waves) {
-        const int cell = ws.over_list[it / kOverWaves], part = it % kOverWaves;
-        pool_l0_cell<MC, AGGR>(cell, kCellCap + 16 * part, 16 * kOverWaves, INT_MAX, false, d, W, H, xlo, ylo, start, slot_it,
-                               x, ldx, pos, ws, nbr_code, nbr_src, deg, slot_xyb, K, r);
+        L.sv[wv * 64 + lane] = (short)vloc;
         __builtin_amdgcn_wave_barrier();
+        // ---- phase A: the step's feature rows as one flat run of pieces
+        const float *xrow = x + (size_t)cs * ldx;
+        constexpr int U = 4;
+        for (int f0 = 0; f0 < 64 * PPN; f0 += 64 * U) {
+            float val[U][VEC];
+            int tgt[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int f = f0 + 64 * u + lane;
+                tgt[u] = -1;
+                if (f < 64 * PPN) {
+                    const int k = PPN > 1 ? (int)__umulhi((unsigned)f, ppn_magic) : f, p = f - k * PPN;
+                    const int v = L.sv[wv * 64 + k];
+                    if (v >= 0) {
+                        tgt[u] = v * C + p * VEC;
+                        if constexpr (VEC == 4) {
+                            const float4 q = *reinterpret_cast<const float4 *>(xrow + (size_t)k * ldx + 4 * p);
+                            val[u][0] = q.x; val[u][1] = q.y; val[u][2] = q.z; val[u][3] = q.w;
+                        } else {
+                            val[u][0] = xrow[(size_t)k * ldx + p];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (tgt[u] >= 0) {
+#pragma unroll
+                    for (int j = 0; j < VEC; j++) {
+                        if (AGGR == 0)
+                            atomicMax(&L.acc[tgt[u] + j], enc_f(val[u][j]));
+                        else
+                            atomicAdd(reinterpret_cast<unsigned long long *>(L.acc) + tgt[u] + j,
+                                      (unsigned long long)(long long)llrint((double)val[u][j] * kFeatScale));
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();   // the step's window slots are re-used by the next step
+    }
+    __syncthreads();
+    // ---- merge the touched voxels into the global accumulators (leak nodes of the sample below and other workgroups
+    //      hit the same slots concurrently: atomics, exactly once per word)
+    const int T = ws.T;
+    for (int i = threadIdx.x; i < VW * C; i += kBlock) {
+        const int v = i / C;
+        if (L.cnt[v] > 0 && raw0 + v < T) {
+            const size_t o = (size_t)(raw0 + v) * C + (i - v * C);
+            if (AGGR == 0) atomicMax(reinterpret_cast<int *>(ws.xacc + o), L.acc[i]);
+            else atomicAdd(reinterpret_cast<unsigned long long *>(ws.xacc + o),
+                           reinterpret_cast<unsigned long long *>(L.acc)[i]);
+        }
+    }
+    for (int v = threadIdx.x; v < VW; v += kBlock) {
+        const int c = L.cnt[v];
+        if (c > 0 && raw0 + v < T) {
+            const int raw = raw0 + v;
+            ws.occupied[raw] = 1;
+            atomicAdd(&w_cnt[raw], c);
+            atomicMax(&ws.perm[raw], L.perm[v]);
+            atomicAdd(reinterpret_cast<unsigned long long *>(w_possum + (size_t)raw * 3 + 0), L.ps[3 * v]);
+            atomicAdd(reinterpret_cast<unsigned long long *>(w_possum + (size_t)raw * 3 + 1), L.ps[3 * v + 1]);
+            atomicAdd(reinterpret_cast<unsigned long long *>(w_possum + (size_t)raw * 3 + 2), L.ps[3 * v + 2]);
+            if (L.nbm[v]) atomicOr(&ws.nbmask[raw], (unsigned long long)L.nbm[v]);
+        }
+    }
+    // sticky counter of the nodes that took the global path (tests assert that it ran where it should)
+    {
+        int tot = n_slow;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) tot += __shfl_xor(tot, off, 64);
+        if (lane == 0 && tot) atomicAdd(&ws.status[5], tot);
     }
 }
 
@@ -533,7 +550,6 @@ __global__ __launch_bounds__(kBlock) void k_pool_rearm(int T, PoolWs ws) {
     ws_cnt(ws, ws_pair(ws))[raw] = 0;
     ws.perm[raw] = -1;
     ws.nbmask[raw] = 0ull;
-    if (raw == 0) ws.status[3] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -756,7 +772,6 @@ __global__ __launch_bounds__(1024) void k_pool_scan(PoolWs ws, int32_t *__restri
     if (threadIdx.x == 0) {
         *n_out = nc;
         *e_out = ne;
-        ws.status[3] = 0;
         if (!KEEP) ws.status[4] ^= 1;   // the next call fills the other accumulator pair; launch (C) reads the one just filled
     }
 }
@@ -950,6 +965,40 @@ int validate_pool(const dagr_pool_desc *d) {
     DAGR_CHECK_ARG(d->vx > 0 && d->vy > 0 && d->two_max > 0, "bad voxel size / cartesian max");
     return DAGR_OK;
 }
+
+// level-0 accumulation: k_pool_l0_slots over the graph builder's slot arrays.  The grid is sized for `n_cap` nodes; the
+// kernel reads the node count from the builder's workspace (start[P]) and shares the nodes that are there among all
+// workgroups, so a launch captured in a HIP graph serves windows of any size up to n_cap.
+int launch_pool_l0_slots(const dagr_pool_desc *desc, const dagr_graph_desc *gdesc, void *graph_ws, const int32_t *xlo,
+                         const int32_t *ylo, const float *x, int ldx, const float *pos, const PoolWs &ws,
+                         const int16_t *nbr_code, const int32_t *nbr_src, const int32_t *deg, int64_t n_cap,
+                         hipStream_t stream) {
+    const int32_t *start; const int2 *slot_it;
+    graph_ws_views(gdesc, graph_ws, &start, &slot_it);
+    const int32_t *slot_xyb = graph_ws_slot_xyb(gdesc, graph_ws);
+    const int32_t *n_ptr = graph_ws_node_count(gdesc, graph_ws);
+    const int C = desc->channels, W = gdesc->width, H = gdesc->height, K = gdesc->max_neighbors;
+    const bool vec4 = C % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0;
+    // LDS window: two voxel rows at least where they fit; 24 KB (six workgroups per CU) when that holds them, else up to
+    // 46 KB (three workgroups per CU)
+    const size_t per_slot = (size_t)C * (desc->aggr == 0 ? 4 : 8) + 36;
+    const size_t budget = (per_slot * 2 * desc->gx <= 24 * 1024 ? 24 : 46) * 1024 - (size_t)(W + H) * 2 - 1024;
+    int VW = (int)std::min<size_t>(1024, budget / per_slot);
+    VW = std::max(VW, desc->gx) / 2 * 2 + 2;
+    const size_t lds = desc->aggr == 0 ? pool_l0_lds_bytes<0>(VW, C, W, H) : pool_l0_lds_bytes<1>(VW, C, W, H);
+    DAGR_CHECK_ARG(lds <= 64 * 1024, "level-0 pooling: one voxel row of accumulators does not fit the LDS window");
+    DAGR_CHECK_ARG(desc->gx < 65536 && desc->gy < 65536 && VW < 32768, "voxel grid too large for the level-0 pooling kernel");
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(4 * device_cu_count(), ceil_div(n_cap, 256)));
+#define DAGR_POOL_L0_LAUNCH(AG, VEC)                                                                                  \
+    k_pool_l0_slots<AG, VEC><<<grid, kBlock, lds, stream>>>(*desc, W, H, (int)n_cap, VW, n_ptr, xlo, ylo, slot_it,      \
+                                                             slot_xyb, x, ldx, pos, ws, nbr_code, nbr_src, deg, K,      \
+                                                             gdesc->radius)
+    if (desc->aggr == 0) { if (vec4) DAGR_POOL_L0_LAUNCH(0, 4); else DAGR_POOL_L0_LAUNCH(0, 1); }
+    else                 { if (vec4) DAGR_POOL_L0_LAUNCH(1, 4); else DAGR_POOL_L0_LAUNCH(1, 1); }
+#undef DAGR_POOL_L0_LAUNCH
+    DAGR_CHECK_LAUNCH();
+    return DAGR_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -979,7 +1028,6 @@ int dagr_pool_workspace_init(const dagr_pool_desc *desc, void *workspace, size_t
     DAGR_CHECK_HIP(hipMemsetAsync(ws.rowcnt, 0, (T + 32) * 4, stream));
     DAGR_CHECK_HIP(hipMemsetAsync(ws.status, 0, 32, stream));
     DAGR_CHECK_HIP(hipMemsetAsync(ws.nbmask, 0, (T + 9) * 8, stream));
-    DAGR_CHECK_HIP(hipMemsetAsync(ws.over_list, 0, (T + 9) * 4, stream));
     // feature accumulators: ordered-int minimum for max, 0 for mean
     {
         const size_t n = T * (size_t)desc->channels;
@@ -1022,7 +1070,7 @@ int dagr_pool_l0(const dagr_pool_desc *desc, void *pool_ws, const dagr_graph_des
     int rc = validate_pool(desc);
     if (rc != DAGR_OK) return rc;
     DAGR_CHECK_ARG(pool_ws && gdesc && graph_ws, "NULL workspace/desc");
-    DAGR_CHECK_ARG(desc->channels <= 16 * kMaxChunks, "too many channels for the level-0 pooling kernel");
+    DAGR_CHECK_ARG(desc->channels <= kMaxL0Channels, "too many channels for the level-0 pooling kernel");
     DAGR_CHECK_ARG(desc->batch_size == gdesc->batch_size, "batch_size mismatch");
     DAGR_CHECK_ARG(n_out && rowptr_out && e_out, "NULL output");
     hipStream_t stream = (hipStream_t)stream_;
@@ -1039,29 +1087,9 @@ int dagr_pool_l0(const dagr_pool_desc *desc, void *pool_ws, const dagr_graph_des
                             gdesc->width <= 4096;
     if (N > 0) {
         DAGR_CHECK_ARG(xlo && ylo && x && pos && batch_nodes && batch && nbr_src && deg && cluster_scratch, "NULL input");
-        const int32_t *start; const int2 *slot_it;
-        graph_ws_views(gdesc, graph_ws, &start, &slot_it);
-        const int ncell = desc->gx * desc->gy * desc->batch_size;
-        const int nchk = (desc->channels + 15) / 16;
-#define DAGR_POOL_L0_A(MC, AG)                                                                                        \
-    k_pool_l0_cells<MC, AG><<<(unsigned)ceil_div(ncell, kBlock / 64), kBlock, 0, stream>>>(                           \
-        *desc, gdesc->width, gdesc->height, xlo, ylo, start, slot_it, x, ldx, pos, ws, fast_edges ? nbr_code : nullptr, \
-        nbr_src, deg, graph_ws_slot_xyb(gdesc, graph_ws), K, gdesc->radius);                                         \
-    k_pool_l0_overflow<MC, AG><<<(unsigned)(2 * device_cu_count()), kBlock, 0, stream>>>(                             \
-        *desc, gdesc->width, gdesc->height, xlo, ylo, start, slot_it, x, ldx, pos, ws, fast_edges ? nbr_code : nullptr, \
-        nbr_src, deg, graph_ws_slot_xyb(gdesc, graph_ws), K, gdesc->radius)
-#define DAGR_POOL_L0(MC)                                                                                              \
-    do {                                                                                                              \
-        if (desc->aggr == 0) { DAGR_POOL_L0_A(MC, 0); }                                                               \
-        else { DAGR_POOL_L0_A(MC, 1); }                                                                               \
-    } while (0)
-        if (nchk <= 1) DAGR_POOL_L0(1);
-        else if (nchk <= 2) DAGR_POOL_L0(2);
-        else if (nchk <= 5) DAGR_POOL_L0(5);
-        else DAGR_POOL_L0(kMaxChunks);
-#undef DAGR_POOL_L0
-#undef DAGR_POOL_L0_A
-        DAGR_CHECK_LAUNCH();
+        rc = launch_pool_l0_slots(desc, gdesc, graph_ws, xlo, ylo, x, ldx, pos, ws, fast_edges ? nbr_code : nullptr, nbr_src,
+                                  deg, N, stream);
+        if (rc != DAGR_OK) return rc;
     }
     if (fast_edges) {
         // (S) ids + row pointers from the occupancy flags and the bitmap populations, (C) nodes + CSR rows
@@ -1100,7 +1128,7 @@ int dagr_pool_l0_stream(const dagr_pool_desc *desc, void *pool_ws, int32_t rebui
     int rc = validate_pool(desc);
     if (rc != DAGR_OK) return rc;
     DAGR_CHECK_ARG(pool_ws && gdesc && graph_ws, "NULL workspace/desc");
-    DAGR_CHECK_ARG(desc->channels <= 16 * kMaxChunks, "too many channels for the level-0 pooling kernel");
+    DAGR_CHECK_ARG(desc->channels <= kMaxL0Channels, "too many channels for the level-0 pooling kernel");
     DAGR_CHECK_ARG(desc->batch_size == gdesc->batch_size, "batch_size mismatch");
     DAGR_CHECK_ARG(n_out && rowptr_out && e_out && xlo && ylo && x && pos && batch_events && nbr_src && nbr_code && deg,
                    "NULL pointer");
@@ -1119,29 +1147,9 @@ int dagr_pool_l0_stream(const dagr_pool_desc *desc, void *pool_ws, int32_t rebui
         rc = dagr_pool_workspace_init(desc, pool_ws, pool_carve(*desc, nullptr, nullptr), stream_);
         if (rc != DAGR_OK) return rc;
         if (n_window > 0) {
-            const int32_t *start; const int2 *slot_it;
-            graph_ws_views(gdesc, graph_ws, &start, &slot_it);
-            const int ncell = desc->gx * desc->gy * desc->batch_size;
-            const int nchk = (desc->channels + 15) / 16;
-#define DAGR_POOL_L0_A(MC, AG)                                                                                        \
-    k_pool_l0_cells<MC, AG><<<(unsigned)ceil_div(ncell, kBlock / 64), kBlock, 0, stream>>>(                           \
-        *desc, gdesc->width, gdesc->height, xlo, ylo, start, slot_it, x, ldx, pos, ws, nbr_code, nbr_src, deg,        \
-        graph_ws_slot_xyb(gdesc, graph_ws), K, gdesc->radius);                                                        \
-    k_pool_l0_overflow<MC, AG><<<(unsigned)(2 * device_cu_count()), kBlock, 0, stream>>>(                             \
-        *desc, gdesc->width, gdesc->height, xlo, ylo, start, slot_it, x, ldx, pos, ws, nbr_code, nbr_src, deg,        \
-        graph_ws_slot_xyb(gdesc, graph_ws), K, gdesc->radius)
-#define DAGR_POOL_L0(MC)                                                                                              \
-    do {                                                                                                              \
-        if (desc->aggr == 0) { DAGR_POOL_L0_A(MC, 0); }                                                               \
-        else { DAGR_POOL_L0_A(MC, 1); }                                                                               \
-    } while (0)
-            if (nchk <= 1) DAGR_POOL_L0(1);
-            else if (nchk <= 2) DAGR_POOL_L0(2);
-            else if (nchk <= 5) DAGR_POOL_L0(5);
-            else DAGR_POOL_L0(kMaxChunks);
-#undef DAGR_POOL_L0
-#undef DAGR_POOL_L0_A
-            DAGR_CHECK_LAUNCH();
+            rc = launch_pool_l0_slots(desc, gdesc, graph_ws, xlo, ylo, x, ldx, pos, ws, nbr_code, nbr_src, deg, n_window,
+                                      stream);
+            if (rc != DAGR_OK) return rc;
             k_pool_perm_keys<<<(unsigned)ceil_div(T, kBlock), kBlock, 0, stream>>>(T, batch_events, ws);
             DAGR_CHECK_LAUNCH();
         }
@@ -1194,6 +1202,17 @@ int dagr_pool_status(const dagr_pool_desc *desc, void *pool_ws, int32_t *flags_h
     PoolWs ws;
     pool_carve(*desc, (char *)pool_ws, &ws);
     DAGR_CHECK_HIP(hipMemcpyAsync(flags_host, ws.status, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    DAGR_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return DAGR_OK;
+}
+
+int dagr_pool_counters(const dagr_pool_desc *desc, void *pool_ws, int32_t *out8_host, void *stream) {
+    int rc = validate_pool(desc);
+    if (rc != DAGR_OK) return rc;
+    DAGR_CHECK_ARG(pool_ws && out8_host, "NULL pointer");
+    PoolWs ws;
+    pool_carve(*desc, (char *)pool_ws, &ws);
+    DAGR_CHECK_HIP(hipMemcpyAsync(out8_host, ws.status, 32, hipMemcpyDeviceToHost, (hipStream_t)stream));
     DAGR_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
     return DAGR_OK;
 }

@@ -358,412 +358,6 @@ __global__ __launch_bounds__(kBlock, 4) void k_conv_l0(int N, int K, int ncodes,
     }
 }
 
-// Narrow-input variant (CIN <= 4, no skip branch: conv_block1.conv_block1 of the events-only model,
-// 3 -> 16).  With 3 input channels the channel-per-lane mapping above leaves 13 of 16 lanes idle, so
-// here lane k owns kernel tap k of the window (NT <= 15) and lane NT owns the root weight:
-//   A_k[i] = sum_j tab[code_j][k] * x_j[i]   (one LDS word + CIN FMAs per edge and lane),
-// then every lane contracts its CIN rows of the packed weights and the same 16-lane transpose-reduce
-// produces the 16 outputs.
-template <int CIN, int NT>
-__global__ __launch_bounds__(kBlock) void k_conv_l0_narrow(int N, int K, int ncodes,
-                                                          const int32_t *__restrict__ nbr_src,
-                                                          const int16_t *__restrict__ nbr_code,
-                                                          const int32_t *__restrict__ deg,
-                                                          const float *__restrict__ x, int ldx,
-                                                          const float *__restrict__ tab,    // [ncodes][NTP]
-                                                          const float *__restrict__ wpack,  // [(NT+1)*CIN][16]
-                                                          const float *__restrict__ shift, int relu,
-                                                          float *__restrict__ out, int ldo) {
-    static_assert(NT <= 15 && CIN <= 4, "tap-per-lane mapping needs NT+1 <= 16 lanes");
-    constexpr int NTP = (NT + 3) / 4 * 4;
-    constexpr int NROWS = (NT + 1) * CIN;
-    extern __shared__ __align__(16) float lds[];
-    float *w_s = lds;
-    float *tab_s = lds + NROWS * kL0RowStride;
-    for (int i = threadIdx.x; i < NROWS * kL0Out; i += kBlock)
-        w_s[(i >> 4) * kL0RowStride + (i & 15)] = wpack[i];
-    for (int i = threadIdx.x; i < ncodes * NTP; i += kBlock) tab_s[i] = tab[i];
-    __syncthreads();
-    const int l = threadIdx.x & 15;
-    const int groups_per_block = kBlock / 16;
-    const float my_shift = shift[l];
-    const XcdSplit xs = xcd_split(N, groups_per_block, threadIdx.x >> 4);
-    // The chain deg/neighbour row -> source rows -> output is three HBM latencies per node and this kernel is
-    // latency-bound: the next node's degree and neighbour row are fetched one iteration ahead (the row is
-    // K entries long whatever the degree, so it is read without waiting for the degree).
-    int d_nx = 0, src_nx = 0, code_nx = 0;
-    auto prefetch = [&](int n) {
-        if (n < xs.end) {
-            d_nx = deg[n];
-            if (l < K) { src_nx = nbr_src[(int64_t)n * K + l]; code_nx = nbr_code[(int64_t)n * K + l]; }
-        }
-    };
-    prefetch(xs.first);
-    for (int n = xs.first; n < xs.end; n += xs.stride) {
-        const int d = d_nx, src0 = src_nx, code0 = code_nx;
-        prefetch(n + xs.stride);
-        const int64_t row = (int64_t)n * K;
-        float A[CIN];
-#pragma unroll
-        for (int i = 0; i < CIN; i++) A[i] = 0.0f;
-        for (int j0 = 0; j0 < d; j0 += 16) {
-            int my_src = src0, my_code = code0;
-            if (j0 > 0) {
-                my_src = my_code = 0;
-                if (j0 + l < d) { my_src = nbr_src[row + j0 + l]; my_code = nbr_code[row + j0 + l]; }
-            }
-            const int cnt = min(16, d - j0);
-            float v[16][CIN];
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const int src = __shfl(my_src, j, 16);
-#pragma unroll
-                for (int i = 0; i < CIN; i++) v[j][i] = (j < cnt) ? x[(size_t)src * ldx + i] : 0.0f;
-            }
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                if (j < cnt) {
-                    const int code = __shfl(my_code, j, 16);
-                    const float tk = (l < NTP) ? tab_s[code * NTP + l] : 0.0f;   // pad columns are zero
-#pragma unroll
-                    for (int i = 0; i < CIN; i++) A[i] = fmaf(tk, v[j][i], A[i]);
-                }
-            }
-        }
-        if (l == NT) {
-#pragma unroll
-            for (int i = 0; i < CIN; i++) A[i] = x[(size_t)n * ldx + i];   // root weight rows
-        }
-        float p[16];
-#pragma unroll
-        for (int o = 0; o < 16; o++) p[o] = 0.0f;
-        if (l <= NT) {
-#pragma unroll
-            for (int i = 0; i < CIN; i++) {
-                const float4 *w4 = reinterpret_cast<const float4 *>(w_s + (l * CIN + i) * kL0RowStride);
-                const float4 w0 = w4[0], w1 = w4[1], w2 = w4[2], w3 = w4[3];
-                const float a = A[i];
-                p[0] = fmaf(a, w0.x, p[0]); p[1] = fmaf(a, w0.y, p[1]); p[2] = fmaf(a, w0.z, p[2]); p[3] = fmaf(a, w0.w, p[3]);
-                p[4] = fmaf(a, w1.x, p[4]); p[5] = fmaf(a, w1.y, p[5]); p[6] = fmaf(a, w1.z, p[6]); p[7] = fmaf(a, w1.w, p[7]);
-                p[8] = fmaf(a, w2.x, p[8]); p[9] = fmaf(a, w2.y, p[9]); p[10] = fmaf(a, w2.z, p[10]); p[11] = fmaf(a, w2.w, p[11]);
-                p[12] = fmaf(a, w3.x, p[12]); p[13] = fmaf(a, w3.y, p[13]); p[14] = fmaf(a, w3.z, p[14]); p[15] = fmaf(a, w3.w, p[15]);
-            }
-        }
-        float q8[8], q4[4], q2[2], r;
-        {
-            const bool hi = (l & 8) != 0;
-#pragma unroll
-            for (int m = 0; m < 8; m++) q8[m] = (hi ? p[m + 8] : p[m]) + __shfl_xor(hi ? p[m] : p[m + 8], 8, 16);
-        }
-        {
-            const bool hi = (l & 4) != 0;
-#pragma unroll
-            for (int m = 0; m < 4; m++) q4[m] = (hi ? q8[m + 4] : q8[m]) + __shfl_xor(hi ? q8[m] : q8[m + 4], 4, 16);
-        }
-        {
-            const bool hi = (l & 2) != 0;
-#pragma unroll
-            for (int m = 0; m < 2; m++) q2[m] = (hi ? q4[m + 2] : q4[m]) + __shfl_xor(hi ? q4[m] : q4[m + 2], 2, 16);
-        }
-        {
-            const bool hi = (l & 1) != 0;
-            r = (hi ? q2[1] : q2[0]) + __shfl_xor(hi ? q2[0] : q2[1], 1, 16);
-        }
-        r += my_shift;
-        if (relu) r = fmaxf(r, 0.0f);
-        out[(size_t)n * ldo + l] = r;
-    }
-}
-
-// Mixed variant for CIN = 16 + CEX (CEX <= 4; the --use_image first conv: 1 polarity + 16 image channels + 2
-// position channels = 19).  A second 16-lane channel slot for 3 channels would double the work, so:
-// channels [0,16) run lane-per-channel exactly as k_conv_l0, channels [16, CIN) run tap-per-lane as in
-// k_conv_l0_narrow (lane k owns tap k of the window, lane NT the root rows).  Both partial results land
-// in the same 16 per-lane partial outputs before the transpose-reduce.  No skip branch (first conv).
-template <int CEX, int NT>
-__global__ __launch_bounds__(kBlock, 4) void k_conv_l0_mixed(int N, int K, int ncodes,
-                                                            const int32_t *__restrict__ nbr_src,
-                                                            const int16_t *__restrict__ nbr_code,
-                                                            const int32_t *__restrict__ deg,
-                                                            const float *__restrict__ x, int ldx,
-                                                            const float *__restrict__ tab,    // [ncodes][NTP]
-                                                            const float *__restrict__ wpack,  // [(NT+1)*CIN][16]
-                                                            const float *__restrict__ shift, int relu,
-                                                            float *__restrict__ out, int ldo) {
-    static_assert(NT <= 15 && CEX >= 1 && CEX <= 4, "tap-per-lane part needs NT+1 <= 16 lanes");
-    constexpr int CIN = 16 + CEX;
-    constexpr int NTP = (NT + 3) / 4 * 4;
-    constexpr int NROWS = (NT + 1) * CIN;
-    extern __shared__ __align__(16) float lds[];
-    float *w_s = lds;
-    float *tab_s = lds + NROWS * kL0RowStride;
-    for (int i = threadIdx.x; i < NROWS * kL0Out; i += kBlock)
-        w_s[(i >> 4) * kL0RowStride + (i & 15)] = wpack[i];
-    for (int i = threadIdx.x; i < ncodes * NTP; i += kBlock) tab_s[i] = tab[i];
-    __syncthreads();
-    const int l = threadIdx.x & 15;
-    const int groups_per_block = kBlock / 16;
-    const float my_shift = shift[l];
-    const XcdSplit xs = xcd_split(N, groups_per_block, threadIdx.x >> 4);
-    // next node's degree and neighbour row one iteration ahead (see k_conv_l0_narrow)
-    int d_nx = 0, src_nx = 0, code_nx = 0;
-    auto prefetch = [&](int n) {
-        if (n < xs.end) {
-            d_nx = deg[n];
-            if (l < K) { src_nx = nbr_src[(int64_t)n * K + l]; code_nx = nbr_code[(int64_t)n * K + l]; }
-        }
-    };
-    prefetch(xs.first);
-    for (int n = xs.first; n < xs.end; n += xs.stride) {
-        const int d = d_nx, src0 = src_nx, code0 = code_nx;   // entries 0..15 of the row, one per lane
-        prefetch(n + xs.stride);
-        const int64_t row = (int64_t)n * K;
-        float A[NTP], AX[CEX];
-#pragma unroll
-        for (int k = 0; k < NTP; k++) A[k] = 0.0f;
-#pragma unroll
-        for (int i = 0; i < CEX; i++) AX[i] = 0.0f;
-        for (int j0 = 0; j0 < d; j0 += 8) {   // 8 source rows in flight per lane
-            int my_src, my_code;
-            if (j0 < 16) {   // wave-uniform: lanes 0..7 take entries j0..j0+7 of the prefetched row
-                my_src = __shfl(src0, (j0 + l) & 15, 16);
-                my_code = __shfl(code0, (j0 + l) & 15, 16);
-            } else {
-                my_src = my_code = 0;
-                if (l < 8 && j0 + l < d) { my_src = nbr_src[row + j0 + l]; my_code = nbr_code[row + j0 + l]; }
-            }
-            const int cnt = min(8, d - j0);
-            float v[8], vx[8][CEX];
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int src = __shfl(my_src, j, 16);
-                const float *xsrc = x + (size_t)src * ldx;
-                v[j] = (j < cnt) ? xsrc[l] : 0.0f;
-#pragma unroll
-                for (int i = 0; i < CEX; i++) vx[j][i] = (j < cnt) ? xsrc[16 + i] : 0.0f;
-            }
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                if (j < cnt) {
-                    const int code = __shfl(my_code, j, 16);
-                    float t[NTP];
-#pragma unroll
-                    for (int q = 0; q < NTP / 4; q++) {
-                        const float4 tq = *reinterpret_cast<const float4 *>(tab_s + code * NTP + 4 * q);
-                        t[4 * q] = tq.x; t[4 * q + 1] = tq.y; t[4 * q + 2] = tq.z; t[4 * q + 3] = tq.w;
-                    }
-#pragma unroll
-                    for (int k = 0; k < NT; k++) A[k] = fmaf(t[k], v[j], A[k]);
-                    const float tk = tab_s[code * NTP + l];     // lane's own tap (pad columns are zero)
-#pragma unroll
-                    for (int i = 0; i < CEX; i++) AX[i] = fmaf(tk, vx[j][i], AX[i]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        const float *xn = x + (size_t)n * ldx;
-        if (l == NT) {
-#pragma unroll
-            for (int i = 0; i < CEX; i++) AX[i] = xn[16 + i];   // root rows of the extra channels
-        }
-        float p[16];
-#pragma unroll
-        for (int o = 0; o < 16; o++) p[o] = 0.0f;
-        auto fma_row = [&](float a, int r) {
-            const float4 *w4 = reinterpret_cast<const float4 *>(w_s + r * kL0RowStride);
-            const float4 w0 = w4[0], w1 = w4[1], w2 = w4[2], w3 = w4[3];
-            p[0] = fmaf(a, w0.x, p[0]); p[1] = fmaf(a, w0.y, p[1]); p[2] = fmaf(a, w0.z, p[2]); p[3] = fmaf(a, w0.w, p[3]);
-            p[4] = fmaf(a, w1.x, p[4]); p[5] = fmaf(a, w1.y, p[5]); p[6] = fmaf(a, w1.z, p[6]); p[7] = fmaf(a, w1.w, p[7]);
-            p[8] = fmaf(a, w2.x, p[8]); p[9] = fmaf(a, w2.y, p[9]); p[10] = fmaf(a, w2.z, p[10]); p[11] = fmaf(a, w2.w, p[11]);
-            p[12] = fmaf(a, w3.x, p[12]); p[13] = fmaf(a, w3.y, p[13]); p[14] = fmaf(a, w3.z, p[14]); p[15] = fmaf(a, w3.w, p[15]);
-        };
-#pragma unroll
-        for (int k = 0; k < NT; k++) fma_row(A[k], k * CIN + l);     // channels 0..15: lane = channel
-        fma_row(xn[l], NT * CIN + l);                                // their root rows
-        if (l <= NT) {                                               // channels 16..: lane = tap (NT = root)
-#pragma unroll
-            for (int i = 0; i < CEX; i++) fma_row(AX[i], l * CIN + 16 + i);
-        }
-        float q8[8], q4[4], q2[2], r;
-        {
-            const bool hi = (l & 8) != 0;
-#pragma unroll
-            for (int m = 0; m < 8; m++) q8[m] = (hi ? p[m + 8] : p[m]) + __shfl_xor(hi ? p[m] : p[m + 8], 8, 16);
-        }
-        {
-            const bool hi = (l & 4) != 0;
-#pragma unroll
-            for (int m = 0; m < 4; m++) q4[m] = (hi ? q8[m + 4] : q8[m]) + __shfl_xor(hi ? q8[m] : q8[m + 4], 4, 16);
-        }
-        {
-            const bool hi = (l & 2) != 0;
-#pragma unroll
-            for (int m = 0; m < 2; m++) q2[m] = (hi ? q4[m + 2] : q4[m]) + __shfl_xor(hi ? q4[m] : q4[m + 2], 2, 16);
-        }
-        {
-            const bool hi = (l & 1) != 0;
-            r = (hi ? q2[1] : q2[0]) + __shfl_xor(hi ? q2[0] : q2[1], 1, 16);
-        }
-        r += my_shift;
-        if (relu) r = fmaxf(r, 0.0f);
-        out[(size_t)n * ldo + l] = r;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// MFMA variant of the level-0 SplineConv for 16 input channels (conv_block1.conv_block2: 16 -> 16 + skip).
-// PMC showed k_conv_l0 saturating the LDS pipe (broadcast table reads, weight rows, ds_bpermute) and VALU
-// issue while HBM traffic sat far below the roofline, so both contractions move to the matrix pipe
-// (v_mfma_f32_16x16x4_f32: exact fp32 FMA at the vector rate, but its operands are one float per lane):
-//   phase 1, per node:   D[tap][ch] = sum_edges T[edge][tap] * X[edge][ch]   (16 x 16 x deg: 4 MFMAs for K=16)
-//        A operand = the offset-table row of the edge (one LDS word), B operand = the gathered source row
-//        (16 lanes read 64 contiguous bytes per edge);
-//   phase 2, per 16 nodes: out[node][o] = sum_k A[node][k] * Wp[k][o],  k over (tap, ch) | root | skip
-//        A operand from an LDS staging tile (phase 1 results) resp. straight from global (root / skip rows).
-// One wave owns a tile of 16 consecutive nodes; 8 waves per workgroup share the packed weights and the
-// offset table in LDS (block = 512 threads, ~152 KB LDS, one workgroup per CU, persistent over an
-// XCD-contiguous node range).  Summation order differs from k_conv_l0 only by fp32 re-association.
-using f32x4_t = __attribute__((ext_vector_type(4))) float;
-constexpr int kMfmaWaves = 8;
-
-template <int CSKIP, int NT>
-__global__ __launch_bounds__(kMfmaWaves * 64) void k_conv_l0_mfma(
-    int N, int K, int ncodes, const int32_t *__restrict__ nbr_src, const int16_t *__restrict__ nbr_code,
-    const int32_t *__restrict__ deg, const float *__restrict__ x, int ldx, const float *__restrict__ xskip, int ldskip,
-    const float *__restrict__ tab, const float *__restrict__ wpack, const float *__restrict__ shift, int relu,
-    float *__restrict__ out, int ldo) {
-    constexpr int NTP = (NT + 3) / 4 * 4;
-    constexpr int KT = NT * 16;                    // tap rows
-    constexpr int KS = (CSKIP + 3) / 4 * 4;        // skip rows, zero padded
-    constexpr int KTOT = KT + 16 + KS;
-    constexpr int AS = KT + 1;                     // staging row stride (odd: conflict-free column reads)
-    extern __shared__ __align__(16) float lds[];
-    float *w_s = lds;                              // [KTOT][16]
-    float *tab_s = w_s + KTOT * 16;                // [ncodes][NTP]
-    float *a_all = tab_s + ncodes * NTP;           // [waves][16][AS]
-    for (int i = threadIdx.x; i < KTOT * 16; i += blockDim.x) {
-        const int r = i >> 4;
-        w_s[i] = (r < KT + 16 + CSKIP) ? wpack[i] : 0.0f;
-    }
-    for (int i = threadIdx.x; i < ncodes * NTP; i += blockDim.x) tab_s[i] = tab[i];
-    __syncthreads();
-    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int c = l & 15, q = l >> 4;
-    float *a_s = a_all + w * 16 * AS;
-    const float my_shift = shift[c];
-    // contiguous node range per block (XCD-contiguous), 16-node tiles dealt round-robin to the waves
-    const int G = gridDim.x, nx = (G % 8 == 0) ? 8 : 1;
-    const int xcd = blockIdx.x % nx, lb = blockIdx.x / nx, bpx = G / nx;
-    const int chunk = ((N + nx - 1) / nx + 15) / 16 * 16;
-    const int per_block = ((chunk + bpx - 1) / bpx + 15) / 16 * 16;
-    const int n_begin = xcd * chunk + lb * per_block;
-    const int n_end = min(min(N, (xcd + 1) * chunk), n_begin + per_block);
-    // Software pipeline: the neighbour lists of a tile (16 nodes x 16 slots) are read coalesced -- lane l
-    // holds slots l, l+64, l+128, l+192 of the tile -- one tile ahead of their use; all 64 source-row
-    // gathers of a tile are in flight before the first MFMA consumes one.  (K == 16 on this path.)
-    auto load_tile_idx = [&](int n0, int (&src)[4], int (&code)[4], int &dg) {
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-            const int64_t f = (int64_t)n0 * 16 + l + 64 * m;
-            const bool ok = f < (int64_t)n_end * 16;
-            src[m] = ok ? nbr_src[f] : 0;
-            code[m] = ok ? (int)nbr_code[f] : 0;
-        }
-        dg = (l < 16 && n0 + l < n_end) ? deg[n0 + l] : 0;
-    };
-    int cur_src[4], cur_code[4], cur_deg;
-    int n0 = n_begin + 16 * w;
-    if (n0 < n_end) load_tile_idx(n0, cur_src, cur_code, cur_deg);
-    for (; n0 < n_end; n0 += 16 * kMfmaWaves) {
-        int nxt_src[4] = {0, 0, 0, 0}, nxt_code[4] = {0, 0, 0, 0}, nxt_deg = 0;
-        if (n0 + 16 * kMfmaWaves < n_end) load_tile_idx(n0 + 16 * kMfmaWaves, nxt_src, nxt_code, nxt_deg);
-        // ---- phase 1a: every operand of the tile's 64 MFMAs is requested up front: source rows (global
-        // gathers) and offset-table words (LDS).  The coalesced-loaded neighbour lists are re-laid through the
-        // (still free) staging tile instead of 144 ds_bpermutes: lane (c, q) then reads its 4 consecutive
-        // edges 4q..4q+3 of node i as one 16-byte word (MFMA k index <-> edge is any bijection).
-        // (kept as float bit patterns: same type as the tile's later contents, so the compiler orders them)
-        float *idx_s = a_s;                                 // [256] src | [256] code | [16] deg
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-            idx_s[l + 64 * m] = __int_as_float(cur_src[m]);
-            idx_s[256 + l + 64 * m] = __int_as_float(cur_code[m]);
-        }
-        if (l < 16) idx_s[512 + l] = __int_as_float(cur_deg);
-        __builtin_amdgcn_wave_barrier();
-        // root / skip operands of phase 2: requested now, consumed after the tap contraction
-        const int nn = n0 + c;                               // this lane's node for the root / skip operands
-        const bool nn_ok = nn < n_end;
-        float xroot[4], xsk[KS / 4 > 0 ? KS / 4 : 1];
-#pragma unroll
-        for (int kb = 0; kb < 16; kb += 4) xroot[kb / 4] = nn_ok ? x[(size_t)nn * ldx + kb + q] : 0.f;
-#pragma unroll
-        for (int kb = 0; kb < KS; kb += 4)
-            xsk[kb / 4] = (nn_ok && kb + q < CSKIP) ? xskip[(size_t)nn * ldskip + kb + q] : 0.f;
-        float xv[16][4], tv[16][4];
-        int dd[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            dd[i] = __float_as_int(idx_s[512 + i]);
-            const float *sp = idx_s + i * 16 + 4 * q, *cp = idx_s + 256 + i * 16 + 4 * q;
-            const int srcs[4] = {__float_as_int(sp[0]), __float_as_int(sp[1]), __float_as_int(sp[2]), __float_as_int(sp[3])};
-            const int codes[4] = {__float_as_int(cp[0]), __float_as_int(cp[1]), __float_as_int(cp[2]), __float_as_int(cp[3])};
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) {
-                const bool ok = 4 * q + kk < dd[i];
-                xv[i][kk] = ok ? x[(size_t)srcs[kk] * ldx + c] : 0.0f;
-                tv[i][kk] = (ok && c < NT) ? tab_s[codes[kk] * NTP + c] : 0.0f;
-            }
-        }
-        // ---- phase 1b: D[tap][ch] = sum_edges T[edge][tap] * X[edge][ch], <= 4 MFMAs per node
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++)
-                if (kk < dd[i])   // wave-uniform: step kk holds edges kk, 4 + kk, 8 + kk, 12 + kk
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(tv[i][kk], xv[i][kk], acc, 0, 0, 0);
-            float *dst = a_s + i * AS + (4 * q) * 16 + c;   // D[tap = 4q + r][ch = c]
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-                if (4 * q + r < NT) dst[r * 16] = acc[r];
-        }
-#pragma unroll
-        for (int m = 0; m < 4; m++) { cur_src[m] = nxt_src[m]; cur_code[m] = nxt_code[m]; }
-        cur_deg = nxt_deg;
-        __builtin_amdgcn_wave_barrier();
-        // ---- phase 2: 16 nodes x KTOT x 16 outputs
-        f32x4_t o = {0.f, 0.f, 0.f, 0.f};
-        const float *arow = a_s + c * AS + q;               // A[node = c][k = kb + q]
-        const float *wrow = w_s + q * 16 + c;               // B[k = kb + q][o = c]
-        // operands of 12 k-steps are read before their MFMAs issue (LDS latency off the dependent chain)
-        static_assert(KT % 48 == 0, "tap rows come in blocks of 48");
-        for (int kb0 = 0; kb0 < KT; kb0 += 48) {
-            float av[12], wv[12];
-#pragma unroll
-            for (int u = 0; u < 12; u++) { av[u] = arow[kb0 + 4 * u]; wv[u] = wrow[(kb0 + 4 * u) * 16]; }
-#pragma unroll
-            for (int u = 0; u < 12; u++) o = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], wv[u], o, 0, 0, 0);
-        }
-#pragma unroll
-        for (int kb = 0; kb < 16; kb += 4)
-            o = __builtin_amdgcn_mfma_f32_16x16x4f32(xroot[kb / 4], wrow[(KT + kb) * 16], o, 0, 0, 0);
-#pragma unroll
-        for (int kb = 0; kb < KS; kb += 4)
-            o = __builtin_amdgcn_mfma_f32_16x16x4f32(xsk[kb / 4], wrow[(KT + 16 + kb) * 16], o, 0, 0, 0);
-        // o[r] = out[node = 4q + r][channel c]
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int n = n0 + 4 * q + r;
-            if (n < n_end) {
-                float v = o[r] + my_shift;
-                if (relu) v = fmaxf(v, 0.f);
-                out[(size_t)n * ldo + c] = v;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();   // staging tile is reused by the next tile of this wave
-    }
-}
-
 // One thread per offset code: the window products bx[a]*by[b] at [a + tx*b], row stride ntp.
 __global__ void k_build_l0_table(int rx, int ry, float den_x, float den_y, int win_x, int tx, int win_y, int ty,
                                  int ntp, float *__restrict__ tab, int32_t *__restrict__ bad) {
@@ -835,71 +429,6 @@ int dagr_spline_conv_l0(int32_t cin, int32_t cskip, int32_t ntaps, int64_t N, in
     const int groups = kBlock / 16;
     const int64_t useful = ceil_div(N, groups);
     unsigned grid = 1;
-#define DAGR_L0_NARROW(CI, NTAPS)                                                                                  \
-    if (cin == CI && cskip == 0 && ntaps == NTAPS) {                                                               \
-        {                                                                                                          \
-            static thread_local size_t set_for = 0;                                                                \
-            if (set_for != lds_bytes) {                                                                            \
-                DAGR_CHECK_HIP(hipFuncSetAttribute((const void *)k_conv_l0_narrow<CI, NTAPS>,                      \
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));    \
-                set_for = lds_bytes;                                                                               \
-            }                                                                                                      \
-        }                                                                                                          \
-        grid = round_grid8(persistent_grid(k_conv_l0_narrow<CI, NTAPS>, kBlock, lds_bytes, useful));                            \
-        k_conv_l0_narrow<CI, NTAPS><<<grid, kBlock, lds_bytes, stream>>>((int)N, K, ncodes, nbr_src, nbr_code, deg, \
-                                                                         x, ldx, tab, wpack, shift, relu, out, ldo); \
-        DAGR_CHECK_LAUNCH();                                                                                       \
-        return DAGR_OK;                                                                                            \
-    }
-    DAGR_L0_NARROW(3, 9)
-    DAGR_L0_NARROW(3, 15)
-#undef DAGR_L0_NARROW
-#define DAGR_L0_MIXED(CEX, NTAPS)                                                                                  \
-    if (cin == 16 + CEX && cskip == 0 && ntaps == NTAPS) {                                                         \
-        {                                                                                                          \
-            static thread_local size_t set_for = 0;                                                                \
-            if (set_for != lds_bytes) {                                                                            \
-                DAGR_CHECK_HIP(hipFuncSetAttribute((const void *)k_conv_l0_mixed<CEX, NTAPS>,                      \
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));    \
-                set_for = lds_bytes;                                                                               \
-            }                                                                                                      \
-        }                                                                                                          \
-        grid = round_grid8(persistent_grid(k_conv_l0_mixed<CEX, NTAPS>, kBlock, lds_bytes, useful));               \
-        k_conv_l0_mixed<CEX, NTAPS><<<grid, kBlock, lds_bytes, stream>>>((int)N, K, ncodes, nbr_src, nbr_code, deg, \
-                                                                         x, ldx, tab, wpack, shift, relu, out, ldo); \
-        DAGR_CHECK_LAUNCH();                                                                                       \
-        return DAGR_OK;                                                                                            \
-    }
-    DAGR_L0_MIXED(3, 9)
-    DAGR_L0_MIXED(3, 15)
-#undef DAGR_L0_MIXED
-#define DAGR_L0_MFMA(CS, NTAPS)                                                                                    \
-    if (use_mfma && cin == 16 && cskip == CS && ntaps == NTAPS && K == 16) {                                       \
-        constexpr int kt = NTAPS * 16, ks = (CS + 3) / 4 * 4;                                                      \
-        const size_t mlds = ((size_t)(kt + 16 + ks) * 16 + (size_t)ncodes * ntp + (size_t)kMfmaWaves * 16 * (kt + 1)) * 4; \
-        if (mlds <= 160 * 1024) {                                                                                  \
-            static thread_local size_t set_for = 0;                                                                \
-            if (set_for != mlds) {                                                                                 \
-                DAGR_CHECK_HIP(hipFuncSetAttribute((const void *)k_conv_l0_mfma<CS, NTAPS>,                        \
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));         \
-                set_for = mlds;                                                                                    \
-            }                                                                                                      \
-            const unsigned mg = round_grid8(std::min<int64_t>(ceil_div(N, 16 * kMfmaWaves), device_cu_count()));   \
-            k_conv_l0_mfma<CS, NTAPS><<<mg, kMfmaWaves * 64, mlds, stream>>>((int)N, K, ncodes, nbr_src, nbr_code, deg, \
-                                                                             x, ldx, xskip, ldskip, tab, wpack, shift, \
-                                                                             relu, out, ldo);                       \
-            DAGR_CHECK_LAUNCH();                                                                                   \
-            return DAGR_OK;                                                                                        \
-        }                                                                                                          \
-    }
-    // matrix-pipe variant (k_conv_l0_mfma): 0.30 vs 0.35 ms for the VALU kernel on an idle GPU, equal under
-    // two-engine overlap; DAGR_L0_MFMA=0 selects the VALU kernel (A/B and fallback)
-    static const bool use_mfma = [] { const char *e = std::getenv("DAGR_L0_MFMA"); return !(e && e[0] == '0'); }();
-    DAGR_L0_MFMA(3, 9)
-    DAGR_L0_MFMA(3, 15)
-    DAGR_L0_MFMA(19, 9)
-    DAGR_L0_MFMA(19, 15)
-#undef DAGR_L0_MFMA
 #define DAGR_L0_CASE(CI, CS, NTAPS)                                                                                \
     if (cin == CI && cskip == CS && ntaps == NTAPS) {                                                              \
         {                                                                                                          \

@@ -67,12 +67,19 @@ class SyntheticObjects:
         self.use_image = bool(use_image)       # DSEC-style samples: a frame with the object drawn in + bbox0
         self.num_classes = len(self.classes)
         self.time_window = 1000000
+        self.num_us = -1
         if transform is not None and hasattr(transform, "transforms"):
             from .augment import init_transforms
             init_transforms(transform.transforms, self.height, self.width)
 
     def __len__(self):
         return self.n
+
+    def set_num_us(self, num_us):            # dsec_data.py:114-115 (interframe evaluation)
+        self.num_us = int(num_us)
+
+    def sequence_names(self):
+        return [f"objects{int(i):05d}" for i in range(self.n)]
 
     def __getitem__(self, i):
         rng = np.random.default_rng(self.seed + int(i))
@@ -96,6 +103,13 @@ class SyntheticObjects:
         p = rng.choice(np.array([-1, 1], dtype=np.int8), len(px))
         order = rng.permutation(len(px))
         px, py = px[order], py[order]                     # positions are not correlated with time
+        if self.num_us >= 0:                              # dsec_data.py:159-161: the first num_us microseconds only
+            keep = (t - (self.time_window - 50000)) < self.num_us
+            px, py, t, p = px[keep], py[keep], t[keep], p[keep]
+            if len(t):
+                t = (self.time_window - 1 + t - t[-1]).astype(np.int32)
+            else:                                         # keep one event so that the sample stays a graph
+                px, py, t, p = (np.array([v], dtype=a.dtype) for v, a in ((x0, px), (y0, py), (self.time_window - 1, t), (1, p)))
         bbox = np.array([[x0, y0, w, h, cls, 1]], dtype=np.float32)
         extra = {}
         if self.use_image:

@@ -49,15 +49,6 @@ class _ConvPack:
         Wp[: self.K, : self.N] = Wm[:, : self.N]
         # [g, j, kk, c, nn] -> [c, g, kk, nn, j]  (lane l = 16 kk + nn)
         self.Wq = Wp.view(K16 // 16, 4, 4, N16 // 16, 16).permute(3, 0, 2, 4, 1).contiguous()
-        # operand order of dagr_spline_conv_tiles ([column tile][k-step][lane]); None when the channel counts do not fit it
-        self.Wt = None
-        if cin % 16 <= 4 and cskip % 16 <= 4:
-            L = _lib.lib()
-            host = Wm[:, : self.N].detach().float().cpu().contiguous()
-            wt = torch.empty((L.dagr_spline_conv_tiles_pack_elems(cin, cskip, self.N),), dtype=torch.float32)
-            _lib.check(L.dagr_spline_conv_tiles_pack(ctypes.c_void_p(host.data_ptr()), self.N, cin, cskip, self.N,
-                                                     ctypes.c_void_p(wt.data_ptr())), "conv_tiles_pack")
-            self.Wt = wt.to(Wm.device)
 
 
 def _pack_generic(convs, norms, skip=None, relu=True, device="cuda"):
@@ -287,10 +278,6 @@ class WindowEngine:
         self._img_stream = None
         self._net_f = self._cnn_f = None
         self.fuse_convs = os.environ.get("DAGR_FUSE_CONVS", "1") != "0"
-        # dagr_spline_conv_tiles (register-tiled pooled conv, csrc/conv_pooled_tiles.hip): correct for any K, but measured
-        # slower than k_conv_fused on these levels (tail 0.53 vs 0.42 ms at B = 8, 0.26 vs 0.22 ms at B = 1): off by default
-        self.pooled_tiles = os.environ.get("DAGR_POOLED_TILES", "0") != "0"
-        self.tiles_max_nodes = int(os.environ.get("DAGR_TILES_MAX_NODES", "8192"))
         self.fast_coarse_edges = os.environ.get("DAGR_FAST_COARSE_EDGES", "1") != "0"
         self.fuse_image_epilogues = os.environ.get("DAGR_IMG_EPILOGUES", "1") != "0"
         # Latency mode (one window batch at a time, e.g. DAGR.forward): head scale 1 runs beside pool4 / layer5 / head scale
@@ -304,6 +291,7 @@ class WindowEngine:
         self._async_on = False
         self._app = None
         self._n_rows = 0
+        self._N = 0                  # events of the resident window (0: none yet)
         self._prepare(bb, head)
         self.max_events = 0
         self._alloc_events(int(max_events))
@@ -511,6 +499,17 @@ class WindowEngine:
                 self._app[name] = new
         self.rows_cap = cap
 
+    def can_append(self):
+        """Whether ``forward_append`` can attach events to the resident window: the incremental path runs on the tiled
+        level-0 conv and keeps pool1's coarse edges as cell bitmaps (search radius <= two voxels, dagr_pool_l0_stream),
+        and it needs a window of THIS engine to attach to.  ``DAGR.forward(reset=False)`` re-evaluates the running
+        window otherwise (``make_model_synchronous``'s path)."""
+        if not self.l0_tiles or self.no_events or self._N <= 0 or self.B >= 30:
+            return False
+        d, g = self.pool_desc[0], self.graph.params
+        cell_w, cell_h = int(np.floor(np.float32(d.vx) * np.float32(g["width"]))), int(np.floor(np.float32(d.vy) * np.float32(g["height"])))
+        return g["max_neighbors"] <= 16 and g["radius"] <= 2 * min(cell_w, cell_h) and g["width"] <= 4096
+
     def async_begin(self):
         """Turn the resident window (the last ``forward_raw``) into the state of an asynchronous run: per-pixel chains for
         the events to come (empty), the sample index by event id, and pool1's accumulators resident in their own
@@ -616,15 +615,6 @@ class WindowEngine:
         P = _lib.ptr
         code = lvl.code if code is None else code
         scratch = self.A if scratch is None else scratch
-        # small levels (<= 8 k node slots): the register-tiled conv, one workgroup per (16 nodes, 16 columns); larger ones
-        # (level 1 of a B = 8 batch) walk their edges once per tile for all columns in k_conv_fused
-        if self.pooled_tiles and pack.Wt is not None and lvl.T <= self.tiles_max_nodes \
-                and (pack.cin < 16 or ldx % 4 == 0) and (pack.cskip < 16 or ldskip % 4 == 0):
-            _lib.check(L.dagr_spline_conv_tiles(P(lvl.counts), lvl.T, P(lvl.rowptr), P(lvl.col), P(code), x, ldx, pack.cin,
-                                                xskip, ldskip, pack.cskip, dom["rx"], dom["ry"], dom["den_x"],
-                                                dom["den_y"], P(pack.Wt), P(pack.bias), out, ldo, pack.N,
-                                                1 if pack.relu else 0, stream), "spline_conv_tiles")
-            return
         passes = L.dagr_spline_conv_fused_passes(pack.cin, pack.cskip)
         if self.fuse_convs and (passes == 1 or (passes > 1 and lvl.T <= self.fused_passes_max_nodes)):
             # tap aggregation + contraction in one launch (A tile lives in LDS; rows wider than the tile in passes over
@@ -1022,10 +1012,7 @@ class WindowEngine:
             cm = 16 if c0 >= 16 else 0
             return {"l0_conv1": f"k_conv_l0_tiles<{cm}, {c0 - cm}, 0, {tx}, {ty}>",
                     "l0_conv2": f"k_conv_l0_tiles<16, 0, {c0}, {tx}, {ty}>"}
-        mfma = os.environ.get("DAGR_L0_MFMA", "1") != "0"
-        first = f"k_conv_l0_mixed<{c0 - 16}, {nt}>" if self.use_image else f"k_conv_l0_narrow<{c0}, {nt}>"
-        return {"l0_conv1": first,
-                "l0_conv2": f"k_conv_l0_mfma<{c0}, {nt}>" if mfma else f"k_conv_l0<16, {c0}, {nt}>"}
+        return {"l0_conv1": f"k_conv_l0<{c0}, 0, {nt}>", "l0_conv2": f"k_conv_l0<16, {c0}, {nt}>"}
 
     def check_status(self):
         """Raise if any kernel flagged an inconsistency (synchronises)."""

@@ -125,13 +125,19 @@ class GNNHead(YOLOXHeadParams):
         return outputs
 
 
-def _concat_window(batches):
+def _window_part(d):
+    """What a running window remembers of one call: the events (pos, polarity, sample index) -- not the Data object."""
+    batch = d.batch if getattr(d, "batch", None) is not None else \
+        torch.zeros(d.pos.shape[0], dtype=torch.int64, device=d.pos.device)
+    return d.pos.float(), d.x.float().view(-1, 1), batch.long()
+
+
+def _concat_window(parts):
     """All events of the running window ordered by sample, arrival order inside a sample: the layout one reset=True call
-    on the same events has (collation concatenates sample after sample)."""
-    pos = torch.cat([d.pos.float() for d in batches])
-    feat = torch.cat([d.x.float().view(-1, 1) for d in batches])
-    batch = torch.cat([(d.batch if getattr(d, "batch", None) is not None else
-                        torch.zeros(d.pos.shape[0], dtype=torch.int64, device=d.pos.device)).long() for d in batches])
+    on the same events has (collation concatenates sample after sample).  The list is compacted to one part."""
+    if len(parts) > 1:
+        parts[:] = [tuple(torch.cat([p[k] for p in parts]) for k in range(3))]
+    pos, feat, batch = parts[0]
     order = torch.argsort(batch, stable=True)
     return pos[order].contiguous(), feat[order].contiguous(), batch[order].contiguous()
 
@@ -151,7 +157,9 @@ class DAGR(torch.nn.Module):
                             pretrain_cnn=args.pretrain_cnn, args=args)
         self._engine = None
         self._engine_stamp = None
-        self._window = None          # the batches since the last reset=True call (DAGR.forward(reset=False))
+        self._stamp_tensors = None
+        self._window = None          # the events since the last reset=True call (DAGR.forward(reset=False))
+        self._window_image = None
         self.asynchronous = True     # reset=False calls update incrementally (asynchronous.make_model_synchronous: off)
         if bool(args.no_events) and not bool(args.use_image):
             raise ValueError("--no_events returns the image branch's detections (dagr.py:283-284): it needs --use_image")
@@ -273,8 +281,12 @@ class DAGR(torch.nn.Module):
         if reset or self._window is None:
             # a window of its own (every evaluation script's call), or the first call of an asynchronous run
             outputs = eng.forward_data(x)
-            self._window = [x]                   # only remembered: a later reset=False call continues from it
-        elif self.asynchronous:
+            # only remembered: a later reset=False call continues from it.  A running window keeps the FRAME of the call
+            # that opened it (DSEC: the image at the start of the window, dsec_data.py:141-184); later micro-batches
+            # bring events only, in the incremental and in the re-evaluating mode alike.
+            self._window = [_window_part(x)]
+            self._window_image = getattr(x, "image", None)
+        elif self.asynchronous and eng.can_append():
             # dagr.py:90 `x.reset = reset` -> ev_tgn.py:45-56: the new events attach to the running graph.  Incremental:
             # only their level-0 rows are computed, pool1's resident accumulators are extended, the fixed-size part of
             # the network runs as for a window (engine.forward_append).  Equal to one reset=True call on all events so
@@ -282,12 +294,16 @@ class DAGR(torch.nn.Module):
             batch = x.batch if getattr(x, "batch", None) is not None else \
                 torch.zeros(x.pos.shape[0], dtype=torch.int64, device=x.pos.device)
             outputs = eng.forward_append(x.pos, x.x, batch)
-            self._window.append(x)
+            self._window.append(_window_part(x))
+            if len(self._window) > 64:           # bounded bookkeeping on long streams: one concatenated part
+                _concat_window(self._window)
         else:
-            # make_model_synchronous: the whole running window again (the reference's synchronous forward on all events)
-            self._window.append(x)
+            # make_model_synchronous -- and every configuration the incremental path does not cover (max_neighbors != 16,
+            # a 5x5 tap window, --no_events, a search radius beyond two voxels, an engine rebuilt after a weight edit):
+            # the whole running window again (the reference's synchronous forward on all events)
+            self._window.append(_window_part(x))
             pos, feat, batch = _concat_window(self._window)
-            outputs = eng.forward_raw(pos, feat, batch, image=getattr(self._window[0], "image", None))
+            outputs = eng.forward_raw(pos, feat, batch, image=self._window_image)
             eng._async_on = False
         detections = postprocess_network_output(outputs, self.backbone.num_classes, self.conf_threshold,
                                                 self.nms_threshold, filtering=filtering, height=self.height,

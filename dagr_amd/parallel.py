@@ -34,6 +34,51 @@ def gather_detections(rows, group=None):
     return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
 
 
+def gather_evaluation(detections, ground_truth, image_ids, group=None):
+    """The run's per-image detections and ground truth from ALL ranks, ordered by global image id, on every rank: what
+    the reference's single process hands to its evaluation (``scripts/run_test.py:61-65`` ->
+    ``utils/coco_eval.py:64-94``), so that a sharded run prints THE mAP of the run and not one per shard.
+    ``detections[i]`` = {boxes [n,4], scores [n], labels [n]}, ``ground_truth[i]`` = {boxes, labels} of image
+    ``image_ids[i]``.  One gather (counts + padded payload, ``gather_detections``): per image a header row
+    (id, 2, n_gt, n_det), its ground-truth rows (id, 0, box, 0, label) and its detection rows (id, 1, box, score, label),
+    float64 (float32 boxes / scores and integer labels travel exactly).  Without a process group: the inputs, sorted."""
+    import numpy as np
+
+    def host(v):
+        return np.asarray(v.detach().cpu() if torch.is_tensor(v) else v)
+    order = sorted(range(len(image_ids)), key=lambda i: int(image_ids[i]))
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return [detections[i] for i in order], [ground_truth[i] for i in order], [int(image_ids[i]) for i in order]
+    rows = []
+    for i in order:
+        d, g, iid = detections[i], ground_truth[i], float(image_ids[i])
+        gb, db = host(g["boxes"]).reshape(-1, 4).astype(np.float64), host(d["boxes"]).reshape(-1, 4).astype(np.float64)
+        rows.append(np.array([[iid, 2.0, len(gb), len(db), 0, 0, 0, 0]], dtype=np.float64))
+        if len(gb):
+            rows.append(np.concatenate([np.full((len(gb), 1), iid), np.zeros((len(gb), 1)), gb, np.zeros((len(gb), 1)),
+                                        host(g["labels"]).reshape(-1, 1).astype(np.float64)], 1))
+        if len(db):
+            rows.append(np.concatenate([np.full((len(db), 1), iid), np.ones((len(db), 1)), db,
+                                        host(d["scores"]).reshape(-1, 1).astype(np.float64),
+                                        host(d["labels"]).reshape(-1, 1).astype(np.float64)], 1))
+    mine = torch.from_numpy(np.concatenate(rows, 0) if rows else np.zeros((0, 8)))
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    allrows = gather_detections(mine.to(dev), group=group).cpu().numpy()
+    heads = allrows[allrows[:, 1] == 2.0]
+    ids = sorted(int(v) for v in heads[:, 0])
+    if len(set(ids)) != len(ids):
+        raise RuntimeError("gather_evaluation: an image id arrived from two ranks")
+    dets, gts = [], []
+    for iid in ids:
+        r = allrows[allrows[:, 0] == iid]
+        g, d = r[r[:, 1] == 0.0], r[r[:, 1] == 1.0]
+        gts.append(dict(boxes=torch.from_numpy(g[:, 2:6].astype(np.float32)), labels=torch.from_numpy(g[:, 7].astype(np.int64))))
+        dets.append(dict(boxes=torch.from_numpy(d[:, 2:6].astype(np.float32)),
+                         scores=torch.from_numpy(d[:, 6].astype(np.float32)),
+                         labels=torch.from_numpy(d[:, 7].astype(np.int64))))
+    return dets, gts, ids
+
+
 def restore_window_order(rows, window_col=0):
     """Detections gathered rank by rank -> sorted by window id (stable), the order
     ``run_test_interframe.py:34-45`` writes them in."""

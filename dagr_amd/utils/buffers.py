@@ -98,11 +98,15 @@ class DetectionBuffer:
 
     def __init__(self, height, width, classes):
         self.height, self.width, self.classes = height, width, classes
-        self.detections, self.ground_truth = [], []
+        self.detections, self.ground_truth, self.image_ids = [], [], []
 
-    def update(self, detections, groundtruth, dataset=None, height=None, width=None):
+    def update(self, detections, groundtruth, dataset=None, height=None, width=None, image_ids=None):
+        """``image_ids``: the GLOBAL index of every image of the batch in the run (sharded runs: the images of a rank are
+        a subset); default: a running count, i.e. the order of arrival."""
+        n0 = len(self.detections)
         self.detections.extend({k: v.cpu() for k, v in d.items()} for d in detections)
         self.ground_truth.extend({k: v.cpu() for k, v in d.items()} for d in groundtruth)
+        self.image_ids.extend(image_ids if image_ids is not None else range(n0, n0 + len(detections)))
 
     def compile(self, sequences, timestamps):
         def by_sequence(items):
@@ -114,9 +118,13 @@ class DetectionBuffer:
         return by_sequence(self.detections), by_sequence(self.ground_truth)
 
     def compute(self):
-        """mAP & co over everything collected since the last call (buffers.py:113-122)."""
+        """mAP & co over everything collected since the last call (buffers.py:113-122).  Under a process group (window
+        batches sharded over the GPUs of a node) the ranks' images are gathered first -- detections AND ground truth, in
+        global image order -- and every rank evaluates the whole run: ONE mAP, the number the reference's single process
+        prints (run_test.py:61-65)."""
         from .coco_eval import evaluate_detection
-        out = evaluate_detection(self.ground_truth, self.detections, height=self.height, width=self.width,
-                                 classes=self.classes)
-        self.detections, self.ground_truth = [], []
+        from ..parallel import gather_evaluation
+        dets, gts, _ = gather_evaluation(self.detections, self.ground_truth, self.image_ids)
+        out = evaluate_detection(gts, dets, height=self.height, width=self.width, classes=self.classes)
+        self.detections, self.ground_truth, self.image_ids = [], [], []
         return {k.replace("AP", "mAP"): v for k, v in out.items()}

@@ -5,7 +5,9 @@ Per batch: ``data.cuda()`` -> ``format_data`` -> ``model(data)`` -> (optionally)
 sequence / timestamp, feed the mAP buffer.  Differences that follow from this stack: the per-window work is one
 device pipeline with a single synchronisation (the survivor counts of the NMS), visualisation (wandb image logging) is
 not part of the hot path and is skipped, and the COCO evaluation is the numpy restatement in ``utils/coco_eval.py``
-(pycocotools / detectron2 are absent); ``no_eval=True`` skips it (datasets without boxes)."""
+(pycocotools / detectron2 are absent); ``no_eval=True`` skips it (datasets without boxes).  Under a process group the
+window batches are sharded over the ranks; the metrics are those of the WHOLE run on every rank (detections and ground
+truth gathered once, ``parallel.gather_evaluation``)."""
 import torch
 
 from .buffers import DetectionBuffer, format_data
@@ -33,7 +35,9 @@ def run_test_with_visualization(loader, model, dataset: str, log_every_n_batch=-
         ds = loader.dataset
         scorer = DetectionBuffer(height=ds.height, width=ds.width, classes=ds.classes)
     collected = [] if compile_detections else None
-    for data in loader:
+    # global index of an image in the run: batch k of the (possibly sharded) loader holds images [k*B, (k+1)*B)
+    batch_ids = getattr(loader, "batches", None)
+    for step, data in enumerate(loader):
         if torch.cuda.is_available():
             data = data.cuda(non_blocking=True)
         data = format_data(data)
@@ -45,6 +49,8 @@ def run_test_with_visualization(loader, model, dataset: str, log_every_n_batch=-
         if scorer is not None:
             if len(out) < 2:
                 raise RuntimeError("evaluation needs ground-truth boxes (data.bbox); pass no_eval=True without them")
-            scorer.update(detections, out[1], dataset, data.height[0], data.width[0])
+            first = (batch_ids[step] if batch_ids is not None else step) * getattr(loader, "batch_size", len(detections))
+            scorer.update(detections, out[1], dataset, data.height[0], data.width[0],
+                          image_ids=range(first, first + len(detections)))
     metrics = scorer.compute() if scorer is not None else None
     return (metrics, collected) if compile_detections else metrics

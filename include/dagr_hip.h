@@ -135,6 +135,11 @@ int dagr_graph_search_window(const dagr_graph_desc *desc, void *workspace, int64
  * num_edges = sum(deg). */
 int dagr_graph_status(const dagr_graph_desc *desc, void *workspace, int64_t *num_edges /*host*/,
                       int32_t *flags /*host*/, void *stream);
+/* All eight status words of the last build (synchronises `stream`): [0] pixels with more than 64 events, [1] flags,
+ * [2..3] num_edges (uint64), [5] destinations the row kernel deferred to the position-centric sweep (neighbourhoods of
+ * more than 320 candidates), [6] 1 when timestamps were not non-decreasing inside a sample (linear FIFO walk,
+ * ev_graph.cu:58-76, instead of the two binary searches).  Tests use it to show which paths a window took. */
+int dagr_graph_counters(const dagr_graph_desc *desc, void *workspace, int32_t *out8_host, void *stream);
 
 /* Reference-shaped output: edge_index int64[2,E] in the order of
  * `edges[:, edges[1] >= 0]` (graph/utils.py:22), i.e. event ids, destinations ascending.
@@ -238,18 +243,6 @@ int dagr_spline_conv_fused(const int32_t *n_nodes_ptr, int32_t n_nodes_max, cons
                            const float *xskip, int32_t ldskip, int32_t cskip, int32_t rx, int32_t ry,
                            float den_x, float den_y, const float *Wq, const float *bias, float *C, int32_t ldc,
                            int32_t N, int32_t relu, void *stream);
-/* the same contraction as 16-node wave tiles (csrc/conv_pooled_tiles.hip): any K, no A matrix and no LDS tile -- lanes
- * keep A[tap][channel quad] in registers and feed the f32 MFMA from there; one workgroup per (node tile, column tile[s]).
- * cin and cskip must be 16 k + (0..4); x / xskip rows 16-byte aligned when they hold >= 16 channels.
- * Wt = dagr_spline_conv_tiles_pack(Wm): the [K, N] matrix of dagr_gemm_bias_act laid out [column tile][k-step][lane]
- * (dagr_spline_conv_tiles_pack_elems floats; pack runs on HOST arrays). */
-size_t dagr_spline_conv_tiles_pack_elems(int32_t cin, int32_t cskip, int32_t N);
-int dagr_spline_conv_tiles_pack(const float *Wm_host, int32_t ldw, int32_t cin, int32_t cskip, int32_t N, float *Wt_host);
-int dagr_spline_conv_tiles(const int32_t *n_nodes_ptr, int32_t n_nodes_max, const int32_t *rowptr, const int32_t *col,
-                           const int32_t *code, const float *x, int32_t ldx, int32_t cin, const float *xskip,
-                           int32_t ldskip, int32_t cskip, int32_t rx, int32_t ry, float den_x, float den_y,
-                           const float *Wt, const float *bias, float *C, int32_t ldc, int32_t N, int32_t relu,
-                           void *stream);
 /* generic step 2: C[M,N] = act(A[M,K] . Wm[K,N] + bias[N]); M = min(*m_ptr, m_max) */
 int dagr_gemm_bias_act(const int32_t *m_ptr, int32_t m_max, const float *A, int32_t lda,
                        const float *Wm, int32_t ldw, const float *bias, float *C, int32_t ldc,
@@ -345,6 +338,9 @@ int dagr_pool_recode(const int32_t *n_ptr, int32_t n_max, const int32_t *rowptr,
 /* flags bit0: node outside the voxel grid; bit1: > 64 distinct sources for one cluster;
  * bit2: edge capacity exceeded; bit3: LUT coordinate out of range.  Synchronises `stream`. */
 int dagr_pool_status(const dagr_pool_desc *desc, void *pool_ws, int32_t *flags_host, void *stream);
+/* All eight status words (synchronises `stream`): [0] the flags above, [4] accumulator epoch, [5] level-0 nodes merged
+ * through the global path so far (outside the streaming kernel's LDS window, or t == 1.0 nodes; cumulative). */
+int dagr_pool_counters(const dagr_pool_desc *desc, void *pool_ws, int32_t *out8_host, void *stream);
 
 /* ------------------------------------------------------------------------ *
  * to_dense  -- model/layers/spline_conv.py:80-107 (SplineConvToDense tail)
@@ -417,9 +413,6 @@ int dagr_nms_batched(const float *boxes, const float *scores, const int32_t *cls
                      int32_t B, int32_t A, float iou_threshold, float class_offset,
                      int32_t *order_out, int32_t *keep_out, int32_t *n_keep, void *stream);
 
-/* builder instrumentation: the 100-MHz phase clocks image 0 of the last dagr_postprocess launch wrote
- * (0 start, 1 scored, 2 sorted, 3 boxes staged, 6 suppression bits built, 4 chain done, 5 end). */
-int dagr_debug_postprocess_clocks(long long *out8);
 /* collect_outputs + decode_outputs of the eval head (model/networks/dagr.py:283-312; grid/stride cache of
  * model/utils.py:119-134) for one or two scales in one launch: dense logit maps [B, channels = 5+C, Hs, Ws] (reg | obj |
  * cls) -> out[B, A, channels], A = H0*W0 (+ H1*W1), xy = (logit + cell) * stride, wh = exp(logit) * stride, the rest
@@ -468,12 +461,6 @@ int dagr_masked_inplace_BN(const int64_t *indices, const float *x, float *x_out,
 int dagr_downsample_events(const int32_t *order, const int32_t *run_cell, const int32_t *run_end, int32_t n_runs,
                            const int8_t *polarity, int32_t fx, int32_t fy, float *change_map, uint8_t *keep,
                            void *stream);
-
-/* Profiling aid (not on the product path): streams a known number of bytes so that rocprofv3's
- * FETCH_SIZE / WRITE_SIZE can be calibrated on this library's access patterns.
- * mode 0: 4 B/lane reads of n_floats; 1: 16 B/lane reads; 2: n_gathers pseudo-random 64-byte rows
- * read by 16-lane groups; 3: 4 B/lane writes of n_floats. */
-int dagr_debug_calibrate(int32_t mode, float *buf, size_t n_floats, size_t n_gathers, float *sink, void *stream);
 
 /* Host-side helper: first n offsets of the search spiral (spiral.h:1-15), the closed form the
  * search kernel uses.  dx/dy are HOST arrays.  Lets CPU-only tests pin the visiting order. */

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dagr import parallel                                        # noqa: E402
 from dagr.data import DataLoader                                 # noqa: E402
 from dagr.data.augment import Augmentations                      # noqa: E402
-from dagr.data.synthetic_data import SyntheticWindows            # noqa: E402
+from dagr.data.synthetic_data import SyntheticObjects, SyntheticWindows   # noqa: E402
 from dagr.model.networks.dagr import DAGR                        # noqa: E402
 from dagr.model.networks.ema import ModelEMA                     # noqa: E402
 from dagr.utils.args import MODEL_CONFIGS, model_args            # noqa: E402
@@ -36,6 +36,9 @@ def flags(description, extra=None):
                         "hdf5plugin.  Default: the synthetic event stream with the DSEC sample contract")
     p.add_argument("--split", default="test")
     p.add_argument("--no_eval", action="store_true", help="utils/args.py:62: no ground truth is loaded / scored")
+    p.add_argument("--labelled", action="store_true",
+                   help="synthetic windows WITH boxes (dagr/data/synthetic_data.py:SyntheticObjects): the run is scored "
+                        "(COCO-protocol mAP of the whole run, also when it is sharded over several GPUs)")
     p.add_argument("--use_image", action="store_true")
     p.add_argument("--img_net", default="resnet50")
     if extra:
@@ -69,6 +72,9 @@ def dataset_and_loader(a, world, rank):
         interframe = hasattr(a, "num_interframe_steps")
         ds = DSEC(a.dataset_directory, a.split, Augmentations.transform_testing, debug=False, min_bbox_diag=15,
                   min_bbox_height=10, only_perfect_tracks=interframe, no_eval=bool(a.no_eval) if interframe else False)
+    elif getattr(a, "labelled", False):
+        ds = SyntheticObjects(a.windows, a.events_per_window, a.width, a.height, transform=Augmentations.transform_testing,
+                              use_image=a.use_image)
     else:
         ds = SyntheticWindows(a.windows, a.events_per_window, a.width, a.height, a.stream, a.use_image,
                               transform=Augmentations.transform_testing)
@@ -92,6 +98,21 @@ def build_model(a, ds, dev):
         ema.ema.load_state_dict(model.state_dict())
     ema.ema.cache_luts(radius=args.radius, height=ds.height, width=ds.width)
     return args, ema.ema
+
+
+def is_labelled(a):
+    """Whether the run is scored: DSEC with ground truth (run_test.py:43: no_eval stays False), or labelled synthetic data."""
+    return (a.dataset_directory is not None or bool(getattr(a, "labelled", False))) and not a.no_eval
+
+
+def save_metrics(metrics, output_directory, rank, name="metrics.json"):
+    """The run's metrics (ONE set for the whole run: ``DetectionBuffer.compute`` gathers the shards) -> rank 0's file."""
+    if metrics is None or rank != 0:
+        return
+    import json
+    output_directory.mkdir(parents=True, exist_ok=True)
+    with open(output_directory / name, "w") as f:
+        json.dump(metrics, f)
 
 
 def sequence_names(ds):

@@ -6,7 +6,9 @@ Under ``torch.distributed.run`` (one process per GPU) the window batches are sha
 gathered once at the end (RCCL).  The DSEC reader's dependencies are absent here, so the dataset is the benchmark's
 synthetic event stream with the DSEC sample contract (``dagr/data/synthetic_data.py``); without ``--checkpoint`` the model
 keeps seeded random weights.  The synthetic windows carry no boxes, so that run is ``no_eval`` and writes detection records;
-with ``--dataset_directory`` (DSEC) the detections are also scored (COCO-protocol mAP, ``dagr/utils/coco_eval.py``).
+with ``--dataset_directory`` (DSEC) or ``--labelled`` (synthetic objects with boxes) the detections are also scored
+(COCO-protocol mAP, ``dagr/utils/coco_eval.py``): ONE mAP for the run -- a sharded run gathers detections and ground truth
+of all ranks before the evaluation, as the reference's single process sees them (run_test.py:61-65).
 
   python scripts/run_test.py --config dagr-s --windows 64 --batch_size 8 --output_directory /tmp/out
   python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 scripts/run_test.py ...
@@ -32,12 +34,15 @@ def main(argv=None, model_factory=None):
     if rank == 0:
         log_hparams(args)
     t0 = time.perf_counter()
-    labelled = a.dataset_directory is not None and not a.no_eval
+    labelled = C.is_labelled(a)
     with torch.no_grad():
         metrics, detections = run_test_with_visualization(loader, net, dataset="dsec" if labelled else "synthetic",
                                                           compile_detections=True, no_eval=not labelled)
     if labelled and rank == 0:
-        print("metrics of this rank's windows:", metrics)
+        # run_test.py:61-65: ONE set of metrics for the run -- under a process group detections and ground truth of all
+        # ranks were gathered before the evaluation (utils/buffers.py:DetectionBuffer.compute)
+        print(f"metrics of the run ({world} rank(s)):", metrics)
+    C.save_metrics(metrics, out_dir, rank)
     names = C.sequence_names(ds)
     files = C.gather_and_save(C.detection_rows(detections, dev, names), out_dir, rank, names)
     if rank == 0:

@@ -30,11 +30,12 @@ def main(argv=None, model_factory=None):
     with torch.no_grad():
         for n_us in np.linspace(0, 50000, a.num_interframe_steps):
             loader.dataset.set_num_us(int(n_us))
-            labelled = a.dataset_directory is not None and not a.no_eval
+            labelled = C.is_labelled(a)
             metrics, one_offset = run_test_with_visualization(loader, net, dataset="dsec" if labelled else "synthetic",
                                                               compile_detections=True, no_eval=not labelled)
-            if metrics is not None and rank == 0:
-                print(f"Time Window: {int(n_us)} us \t mAP of this rank's windows: {metrics.get('mAP')}")
+            if metrics is not None and rank == 0:     # the run's mAP at this offset (all ranks' windows, gathered)
+                print(f"Time Window: {int(n_us)} us \t mAP: {metrics.get('mAP')}")
+            C.save_metrics(metrics, out_dir, rank, name=f"metrics_{int(n_us):06d}us.json")
             detections.extend(one_offset)
     names = C.sequence_names(ds)
     files = C.gather_and_save(C.detection_rows(detections, dev, names), out_dir, rank, names)

@@ -199,3 +199,38 @@ def test_update_grows_the_row_arrays_and_a_reset_starts_over():
         full2 = eng.forward_raw(pos[:3100], feat[:3100], batch[:3100]).clone()
         assert torch.equal(out2, full2)
     assert eng.rows_cap >= 9000 and cap0 <= eng.rows_cap
+
+
+def test_reset_false_falls_back_where_the_incremental_path_does_not_apply():
+    """configurations outside the incremental path (here max_neighbors = 8: the tiled level-0 conv and the
+    chain search are built for 16) used to raise on reset=False; they now re-evaluate the running window, as the
+    synchronous form does.  Same for an engine rebuilt between calls (weights edited in place)."""
+    from dagr_amd.data import Batch, Data
+    from dagr_amd.utils.buffers import format_data
+    W, H, B = 320, 215, 1
+    raw = syn.edges_window(4000, W, H, seed=77)
+
+    def batch_of(lo, hi):
+        x, y, t, p = (a[lo:hi] for a in raw)
+        d = Data(x=torch.from_numpy(p.reshape(-1, 1)), pos=torch.from_numpy(np.stack([x, y], -1)), t=torch.from_numpy(t),
+                 width=W, height=H, time_window=1000000)
+        return format_data(Batch.from_data_list([d]).cuda())
+
+    with torch.no_grad():
+        args, model = _model(W, H, B, seed=9, max_neighbors=8)
+        assert not model.engine().l0_tiles and not model.engine().can_append()
+        model(batch_of(0, 3000), reset=True, return_targets=False)
+        det, = model(batch_of(3000, 4000), reset=False, return_targets=False)
+        full, = model(batch_of(0, 4000), reset=True, return_targets=False)
+        for key in ("boxes", "scores", "labels"):
+            assert torch.equal(det[0][key], full[0][key]), key
+        # an engine rebuilt between the calls has no resident window: the update re-evaluates instead of failing
+        args, model = _model(W, H, B, seed=9)
+        model(batch_of(0, 3000), reset=True, return_targets=False)
+        assert model.engine().can_append()
+        with torch.no_grad():
+            model.backbone.conv_block1.conv_block1.norm.module.bias.add_(0.0)      # bumps the version: new engine
+        det, = model(batch_of(3000, 4000), reset=False, return_targets=False)
+        full, = model(batch_of(0, 4000), reset=True, return_targets=False)
+        for key in ("boxes", "scores", "labels"):
+            assert torch.equal(det[0][key], full[0][key]), key

@@ -80,6 +80,22 @@ def _log(name, rec):
         f.write(json.dumps(dict(case=name, **rec)) + "\n")
 
 
+def _path_counters(eng):
+    """Which paths the last window took (device-side counters): pixels with more than 64 events (k_order_long),
+    destinations deferred by the row kernel to the position-centric sweep (> 320 candidates), unsorted-timestamp
+    fallback, and -- cumulative -- level-0 nodes the pooling merged through its global path."""
+    import ctypes
+    from dagr_amd import _lib
+    g = eng.graph
+    gc = (ctypes.c_int32 * 8)()
+    _lib.check(eng.L.dagr_graph_counters(ctypes.byref(g.desc), _lib.ptr(g.workspace), ctypes.cast(gc, ctypes.c_void_p),
+                                         _lib.cur_stream(eng.device)), "graph_counters")
+    pc = (ctypes.c_int32 * 8)()
+    _lib.check(eng.L.dagr_pool_counters(ctypes.byref(eng.pool_desc[0]), _lib.ptr(eng.pool_ws[0]),
+                                        ctypes.cast(pc, ctypes.c_void_p), _lib.cur_stream(eng.device)), "pool_counters")
+    return dict(long_pixels=int(gc[0]), deferred=int(gc[5]), unsorted=int(gc[6]), pool1_global_path=int(pc[5]))
+
+
 def _events(gen, n, B, W, H, seed):
     x, y, t, p, b = syn.batch_windows(gen, n, B, W, H, seed=seed)
     pos = syn.format_data_np(x, y, t, W, H)
@@ -125,6 +141,12 @@ def _compare(args, model, sd, W, H, B, x, y, t, p, b, pos, image=None, plain=Fal
     # summation order the reference leaves unspecified; the engine's contract is the exact mean
     out_o, raw_o = om.forward_events(sd, args, H, W, x, y, t, p, b, B, trace=tr_o, image_feat=image_feat,
                                      cnn_out=cnn_out, exact_pos_mean=True)
+    # graph indices: bit-exact (north_star's first clause), at whatever size the case has
+    ei_h, _ = eng.graph.edge_index(tr_h["nbr"][0], tr_h["nbr"][2])
+    assert ei_h.shape == tr_o["edge_index"].shape and torch.equal(ei_h.cpu(), tr_o["edge_index"]), \
+        "edge_index differs from the oracle"
+    rec["edges"] = int(ei_h.shape[1])
+    rec["paths"] = _path_counters(eng)
     if image is not None:
         c = tr_o["x0_image"].shape[1]
         d0 = (tr_h["x0"].cpu()[:, :c] - tr_o["x0_image"]).abs().max().item()
@@ -218,6 +240,15 @@ def test_dagr_l_widths_events_only():
     W, H, B = 320, 215, 2
     args, model, sd = _setup(W, H, B, seed=6, net_stem_width=1.0, yolo_stem_width=1.0)
     _compare(args, model, sd, W, H, B, *_events(syn.edges_window, 5000, B, W, H, seed=17))
+
+
+def test_max_neighbors_8_takes_the_generic_level0_kernel():
+    """A checkpoint trained with max_neighbors != 16 (config key `max_neighbors`, dagr-s-dsec.yaml:10) runs on the generic
+    level-0 kernel (k_conv_l0: any list length, 3x3 / 3x5 / 5x5 tap windows) instead of the 16-node tiles."""
+    W, H, B = 320, 215, 2
+    args, model, sd = _setup(W, H, B, seed=21, max_neighbors=8)
+    assert not model.engine().l0_tiles
+    _compare(args, model, sd, W, H, B, *_events(syn.edges_window, 6000, B, W, H, seed=31))
 
 
 @pytest.mark.parametrize("name,width", [("dagr-m", 0.75), ("dagr-n", 0.25)])
@@ -381,6 +412,42 @@ def test_dagr_l_resnet50_b8():
     with torch.no_grad():
         _compare(args, model, sd, W, H, B, *_events(syn.edges_window, 30000, B, W, H, seed=3234),
                  image=_bench_image(B, H, W, 79), plain=True, log="dagr_l_resnet50_b8")
+
+
+def _last_log(name):
+    import json
+    import os
+    path = os.environ.get("DAGR_PARITY_LOG") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                             "gpurun_out", "parity_stage_errors.jsonl")
+    recs = [json.loads(line) for line in open(path)]
+    return [r for r in recs if r["case"] == name][-1]
+
+
+def test_vga_edges_b8_100k_whole_engine():
+    """S-edges at the BASELINE size (640x480, B = 8 x 100 k) through the whole engine: the stream the latency table
+    reports next to S-uniform.  Its event-dense neighbourhoods leave the row kernel (> 320 candidates: deferred to
+    k_search_tiled, ev_graph.cu:48-78 semantics) and its voxels hold thousands of members."""
+    W, H, B = 640, 480, 8
+    args, model, sd = _setup(W, H, B, seed=0, calibrate=syn.edges_window)
+    name = "vga_edges_events_only_b8_100k"
+    _compare(args, model, sd, W, H, B, *_events(syn.edges_window, 100000, B, W, H, seed=1234), plain=True, log=name)
+    assert _last_log(name)["paths"]["deferred"] > 0, "the dense-neighbourhood path did not run"
+
+
+@pytest.mark.parametrize("stream,n", [("uniform", 200000), ("uniform", 400000), ("edges", 200000), ("edges", 400000)])
+def test_vga_b1_dense_windows(stream, n):
+    """N = 200 k / 400 k events in ONE 50 ms window (the right end of bench.py's latency table), both streams: graph
+    indices exact, features 1e-4 (1 + |b|).  These windows are the ones that leave the fast paths: neighbourhoods beyond
+    320 candidates, pixels beyond the FIFO depth (ev_graph.cu:201-211)."""
+    W, H, B = 640, 480, 1
+    gen = syn.uniform_window if stream == "uniform" else syn.edges_window
+    args, model, sd = _setup(W, H, B, seed=3, calibrate=gen)
+    name = f"vga_b1_{stream}_{n // 1000}k"
+    _compare(args, model, sd, W, H, B, *_events(gen, n, B, W, H, seed=4234), plain=True, log=name)
+    paths = _last_log(name)["paths"]
+    if stream == "edges" or n >= 400000:
+        assert paths["deferred"] > 0, "the dense-neighbourhood path did not run"
+    assert paths["pool1_global_path"] > 0          # the window's t == 1.0 event (QUIRK-1) at least
 
 
 @pytest.mark.parametrize("stream", ["uniform", "edges"])

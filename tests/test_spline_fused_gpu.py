@@ -129,59 +129,3 @@ def test_fused_rejects_oversized_k():
     rc = L.dagr_spline_conv_fused(None, 1, _lib.ptr(z), _lib.ptr(z), _lib.ptr(z), _lib.ptr(f), 2400, 2400, None, 0, 0, 7, 7,
                                   14.0, 14.0, _lib.ptr(f), None, _lib.ptr(f), 64, 64, 1, _lib.cur_stream(dev))
     assert rc != 0 and b"does not fit" in L.dagr_last_error()
-
-
-TILE_CASES = [  # T, cin, cskip, N, max_deg, relu
-    (700, 34, 0, 64, 9, True),        # 2 channel groups + 2 extras (dagr-n widths)
-    (1000, 64, 66, 64, 12, True),     # conv_block2 of a 64-wide level: skip input = 64 + 2 position channels
-    (37, 66, 66, 128, 70, False),     # ragged tile, > 64 edges on a node, 8 column tiles
-    (300, 18, 0, 21, 5, True),        # level 1: 16 + 2, odd N
-    (5000, 82, 0, 64, 8, True),       # --use_image level 1: 16 + 64 + 2 (more tiles than the spread threshold)
-    (16, 3, 3, 7, 0, True),           # no edges at all, extras only
-    (200, 64, 0, 105, 6, False),      # predictor with 100 classes
-    (1200, 130, 130, 64, 7, True),    # --use_image level >= 2: K = 3510 (beyond the fused kernel's LDS tile)
-]
-
-
-@pytest.mark.parametrize("T,cin,cskip,N,max_deg,relu", TILE_CASES)
-def test_tiled_pooled_conv_matches_float64(T, cin, cskip, N, max_deg, relu):
-    """dagr_spline_conv_tiles (csrc/conv_pooled_tiles.hip) through the C ABI, rows padded to 16 bytes as the engine
-    stores them, rectangular offset domain (rx != ry)."""
-    from dagr_amd import _lib
-    L = _lib.lib()
-    dev = torch.device("cuda:0")
-    rng = np.random.default_rng(T * 17 + cin)
-    r, den = 7, (14.0, 17.5)
-    deg = rng.integers(0, max_deg + 1, size=T)
-    rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
-    E = int(rowptr[-1])
-    col = rng.integers(0, T, size=E).astype(np.int32)
-    code = (rng.integers(0, 2 * r + 1, size=E) | (rng.integers(0, 2 * r + 1, size=E) << 16)).astype(np.int32)
-    ldx, lds = (cin + 3) // 4 * 4, (cskip + 3) // 4 * 4
-    x = np.zeros((T, ldx), np.float32); x[:, :cin] = rng.standard_normal((T, cin))
-    xs = None
-    if cskip:
-        xs = np.zeros((T, lds), np.float32); xs[:, :cskip] = rng.standard_normal((T, cskip))
-    K = 26 * cin + cskip
-    Wm = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
-    bias = rng.standard_normal(N).astype(np.float32)
-    want = _reference(rowptr, col, code, x[:, :cin], None if xs is None else xs[:, :cskip], Wm, bias, relu, r, den)
-    scale = max(1.0, float(np.abs(want).max()))
-    wt = np.empty(L.dagr_spline_conv_tiles_pack_elems(cin, cskip, N), np.float32)
-    assert L.dagr_spline_conv_tiles_pack(Wm.ctypes.data, N, cin, cskip, N, wt.ctypes.data) == 0
-    t = lambda a: None if a is None else torch.from_numpy(a).to(dev)
-    d_rowptr, d_col, d_code, d_x, d_xs, d_bias, d_wt = t(rowptr), t(col), t(code), t(x), t(xs), t(bias), t(wt)
-    if E == 0:
-        d_col = torch.zeros(1, dtype=torch.int32, device=dev)
-        d_code = torch.zeros(1, dtype=torch.int32, device=dev)
-    P, S = _lib.ptr, _lib.cur_stream(dev)
-    for n_live in ([T, T - 19] if T > 20 else [T]):
-        n_ptr = torch.tensor([n_live], dtype=torch.int32, device=dev)
-        out = torch.full((T, N), 7.0, dtype=torch.float32, device=dev)
-        _lib.check(L.dagr_spline_conv_tiles(P(n_ptr), T, P(d_rowptr), P(d_col), P(d_code), P(d_x), ldx, cin, P(d_xs), lds,
-                                            cskip, r, r, den[0], den[1], P(d_wt), P(d_bias), P(out), N, N, int(relu), S),
-                   "spline_conv_tiles")
-        torch.cuda.synchronize()
-        got = out.cpu().numpy()
-        assert np.abs(got[:n_live] - want[:n_live]).max() <= 1e-4 * scale
-        assert (got[n_live:] == 7.0).all()           # rows past the device-side count stay untouched

@@ -40,11 +40,4 @@ with torch.no_grad():
         host.append(time.perf_counter() - t0)          # host time to ISSUE the window (no sync inside)
         torch.cuda.synchronize()
     print("host issue time per window (us):", [round(h * 1e6) for h in host])
-    import ctypes
-    from dagr_amd import _lib
-    clk = (ctypes.c_longlong * 8)()
-    _lib.check(_lib.lib().dagr_debug_postprocess_clocks(ctypes.cast(clk, ctypes.c_void_p)), "pp clocks")
-    c = list(clk)
-    print("postprocess phases (us @100MHz): score %.1f sort %.1f stage %.1f masks %.1f chain %.1f compact %.1f total %.1f" % (
-        (c[1] - c[0]) / 100, (c[2] - c[1]) / 100, (c[3] - c[2]) / 100, (c[6] - c[3]) / 100, (c[4] - c[6]) / 100,
-        (c[5] - c[4]) / 100, (c[5] - c[0]) / 100))
+

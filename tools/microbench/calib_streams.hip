@@ -1,4 +1,4 @@
-// debug.hip -- known-byte-count streaming kernels used to calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE on
+// calib_streams.hip (was csrc/debug.hip until round 4; no longer part of libdagr_hip) -- known-byte-count streaming kernels used to calibrate rocprofv3 FETCH_SIZE / WRITE_SIZE on
 // this access pattern (MI355X_MICROARCH.md, HBM section: "calibrate on a known byte count in your own
 // access pattern before trusting an absolute").  Not on the product path.
 #include "common.hpp"
