@@ -57,7 +57,10 @@ def parse():
                     help="independent engine instances (own buffers + stream) that consecutive window batches "
                          "rotate through; windows share no state, so batch i's latency-bound tail overlaps the level 0 "
                          "of batches i+1, i+2")
-    ap.add_argument("--cpu-steps", type=int, default=1, help="steps (of B windows) the CPU baseline leg times")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="steps the CPU baseline legs time (median is reported)")
+    ap.add_argument("--cpu-batch", type=int, default=2,
+                    help="windows per CPU-baseline step (a bounded sample of the GPU step's --batch windows of the same "
+                         "size; the oracle's cost is linear in the number of windows)")
     ap.add_argument("--latency-windows", type=int, default=100)
     ap.add_argument("--latency-warmup", type=int, default=20)
     ap.add_argument("--latency-n", type=str, default="25000,50000,100000,200000,400000")
@@ -120,7 +123,7 @@ def algorithmic_bytes(N, E, r, levels, use_image=False):
     out["l0_sample1"] = sample(fch[1], N)
     n1, e1 = levels[0]
     cp = 16 + fch[1]
-    out["pool1"] = 4 * (cp + 5) * N + 8 * E + 4 * (cp + 4) * n1 + 12 * e1
+    out["pool1"] = 4 * (cp + 5) * N + 8 * E + 4 * (cp + 4) * n1 + 12 * e1      # 8(d): x, pos, batch in + edges in + level 1 out
     tail = 0
     for k, (nn, ee) in enumerate(levels):
         cin = (16 if k == 0 else 64) + fch[k + 1] + 2
@@ -204,11 +207,12 @@ def cpu_baseline(model_cpu, model_sd, W, H, B, n_events, n_steps, stream, use_im
     med = float(np.median(times))
     what = f"dagr-s + {img_net} image branch" if use_image else "events-only dagr-s"
     return dict(value=B * n_events / med, unit="events/s", cores=torch.get_num_threads(), kind="port",
-                step_ms_median=round(1e3 * med, 1), graph_ms_median=round(1e3 * float(np.median(t_graph)), 1),
-                graph_threads=min(B, os.cpu_count() or 1),
-                sample=f"median of {n_steps} steps of B={B} windows x {n_events} events, {W}x{H}, {what} -- the step the "
-                       f"GPU line times; oracle/model.py (torch-CPU fp32 on {torch.get_num_threads()} threads + C graph "
-                       f"builder, one thread per sample), {sum(times):.1f} s of CPU work")
+                step_ms_median=round(1e3 * med, 1), step_ms_all=[round(1e3 * t, 1) for t in times],
+                graph_ms_median=round(1e3 * float(np.median(t_graph)), 1), graph_threads=min(B, os.cpu_count() or 1),
+                sample=f"median of {n_steps} steps of B={B} windows x {n_events} events, {W}x{H}, {what} (the GPU line's "
+                       f"windows and model, {B} windows per step instead of the GPU step's batch); oracle/model.py "
+                       f"(torch-CPU fp32 on {torch.get_num_threads()} threads + C graph builder, one thread per sample), "
+                       f"{sum(times):.1f} s of CPU work")
 
 
 class DryRunRig:
@@ -367,9 +371,12 @@ def stage_timings(rig, slots, n_events_step):
     stages["l0_input"] = time_gpu(lambda: eng.stage_l0_input(feat), iters)
     stages["l0_conv1"] = time_gpu(eng.stage_l0_conv1, iters)
     stages["l0_conv2"] = time_gpu(lambda: eng.stage_l0_conv2(sample=False), iters)
-    if use_image:
-        stages["l0_sample1"] = time_gpu(lambda: (eng.stage_l0_conv2(sample=True)), iters) - stages["l0_conv2"]
+    if use_image:   # the sampling kernel itself (sampling_skip(image_feat[1]) into hp0's columns 16..), not a difference
+        stages["l0_sample1"] = time_gpu(eng.stage_l0_sample1, iters)
     stages["pool1"] = time_gpu(eng.stage_pool1, iters)
+    # pool1's accumulation kernel alone (the one HBM-proportional launch of the stage; scan + emit work on the voxel table)
+    stages["pool1_accumulate"] = time_gpu(eng.pool1_accumulate_again, iters)
+    eng.stage_pool1()            # re-arms the accumulators the repeated launches filled
     stages["tail"] = time_gpu(eng.stage_tail, iters)
     stages["head"] = time_gpu(lambda: eng._decode(eng.stage_head()), iters)
     if not use_image:
@@ -390,14 +397,32 @@ def stage_timings(rig, slots, n_events_step):
     comp["graph_search"] = 4 * rig.W * rig.H * rig.B + 12 * N_ + 6 * ne + 4 * N_
     kernels["graph_search"] = dict(ms=round(stages["graph_search"], 4), alg_MB=round(ab["graph_search"] / 1e6, 2),
                                    alg_GBs=round(ab["graph_search"] / 1e9 / (stages["graph_search"] / 1e3), 1))
-    dom = max(("graph_search", "l0_conv1", "l0_conv2"), key=lambda k: stages[k])
-    achieved = ab[dom] / 1e9 / (stages[dom] / 1e3)
-    kname = dict(eng.l0_kernel_names(), graph_search="k_search_rows<320, false, 4, 7>")[dom]
+    # pool1's accumulation kernel streams every level-0 row once: input rows + positions + ids + degrees + neighbour
+    # codes + slot words in, the (small) level-1 arrays out
+    cp = 16 + (64 if use_image else 0)
+    comp["pool1"] = N_ * (4 * cp + 12 + 8 + 4 + 2 * eng.graph.K + 4) + 4 * (cp + 4) * levels[0][0] + 12 * levels[0][1]
+    ab["pool1_accumulate"] = ab["pool1"]
+    comp["pool1_accumulate"] = comp.pop("pool1")
+    cands = ("graph_search", "l0_conv1", "l0_conv2", "pool1_accumulate")
+    dom = max(cands, key=lambda k: stages[k])
+    names = dict(eng.l0_kernel_names(), graph_search="k_search_rows<320, false, 4, 7>",
+                 pool1_accumulate=f"k_pool_l0_slots<0, {4 if cp % 4 == 0 else 1}>")
+    kname = names[dom]
+    # fp32 work of a level-0 conv launch (conv_l0_tiles.hip): phase 1 updates ALL taps of the TX x TY window per edge
+    # (executed) although an edge weights only 4 of them (useful); phase 2 contracts [(NT + 1) * cin + cskip] x 16 per node
+    nt = eng.ntaps0
+    c0 = 3 + (16 if use_image else 0)
+
+    def conv_flops(cin, cskip):
+        phase2 = 2.0 * N_ * ((nt + 1) * cin + cskip) * 16
+        return 2.0 * ne * nt * cin + phase2, 2.0 * ne * 4 * cin + phase2
+    flops = {"l0_conv1": conv_flops(c0, 0), "l0_conv2": conv_flops(16, c0)}
+    FP32_PEAK_TF = 157.3      # MI355X_MICROARCH.md: fp32 vector / matrix peak (the f32 MFMA runs at the VALU FMA rate)
     # HBM bytes per launch: PMC counters cannot be read from inside this process; the number is the one the
     # rocprofv3 --pmc passes of this same command produced (tools/pmc.sh -> profiles/r*_traffic.json, committed) --
     # accepted only if that file was measured on this build of the kernels (source stamp), else null
-    traffic, src = None, None
     stamp = source_stamp()
+    tj_cfg, src = None, None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
         tj = json.load(open(path))
         if n_events_step != 800000 or (rig.W, rig.H) != (640, 480):
@@ -405,21 +430,35 @@ def stage_timings(rig, slots, n_events_step):
         if tj.get("source_stamp") != stamp:
             src = f"stale: {os.path.basename(path)} was measured on another build of the kernels"
             continue
-        cfg = tj["configs"]["use_image" if use_image else "events_only"]
-        if kname in cfg:
-            traffic, src = cfg[kname].get("traffic_bytes"), "profiles/" + os.path.basename(path)
-            break
-    floor = comp[dom]
-    floor_us = floor / (HBM_ACHIEVABLE_GBS * 1e3)
-    roofline = dict(kernel=kname, stage=dom, bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=src,
-                    frac_traffic=(round(traffic / 1e9 / (stages[dom] / 1e3) / HBM_PEAK_GBS, 4) if traffic else None),
-                    compulsory_bytes=int(floor), floor_us=round(floor_us, 1),
-                    x_over_floor=round(stages[dom] * 1e3 / floor_us, 1),
-                    alg_bytes_per_launch=int(ab[dom]), launch_ms=round(stages[dom], 4), source_stamp=stamp,
-                    candidates={k: dict(ms=round(stages[k], 4), frac=round(ab[k] / 1e9 / (stages[k] / 1e3) / HBM_PEAK_GBS, 4),
-                                        x_over_floor=round(stages[k] * 1e3 / (comp[k] / (HBM_ACHIEVABLE_GBS * 1e3)), 1))
-                                for k in ("graph_search", "l0_conv1", "l0_conv2")})
+        tj_cfg, src = tj["configs"]["use_image" if use_image else "events_only"], "profiles/" + os.path.basename(path)
+        break
+
+    def describe(k):
+        """One kernel against the roofline it is on: the level-0 convs are bound by their fp32 FMAs (the matrix pipe runs
+        f32 at the vector rate: `mfma` against the 157.3 TF fp32 peak), search and pooling by HBM bytes."""
+        ms = stages[k]
+        traffic = tj_cfg[names[k]].get("traffic_bytes") if tj_cfg is not None and names[k] in tj_cfg else None
+        frac_bytes = ab[k] / 1e9 / (ms / 1e3) / HBM_PEAK_GBS
+        out = dict(kernel=names[k], stage=k, launch_ms=round(ms, 4), alg_bytes_per_launch=int(ab[k]),
+                   frac_alg_bytes=round(frac_bytes, 4), traffic=traffic,
+                   frac_traffic=(round(traffic / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4) if traffic else None),
+                   compulsory_bytes=int(comp[k]), floor_us=round(comp[k] / (HBM_ACHIEVABLE_GBS * 1e3), 1),
+                   x_over_floor=round(ms * 1e3 / (comp[k] / (HBM_ACHIEVABLE_GBS * 1e3)), 1))
+        if k in flops:
+            ex, useful = flops[k]
+            tf = ex / 1e12 / (ms / 1e3)
+            out.update(bound="mfma", achieved=round(tf, 1), peak=FP32_PEAK_TF, unit="TFLOP/s", frac=round(tf / FP32_PEAK_TF, 4),
+                       executed_gflop=round(ex / 1e9, 2), useful_gflop=round(useful / 1e9, 2),
+                       frac_useful=round(useful / 1e12 / (ms / 1e3) / FP32_PEAK_TF, 4))
+        else:
+            out.update(bound="hbm", achieved=round(ab[k] / 1e9 / (ms / 1e3), 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                       frac=round(frac_bytes, 4))
+        return out
+    roofline = describe(dom)
+    roofline.update(traffic_source=src, source_stamp=stamp,
+                    candidates={k: {f: v for f, v in describe(k).items()
+                                    if f in ("kernel", "launch_ms", "bound", "achieved", "unit", "frac", "frac_alg_bytes",
+                                             "frac_traffic", "x_over_floor", "frac_useful")} for k in cands})
     image_branch = None
     if use_image:
         # the dense image branch is library code (MIOpen / hipBLASLt fp32): its share and its rate against the fp32 matrix peak
@@ -434,7 +473,7 @@ def stage_timings(rig, slots, n_events_step):
                             frac_of_157=round(gflop / stages["image_branch"] / 157.3, 3),
                             note="ResNet-50 HookModule + CNNHead on PyTorch-ROCm (MIOpen / hipBLASLt fp32), FLOPs counted "
                                  "on the plain modules; not hand-written code")
-    total = sum(v for k, v in stages.items() if k not in ("tail_head_graph", "graph_search"))
+    total = sum(v for k, v in stages.items() if k not in ("tail_head_graph", "graph_search", "pool1_accumulate"))
     return dict(roofline=roofline, stages=kernels, edges_per_step=int(ne), levels=levels, radius=r,
                 batch_latency_ms=round(total, 4), image_branch=image_branch)
 
@@ -627,6 +666,7 @@ def main():
                 "roofline": est["roofline"], "stages": est["stages"], "stage_sum_ms": est["batch_latency_ms"]}
     want_cpu = rank == 0 and world == 1 and not a.no_cpu_baseline
     sd_cpu = rig.sd_cpu
+    ev_sd_cpu = ev_rig.sd_cpu if ev_rig is not None else None
     model_cpu = None
     if want_cpu and use_image:
         _, model_cpu = make_model(W, H, B, use_image=True, img_net=a.img_net)
@@ -646,8 +686,13 @@ def main():
         result["latency_ms"] = lat
         result["async_update"] = async_update_leg(W, H, dev)
     if want_cpu:
-        result["cpu_baseline"] = cpu_baseline(model_cpu, sd_cpu, W, H, B, NPW, a.cpu_steps, a.stream, use_image,
+        Bc = max(1, min(B, a.cpu_batch))
+        result["cpu_baseline"] = cpu_baseline(model_cpu, sd_cpu, W, H, Bc, NPW, a.cpu_steps, a.stream, use_image,
                                               a.img_net)
+        if ev_sd_cpu is not None and "events_only" in result:
+            # BASELINE config 1's shape (events-only dagr-s on the CPU) beside the events_only leg of the GPU line
+            result["events_only"]["cpu_baseline"] = cpu_baseline(None, ev_sd_cpu, W, H, Bc, NPW, a.cpu_steps, a.stream,
+                                                                 False, a.img_net)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:

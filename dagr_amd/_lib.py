@@ -85,6 +85,9 @@ SIGNATURES = {
                                     c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_void_p]),
+    "dagr_pool_l0_accumulate": (ctypes.c_int, [ctypes.POINTER(PoolDesc), c_void_p, ctypes.POINTER(GraphDesc), c_void_p,
+                                               c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_i64, c_void_p, c_void_p,
+                                               c_void_p, c_void_p]),
     "dagr_pool_csr": (ctypes.c_int, [ctypes.POINTER(PoolDesc), c_void_p, c_void_p, c_i32, c_void_p, c_i32, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_void_p]),

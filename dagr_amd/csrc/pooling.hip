@@ -35,6 +35,7 @@ namespace dagr {
 namespace {
 
 constexpr int kRowSlots = 64;           // coarse in-degree bound per cluster (flagged if exceeded)
+constexpr int kPoolScanTile = 2048;     // table slots per workgroup of the chained scan (256 threads x 8)
 constexpr int kMaxL0Channels = 512;     // feature channels of a level-0 pooling (LDS window: at least one voxel row)
 constexpr double kPosScale = 1099511627776.0;  // 2^40
 constexpr double kFeatScale = 4294967296.0;    // 2^32
@@ -49,7 +50,9 @@ struct PoolWs {
     long long *xacc;     // [T][C]: ordered-int max (low 32 bits) or fixed-point sum
     int32_t *rows;       // [T][64] source-cluster sets, -1 = empty (raw ids on the 3-launch path)
     int32_t *rowcnt;     // [T+1]
-    int32_t *status;     // [8]: 0 flags (sticky); 4 = epoch; 5 = level-0 nodes merged through the global path (sticky, cumulative)
+    int32_t *status;     // [8]: 0 flags (sticky); 4 = epoch; 5 = level-0 nodes merged through the global path (sticky, cumulative);
+                         //      6 = launch tag of the chained scan; 7 = its tile ticket counter (zero between launches)
+    unsigned long long *tile_state;   // [ceil((T + 1) / kPoolScanTile) + 8] chained scan: tag | flag | clusters | edges
     unsigned long long *nbmask;  // [T] level 0: 5x5 bitmaps of source cells, zero between calls: bits 0-24 cells of the
                                  // slot's own sample plane, bits 32-56 cells of the plane below (sources of the slot's
                                  // t == 1.0 members, QUIRK-1)
@@ -75,6 +78,7 @@ __host__ __device__ inline size_t pool_carve(const dagr_pool_desc &d, char *base
     w.rows = (int32_t *)take(T * (size_t)kRowSlots * 4);
     w.rowcnt = (int32_t *)take((T + 32) * 4);
     w.status = (int32_t *)take(32);
+    w.tile_state = (unsigned long long *)take(((T + 1 + kPoolScanTile - 1) / kPoolScanTile + 8) * 8);
     w.nbmask = (unsigned long long *)take((T + 9) * 8);
     w.T = (int)T;
     if (ws) *ws = w;
@@ -193,92 +197,90 @@ __global__ __launch_bounds__(kBlock) void k_pool_accumulate(dagr_pool_desc d, co
 // ---------------------------------------------------------------------------------------------
 // level 0, streaming form.  Nodes are CSR slots in (sample, y, x, time) order, so all voxels of one sample / voxel row
 // (a "band") own ONE contiguous run of slots, and their table ids are contiguous too (raw = cx + gx * (cy + gy * b)).
-// The kernel therefore never looks a member up: every workgroup streams a contiguous run of slots -- feature rows,
-// positions, ids, degrees and neighbour codes as fully coalesced reads -- and accumulates into an LDS window of VW
-// table slots that starts at the band of its first slot:
+// The kernel therefore never looks a member up: the slots are cut into EQUAL contiguous runs, one per workgroup (balanced
+// whatever the event density: S-edges puts thousands of members into a few voxels), and every workgroup streams its run
+// -- feature rows, positions, ids, degrees and neighbour codes as fully coalesced reads -- into an LDS window of VW table
+// slots that starts at the band of its first slot:
 //   phase B  one lane per node (64 nodes per wave step): voxel from two per-pixel LDS tables, count / largest id /
 //            64-bit fixed-point position sums as LDS atomics, the 5x5 source-cell bitmap from the node's neighbour codes;
 //   phase A  the step's 64 feature rows as one flat run of 16-byte pieces across the wave (lane f: node f / PPN, piece
-//            f % PPN), each piece merged by LDS atomics (ordered-int max / 64-bit fixed-point add).
-// Nodes outside the window (a run of a sparse window spans several bands) and t == 1.0 nodes (QUIRK-1: their cluster is
-// the same cell one sample plane up) go straight to the global accumulators; status[5] counts them (sticky).  At the end the
-// workgroup merges the voxels it touched into the global accumulators with one atomic per word: every reduction is
-// order-free (integer max / integer sums), so the result does not depend on how slots are cut into workgroups.
-// Before: one wave per voxel walking its members through a row table in LDS -- a chain of dependent loads per member,
-// 0.18 - 0.23 of HBM peak, and a second launch for the tails of event-dense voxels.
-struct PoolL0Lds {
-    int *acc;                    // [VW][C] ordered-int max, or [VW][C] u64 sums
-    int *cnt, *perm;             // [VW]
-    unsigned *nbm;               // [VW]
-    unsigned long long *ps;      // [VW][3]
-    unsigned short *xlut, *ylut; // [W], [H] voxel column / row of a pixel
-    short *sv;                   // [waves][64] window slot of the nodes of the wave's current step (-1: none)
-};
+//            f % PPN), each piece merged by LDS atomics (ordered-int max / 64-bit fixed-point add).  The first pieces are
+//            requested BEFORE phase B's arithmetic and every further batch before the previous one is merged: a wave
+//            keeps ~8 KB in flight.
+// Workgroups are large (16 waves, one or two per CU): a workgroup merges every voxel it touched into the global
+// accumulators with one atomic per word, and a band cut into fewer runs means fewer of those.  A run longer than the
+// window's bands is walked in segments (the window is merged, re-armed and moved: bands ascend along the slots);
+// t == 1.0 nodes (QUIRK-1: their cluster is the same cell one sample plane up) go straight to the global
+// accumulators; status[5] counts them (sticky).  Every reduction is
+// order-free (integer max / integer sums), so the result does not depend on how slots are cut into runs, steps or waves.
+// Before (round 3): one wave per voxel walking its members through a row table in LDS -- a chain of dependent loads per
+// member, 0.18 - 0.23 of HBM peak, and a second launch for the tails of event-dense voxels.
+constexpr int kPoolL0Block = 1024;
 
 template <int AGGR>
 __host__ __device__ inline size_t pool_l0_lds_bytes(int VW, int C, int W, int H) {
-    size_t b = (size_t)VW * C * (AGGR == 0 ? 4 : 8);
-    b += (size_t)VW * (4 + 4 + 4 + 24);
-    b += ((size_t)(W + H) * 2 + 7) / 8 * 8;
-    b += (kBlock / 64) * 64 * 2;
+    size_t b = ((size_t)VW * C * (AGGR == 0 ? 4 : 8) + 7) / 8 * 8;   // feature accumulators
+    b += (size_t)VW * (24 + 4 + 4 + 4);                                 // position sums, count, largest id, bitmap
+    b += (kPoolL0Block / 64) * 64 * 2;                                  // per wave: window slot of the step's nodes
+    b += ((size_t)(W + H) * 2 + 7) / 8 * 8;                             // pixel -> voxel column / row
     return b + 64;
 }
 
 template <int AGGR, int VEC>   // 0 = max, 1 = mean; VEC = floats per piece (4: rows are 16-byte aligned, 1: any layout)
-__global__ __launch_bounds__(kBlock) void k_pool_l0_slots(dagr_pool_desc d, int W, int H, int n_cap, int VW,
-                                                         const int32_t *__restrict__ n_ptr,
-                                                         const int32_t *__restrict__ xlo,  // [gx+1] pixel bounds
-                                                         const int32_t *__restrict__ ylo,  // [gy+1]
-                                                         const int2 *__restrict__ slot_it,
-                                                         const int32_t *__restrict__ slot_xyb,
-                                                         const float *__restrict__ x, int ldx,
-                                                         const float *__restrict__ pos, PoolWs ws,
-                                                         // coarse-edge fast path (NULL = off): neighbour offset codes
-                                                         const int16_t *__restrict__ nbr_code,
-                                                         const int32_t *__restrict__ nbr_src,
-                                                         const int32_t *__restrict__ deg, int K, int r) {
+__global__ __launch_bounds__(kPoolL0Block) void k_pool_l0_slots(dagr_pool_desc d, int W, int H, int n_cap, int VW,
+                                                               const int32_t *__restrict__ n_ptr,
+                                                               const int32_t *__restrict__ xlo,  // [gx+1] pixel bounds
+                                                               const int32_t *__restrict__ ylo,  // [gy+1]
+                                                               const int32_t *__restrict__ start,
+                                                               const int2 *__restrict__ slot_it,
+                                                               const int32_t *__restrict__ slot_xyb,
+                                                               const float *__restrict__ x, int ldx,
+                                                               const float *__restrict__ pos, PoolWs ws,
+                                                               // coarse-edge fast path (NULL = off): offset codes
+                                                               const int16_t *__restrict__ nbr_code,
+                                                               const int32_t *__restrict__ nbr_src,
+                                                               const int32_t *__restrict__ deg, int K, int r) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
+    constexpr int NW = kPoolL0Block / 64;
     const int n = min(*n_ptr, n_cap);
     // every workgroup takes the same share of the nodes that are there (n comes from the device: the launch is sized
     // for the capacity, so that a captured graph serves windows of any size)
-    const int per_block = max(256, (int)(((long long)n + gridDim.x - 1) / gridDim.x + 63) / 64 * 64);
+    const int per_block = max(64 * NW, (int)(((long long)n + gridDim.x - 1) / gridDim.x + 63) / 64 * 64);
     const int s_begin = blockIdx.x * per_block;
     if (s_begin >= n) return;
     const int s_end = min(n, s_begin + per_block);
     const int C = d.channels;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    PoolL0Lds L;
+    int *l_acc; unsigned long long *l_ps; int *l_cnt, *l_perm; unsigned *l_nbm; short *l_sv; unsigned short *l_xlut, *l_ylut;
     {
         unsigned char *p = lds_raw;
-        L.acc = reinterpret_cast<int *>(p); p += (size_t)VW * C * (AGGR == 0 ? 4 : 8);
-        L.ps = reinterpret_cast<unsigned long long *>(p); p += (size_t)VW * 24;
-        L.cnt = reinterpret_cast<int *>(p); p += (size_t)VW * 4;
-        L.perm = reinterpret_cast<int *>(p); p += (size_t)VW * 4;
-        L.nbm = reinterpret_cast<unsigned *>(p); p += (size_t)VW * 4;
-        L.sv = reinterpret_cast<short *>(p); p += (kBlock / 64) * 64 * 2;
-        L.xlut = reinterpret_cast<unsigned short *>(p); p += (size_t)W * 2;
-        L.ylut = reinterpret_cast<unsigned short *>(p);
+        l_acc = reinterpret_cast<int *>(p); p += ((size_t)VW * C * (AGGR == 0 ? 4 : 8) + 7) / 8 * 8;
+        l_ps = reinterpret_cast<unsigned long long *>(p); p += (size_t)VW * 24;
+        l_cnt = reinterpret_cast<int *>(p); p += (size_t)VW * 4;
+        l_perm = reinterpret_cast<int *>(p); p += (size_t)VW * 4;
+        l_nbm = reinterpret_cast<unsigned *>(p); p += (size_t)VW * 4;
+        l_sv = reinterpret_cast<short *>(p); p += NW * 64 * 2;
+        l_xlut = reinterpret_cast<unsigned short *>(p); p += (size_t)W * 2;
+        l_ylut = reinterpret_cast<unsigned short *>(p);
     }
-    for (int i = threadIdx.x; i < VW * C; i += kBlock) {
-        if (AGGR == 0) L.acc[i] = kEncMin;
-        else reinterpret_cast<unsigned long long *>(L.acc)[i] = 0ull;
-    }
-    for (int i = threadIdx.x; i < VW; i += kBlock) {
-        L.cnt[i] = 0; L.perm[i] = -1; L.nbm[i] = 0u;
-        L.ps[3 * i] = 0ull; L.ps[3 * i + 1] = 0ull; L.ps[3 * i + 2] = 0ull;
-    }
+    auto arm_window = [&]() {
+        for (int i = threadIdx.x; i < VW * C; i += kPoolL0Block) {
+            if (AGGR == 0) l_acc[i] = kEncMin;
+            else reinterpret_cast<unsigned long long *>(l_acc)[i] = 0ull;
+        }
+        for (int i = threadIdx.x; i < VW; i += kPoolL0Block) {
+            l_cnt[i] = 0; l_perm[i] = -1; l_nbm[i] = 0u;
+            l_ps[3 * i] = 0ull; l_ps[3 * i + 1] = 0ull; l_ps[3 * i + 2] = 0ull;
+        }
+    };
+    arm_window();
     // pixel -> voxel column / row (cell c owns the pixels [lo[c], lo[c+1]): the host's fp32 division, tabulated)
-    for (int c = threadIdx.x; c < d.gx; c += kBlock)
-        for (int px = xlo[c]; px < min(xlo[c + 1], W); px++) L.xlut[px] = (unsigned short)c;
-    for (int c = threadIdx.x; c < d.gy; c += kBlock)
-        for (int py = ylo[c]; py < min(ylo[c + 1], H); py++) L.ylut[py] = (unsigned short)c;
+    for (int c = threadIdx.x; c < d.gx; c += kPoolL0Block)
+        for (int px = xlo[c]; px < min(xlo[c + 1], W); px++) l_xlut[px] = (unsigned short)c;
+    for (int c = threadIdx.x; c < d.gy; c += kPoolL0Block)
+        for (int py = ylo[c]; py < min(ylo[c + 1], H); py++) l_ylut[py] = (unsigned short)c;
     __syncthreads();
     const int cells = d.gx * d.gy;
-    int raw0;
-    {
-        const int c0 = slot_xyb[s_begin];
-        raw0 = d.gx * ((int)L.ylut[(c0 >> 12) & 4095] + d.gy * ((c0 >> 24) & 127));
-    }
     const int pair = ws_pair(ws);
     long long *w_possum = ws_possum(ws, pair);
     int32_t *w_cnt = ws_cnt(ws, pair);
@@ -287,17 +289,74 @@ __global__ __launch_bounds__(kBlock) void k_pool_l0_slots(dagr_pool_desc d, int 
     const int PPN = C / VEC;                            // pieces per node
     // f / PPN == umulhi(f, ceil(2^32 / PPN)) for f * PPN < 2^32
     const unsigned ppn_magic = PPN > 1 ? (unsigned)((0x100000000ull + (unsigned)PPN - 1) / (unsigned)PPN) : 0u;
+    constexpr int kBig = 1 << 28;
     int n_slow = 0;
-    for (int cs = s_begin + 64 * wv; cs < s_end; cs += 64 * (kBlock / 64)) {
-        // ---- phase B: one lane per node
+    const int T = ws.T;
+    const int WB = VW / d.gx;          // whole bands the window holds (>= 1)
+    // The run is walked in segments: the window covers the band of the segment's first slot and the WB - 1 bands after it;
+    // bands ascend along the slots, so the segment ends where band q0 + WB starts -- one entry of the builder's per-pixel
+    // offsets.  A run of a full-size window is one segment (sometimes two); sparse windows move the window often, on few
+    // nodes.
+    for (int seg_begin = s_begin; seg_begin < s_end;) {
+    int raw0, seg_end = s_end;
+    {
+        const int c0 = slot_xyb[seg_begin];
+        const int q0 = (int)l_ylut[(c0 >> 12) & 4095] + d.gy * ((c0 >> 24) & 127);
+        raw0 = d.gx * q0;
+        const int qe = q0 + WB;
+        if (qe < d.gy * d.batch_size) {
+            const int be = qe / d.gy, cye = qe - be * d.gy;
+            seg_end = min(s_end, max(seg_begin + 1, start[W * (min(ylo[cye], H) + H * be)]));
+        }
+    }
+    for (int cs = seg_begin + 64 * wv; cs < seg_end; cs += 64 * NW) {
+        // ---- phase B loads: one lane per node
         const int s = cs + lane;
+        const bool live = s < seg_end;
+        int c = 0, id = 0, dg = 0;
+        float px = 0.f, py = 0.f, pt = 0.f;
+        int4 lo4 = make_int4(0, 0, 0, 0), hi4 = lo4;
+        if (live) {
+            c = slot_xyb[s];
+            px = pos[3 * (size_t)s]; py = pos[3 * (size_t)s + 1]; pt = pos[3 * (size_t)s + 2];
+            id = slot_it[s].x;       // event id: consecutive_cluster's `perm`
+            if (nbr_code) {
+                dg = min(deg[s], K);
+                if (K == 16) {
+                    lo4 = *reinterpret_cast<const int4 *>(nbr_code + (size_t)s * 16);
+                    hi4 = *reinterpret_cast<const int4 *>(nbr_code + (size_t)s * 16 + 8);
+                }
+            }
+        }
+        // ---- phase A, first batch of pieces: requested before phase B's arithmetic (rows cs .. cs + 63 are contiguous)
+        const float *xrow = x + (size_t)cs * ldx;
+        const int n_live = min(64, seg_end - cs);
+        constexpr int U = 4;
+        float val[U][VEC];
+        int who[U];       // node << 16 | piece, or -1
+        auto request = [&](int f0) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int f = f0 + 64 * u + lane;
+                who[u] = -1;
+                if (f < n_live * PPN) {
+                    const int k = PPN > 1 ? (int)__umulhi((unsigned)f, ppn_magic) : f, p = f - k * PPN;
+                    who[u] = (k << 16) | p;
+                    if constexpr (VEC == 4) {
+                        const float4 qv = *reinterpret_cast<const float4 *>(xrow + (size_t)k * ldx + 4 * p);
+                        val[u][0] = qv.x; val[u][1] = qv.y; val[u][2] = qv.z; val[u][3] = qv.w;
+                    } else {
+                        val[u][0] = xrow[(size_t)k * ldx + p];
+                    }
+                }
+            }
+        };
+        request(0);
+        // ---- phase B arithmetic
         int vloc = -1;
-        if (s < s_end) {
-            const int c = slot_xyb[s];
+        if (live) {
             const int xp = c & 4095, yp = (c >> 12) & 4095, b = (c >> 24) & 127;
-            const float px = pos[3 * (size_t)s], py = pos[3 * (size_t)s + 1], pt = pos[3 * (size_t)s + 2];
-            const int id = slot_it[s].x;       // event id: consecutive_cluster's `perm`
-            const int cx = L.xlut[xp], cy = L.ylut[yp];
+            const int cx = l_xlut[xp], cy = l_ylut[yp];
             const bool leak = pt >= 1.0f;
             const int raw = cx + d.gx * (cy + d.gy * b);
             const int rel = raw - raw0;
@@ -310,18 +369,15 @@ __global__ __launch_bounds__(kBlock) void k_pool_l0_slots(dagr_pool_desc d, int 
             // cx-1 .. cx+2 (and rows): the source's cell = cx-2 + #(bounds <= its pixel).
             unsigned nbm = 0, nbm_up = 0, nbm_low = 0;
             if (nbr_code) {
-                int bx[4], by[4];
+                int tx[4], ty[4];      // thresholds on the offset code's (ox, oy): xs >= bound  <=>  ox >= bound - xp + r
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int qx = cx - 1 + i, qy = cy - 1 + i;
-                    bx[i] = qx <= 0 ? INT_MIN : (qx >= d.gx ? INT_MAX : xlo[qx]);
-                    by[i] = qy <= 0 ? INT_MIN : (qy >= d.gy ? INT_MAX : ylo[qy]);
+                for (int k = 0; k < 4; k++) {
+                    const int qx = cx - 1 + k, qy = cy - 1 + k;
+                    tx[k] = (qx <= 0 ? -kBig : (qx >= d.gx ? kBig : xlo[qx])) - xp + r;
+                    ty[k] = (qy <= 0 ? -kBig : (qy >= d.gy ? kBig : ylo[qy])) - yp + r;
                 }
-                const int dg = min(deg[s], K);
                 int codes[16];
                 if (K == 16) {
-                    const int4 lo4 = *reinterpret_cast<const int4 *>(nbr_code + (size_t)s * 16);
-                    const int4 hi4 = *reinterpret_cast<const int4 *>(nbr_code + (size_t)s * 16 + 8);
                     const int w8[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
 #pragma unroll
                     for (int j = 0; j < 8; j++) { codes[2 * j] = (short)(w8[j] & 0xffff); codes[2 * j + 1] = w8[j] >> 16; }
@@ -334,9 +390,8 @@ __global__ __launch_bounds__(kBlock) void k_pool_l0_slots(dagr_pool_desc d, int 
                     if (j < dg) {
                         const int code = codes[j];
                         const int ox = (code * side_magic) >> 16, oy = code - ox * side;
-                        const int xs = xp + ox - r, ys = yp + oy - r;
-                        const int dcx = (xs >= bx[0]) + (xs >= bx[1]) + (xs >= bx[2]) + (xs >= bx[3]);   // 0..4, 2 = own cell
-                        const int dcy = (ys >= by[0]) + (ys >= by[1]) + (ys >= by[2]) + (ys >= by[3]);
+                        const int dcx = (ox >= tx[0]) + (ox >= tx[1]) + (ox >= tx[2]) + (ox >= tx[3]);   // 0..4, 2 = own cell
+                        const int dcy = (oy >= ty[0]) + (oy >= ty[1]) + (oy >= ty[2]) + (oy >= ty[3]);
                         const unsigned bit = 1u << (dcy * 5 + dcx);
                         if (!leak) {
                             nbm |= bit;
@@ -355,12 +410,12 @@ __global__ __launch_bounds__(kBlock) void k_pool_l0_slots(dagr_pool_desc d, int 
             }
             if (inwin) {
                 vloc = rel;
-                atomicAdd(&L.cnt[rel], 1);
-                atomicMax(&L.perm[rel], id);
-                atomicAdd(&L.ps[3 * rel], q0);
-                atomicAdd(&L.ps[3 * rel + 1], q1);
-                atomicAdd(&L.ps[3 * rel + 2], q2);
-                if (nbm) atomicOr(&L.nbm[rel], nbm);
+                atomicAdd(&l_cnt[rel], 1);
+                atomicMax(&l_perm[rel], id);
+                atomicAdd(&l_ps[3 * rel], q0);
+                atomicAdd(&l_ps[3 * rel + 1], q1);
+                atomicAdd(&l_ps[3 * rel + 2], q2);
+                if (nbm) atomicOr(&l_nbm[rel], nbm);
             } else {
                 // outside the window, or a t == 1.0 node: this lane merges its node into the global accumulators
                 const int rl = leak ? raw + cells : raw;
@@ -386,42 +441,33 @@ __global__ __launch_bounds__(kBlock) void k_pool_l0_slots(dagr_pool_desc d, int 
                 }
             }
         }
-        L.sv[wv * 64 + lane] = (short)vloc;
+        l_sv[wv * 64 + lane] = (short)vloc;
         __builtin_amdgcn_wave_barrier();
-        // ---- phase A: the step's feature rows as one flat run of pieces
-        const float *xrow = x + (size_t)cs * ldx;
-        constexpr int U = 4;
-        for (int f0 = 0; f0 < 64 * PPN; f0 += 64 * U) {
-            float val[U][VEC];
+        // ---- phase A: merge a batch while the next one is in flight
+        for (int f0 = 0; f0 < n_live * PPN; f0 += 64 * U) {
+            float cur[U][VEC];
             int tgt[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const int f = f0 + 64 * u + lane;
                 tgt[u] = -1;
-                if (f < 64 * PPN) {
-                    const int k = PPN > 1 ? (int)__umulhi((unsigned)f, ppn_magic) : f, p = f - k * PPN;
-                    const int v = L.sv[wv * 64 + k];
-                    if (v >= 0) {
-                        tgt[u] = v * C + p * VEC;
-                        if constexpr (VEC == 4) {
-                            const float4 q = *reinterpret_cast<const float4 *>(xrow + (size_t)k * ldx + 4 * p);
-                            val[u][0] = q.x; val[u][1] = q.y; val[u][2] = q.z; val[u][3] = q.w;
-                        } else {
-                            val[u][0] = xrow[(size_t)k * ldx + p];
-                        }
-                    }
+                if (who[u] >= 0) {
+                    const int v = l_sv[wv * 64 + (who[u] >> 16)];
+                    if (v >= 0) tgt[u] = v * C + (who[u] & 0xffff) * VEC;
                 }
+#pragma unroll
+                for (int j = 0; j < VEC; j++) cur[u][j] = val[u][j];
             }
+            if (f0 + 64 * U < n_live * PPN) request(f0 + 64 * U);
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 if (tgt[u] >= 0) {
 #pragma unroll
                     for (int j = 0; j < VEC; j++) {
                         if (AGGR == 0)
-                            atomicMax(&L.acc[tgt[u] + j], enc_f(val[u][j]));
+                            atomicMax(&l_acc[tgt[u] + j], enc_f(cur[u][j]));
                         else
-                            atomicAdd(reinterpret_cast<unsigned long long *>(L.acc) + tgt[u] + j,
-                                      (unsigned long long)(long long)llrint((double)val[u][j] * kFeatScale));
+                            atomicAdd(reinterpret_cast<unsigned long long *>(l_acc) + tgt[u] + j,
+                                      (unsigned long long)(long long)llrint((double)cur[u][j] * kFeatScale));
                     }
                 }
             }
@@ -429,31 +475,37 @@ __global__ __launch_bounds__(kBlock) void k_pool_l0_slots(dagr_pool_desc d, int 
         __builtin_amdgcn_wave_barrier();   // the step's window slots are re-used by the next step
     }
     __syncthreads();
-    // ---- merge the touched voxels into the global accumulators (leak nodes of the sample below and other workgroups
+    // ---- merge the touched voxels into the global accumulators (t == 1.0 nodes of the sample below and other workgroups
     //      hit the same slots concurrently: atomics, exactly once per word)
-    const int T = ws.T;
-    for (int i = threadIdx.x; i < VW * C; i += kBlock) {
+    for (int i = threadIdx.x; i < VW * C; i += kPoolL0Block) {
         const int v = i / C;
-        if (L.cnt[v] > 0 && raw0 + v < T) {
+        if (l_cnt[v] > 0 && raw0 + v < T) {
             const size_t o = (size_t)(raw0 + v) * C + (i - v * C);
-            if (AGGR == 0) atomicMax(reinterpret_cast<int *>(ws.xacc + o), L.acc[i]);
+            if (AGGR == 0) atomicMax(reinterpret_cast<int *>(ws.xacc + o), l_acc[i]);
             else atomicAdd(reinterpret_cast<unsigned long long *>(ws.xacc + o),
-                           reinterpret_cast<unsigned long long *>(L.acc)[i]);
+                           reinterpret_cast<unsigned long long *>(l_acc)[i]);
         }
     }
-    for (int v = threadIdx.x; v < VW; v += kBlock) {
-        const int c = L.cnt[v];
-        if (c > 0 && raw0 + v < T) {
+    for (int v = threadIdx.x; v < VW; v += kPoolL0Block) {
+        const int cn = l_cnt[v];
+        if (cn > 0 && raw0 + v < T) {
             const int raw = raw0 + v;
             ws.occupied[raw] = 1;
-            atomicAdd(&w_cnt[raw], c);
-            atomicMax(&ws.perm[raw], L.perm[v]);
-            atomicAdd(reinterpret_cast<unsigned long long *>(w_possum + (size_t)raw * 3 + 0), L.ps[3 * v]);
-            atomicAdd(reinterpret_cast<unsigned long long *>(w_possum + (size_t)raw * 3 + 1), L.ps[3 * v + 1]);
-            atomicAdd(reinterpret_cast<unsigned long long *>(w_possum + (size_t)raw * 3 + 2), L.ps[3 * v + 2]);
-            if (L.nbm[v]) atomicOr(&ws.nbmask[raw], (unsigned long long)L.nbm[v]);
+            atomicAdd(&w_cnt[raw], cn);
+            atomicMax(&ws.perm[raw], l_perm[v]);
+            atomicAdd(reinterpret_cast<unsigned long long *>(w_possum + (size_t)raw * 3 + 0), l_ps[3 * v]);
+            atomicAdd(reinterpret_cast<unsigned long long *>(w_possum + (size_t)raw * 3 + 1), l_ps[3 * v + 1]);
+            atomicAdd(reinterpret_cast<unsigned long long *>(w_possum + (size_t)raw * 3 + 2), l_ps[3 * v + 2]);
+            if (l_nbm[v]) atomicOr(&ws.nbmask[raw], (unsigned long long)l_nbm[v]);
         }
     }
+    seg_begin = seg_end;
+    if (seg_begin < s_end) {            // the window moves on: start it over
+        __syncthreads();
+        arm_window();
+        __syncthreads();
+    }
+    }   // segments
     // sticky counter of the nodes that took the global path (tests assert that it ran where it should)
     {
         int tot = n_slow;
@@ -681,98 +733,140 @@ __global__ __launch_bounds__(kBlock) void k_recode(const int32_t *__restrict__ n
 }
 
 // ---------------------------------------------------------------------------------------------
-// launch (S): one workgroup scans the occupancy flags (-> consecutive ids, torch.unique's order) and the row sizes
-// (-> CSR row pointers of the relabelled clusters) of the T + 1 table slots together, 16 consecutive slots per thread
-// and 16 Ki slots per round; clears both inputs, closes the epoch.  Row sizes: the insert counters (pooled levels) or
-// the population of the cell bitmaps (level 0).
+// launch (S): scans the occupancy flags (-> consecutive ids, torch.unique's order) and the row sizes (-> CSR row pointers of
+// the relabelled clusters) of the T + 1 table slots together; clears both inputs, closes the epoch.  Row sizes: the insert
+// counters (pooled levels) or the population of the cell bitmaps (level 0).
 // KEEP (asynchronous updates, dagr_pool_l0_stream): the accumulators stay as they are -- nothing is cleared and the epoch
 // stays open, so that later micro-batches keep adding to the same voxels.
+// ceil((T + 1) / 2048) workgroups in ONE launch (until round 4 one workgroup walked the table in rounds: 28 us for the
+// 20 k slots of a B = 8 level-0 table, a single CU issuing every load, clear and store; now ~7 us).  Decoupled look-back: a workgroup takes the next tile (ticket
+// counter: tiles are handed out in the order workgroups start, so a tile's predecessors are always running or done),
+// scans it, publishes its totals in one 64-bit word -- launch tag (12 bits) | flag (1 = tile totals, 2 = totals of all
+// tiles up to here) | clusters (22 bits) | edges (28 bits) -- and a wave looks back over its predecessors' words until
+// it meets an inclusive one.  The tile that takes the last ticket writes the counts, the empty tail rows, closes the
+// epoch and re-arms ticket counter and tag.  Integers throughout: the result is the single-workgroup kernel's, bit for
+// bit.
 template <bool MASKS, bool KEEP = false>
-__global__ __launch_bounds__(1024) void k_pool_scan(PoolWs ws, int32_t *__restrict__ n_out,
-                                                   int32_t *__restrict__ rowptr_out, int32_t *__restrict__ e_out) {
-    constexpr int PER = 16;
-    __shared__ int w_occ[16], w_cnt[16];
-    __shared__ int carry[2];
-    __shared__ __align__(16) unsigned char st_occ[1024 * PER], st_cnt[1024 * PER];
+__global__ __launch_bounds__(kBlock) void k_pool_scan_chained(PoolWs ws, int32_t *__restrict__ n_out,
+                                                             int32_t *__restrict__ rowptr_out,
+                                                             int32_t *__restrict__ e_out) {
+    constexpr int PER = kPoolScanTile / kBlock;   // 8
+    __shared__ __align__(16) unsigned char st_occ[kPoolScanTile], st_cnt[kPoolScanTile];
+    __shared__ int sm_scan[8];
+    __shared__ int sh_tile, sh_base_occ, sh_base_cnt;
+    __shared__ unsigned sh_tag;
     const int n = ws.T + 1;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    if (threadIdx.x == 0) { carry[0] = 0; carry[1] = 0; }
+    const int ntiles = (n + kPoolScanTile - 1) / kPoolScanTile;
+    if (threadIdx.x == 0) {
+        sh_tile = atomicAdd(&ws.status[7], 1);
+        sh_tag = (unsigned)__hip_atomic_load(&ws.status[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xfffu;
+    }
     __syncthreads();
-    for (int base = 0; base < n; base += 1024 * PER) {
-        const int i0 = base + threadIdx.x * PER;
-        int occ[PER], cnt[PER];
-        // Load phase, coalesced: thread t takes elements base + 1024 j + t (one 4-KiB row of each table per step, the
-        // clearing stores ride on the same addresses) and parks them as bytes in LDS -- a flag is 0/1, a row size or bitmap
-        // population is <= 64; the scan below then reads its 16 CONSECUTIVE slots as one 16-byte LDS word per table.
-        // (Reading 16 consecutive slots per thread straight from memory touched 64 cache lines per load instruction:
-        // 35 us for the 20 k slots of a B = 8 level-0 table.)
-        {
-            int ov[PER];
-            unsigned long long mv[PER];
-            int cv[PER];
-            // all 16 (x2) loads of a thread are issued before anything waits on them: one memory round trip per round
+    const int tile = sh_tile;
+    const unsigned long long tag = (unsigned long long)sh_tag << 52;
+    const int base = tile * kPoolScanTile;
+    // load phase, coalesced: thread t takes elements base + 256 j + t; parked as bytes in LDS (a flag is 0/1, a row size or
+    // bitmap population is <= 64), then every thread scans 8 CONSECUTIVE slots
+    {
+        int ov[PER], cv[PER];
+        unsigned long long mv[PER];
 #pragma unroll
-            for (int j = 0; j < PER; j++) {
-                const int e = base + j * 1024 + (int)threadIdx.x;
-                ov[j] = (e < n) ? ws.occupied[e] : 0;
-                if (MASKS) mv[j] = (e < ws.T) ? ws.nbmask[e] : 0ull;
-                else cv[j] = (e < n) ? ws.rowcnt[e] : 0;
-            }
-#pragma unroll
-            for (int j = 0; j < PER; j++) {
-                const int e = base + j * 1024 + (int)threadIdx.x;
-                if (e < n && !KEEP) {
-                    ws.occupied[e] = 0;
-                    if (!MASKS) ws.rowcnt[e] = 0;
-                }
-                const int c = MASKS ? __popcll(mv[j]) : cv[j];
-                st_occ[j * 1024 + threadIdx.x] = (unsigned char)ov[j];
-                st_cnt[j * 1024 + threadIdx.x] = (unsigned char)min(c, 255);
-            }
+        for (int j = 0; j < PER; j++) {
+            const int e = base + j * kBlock + (int)threadIdx.x;
+            ov[j] = (e < n) ? ws.occupied[e] : 0;
+            if (MASKS) mv[j] = (e < ws.T) ? ws.nbmask[e] : 0ull;
+            else cv[j] = (e < n) ? ws.rowcnt[e] : 0;
         }
-        __syncthreads();
-        {
-            const uint4 po = *reinterpret_cast<const uint4 *>(st_occ + threadIdx.x * PER);
-            const uint4 pc = *reinterpret_cast<const uint4 *>(st_cnt + threadIdx.x * PER);
-            const unsigned wo[4] = {po.x, po.y, po.z, po.w}, wc[4] = {pc.x, pc.y, pc.z, pc.w};
 #pragma unroll
-            for (int k = 0; k < PER; k++) {
-                occ[k] = (wo[k >> 2] >> (8 * (k & 3))) & 0xff;
-                cnt[k] = (wc[k >> 2] >> (8 * (k & 3))) & 0xff;
+        for (int j = 0; j < PER; j++) {
+            const int e = base + j * kBlock + (int)threadIdx.x;
+            if (e < n && !KEEP) {
+                ws.occupied[e] = 0;
+                if (!MASKS) ws.rowcnt[e] = 0;
             }
+            const int c = MASKS ? __popcll(mv[j]) : cv[j];
+            st_occ[j * kBlock + threadIdx.x] = (unsigned char)ov[j];
+            st_cnt[j * kBlock + threadIdx.x] = (unsigned char)min(c, 255);
         }
-        int s_occ = 0, s_cnt = 0;
-#pragma unroll
-        for (int k = 0; k < PER; k++) { s_occ += occ[k]; s_cnt += cnt[k]; }
-        const int i_occ = wave_inclusive_scan(s_occ), i_cnt = wave_inclusive_scan(s_cnt);
-        if (lane == 63) { w_occ[wid] = i_occ; w_cnt[wid] = i_cnt; }
-        __syncthreads();
-        int b_occ = carry[0], b_cnt = carry[1], t_occ = 0, t_cnt = 0;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int a = w_occ[k], c = w_cnt[k];
-            if (k < wid) { b_occ += a; b_cnt += c; }
-            t_occ += a; t_cnt += c;
-        }
-        int e_occ = b_occ + i_occ - s_occ, e_cnt = b_cnt + i_cnt - s_cnt;
+    }
+    __syncthreads();
+    int occ[PER], cnt[PER];
+    {
+        const uint2 po = *reinterpret_cast<const uint2 *>(st_occ + threadIdx.x * PER);
+        const uint2 pc = *reinterpret_cast<const uint2 *>(st_cnt + threadIdx.x * PER);
+        const unsigned wo[2] = {po.x, po.y}, wc[2] = {pc.x, pc.y};
 #pragma unroll
         for (int k = 0; k < PER; k++) {
-            if (i0 + k < n) {
-                ws.newid[i0 + k] = e_occ;
-                if (occ[k]) rowptr_out[e_occ] = e_cnt;
-            }
-            e_occ += occ[k]; e_cnt += cnt[k];
+            occ[k] = (wo[k >> 2] >> (8 * (k & 3))) & 0xff;
+            cnt[k] = (wc[k >> 2] >> (8 * (k & 3))) & 0xff;
         }
-        __syncthreads();
-        if (threadIdx.x == 0) { carry[0] += t_occ; carry[1] += t_cnt; }
-        __syncthreads();
     }
-    const int nc = carry[0], ne = carry[1];
-    for (int c = nc + threadIdx.x; c <= ws.T; c += 1024) rowptr_out[c] = ne;   // rows past the last cluster are empty
-    if (threadIdx.x == 0) {
-        *n_out = nc;
-        *e_out = ne;
-        if (!KEEP) ws.status[4] ^= 1;   // the next call fills the other accumulator pair; launch (C) reads the one just filled
+    int s_occ = 0, s_cnt = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { s_occ += occ[k]; s_cnt += cnt[k]; }
+    int t_occ, t_cnt;
+    const int x_occ = block_exclusive_scan(s_occ, sm_scan, t_occ);
+    const int x_cnt = block_exclusive_scan(s_cnt, sm_scan + 4, t_cnt);
+    // publish this tile's totals, then look back (wave 0): lane l reads the word of tile - 1 - l
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        auto pack = [&](int flag, int o, int c) {
+            return tag | ((unsigned long long)flag << 50) | ((unsigned long long)(unsigned)o << 28) | (unsigned long long)(unsigned)c;
+        };
+        if (lane == 0)
+            __hip_atomic_store(&ws.tile_state[tile], pack(tile == 0 ? 2 : 1, t_occ, t_cnt), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        int b_occ = 0, b_cnt = 0;
+        for (int hi = tile - 1; hi >= 0;) {        // window of predecessors hi, hi - 1, ..., hi - 63
+            const int pidx = hi - lane;
+            unsigned long long wd = 0;
+            bool ready = pidx < 0;
+            while (!__all(ready)) {                // spin until every predecessor of the window has published
+                if (!ready) {
+                    wd = __hip_atomic_load(&ws.tile_state[pidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ready = (wd >> 52) == (unsigned long long)sh_tag && ((wd >> 50) & 3ull) != 0ull;
+                }
+            }
+            const bool incl = pidx >= 0 && ((wd >> 50) & 3ull) == 2ull;
+            const unsigned long long im = __ballot(incl);
+            const int stop = im ? (__ffsll((long long)im) - 1) : 63;     // nearest predecessor with inclusive totals
+            int vo = (pidx >= 0 && lane <= stop) ? (int)((wd >> 28) & 0x3fffffull) : 0;
+            int vc = (pidx >= 0 && lane <= stop) ? (int)(wd & 0xfffffffull) : 0;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { vo += __shfl_xor(vo, off, 64); vc += __shfl_xor(vc, off, 64); }
+            b_occ += vo; b_cnt += vc;
+            if (im) break;
+            hi -= 64;
+        }
+        if (lane == 0) {
+            sh_base_occ = b_occ; sh_base_cnt = b_cnt;
+            if (tile > 0)
+                __hip_atomic_store(&ws.tile_state[tile], pack(2, b_occ + t_occ, b_cnt + t_cnt), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    int e_occ = sh_base_occ + x_occ, e_cnt = sh_base_cnt + x_cnt;
+    const int i0 = base + threadIdx.x * PER;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        if (i0 + k < n) {
+            ws.newid[i0 + k] = e_occ;
+            if (occ[k]) rowptr_out[e_occ] = e_cnt;
+        }
+        e_occ += occ[k]; e_cnt += cnt[k];
+    }
+    if (tile == ntiles - 1) {
+        // the last ticket: every other tile has published its totals before this one could finish its look-back
+        const int nc = sh_base_occ + t_occ, ne = sh_base_cnt + t_cnt;
+        for (int c = nc + threadIdx.x; c <= ws.T; c += kBlock) rowptr_out[c] = ne;   // rows past the last cluster are empty
+        if (threadIdx.x == 0) {
+            *n_out = nc;
+            *e_out = ne;
+            if (!KEEP) ws.status[4] ^= 1;   // the next call fills the other accumulator pair; launch (C) reads the one just filled
+            ws.status[7] = 0;
+            ws.status[6] = (int)((sh_tag + 1u) & 0xfffu);
+        }
     }
 }
 
@@ -960,7 +1054,7 @@ namespace {
 int validate_pool(const dagr_pool_desc *d) {
     DAGR_CHECK_ARG(d != nullptr, "desc is NULL");
     DAGR_CHECK_ARG(d->gx > 0 && d->gy > 0 && d->batch_size > 0 && d->channels > 0, "bad sizes");
-    DAGR_CHECK_ARG((int64_t)d->gx * d->gy * (d->batch_size + 1) < (1 << 28), "voxel table too large");
+    DAGR_CHECK_ARG((int64_t)d->gx * d->gy * (d->batch_size + 1) < (1 << 22), "voxel table too large");
     DAGR_CHECK_ARG(d->aggr == 0 || d->aggr == 1, "aggr must be 0 (max) or 1 (mean)");
     DAGR_CHECK_ARG(d->vx > 0 && d->vy > 0 && d->two_max > 0, "bad voxel size / cartesian max");
     return DAGR_OK;
@@ -979,20 +1073,24 @@ int launch_pool_l0_slots(const dagr_pool_desc *desc, const dagr_graph_desc *gdes
     const int32_t *n_ptr = graph_ws_node_count(gdesc, graph_ws);
     const int C = desc->channels, W = gdesc->width, H = gdesc->height, K = gdesc->max_neighbors;
     const bool vec4 = C % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0;
-    // LDS window: two voxel rows at least where they fit; 24 KB (six workgroups per CU) when that holds them, else up to
-    // 46 KB (three workgroups per CU)
+    // LDS window: up to 60 KB of accumulators per (16-wave) workgroup, at least one voxel row, at most 1024 table slots
     const size_t per_slot = (size_t)C * (desc->aggr == 0 ? 4 : 8) + 36;
-    const size_t budget = (per_slot * 2 * desc->gx <= 24 * 1024 ? 24 : 46) * 1024 - (size_t)(W + H) * 2 - 1024;
+    const size_t budget = (size_t)60 * 1024 - (size_t)(W + H) * 2 - 2048 - 1024;
     int VW = (int)std::min<size_t>(1024, budget / per_slot);
     VW = std::max(VW, desc->gx) / 2 * 2 + 2;
     const size_t lds = desc->aggr == 0 ? pool_l0_lds_bytes<0>(VW, C, W, H) : pool_l0_lds_bytes<1>(VW, C, W, H);
     DAGR_CHECK_ARG(lds <= 64 * 1024, "level-0 pooling: one voxel row of accumulators does not fit the LDS window");
     DAGR_CHECK_ARG(desc->gx < 65536 && desc->gy < 65536 && VW < 32768, "voxel grid too large for the level-0 pooling kernel");
-    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(4 * device_cu_count(), ceil_div(n_cap, 256)));
+    // one 16-wave workgroup per CU is resident at a time (114 registers); wide rows run two rounds of shorter runs, which
+    // overlaps one round's merge with the other's streaming (measured: 112 vs 127 us at 80 channels, 47 vs 44 us at 16)
+    static const int gmult_env = [] { const char *e = getenv("DAGR_POOL_GRID_MULT"); return e ? atoi(e) : 0; }();
+    const int gmult = gmult_env > 0 ? gmult_env : (C > 32 ? 2 : 1);
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)gmult * device_cu_count(),
+                                                                          ceil_div(n_cap, kPoolL0Block)));
 #define DAGR_POOL_L0_LAUNCH(AG, VEC)                                                                                  \
-    k_pool_l0_slots<AG, VEC><<<grid, kBlock, lds, stream>>>(*desc, W, H, (int)n_cap, VW, n_ptr, xlo, ylo, slot_it,      \
-                                                             slot_xyb, x, ldx, pos, ws, nbr_code, nbr_src, deg, K,      \
-                                                             gdesc->radius)
+    k_pool_l0_slots<AG, VEC><<<grid, kPoolL0Block, lds, stream>>>(*desc, W, H, (int)n_cap, VW, n_ptr, xlo, ylo, start, slot_it, \
+                                                                   slot_xyb, x, ldx, pos, ws, nbr_code, nbr_src, deg, K, \
+                                                                   gdesc->radius)
     if (desc->aggr == 0) { if (vec4) DAGR_POOL_L0_LAUNCH(0, 4); else DAGR_POOL_L0_LAUNCH(0, 1); }
     else                 { if (vec4) DAGR_POOL_L0_LAUNCH(1, 4); else DAGR_POOL_L0_LAUNCH(1, 1); }
 #undef DAGR_POOL_L0_LAUNCH
@@ -1027,6 +1125,7 @@ int dagr_pool_workspace_init(const dagr_pool_desc *desc, void *workspace, size_t
     DAGR_CHECK_HIP(hipMemsetAsync(ws.rows, 0xff, T * (size_t)kRowSlots * 4, stream));
     DAGR_CHECK_HIP(hipMemsetAsync(ws.rowcnt, 0, (T + 32) * 4, stream));
     DAGR_CHECK_HIP(hipMemsetAsync(ws.status, 0, 32, stream));
+    DAGR_CHECK_HIP(hipMemsetAsync(ws.tile_state, 0, ((T + 1 + kPoolScanTile - 1) / kPoolScanTile + 8) * 8, stream));
     DAGR_CHECK_HIP(hipMemsetAsync(ws.nbmask, 0, (T + 9) * 8, stream));
     // feature accumulators: ordered-int minimum for max, 0 for mean
     {
@@ -1041,6 +1140,10 @@ int dagr_pool_workspace_init(const dagr_pool_desc *desc, void *workspace, size_t
     return DAGR_OK;
 }
 
+
+// launch (S): one workgroup per 2048 table slots
+#define DAGR_POOL_SCAN(MASKS, KEEP)                                                                                   \
+    k_pool_scan_chained<MASKS, KEEP><<<(unsigned)ceil_div(T + 1, kPoolScanTile), kBlock, 0, stream>>>(ws, n_out, rowptr_out, e_out)
 
 static int pool_tail(const dagr_pool_desc *d, PoolWs &ws, const int32_t *batch32, const int64_t *batch64,
                      float *x_out, int ldo, int xoff, float *pos_out, int32_t *batch_out, int32_t *n_out,
@@ -1093,7 +1196,7 @@ int dagr_pool_l0(const dagr_pool_desc *desc, void *pool_ws, const dagr_graph_des
     }
     if (fast_edges) {
         // (S) ids + row pointers from the occupancy flags and the bitmap populations, (C) nodes + CSR rows
-        k_pool_scan<true><<<1, 1024, 0, stream>>>(ws, n_out, rowptr_out, e_out);
+        DAGR_POOL_SCAN(true, false);
         DAGR_CHECK_LAUNCH();
         k_pool_emit<true><<<(unsigned)ceil_div(T, kBlock / 64), kBlock, 0, stream>>>(
             *desc, ws, b32, b64, x_out, ldo, xoff, pos_out, batch_out, rowptr_out, col_out, code_out, e_cap);
@@ -1117,6 +1220,24 @@ int dagr_pool_l0(const dagr_pool_desc *desc, void *pool_ws, const dagr_graph_des
     }
     return pool_tail(desc, ws, b32, b64, x_out, ldo, xoff, pos_out, batch_out, n_out, rowptr_out, col_out, code_out,
                      e_out, e_cap, stream);
+}
+
+int dagr_pool_l0_accumulate(const dagr_pool_desc *desc, void *pool_ws, const dagr_graph_desc *gdesc, void *graph_ws,
+                            const int32_t *xlo, const int32_t *ylo, const float *x, int32_t ldx, const float *pos,
+                            int64_t N, const int32_t *nbr_src, const int16_t *nbr_code, const int32_t *deg,
+                            void *stream_) {
+    int rc = validate_pool(desc);
+    if (rc != DAGR_OK) return rc;
+    DAGR_CHECK_ARG(pool_ws && gdesc && graph_ws && xlo && ylo && x && pos && nbr_src && deg && N > 0, "bad arguments");
+    DAGR_CHECK_ARG(desc->channels <= kMaxL0Channels && desc->batch_size == gdesc->batch_size, "bad descriptors");
+    PoolWs ws;
+    pool_carve(*desc, (char *)pool_ws, &ws);
+    const int K = gdesc->max_neighbors;
+    const int cell_w = (int)floorf(desc->vx * (float)gdesc->width), cell_h = (int)floorf(desc->vy * (float)gdesc->height);
+    const bool fast_edges = nbr_code != nullptr && K <= 16 && gdesc->radius <= 2 * std::min(cell_w, cell_h) &&
+                            gdesc->width <= 4096;
+    return launch_pool_l0_slots(desc, gdesc, graph_ws, xlo, ylo, x, ldx, pos, ws, fast_edges ? nbr_code : nullptr, nbr_src,
+                                deg, N, (hipStream_t)stream_);
 }
 
 int dagr_pool_l0_stream(const dagr_pool_desc *desc, void *pool_ws, int32_t rebuild, const dagr_graph_desc *gdesc,
@@ -1160,7 +1281,7 @@ int dagr_pool_l0_stream(const dagr_pool_desc *desc, void *pool_ws, int32_t rebui
             nbr_src, deg, K, gdesc->radius);
         DAGR_CHECK_LAUNCH();
     }
-    k_pool_scan<true, true><<<1, 1024, 0, stream>>>(ws, n_out, rowptr_out, e_out);
+    DAGR_POOL_SCAN(true, true);
     DAGR_CHECK_LAUNCH();
     k_pool_emit<true, true><<<(unsigned)ceil_div(T, kBlock / 64), kBlock, 0, stream>>>(
         *desc, ws, batch_events, nullptr, x_out, ldo, xoff, pos_out, batch_out, rowptr_out, col_out, code_out, e_cap);
@@ -1187,7 +1308,7 @@ int dagr_pool_csr(const dagr_pool_desc *desc, void *pool_ws, const int32_t *n_pt
             *desc, n_ptr, n_max, x, ldx, pos, batch, rowptr, col, ws, cluster_scratch);
         DAGR_CHECK_LAUNCH();
     }
-    k_pool_scan<false><<<1, 1024, 0, stream>>>(ws, n_out, rowptr_out, e_out);
+    DAGR_POOL_SCAN(false, false);
     DAGR_CHECK_LAUNCH();
     k_pool_emit<false><<<(unsigned)ceil_div(T, kBlock / 64), kBlock, 0, stream>>>(
         *desc, ws, batch, nullptr, x_out, ldo, xoff, pos_out, batch_out, rowptr_out, col_out, code_out, e_cap);

@@ -797,6 +797,10 @@ class WindowEngine:
         if self.use_image and sample:
             self._sample(None, self._N, self.pos_n, self.batch_n, 0, self._img_feats[1], self.hp0[:self._N], 16)
 
+    def stage_l0_sample1(self):
+        """sampling_skip(image_feat[1]) (net.py:129) alone: the level-0 nodes' features of the second map into hp0[:, 16:]."""
+        self._sample(None, self._N, self.pos_n, self.batch_n, 0, self._img_feats[1], self.hp0[:self._N], 16)
+
     def stage_pool1(self):
         """pool1 (net.py:131) on the event graph."""
         L, P = self.L, _lib.ptr
@@ -812,6 +816,17 @@ class WindowEngine:
                                   l1.x.shape[1], 0, P(l1.pos), P(l1.batch), P(l1.counts), P(l1.rowptr), P(l1.col),
                                   P(l1.code), ctypes.c_void_p(l1.counts.data_ptr() + 4), l1.e_cap,
                                   _lib.cur_stream(self.device)), "pool_l0")
+
+    def pool1_accumulate_again(self):
+        """pool1's accumulation kernel alone on the resident window (measurement: bench.py); follow with ``stage_pool1``."""
+        L, P = self.L, _lib.ptr
+        g = self.graph
+        nbr_src, nbr_code, deg = self._nbr
+        _lib.check(L.dagr_pool_l0_accumulate(ctypes.byref(self.pool_desc[0]), P(self.pool_ws[0]), ctypes.byref(g.desc),
+                                             P(g.workspace), P(self.xlo), P(self.ylo), P(self.hp0), self.hp0.shape[1],
+                                             P(self.pos_n), self._N, P(nbr_src),
+                                             P(nbr_code) if self.fast_coarse_edges else None, P(deg),
+                                             _lib.cur_stream(self.device)), "pool_l0_accumulate")
 
     def _stage_level(self, k, trace=None):
         """Layer k+2 on pooled level k+1 (conv pair), then -- for k < 3 -- [sampling_skip] + pool k+2 (net.py:137-184)."""

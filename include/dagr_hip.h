@@ -309,6 +309,13 @@ int dagr_async_graph_append(const dagr_graph_desc *desc, void *graph_ws, int64_t
                              * dagr_graph_gather_inputs writes them for a window, and the sample index by event id */
                             const float *feat, float *pos_nodes, int32_t *batch_nodes, int32_t *batch_events, float *x0,
                             int32_t ldx0, int32_t col_feat, int32_t col_pos, void *stream);
+/* Launch (A) of dagr_pool_l0 alone: the level-0 accumulation kernel over the window last built on `graph_ws`, into the
+ * accumulators of `pool_ws` (max / fixed-point sums: repeating it leaves max accumulators unchanged and scales the sums;
+ * the next dagr_pool_l0 call re-arms everything).  For measurement (bench.py times the kernel on its own with HIP
+ * events); a product caller has no use for it. */
+int dagr_pool_l0_accumulate(const dagr_pool_desc *desc, void *pool_ws, const dagr_graph_desc *gdesc, void *graph_ws,
+                            const int32_t *xlo, const int32_t *ylo, const float *x, int32_t ldx, const float *pos,
+                            int64_t N, const int32_t *nbr_src, const int16_t *nbr_code, const int32_t *deg, void *stream);
 /* pool1 with RESIDENT accumulators (its own workspace, dagr_pool_workspace_bytes): rebuild != 0 recomputes them from the
  * window (nodes [0, n_window) through the builder's pixel index); rows [first_row, first_row + n_rows) -- appended
  * nodes, first_row >= n_window -- are added; then level 1 is emitted exactly as dagr_pool_l0 emits it, and the
