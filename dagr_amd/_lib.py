@@ -64,7 +64,13 @@ SIGNATURES = {
                                                 c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p]),
     "dagr_spline_conv_l0_tiles": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_float,
                                                  c_float, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_i32,
-                                                 c_void_p, c_i32, c_void_p, c_void_p, c_i32, c_void_p, c_i32, c_void_p]),
+                                                 c_void_p, c_i32, c_void_p, c_void_p, c_i32, c_void_p, c_i32, c_void_p,
+                                                 c_void_p]),
+    "dagr_graph_build_window_dev": (ctypes.c_int, [ctypes.POINTER(GraphDesc), c_void_p, c_void_p, c_i32, c_void_p,
+                                                   c_i32, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dagr_graph_node_count_ptr": (c_void_p, [ctypes.POINTER(GraphDesc), c_void_p]),
+    "dagr_stage_window": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_i32, c_i64, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p]),
     "dagr_spiral_offsets": (ctypes.c_int, [c_i32, c_void_p, c_void_p]),
     "dagr_spline_tap_window": (ctypes.c_int, [c_i32, c_float, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
     "dagr_spline_l0_table": (ctypes.c_int, [c_i32, c_i32, c_float, c_float, c_i32, c_i32, c_i32, c_i32, c_void_p,
@@ -122,7 +128,7 @@ SIGNATURES = {
     "dagr_spline_conv_l0_tiles_rows": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_float,
                                                       c_float, c_i64, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_void_p,
                                                       c_i32, c_void_p, c_i32, c_void_p, c_void_p, c_i32, c_void_p, c_i32,
-                                                      c_void_p]),
+                                                      c_void_p, c_void_p]),
     "dagr_async_graph_append": (ctypes.c_int, [ctypes.POINTER(GraphDesc), c_void_p, c_i64, c_i64, c_void_p, c_void_p,
                                                c_void_p, c_i64, c_void_p, c_i32, c_void_p, c_i32, c_i64, c_void_p, c_void_p,
                                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32,

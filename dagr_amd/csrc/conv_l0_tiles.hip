@@ -63,7 +63,7 @@ constexpr int kTileWaves = 4;   // waves per workgroup (each owns its tiles; the
 
 template <int CM, int CE, int CS, int TX, int TY>
 __global__ __launch_bounds__(kTileWaves * 64, 2) void k_conv_l0_tiles(
-    int n_first, int N, int rx, int ry, float den_x, float den_y, int win_x, int win_y, const int32_t *__restrict__ nbr_src,
+    int n_first, int N, const int32_t *__restrict__ n_ptr, int rx, int ry, float den_x, float den_y, int win_x, int win_y, const int32_t *__restrict__ nbr_src,
     const int16_t *__restrict__ nbr_code, const int32_t *__restrict__ deg, const float *__restrict__ x, int ldx,
     const float *__restrict__ xskip, int ldskip, const float *__restrict__ wpack, const float *__restrict__ shift,
     int relu, float *__restrict__ out, int ldo) {
@@ -90,6 +90,8 @@ __global__ __launch_bounds__(kTileWaves * 64, 2) void k_conv_l0_tiles(
     }
     __syncthreads();
 
+    // n_ptr: the level's node count in device memory (launches sized for a capacity N: captured HIP graphs)
+    if (n_ptr) N = max(0, min(N, *n_ptr - n_first));
     const int l = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int c = l & 15, q = l >> 4;
     const float my_shift = shift[c];
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(kTileWaves * 64, 2) void k_conv_l0_tiles(
 }
 
 template <int CM, int CE, int CS, int TX, int TY>
-int launch_tiles(int64_t n_first, int64_t N, int rx, int ry, float den_x, float den_y, int win_x, int win_y, const int32_t *nbr_src,
+int launch_tiles(int64_t n_first, int64_t N, const int32_t *n_ptr, int rx, int ry, float den_x, float den_y, int win_x, int win_y, const int32_t *nbr_src,
                  const int16_t *nbr_code, const int32_t *deg, const float *x, int ldx, const float *xskip, int ldskip,
                  const float *wpack, const float *shift, int relu, float *out, int ldo, hipStream_t stream) {
     using S = L0Steps<CM, CE, CS, TX, TY>;
@@ -271,7 +273,7 @@ int launch_tiles(int64_t n_first, int64_t N, int rx, int ry, float den_x, float 
     }
     const int64_t tiles = ceil_div(N, 16);
     const unsigned grid = round_grid8(persistent_grid(kern, kTileWaves * 64, lds_bytes, ceil_div(tiles, kTileWaves)));
-    kern<<<grid, kTileWaves * 64, lds_bytes, stream>>>((int)n_first, (int)N, rx, ry, den_x, den_y, win_x, win_y, nbr_src, nbr_code, deg,
+    kern<<<grid, kTileWaves * 64, lds_bytes, stream>>>((int)n_first, (int)N, n_ptr, rx, ry, den_x, den_y, win_x, win_y, nbr_src, nbr_code, deg,
                                                        x, ldx, xskip, ldskip, wpack, shift, relu, out, ldo);
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;
@@ -287,16 +289,16 @@ extern "C" int dagr_spline_conv_l0_tiles_rows(int32_t cmain, int32_t cextra, int
                                               int64_t first_node, int64_t N, int32_t K, const int32_t *nbr_src,
                                               const int16_t *nbr_code, const int32_t *deg, const float *x, int32_t ldx,
                                               const float *xskip, int32_t ldskip, const float *wpack, const float *shift,
-                                              int32_t relu, float *out, int32_t ldo, void *stream_);
+                                              int32_t relu, float *out, int32_t ldo, const int32_t *n_ptr, void *stream_);
 
 extern "C" int dagr_spline_conv_l0_tiles(int32_t cmain, int32_t cextra, int32_t cskip, int32_t win_x, int32_t tx,
                                          int32_t win_y, int32_t ty, int32_t rx, int32_t ry, float den_x, float den_y,
                                          int64_t N, int32_t K, const int32_t *nbr_src, const int16_t *nbr_code,
                                          const int32_t *deg, const float *x, int32_t ldx, const float *xskip,
                                          int32_t ldskip, const float *wpack, const float *shift, int32_t relu,
-                                         float *out, int32_t ldo, void *stream_) {
+                                         float *out, int32_t ldo, const int32_t *n_ptr, void *stream_) {
     return dagr_spline_conv_l0_tiles_rows(cmain, cextra, cskip, win_x, tx, win_y, ty, rx, ry, den_x, den_y, 0, N, K, nbr_src,
-                                          nbr_code, deg, x, ldx, xskip, ldskip, wpack, shift, relu, out, ldo, stream_);
+                                          nbr_code, deg, x, ldx, xskip, ldskip, wpack, shift, relu, out, ldo, n_ptr, stream_);
 }
 
 extern "C" int dagr_spline_conv_l0_tiles_rows(int32_t cmain, int32_t cextra, int32_t cskip, int32_t win_x, int32_t tx,
@@ -304,7 +306,7 @@ extern "C" int dagr_spline_conv_l0_tiles_rows(int32_t cmain, int32_t cextra, int
                                               int64_t first_node, int64_t N, int32_t K, const int32_t *nbr_src,
                                               const int16_t *nbr_code, const int32_t *deg, const float *x, int32_t ldx,
                                               const float *xskip, int32_t ldskip, const float *wpack, const float *shift,
-                                              int32_t relu, float *out, int32_t ldo, void *stream_) {
+                                              int32_t relu, float *out, int32_t ldo, const int32_t *n_ptr, void *stream_) {
     DAGR_CHECK_ARG(N >= 0 && first_node >= 0 && first_node + N < (1ll << 31), "bad node range");
     if (N == 0) return DAGR_OK;
     DAGR_CHECK_ARG(nbr_src && nbr_code && deg && x && wpack && shift && out, "NULL pointer");
@@ -318,7 +320,7 @@ extern "C" int dagr_spline_conv_l0_tiles_rows(int32_t cmain, int32_t cextra, int
     hipStream_t stream = (hipStream_t)stream_;
 #define DAGR_TILES(CM_, CE_, CS_, TX_, TY_)                                                                        \
     if (cmain == CM_ && cextra == CE_ && cskip == CS_ && tx == TX_ && ty == TY_)                                   \
-        return launch_tiles<CM_, CE_, CS_, TX_, TY_>(first_node, N, rx, ry, den_x, den_y, win_x, win_y, nbr_src, nbr_code, deg, x, \
+        return launch_tiles<CM_, CE_, CS_, TX_, TY_>(first_node, N, n_ptr, rx, ry, den_x, den_y, win_x, win_y, nbr_src, nbr_code, deg, x, \
                                                     ldx, xskip, ldskip, wpack, shift, relu, out, ldo, stream);
 #define DAGR_TILES_WIN(TX_, TY_)                                                                   \
     DAGR_TILES(0, 3, 0, TX_, TY_)    /* events-only conv_block1.conv_block1: 3 -> 16 (net.py:75) */  \

@@ -92,12 +92,13 @@ int validate(const dagr_graph_desc *d) {
 //   -ffp-contract=off), truncation toward zero.
 template <typename BatchT, bool kIntPos>
 __global__ __launch_bounds__(kBlock) void k_count(const void *__restrict__ pos_, const BatchT *__restrict__ batch,
-                                                 int N, int W, int H, int B, float fW, float fH, float fT,
-                                                 int32_t *__restrict__ cnt, int32_t *__restrict__ ev_xyb,
-                                                 int32_t *__restrict__ ev_t, int32_t *__restrict__ ev_rank,
-                                                 int32_t *__restrict__ status) {
+                                                 int N, const int32_t *__restrict__ n_dev, int W, int H, int B, float fW,
+                                                 float fH, float fT, int32_t *__restrict__ cnt,
+                                                 int32_t *__restrict__ ev_xyb, int32_t *__restrict__ ev_t,
+                                                 int32_t *__restrict__ ev_rank, int32_t *__restrict__ status) {
     const int e = blockIdx.x * kBlock + threadIdx.x;
-    if (e >= N) return;
+    // n_dev: the window's event count in device memory (launches sized for a capacity N: captured HIP graphs)
+    if (e >= N || (n_dev && e >= *n_dev)) return;
     int x, y, t;
     if (kIntPos) {  // already-denormalised int32 [N,3] (SlidingWindowGraph.forward's own input contract)
         const int32_t *pos = static_cast<const int32_t *>(pos_);
@@ -133,12 +134,13 @@ __global__ __launch_bounds__(kBlock) void k_count(const void *__restrict__ pos_,
 }
 
 // K3: scatter event ids into their pixel segment (arrival order).
-__global__ __launch_bounds__(kBlock) void k_scatter(int N, int W, int H, const int32_t *__restrict__ ev_xyb,
+__global__ __launch_bounds__(kBlock) void k_scatter(int N, const int32_t *__restrict__ n_dev, int W, int H,
+                                                   const int32_t *__restrict__ ev_xyb,
                                                    const int32_t *__restrict__ ev_rank,
                                                    const int32_t *__restrict__ start,
                                                    int32_t *__restrict__ slot_tmp, int32_t *__restrict__ ev_slot) {
     const int e = blockIdx.x * kBlock + threadIdx.x;
-    if (e >= N) return;
+    if (e >= N || (n_dev && e >= *n_dev)) return;
     const int c = ev_xyb[e];
     if (c < 0) { ev_slot[e] = -1; return; }
     const int p = (c & 4095) + W * (((c >> 12) & 4095) + H * (c >> 24));
@@ -893,6 +895,23 @@ __global__ __launch_bounds__(kBlock) void k_gather_inputs(const int32_t *__restr
     row[col_pos + 1] = py;
 }
 
+// the caller's window -> the engine's static input buffers + the event count in device memory (captured-graph mode)
+template <typename BatchT>
+__global__ __launch_bounds__(kBlock) void k_stage_window(const float *__restrict__ pos, const float *__restrict__ feat,
+                                                        const BatchT *__restrict__ batch, int N,
+                                                        float *__restrict__ pos_out, float *__restrict__ feat_out,
+                                                        int32_t *__restrict__ batch_out, int32_t *__restrict__ n_dev) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i == 0) *n_dev = N;
+    if (i < N) {
+        feat_out[i] = feat[i];
+        batch_out[i] = (int32_t)batch[i];
+    }
+    if (i < 3 * N) pos_out[i] = pos[i];
+    if (i + gridDim.x * kBlock < 3 * N) pos_out[i + gridDim.x * kBlock] = pos[i + gridDim.x * kBlock];
+    if (i + 2 * gridDim.x * kBlock < 3 * N) pos_out[i + 2 * gridDim.x * kBlock] = pos[i + 2 * gridDim.x * kBlock];
+}
+
 __global__ void k_format_events(const int16_t *__restrict__ xy, const int32_t *__restrict__ t,
                                 const int8_t *__restrict__ p, int64_t N, float fW, float fH, float fT,
                                 float *__restrict__ pos, float *__restrict__ feat) {
@@ -1005,9 +1024,9 @@ static int launch_search(const dagr_graph_desc *desc, const GraphWs &ws, int64_t
     return DAGR_OK;
 }
 
-int dagr_graph_build_window(const dagr_graph_desc *desc, void *workspace, const void *pos, int32_t pos_is_int32,
-                            const void *batch, int32_t batch_is_int64, int64_t N, int32_t *nbr_src, int16_t *nbr_code, int32_t *deg,
-                            void *stream_) {
+static int build_window(const dagr_graph_desc *desc, void *workspace, const void *pos, int32_t pos_is_int32,
+                        const void *batch, int32_t batch_is_int64, int64_t N, const int32_t *n_dev, int32_t *nbr_src,
+                        int16_t *nbr_code, int32_t *deg, void *stream_) {
     int rc = validate(desc);
     if (rc != DAGR_OK) return rc;
     DAGR_CHECK_ARG(workspace != nullptr, "workspace is NULL");
@@ -1025,7 +1044,7 @@ int dagr_graph_build_window(const dagr_graph_desc *desc, void *workspace, const 
     const int W = desc->width, H = desc->height, B = desc->batch_size;
     DAGR_CHECK_HIP(hipMemsetAsync(ws.status, 0, 8 * 4, stream));
 #define DAGR_LAUNCH_COUNT(BT, IP)                                                                          \
-    k_count<BT, IP><<<gN, kBlock, 0, stream>>>(pos, (const BT *)batch, n, W, H, B, (float)W, (float)H,       \
+    k_count<BT, IP><<<gN, kBlock, 0, stream>>>(pos, (const BT *)batch, n, n_dev, W, H, B, (float)W, (float)H, \
                                                (float)desc->time_window, ws.cnt, ws.ev_xyb, ws.ev_t,         \
                                                ws.ev_rank, ws.status)
     if (batch_is_int64) { if (pos_is_int32) DAGR_LAUNCH_COUNT(int64_t, true); else DAGR_LAUNCH_COUNT(int64_t, false); }
@@ -1034,7 +1053,7 @@ int dagr_graph_build_window(const dagr_graph_desc *desc, void *workspace, const 
     DAGR_CHECK_LAUNCH();
     // start = exclusive_scan(cnt); cnt is re-zeroed in the same pass (invariant for the next window)
     DAGR_CHECK_HIP(exclusive_scan_i32(ws.cnt, ws.start, ws.P + 1, ws.scan_tmp, true, stream));
-    k_scatter<<<gN, kBlock, 0, stream>>>(n, W, H, ws.ev_xyb, ws.ev_rank, ws.start, ws.slot_tmp, ws.ev_slot);
+    k_scatter<<<gN, kBlock, 0, stream>>>(n, n_dev, W, H, ws.ev_xyb, ws.ev_rank, ws.start, ws.slot_tmp, ws.ev_slot);
     DAGR_CHECK_LAUNCH();
     // number of occupied CSR slots M = start[P] <= N (dropped events excluded); slots are a
     // prefix [0, M) so launching N threads with an in-kernel bound read would need M on the host.
@@ -1048,6 +1067,39 @@ int dagr_graph_build_window(const dagr_graph_desc *desc, void *workspace, const 
                                             ws.long_list, long_cap, ws.status);
     DAGR_CHECK_LAUNCH();
     return launch_search(desc, ws, N, nbr_src, nbr_code, deg, stream);
+}
+
+int dagr_graph_build_window(const dagr_graph_desc *desc, void *workspace, const void *pos, int32_t pos_is_int32,
+                            const void *batch, int32_t batch_is_int64, int64_t N, int32_t *nbr_src, int16_t *nbr_code,
+                            int32_t *deg, void *stream) {
+    return build_window(desc, workspace, pos, pos_is_int32, batch, batch_is_int64, N, nullptr, nbr_src, nbr_code, deg, stream);
+}
+
+int dagr_graph_build_window_dev(const dagr_graph_desc *desc, void *workspace, const void *pos, int32_t pos_is_int32,
+                                const void *batch, int32_t batch_is_int64, int64_t n_cap, const int32_t *n_dev,
+                                int32_t *nbr_src, int16_t *nbr_code, int32_t *deg, void *stream) {
+    DAGR_CHECK_ARG(n_dev != nullptr && n_cap > 0, "n_dev is NULL / empty capacity");
+    return build_window(desc, workspace, pos, pos_is_int32, batch, batch_is_int64, n_cap, n_dev, nbr_src, nbr_code, deg, stream);
+}
+
+const int32_t *dagr_graph_node_count_ptr(const dagr_graph_desc *desc, void *workspace) {
+    if (validate(desc) != DAGR_OK || workspace == nullptr) return nullptr;
+    return graph_ws_node_count(desc, workspace);
+}
+
+int dagr_stage_window(const float *pos, const float *feat, const void *batch, int32_t batch_is_int64, int64_t N,
+                      float *pos_out, float *feat_out, int32_t *batch_out, int32_t *n_dev, void *stream) {
+    DAGR_CHECK_ARG(N >= 0 && N < (1ll << 30) && pos_out && feat_out && batch_out && n_dev, "bad arguments");
+    DAGR_CHECK_ARG(N == 0 || (pos && feat && batch), "NULL input");
+    const unsigned grid = (unsigned)std::max<int64_t>(1, ceil_div(N, kBlock));
+    if (batch_is_int64)
+        k_stage_window<int64_t><<<grid, kBlock, 0, (hipStream_t)stream>>>(pos, feat, (const int64_t *)batch, (int)N, pos_out,
+                                                                         feat_out, batch_out, n_dev);
+    else
+        k_stage_window<int32_t><<<grid, kBlock, 0, (hipStream_t)stream>>>(pos, feat, (const int32_t *)batch, (int)N, pos_out,
+                                                                         feat_out, batch_out, n_dev);
+    DAGR_CHECK_LAUNCH();
+    return DAGR_OK;
 }
 
 int dagr_graph_search_window(const dagr_graph_desc *desc, void *workspace, int64_t N, int32_t *nbr_src, int16_t *nbr_code,

@@ -288,6 +288,10 @@ class WindowEngine:
         self.set_low_latency(os.environ.get("DAGR_LOW_LATENCY", "1") != "0")
         self._head_stream = self._head_join = self._graph = self._graph_out = None
         self._graph_warm = 0
+        self._wg = self._wg_out = None       # the whole window as one captured HIP graph (latency mode)
+        self._wg_warm = 0
+        self._dev_mode = False               # stages bound by the device-side event / node counts (inside the capture)
+        self.in_image = None
         self._async_on = False
         self._app = None
         self._n_rows = 0
@@ -453,6 +457,9 @@ class WindowEngine:
     def set_low_latency(self, on):
         self.overlap_heads = bool(on) and os.environ.get("DAGR_OVERLAP_HEADS", "1") != "0"
         self.tail_graph = bool(on) and os.environ.get("DAGR_TAIL_GRAPH", "1") != "0"
+        # the WHOLE window (image branch, graph build, level 0, tail, heads, decode) as one HIP graph: every launch is sized
+        # for the engine's event capacity and bounded by counts that live in device memory
+        self.window_graph = bool(on) and os.environ.get("DAGR_WINDOW_GRAPH", "1") != "0"
         return self
 
     def _alloc_events(self, n):
@@ -474,6 +481,13 @@ class WindowEngine:
         self.cluster0 = torch.zeros((n,), dtype=torch.int32, device=dev)
         self.pos_n = torch.zeros((n, 3), dtype=torch.float32, device=dev)     # node (slot) order
         self.batch_n = torch.zeros((n,), dtype=torch.int32, device=dev)
+        # static inputs of the captured window (latency mode): the caller's events are staged here by one launch
+        self.in_pos = torch.zeros((n, 3), dtype=torch.float32, device=dev)
+        self.in_feat = torch.zeros((n,), dtype=torch.float32, device=dev)
+        self.in_batch = torch.zeros((n,), dtype=torch.int32, device=dev)
+        self.n_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self._wg = self._wg_out = None       # captured on the old buffers
+        self._wg_warm = 0
         self.rows_cap = n
         self._async_on = False
         self._app = None
@@ -559,7 +573,7 @@ class WindowEngine:
         cm = 16 if cin >= 16 else 0
         _lib.check(L.dagr_spline_conv_l0_tiles_rows(cm, cin - cm, cskip, wx, tx, wy, ty, d0["rx"], d0["ry"], d0["den_x"],
                                                     d0["den_y"], first, n, self.graph.K, P(self.nbr_src), P(self.nbr_code),
-                                                    P(self.deg), x, ldx, xskip, ldskip, P(w), P(s), 1, out, ldo,
+                                                    P(self.deg), x, ldx, xskip, ldskip, P(w), P(s), 1, out, ldo, None,
                                                     _lib.cur_stream(self.device)), "conv_l0_tiles_rows")
 
     def forward_append(self, pos, feat, batch):
@@ -639,9 +653,14 @@ class WindowEngine:
         self._N = N
         self._pos, self._batch = pos, batch
         self._nbr = (self.nbr_src[:N], self.nbr_code[:N], self.deg[:N])
-        self.graph.build(pos, batch, out=self._nbr)
+        self.graph.build(pos, batch, out=self._nbr, n_dev=self.n_dev if self._dev_mode else None)
         self._n_rows = N              # a new window: the asynchronous state of the previous one is gone
         self._async_on = False
+
+    def _nptr(self):
+        """``n_ptr`` of the level-0 kernels: the builder's device-side node count inside a captured window, else NULL (the
+        host passes the exact count)."""
+        return self.graph.node_count_ptr() if self._dev_mode else None
 
     def _sample(self, n_ptr, n_max, pos, batch, b64, fmap, out, coff):
         """sample_features (net.py:193-221) of one channels-last feature map into out[:, coff:coff+C]."""
@@ -762,7 +781,7 @@ class WindowEngine:
                                                    _lib.ptr(x0), self.x0_ld, self.x0_feat_col, self.x0_pos_col,
                                                    _lib.cur_stream(self.device)), "graph_gather_inputs")
         if self.use_image:
-            self._sample(None, N, self.pos_n, self.batch_n, 0, self._img_feats[0], x0, self.x0_img_col)
+            self._sample(self._nptr(), N, self.pos_n, self.batch_n, 0, self._img_feats[0], x0, self.x0_img_col)
         self._x0 = x0
 
     def _conv_l0(self, pack, x, ldx, xskip, ldskip, out, ldo):
@@ -776,7 +795,7 @@ class WindowEngine:
             cm = 16 if cin >= 16 else 0
             _lib.check(L.dagr_spline_conv_l0_tiles(cm, cin - cm, cskip, wx, tx, wy, ty, d0["rx"], d0["ry"], d0["den_x"],
                                                    d0["den_y"], self._N, self.graph.K, P(nbr_src), P(nbr_code), P(deg),
-                                                   x, ldx, xskip, ldskip, P(w), P(s), 1, out, ldo, stream),
+                                                   x, ldx, xskip, ldskip, P(w), P(s), 1, out, ldo, self._nptr(), stream),
                        "conv_l0_tiles")
         else:
             _lib.check(L.dagr_spline_conv_l0(cin, cskip, self.ntaps0, self._N, self.graph.K, self.ncodes0, P(nbr_src),
@@ -795,7 +814,7 @@ class WindowEngine:
         P = _lib.ptr
         self._conv_l0(self.l0_conv2, P(self.h1), 16, P(self._x0), self.x0_ld, P(self.hp0), self.hp0.shape[1])
         if self.use_image and sample:
-            self._sample(None, self._N, self.pos_n, self.batch_n, 0, self._img_feats[1], self.hp0[:self._N], 16)
+            self._sample(self._nptr(), self._N, self.pos_n, self.batch_n, 0, self._img_feats[1], self.hp0[:self._N], 16)
 
     def stage_l0_sample1(self):
         """sampling_skip(image_feat[1]) (net.py:129) alone: the level-0 nodes' features of the second map into hp0[:, 16:]."""
@@ -936,6 +955,9 @@ class WindowEngine:
         """pos fp32[N,3] normalised (format_data), feat fp32[N,1], batch int32/int64[N] on the device;
         image fp32[B,3,H,W] in [0,1] when the model was built with --use_image.
         Returns decoded head outputs [B, n_anchors, 5+num_classes] (GNNHead.forward eval)."""
+        if trace is None and image_handle is None and self.window_graph and self.l0_tiles and not self.no_events \
+                and (image is not None or not self.use_image):
+            return self._forward_window_graph(pos, feat, batch, image)
         self._cnn_out = None
         if self.use_image:
             if image_handle is not None:
@@ -969,6 +991,66 @@ class WindowEngine:
         if trace is not None:
             trace["head_dense"] = [o.clone() for o in outs]
         return self._decode(outs)
+
+    def _forward_static(self):
+        """One window on the engine's static input buffers with every launch sized for the event capacity and bounded by
+        the device-side counts: the body of the captured window graph (and of its eager warm-up runs)."""
+        self._dev_mode = True
+        try:
+            self._cnn_out = None
+            if self.use_image:
+                self.stage_image(self.in_image)
+            self.stage_graph(self.in_pos, self.in_batch)
+            self.stage_l0_input(self.in_feat)
+            self.stage_l0_conv1()
+            self.stage_l0_conv2()
+            self.stage_pool1()
+            return self._decode(self._tail_and_head())
+        finally:
+            self._dev_mode = False
+
+    def _forward_window_graph(self, pos, feat, batch, image):
+        """Latency mode: the caller's window is staged into the static buffers by ONE launch (which also writes the event
+        count to device memory); everything else -- image branch, graph build, level 0, pooled levels, heads, decode: ~45
+        launches events-only, several hundred with the ResNet-50 branch -- is one replayed HIP graph.  Until round 4 only the
+        part after pool1 was captured and the image model not at all (the host issued every MIOpen launch of a window)."""
+        L, P = self.L, _lib.ptr
+        N = int(pos.shape[0])
+        if N > self.max_events:
+            self._alloc_events(max(N, 2 * self.max_events))
+        pos = pos.float().contiguous()
+        feat = feat.float().reshape(-1).contiguous()
+        batch = batch.contiguous()
+        _lib.check(L.dagr_stage_window(P(pos), P(feat), P(batch), 1 if batch.dtype == torch.int64 else 0, N, P(self.in_pos),
+                                       P(self.in_feat), P(self.in_batch), P(self.n_dev), _lib.cur_stream(self.device)),
+                   "stage_window")
+        if self.use_image:
+            if self.in_image is None or self.in_image.shape != image.shape:
+                self.in_image = torch.empty(tuple(image.shape), dtype=torch.float32, device=self.device)
+                self._wg = None
+                self._wg_warm = 0
+            self.in_image.copy_(image)
+        if self._wg is None:
+            if self._wg_warm < 2:                    # lazy one-time work (kernel attributes, MIOpen's search) stays eager
+                self._wg_warm += 1
+                out = self._forward_static()
+            else:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    out = self._forward_static()
+                self._wg, self._wg_out = g, out
+                g.replay()
+        else:
+            self._wg.replay()
+            out = self._wg_out
+        # the resident window (what check_status / an asynchronous update / the probes look at): the actual count
+        self._N = N
+        self._n_rows = N
+        self._async_on = False
+        self._pos, self._batch = self.in_pos[:N], self.in_batch[:N]
+        self._nbr = (self.nbr_src[:N], self.nbr_code[:N], self.deg[:N])
+        self._x0 = self.x0buf[:N]
+        return out.clone()   # the graph's output buffer is rewritten by the next window
 
     def _replay_tail(self):
         """Everything after pool1 has launch shapes that do not depend on the window (node / edge counts stay on the

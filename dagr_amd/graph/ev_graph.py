@@ -54,7 +54,16 @@ class WindowGraphBuilder:
     def K(self):
         return self.params["max_neighbors"]
 
-    def build(self, pos, batch, out=None):
+    def node_count_ptr(self):
+        """Device address of the node count of the last build (the ``n_ptr`` of the kernels that follow it in a captured
+        window), as a ctypes void pointer."""
+        import ctypes as _c
+        return _c.c_void_p(_lib.lib().dagr_graph_node_count_ptr(ctypes.byref(self.desc), _lib.ptr(self.workspace)))
+
+    def build(self, pos, batch, out=None, n_dev=None):
+        """``n_dev`` (int32[1] on the device): the event count lives in device memory -- ``pos`` / ``batch`` are capacity-sized
+        buffers and every launch is bounded by ``*n_dev`` on the device (a window captured once as a HIP graph then serves
+        windows of any size)."""
         N = int(pos.shape[0])
         assert pos.is_cuda and pos.is_contiguous() and pos.shape[1] == 3
         if pos.dtype not in (torch.float32, torch.int32):
@@ -72,6 +81,13 @@ class WindowGraphBuilder:
         else:
             nbr_src, nbr_code, deg = out
         L = _lib.lib()
+        if n_dev is not None:
+            _lib.check(L.dagr_graph_build_window_dev(ctypes.byref(self.desc), _lib.ptr(self.workspace), _lib.ptr(pos),
+                                                     1 if pos.dtype == torch.int32 else 0, _lib.ptr(batch),
+                                                     1 if batch.dtype == torch.int64 else 0, N, _lib.ptr(n_dev),
+                                                     _lib.ptr(nbr_src), _lib.ptr(nbr_code), _lib.ptr(deg),
+                                                     _lib.cur_stream(self.device)), "graph_build_window_dev")
+            return nbr_src, nbr_code, deg
         _lib.check(L.dagr_graph_build_window(ctypes.byref(self.desc), _lib.ptr(self.workspace), _lib.ptr(pos),
                                              1 if pos.dtype == torch.int32 else 0, _lib.ptr(batch),
                                              1 if batch.dtype == torch.int64 else 0, N, _lib.ptr(nbr_src),

@@ -124,6 +124,20 @@ int dagr_graph_build_window(const dagr_graph_desc *desc, void *workspace,
                             const void *batch, int32_t batch_is_int64, int64_t N,
                             int32_t *nbr_src, int16_t *nbr_code, int32_t *deg, void *stream);
 
+/* dagr_graph_build_window with the event count in DEVICE memory: every launch is sized for `n_cap` events and bounded by
+ * *n_dev (<= n_cap) on the device, so the call can be captured in a HIP graph once and replayed for windows of any size.
+ * pos / batch must hold n_cap entries' worth of storage (entries past *n_dev are not read). */
+int dagr_graph_build_window_dev(const dagr_graph_desc *desc, void *workspace, const void *pos, int32_t pos_is_int32,
+                                const void *batch, int32_t batch_is_int64, int64_t n_cap, const int32_t *n_dev,
+                                int32_t *nbr_src, int16_t *nbr_code, int32_t *deg, void *stream);
+/* device address of the number of nodes (indexed events) of the last build on this workspace: the `n_ptr` of the kernels
+ * that follow it in a captured window */
+const int32_t *dagr_graph_node_count_ptr(const dagr_graph_desc *desc, void *workspace);
+/* One launch that copies a caller's window (format_data output: pos fp32[N,3], feat fp32[N], batch int32/int64[N]) into
+ * static buffers (batch as int32) and writes N to *n_dev: the only per-window launch in front of a captured window graph. */
+int dagr_stage_window(const float *pos, const float *feat, const void *batch, int32_t batch_is_int64, int64_t N,
+                      float *pos_out, float *feat_out, int32_t *batch_out, int32_t *n_dev, void *stream);
+
 /* The neighbour search alone, again, on the pixel index the last dagr_graph_build_window left in `workspace` (same N):
  * rewrites nbr_src / nbr_code / deg and the edge count.  For measurement (bench.py times the search kernels on their own
  * stream with HIP events); a product caller has no use for it. */
@@ -200,15 +214,17 @@ int dagr_spline_conv_l0_tiles(int32_t cmain, int32_t cextra, int32_t cskip, int3
                               int32_t ty, int32_t rx, int32_t ry, float den_x, float den_y, int64_t N, int32_t K,
                               const int32_t *nbr_src, const int16_t *nbr_code, const int32_t *deg, const float *x,
                               int32_t ldx, const float *xskip, int32_t ldskip, const float *wpack, const float *shift,
-                              int32_t relu, float *out, int32_t ldo, void *stream);
-/* the same on the nodes [first_node, first_node + N) only (all arrays are the full level's: an asynchronous update
+                              int32_t relu, float *out, int32_t ldo, const int32_t *n_ptr, void *stream);
+/* n_ptr (device, may be NULL): the level's node count; the rows processed are min(N, *n_ptr - first_node) -- a launch
+ * sized for a capacity N then serves windows of any size (captured HIP graphs).
+ * the same on the nodes [first_node, first_node + N) only (all arrays are the full level's: an asynchronous update
  * computes the rows it appended; a node's result does not depend on which nodes share its tile) */
 int dagr_spline_conv_l0_tiles_rows(int32_t cmain, int32_t cextra, int32_t cskip, int32_t win_x, int32_t tx, int32_t win_y,
                                    int32_t ty, int32_t rx, int32_t ry, float den_x, float den_y, int64_t first_node,
                                    int64_t N, int32_t K, const int32_t *nbr_src, const int16_t *nbr_code,
                                    const int32_t *deg, const float *x, int32_t ldx, const float *xskip, int32_t ldskip,
                                    const float *wpack, const float *shift, int32_t relu, float *out, int32_t ldo,
-                                   void *stream);
+                                   const int32_t *n_ptr, void *stream);
 /* generic step 1: A[n] = [sum_j basis*x_j per tap (25*cin) | x[n] (cin) | xskip[n] (cskip)] over a
  * CSR-by-destination graph; code[e] = ix | iy<<16.  n_nodes_ptr (device, may be NULL) bounds the
  * rows actually processed (<= n_nodes_max) without a host sync. */

@@ -77,7 +77,7 @@ def test_tiles_match_float64(N, cm_ce, cskip, r, den, relu):
     out = torch.full((N, 16), float("nan"), device=dev)
     _lib.check(L.dagr_spline_conv_l0_tiles(cm, ce, cskip, wx0, tx, wy0, ty, r, r, den[0], den[1], N, K, P(d_src),
                                            P(d_code), P(d_deg), P(d_x), ldx, P(d_xs) if cskip else None, lds, P(d_w),
-                                           P(d_s), 1 if relu else 0, P(out), 16, _lib.cur_stream(dev)), "l0_tiles")
+                                           P(d_s), 1 if relu else 0, P(out), 16, None, _lib.cur_stream(dev)), "l0_tiles")
     torch.cuda.synchronize()
     got = out.cpu().numpy().astype(np.float64)
     assert np.isfinite(got).all()

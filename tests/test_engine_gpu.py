@@ -524,25 +524,81 @@ def test_round_to_pixel_near_tie_follows_the_exact_mean():
         assert abs(float(got[0, 2]) - float(mean[2])) < 1e-7
 
 
-def test_tail_graph_replay_matches_eager_launches():
-    """After pool1 a window is ~70 small launches whose shapes do not depend on the window: forward_raw replays them as
-    one captured HIP graph (head scale 1 beside pool4 / layer5 / head scale 2).  Same kernels, same order per buffer:
-    the outputs are bit-identical to the launch-by-launch (trace) path, window after window."""
+def _dev_window(gen, n, B, W, H, seed):
+    dev = torch.device("cuda:0")
+    x, y, t, p, b, pos = _events(gen, n, B, W, H, seed=seed)
+    return (torch.from_numpy(pos).to(dev), torch.from_numpy(p.astype(np.float32)).view(-1, 1).to(dev),
+            torch.from_numpy(b).to(dev))
+
+
+def test_window_graph_replay_matches_eager_launches():
+    """Latency mode: forward_raw stages the caller's window with one launch and replays the WHOLE window -- graph build,
+    level 0, pooling, tail, heads, decode -- as one captured HIP graph whose launches are sized for the engine's event
+    capacity and bounded by device-side counts.  Same kernels, same order per buffer: the outputs are bit-identical to
+    the launch-by-launch (trace) path, for windows of DIFFERENT sizes through the same captured graph, an empty window
+    included."""
     W, H, B = 320, 215, 2
     args, model, sd = _setup(W, H, B, seed=12)
     dev = torch.device("cuda:0")
     eng = model.engine().set_low_latency(True)
-    wins = []
-    for seed in (41, 43):
-        x, y, t, p, b, pos = _events(syn.edges_window, 4000, B, W, H, seed=seed)
-        wins.append((torch.from_numpy(pos).to(dev), torch.from_numpy(p.astype(np.float32)).view(-1, 1).to(dev),
-                     torch.from_numpy(b).to(dev)))
+    wins = [_dev_window(syn.edges_window, n, B, W, H, seed) for n, seed in ((4000, 41), (2500, 43), (6000, 45), (1, 47))]
+    wins.append((torch.zeros((0, 3), device=dev), torch.zeros((0, 1), device=dev), torch.zeros((0,), dtype=torch.int64, device=dev)))
     eager = [eng.forward_raw(*w, trace={}).clone() for w in wins]
     got = []
     for rep in range(3):
         for k, w in enumerate(wins):
             got.append((k, eng.forward_raw(*w)))
-    assert eng._graph is not None, "the tail was not captured"
+    assert eng._wg is not None, "the window was not captured"
     eng.check_status()
     for k, o in got:
-        assert torch.equal(o, eager[k])
+        assert torch.equal(o, eager[k]), k
+    # a window beyond the capacity grows the buffers and re-captures
+    cap0 = eng.max_events
+    big = _dev_window(syn.uniform_window, cap0 // B + 500, B, W, H, seed=49)
+    want = eng.forward_raw(*big, trace={}).clone()
+    for rep in range(4):
+        assert torch.equal(eng.forward_raw(*big), want)
+    assert eng.max_events > cap0 and eng._wg is not None
+    assert torch.equal(eng.forward_raw(*wins[0]), eager[0])
+
+
+def test_window_graph_with_the_image_branch():
+    """--use_image: the dense branch (ResNet + CNN head on PyTorch-ROCm) sits inside the captured window too, on a static
+    frame buffer.  Replayed windows are bit-identical from replay to replay (different frames and window sizes through the
+    same graph) and equal the launch-by-launch path to the library convolutions' rounding (MIOpen may pick another
+    solver between its first and later calls)."""
+    W, H, B = 320, 215, 2
+    args, model, sd = _setup(W, H, B, seed=13, use_image=True, img_net="resnet18")
+    eng = model.engine().set_low_latency(True)
+    wins = [_dev_window(syn.uniform_window, n, B, W, H, seed) for n, seed in ((3000, 51), (5000, 53))]
+    imgs = [torch.rand((B, 3, H, W), generator=torch.Generator().manual_seed(s)).cuda() for s in (7, 8)]
+    with torch.no_grad():
+        eager = [eng.forward_raw(*w, image=im, trace={}).clone() for w, im in zip(wins, imgs)]
+        runs = [[eng.forward_raw(*wins[k], image=imgs[k]) for k in range(2)] for rep in range(5)]
+    assert eng._wg is not None
+    eng.check_status()
+    for k in range(2):
+        assert _decoded_err(eng, runs[-1][k], eager[k].cpu()) < 1e-4, k
+        for rep in (3, 4):          # replays of the captured graph
+            assert torch.equal(runs[rep][k], runs[2][k]), (rep, k)
+    assert not torch.equal(runs[-1][0], runs[-1][1])
+
+
+def test_tail_graph_replay_matches_eager_launches():
+    """The asynchronous update (forward_append) replays everything after pool1 as one captured HIP graph (head scale 1
+    beside pool4 / layer5 / head scale 2): bit-identical to the launch-by-launch path."""
+    W, H, B = 320, 215, 2
+    args, model, sd = _setup(W, H, B, seed=12)
+    eng = model.engine().set_low_latency(True)
+    w0 = _dev_window(syn.edges_window, 4000, B, W, H, 41)
+    upd = [_dev_window(syn.edges_window, 300, B, W, H, s) for s in (61, 62, 63, 64)]
+    eng.tail_graph = False
+    eng.forward_raw(*w0)
+    eager = [eng.forward_append(*u).clone() for u in upd]
+    eng.tail_graph = True
+    eng.forward_raw(*w0)
+    got = [eng.forward_append(*u).clone() for u in upd]
+    assert eng._graph is not None, "the tail was not captured"
+    eng.check_status()
+    for a_, b_ in zip(got, eager):
+        assert torch.equal(a_, b_)
