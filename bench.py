@@ -378,7 +378,7 @@ def stage_timings(rig, slots, n_events_step):
     stages["pool1_accumulate"] = time_gpu(eng.pool1_accumulate_again, iters)
     eng.stage_pool1()            # re-arms the accumulators the repeated launches filled
     stages["tail"] = time_gpu(eng.stage_tail, iters)
-    stages["head"] = time_gpu(lambda: eng._decode(eng.stage_head()), iters)
+    stages["head"] = time_gpu(eng.stage_head, iters)
     if not use_image:
         # what a latency-mode engine runs after pool1: tail + both heads + decode as ONE replayed HIP graph (head scale 1
         # beside pool4 / layer5 / head scale 2); `tail` and `head` above are the same kernels launched one by one
@@ -493,7 +493,8 @@ def latency_sweep(W, H, use_image, img_net, dev, Ns, n_warm, n_timed):
 
                 def window(i):
                     pos, feat, batch, image = slots[i % 2]
-                    o = eng.forward_raw(pos, feat, batch, image=image)
+                    # forward + post-processing as DAGR.forward runs them (the outputs are consumed at once)
+                    o = eng.forward_raw(pos, feat, batch, image=image, static_out=True)
                     return postprocess_device(o, rig.num_classes, 0.001, 0.65, H, W)
                 for i in range(n_warm):
                     window(i)
@@ -567,14 +568,14 @@ def async_update_leg(W, H, dev, n_window=25000, sizes=(1, 10, 100), n_updates=10
         return postprocess_device(o, rig.num_classes, 0.001, 0.65, H, W)
     out = {"window_events": n_window, "protocol": f"{n_warm} warm-up + {n_updates} timed updates per micro-batch size, one at "
                                                    "a time, HIP events around update + post-processing"}
-    full = timed(lambda i: post(eng.forward_raw(pos[:n_window], feat[:n_window], batch[:n_window])), 30)[10:]
+    full = timed(lambda i: post(eng.forward_raw(pos[:n_window], feat[:n_window], batch[:n_window], static_out=True)), 30)[10:]
     out["reevaluate_window_us"] = dict(p50=round(1e3 * float(np.median(full)), 1), p95=round(1e3 * float(np.percentile(full, 95)), 1))
     for m in sizes:
         eng.forward_raw(pos[:n_window], feat[:n_window], batch[:n_window])
 
         def upd(i, m=m):
             lo = n_window + i * m
-            post(eng.forward_append(pos[lo:lo + m], feat[lo:lo + m], batch[lo:lo + m]))
+            post(eng.forward_append(pos[lo:lo + m], feat[lo:lo + m], batch[lo:lo + m], static_out=True))
         us = 1e3 * timed(upd, n_warm + n_updates)[n_warm:]
         eng.check_status()
         out[f"update_{m}_events_us"] = dict(p50=round(float(np.median(us)), 1), p95=round(float(np.percentile(us, 95)), 1),

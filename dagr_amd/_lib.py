@@ -34,6 +34,13 @@ class GraphDesc(ctypes.Structure):
                 ("max_events", c_i64)]
 
 
+class HeadScale(ctypes.Structure):
+    """``dagr_head_scale`` (include/dagr_hip.h)."""
+    _fields_ = [("n_ptr", c_void_p), ("n_max", c_i32), ("pred", c_void_p), ("ld", c_i32), ("pos", c_void_p),
+                ("batch", c_void_p), ("vx", c_float), ("vy", c_float), ("stride", c_float), ("Hc", c_i32), ("Wc", c_i32),
+                ("cnn", c_void_p * 3), ("cnn_stride", (c_i32 * 4) * 3), ("dense", c_void_p)]
+
+
 # name -> (restype, argtypes); the single source of truth for the symbols we bind.  The CPU-only
 # test-suite checks that every function declared in include/dagr_hip.h appears here and resolves.
 SIGNATURES = {
@@ -69,8 +76,8 @@ SIGNATURES = {
     "dagr_graph_build_window_dev": (ctypes.c_int, [ctypes.POINTER(GraphDesc), c_void_p, c_void_p, c_i32, c_void_p,
                                                    c_i32, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dagr_graph_node_count_ptr": (c_void_p, [ctypes.POINTER(GraphDesc), c_void_p]),
-    "dagr_stage_window": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_i32, c_i64, c_void_p, c_void_p, c_void_p,
-                                         c_void_p, c_void_p]),
+    "dagr_stage_window": (ctypes.c_int, [ctypes.POINTER(GraphDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i64,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dagr_spiral_offsets": (ctypes.c_int, [c_i32, c_void_p, c_void_p]),
     "dagr_spline_tap_window": (ctypes.c_int, [c_i32, c_float, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
     "dagr_spline_l0_table": (ctypes.c_int, [c_i32, c_i32, c_float, c_float, c_i32, c_i32, c_i32, c_i32, c_void_p,
@@ -103,8 +110,6 @@ SIGNATURES = {
     "dagr_pool_counters": (ctypes.c_int, [ctypes.POINTER(PoolDesc), c_void_p, c_void_p, c_void_p]),
     "dagr_to_dense": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_i32, c_i32, c_void_p, c_void_p, c_float, c_float,
                                      c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "dagr_to_dense_armed": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_i32, c_i32, c_void_p, c_void_p, c_float, c_float,
-                                           c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dagr_pool_argmax": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_i32, c_i32, c_void_p, c_i32, c_i32, c_void_p, c_void_p]),
     "dagr_pool_grad": (ctypes.c_int, [c_void_p, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_i32,
                                       c_void_p]),
@@ -114,6 +119,8 @@ SIGNATURES = {
                                             c_i32, c_i32, c_i32, c_void_p, c_i32, c_i32, c_void_p]),
     "dagr_nms_batched": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_float, c_float, c_void_p,
                                         c_void_p, c_void_p, c_void_p]),
+    "dagr_heads_finish": (ctypes.c_int, [ctypes.POINTER(HeadScale), ctypes.POINTER(HeadScale), c_i32, c_i32, c_void_p,
+                                         c_void_p, c_void_p]),
     "dagr_decode_heads": (ctypes.c_int, [c_void_p, c_i32, c_i32, c_float, c_void_p, c_i32, c_i32, c_float, c_i32, c_i32,
                                          c_void_p, c_void_p]),
     "dagr_postprocess": (ctypes.c_int, [c_void_p, c_i32, c_i32, c_i32, c_float, c_float, c_float, c_void_p, c_void_p,
@@ -142,6 +149,9 @@ SIGNATURES = {
     "dagr_spline_conv_fused": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32,
                                               c_void_p, c_i32, c_i32, c_i32, c_i32, c_float, c_float, c_void_p,
                                               c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p]),
+    "dagr_spline_conv_fused_pair": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32,
+                                                   c_float, c_float, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                   c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_void_p]),
     "dagr_add_relu": (ctypes.c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
     "dagr_bias_relu": (ctypes.c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p]),
     "dagr_bias_silu": (ctypes.c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p]),

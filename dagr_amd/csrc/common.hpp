@@ -147,6 +147,10 @@ size_t scan_scratch_elems(int64_t n);
 // only if !zero_input.  scratch: scan_scratch_elems(n) ints.
 hipError_t exclusive_scan_i32(int32_t *in, int32_t *out, int64_t n, int32_t *scratch, bool zero_input,
                               hipStream_t stream);
+// the same in one launch (decoupled look-back); state: scan_chained_state_bytes(n) bytes, zero before the first launch
+size_t scan_chained_state_bytes(int64_t n);
+hipError_t exclusive_scan_i32_chained(int32_t *in, int32_t *out, int64_t n, void *state, bool zero_input,
+                                      hipStream_t stream);
 
 
 hipError_t launch_gemm_mfma(const int32_t *m_ptr, int m_max, const float *A, int lda, const float *Wm, int ldw,

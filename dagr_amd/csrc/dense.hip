@@ -33,44 +33,10 @@ __global__ __launch_bounds__(kBlock) void k_dense_write(int B, int C, int Hc, in
     dense[gid] = n >= 0 ? x[(size_t)n * ldx + ch] : 0.0f;
 }
 
-// one thread per map cell: all channels of the cell, then the cell's scratch entry back to "empty" -- the armed variant
-// needs no fill launch before the next call
-__global__ __launch_bounds__(kBlock) void k_dense_cells(int B, int C, int Hc, int Wc, int32_t *__restrict__ winner,
-                                                       const float *__restrict__ x, int ldx,
-                                                       float *__restrict__ dense) {
-    const int cell = blockIdx.x * kBlock + threadIdx.x;
-    if (cell >= B * Hc * Wc) return;
-    const int n = winner[cell];
-    winner[cell] = -1;
-    const int b = cell / (Hc * Wc), yx = cell % (Hc * Wc);
-    float *d = dense + (size_t)b * C * Hc * Wc + yx;
-    for (int ch = 0; ch < C; ch++) d[(size_t)ch * Hc * Wc] = n >= 0 ? x[(size_t)n * ldx + ch] : 0.0f;
-}
-
 }  // namespace
 }  // namespace dagr
 
 using namespace dagr;
-
-extern "C" int dagr_to_dense_armed(const int32_t *n_ptr, int32_t n_max, const float *x, int32_t ldx, int32_t channels,
-                                   const float *pos, const int32_t *batch, float vx, float vy, int32_t batch_size,
-                                   int32_t Hc, int32_t Wc, int32_t *winner_armed, float *dense, int32_t *status,
-                                   void *stream_) {
-    DAGR_CHECK_ARG(batch_size > 0 && Hc > 0 && Wc > 0 && channels > 0, "bad sizes");
-    DAGR_CHECK_ARG(winner_armed && dense && status, "NULL pointer");
-    hipStream_t stream = (hipStream_t)stream_;
-    const int cells = batch_size * Hc * Wc;
-    if (n_max > 0) {
-        DAGR_CHECK_ARG(x && pos && batch, "NULL input");
-        k_dense_winner<<<(unsigned)ceil_div(n_max, kBlock), kBlock, 0, stream>>>(n_ptr, n_max, pos, batch, vx, vy,
-                                                                               batch_size, Hc, Wc, winner_armed, status);
-        DAGR_CHECK_LAUNCH();
-    }
-    k_dense_cells<<<(unsigned)ceil_div(cells, kBlock), kBlock, 0, stream>>>(batch_size, channels, Hc, Wc, winner_armed, x,
-                                                                           ldx, dense);
-    DAGR_CHECK_LAUNCH();
-    return DAGR_OK;
-}
 
 extern "C" int dagr_to_dense(const int32_t *n_ptr, int32_t n_max, const float *x, int32_t ldx, int32_t channels,
                              const float *pos, const int32_t *batch, float vx, float vy, int32_t batch_size,

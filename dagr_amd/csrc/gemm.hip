@@ -168,6 +168,11 @@ struct AxisF {
     int k0, k1;
     float b0, b1;
 };
+struct ConvJob2 {       // what differs between the two convs of a paired launch
+    const float *x, *Wq, *bias;
+    float *C;
+    int N;
+};
 __device__ __forceinline__ AxisF spline_axis_f(int idx, int r, float den) {   // == spline_axis (spline_conv.hip)
     const float pseudo = (float)(idx - r) / den + 0.5f;
     const float v = pseudo * 4.0f;
@@ -186,7 +191,9 @@ __global__ __launch_bounds__(kGemmThreads) void k_conv_fused(
     const int32_t *__restrict__ n_ptr, int n_max, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const int32_t *__restrict__ code, const float *__restrict__ x, int ldx, int cin, const float *__restrict__ xskip,
     int ldskip, int cskip, int rx, int ry, float den_x, float den_y, const float *__restrict__ Wq,
-    const float *__restrict__ bias, float *__restrict__ C, int ldc, int N, int relu, int KP, int NC) {
+    const float *__restrict__ bias, float *__restrict__ C, int ldc, int N, int relu, int KP, int NC, ConvJob2 second) {
+    // a second conv on the same graph, same shape of input row (dagr_spline_conv_fused_pair): gridDim.z = 2
+    if (blockIdx.z == 1) { x = second.x; Wq = second.Wq; bias = second.bias; C = second.C; N = second.N; }
     extern __shared__ __align__(16) float fl[];
     const int K = 26 * cin + cskip;
     float *At = fl;                                  // [16][KP], columns K..KP-1 zero
@@ -387,7 +394,9 @@ __global__ __launch_bounds__(kGemmThreads) void k_conv_fused_mp(
     const int32_t *__restrict__ n_ptr, int n_max, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const int32_t *__restrict__ code, const float *__restrict__ x, int ldx, int cin, const float *__restrict__ xskip,
     int ldskip, int cskip, int rx, int ry, float den_x, float den_y, const float *__restrict__ Wq,
-    const float *__restrict__ bias, float *__restrict__ C, int ldc, int N, int relu, int KP, int NC, int tp) {
+    const float *__restrict__ bias, float *__restrict__ C, int ldc, int N, int relu, int KP, int NC, int tp, ConvJob2 second) {
+    // a second conv on the same graph, same shape of input row (dagr_spline_conv_fused_pair): gridDim.z = 2
+    if (blockIdx.z == 1) { x = second.x; Wq = second.Wq; bias = second.bias; C = second.C; N = second.N; }
     extern __shared__ __align__(16) float fl[];
     const int K = 26 * cin + cskip;
     float *At = fl;                                  // [16][KP]: the pass's columns, zero behind them
@@ -678,11 +687,11 @@ bool fused_plan(int cin, int cskip, int *tp_out, int *kp_out) {
 }  // namespace
 }  // namespace dagr
 
-extern "C" int dagr_spline_conv_fused(const int32_t *n_nodes_ptr, int32_t n_nodes_max, const int32_t *rowptr,
-                                      const int32_t *col, const int32_t *code, const float *x, int32_t ldx, int32_t cin,
-                                      const float *xskip, int32_t ldskip, int32_t cskip, int32_t rx, int32_t ry,
-                                      float den_x, float den_y, const float *Wq, const float *bias, float *C,
-                                      int32_t ldc, int32_t N, int32_t relu, void *stream) {
+static int launch_conv_fused(const int32_t *n_nodes_ptr, int32_t n_nodes_max, const int32_t *rowptr, const int32_t *col,
+                             const int32_t *code, const float *x, int32_t ldx, int32_t cin, const float *xskip,
+                             int32_t ldskip, int32_t cskip, int32_t rx, int32_t ry, float den_x, float den_y,
+                             const float *Wq, const float *bias, float *C, int32_t ldc, int32_t N, int32_t relu,
+                             const dagr::ConvJob2 *second, void *stream) {
     using namespace dagr;
     DAGR_CHECK_ARG(n_nodes_max >= 0 && cin >= 1 && N >= 1, "bad sizes");
     if (n_nodes_max == 0) return DAGR_OK;
@@ -709,30 +718,54 @@ extern "C" int dagr_spline_conv_fused(const int32_t *n_nodes_ptr, int32_t n_node
     // on 256 CUs, 18.5 us where 141 node tiles took 16.9.
     const int row_blocks = ceil_div(n_nodes_max, 16);
     const int passes = tp >= 25 ? 1 : (25 + tp - 1) / tp;
+    const int jobs = second ? 2 : 1;
+    const int Nmax = second ? std::max(N, second->N) : N;
     int nc = 4, loop_cols = passes == 1 ? 1 : 0;
     float best = 0.0f;
     for (int c = 4; c >= 1; c >>= 1) {
         // single pass, 4 tiles: one workgroup per node tile walks all 64-column blocks over its tile; else gridDim.y
         // workgroups of c tiles each
         const int loop = (c == 4 && passes == 1) ? 1 : 0;
-        const int wgs = loop ? row_blocks : row_blocks * (int)ceil_div(N, 16 * c);
-        const float tiles = loop ? 4.0f * (float)ceil_div(N, 64) : (float)c;
+        const int wgs = jobs * (loop ? row_blocks : row_blocks * (int)ceil_div(Nmax, 16 * c));
+        const float tiles = loop ? 4.0f * (float)ceil_div(Nmax, 64) : (float)c;
         // n_nodes_max is a capacity: a level's table has one sample plane more than the batch fills (QUIRK-1), and
         // workgroups past the device-side count leave at once -- count 9 in 10 as live
         const float cost = (float)ceil_div((int64_t)wgs * 9 / 10, device_cu_count()) * (5.0f * (float)passes + 1.5f * tiles);
         if (best == 0.0f || cost < best) { best = cost; nc = c; loop_cols = loop; }
     }
-    const dim3 grid((unsigned)row_blocks, loop_cols ? 1u : (unsigned)ceil_div(N, 16 * nc));
+    const dim3 grid((unsigned)row_blocks, loop_cols ? 1u : (unsigned)ceil_div(Nmax, 16 * nc), (unsigned)jobs);
+    const ConvJob2 job2 = second ? *second : ConvJob2{nullptr, nullptr, nullptr, nullptr, 0};
     if (mp)
         k_conv_fused_mp<<<grid, kGemmThreads, lds_bytes, (hipStream_t)stream>>>(
             n_nodes_ptr, n_nodes_max, rowptr, col, code, x, ldx, cin, xskip, ldskip, cskip, rx, ry, den_x, den_y, Wq, bias,
-            C, ldc, N, relu, KP, nc, tp);
+            C, ldc, N, relu, KP, nc, tp, job2);
     else
         k_conv_fused<<<grid, kGemmThreads, lds_bytes, (hipStream_t)stream>>>(
             n_nodes_ptr, n_nodes_max, rowptr, col, code, x, ldx, cin, xskip, ldskip, cskip, rx, ry, den_x, den_y, Wq, bias,
-            C, ldc, N, relu, KP, nc);
+            C, ldc, N, relu, KP, nc, job2);
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;
+}
+
+extern "C" int dagr_spline_conv_fused(const int32_t *n_nodes_ptr, int32_t n_nodes_max, const int32_t *rowptr,
+                                      const int32_t *col, const int32_t *code, const float *x, int32_t ldx, int32_t cin,
+                                      const float *xskip, int32_t ldskip, int32_t cskip, int32_t rx, int32_t ry,
+                                      float den_x, float den_y, const float *Wq, const float *bias, float *C,
+                                      int32_t ldc, int32_t N, int32_t relu, void *stream) {
+    return launch_conv_fused(n_nodes_ptr, n_nodes_max, rowptr, col, code, x, ldx, cin, xskip, ldskip, cskip, rx, ry, den_x,
+                             den_y, Wq, bias, C, ldc, N, relu, nullptr, stream);
+}
+
+extern "C" int dagr_spline_conv_fused_pair(const int32_t *n_nodes_ptr, int32_t n_nodes_max, const int32_t *rowptr,
+                                           const int32_t *col, const int32_t *code, int32_t ldx, int32_t cin, int32_t rx,
+                                           int32_t ry, float den_x, float den_y, int32_t ldc, int32_t relu, const float *x_a,
+                                           const float *Wq_a, const float *bias_a, float *C_a, int32_t N_a,
+                                           const float *x_b, const float *Wq_b, const float *bias_b, float *C_b,
+                                           int32_t N_b, void *stream) {
+    DAGR_CHECK_ARG(x_b && Wq_b && C_b && N_b >= 1 && ((uintptr_t)Wq_b % 16) == 0, "bad second conv");
+    const dagr::ConvJob2 second{x_b, Wq_b, bias_b, C_b, N_b};
+    return launch_conv_fused(n_nodes_ptr, n_nodes_max, rowptr, col, code, x_a, ldx, cin, nullptr, 0, 0, rx, ry, den_x, den_y,
+                             Wq_a, bias_a, C_a, ldc, N_a, relu, &second, stream);
 }
 
 extern "C" size_t dagr_spline_conv_fused_lds_bytes(int32_t cin, int32_t cskip) {

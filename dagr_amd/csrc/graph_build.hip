@@ -35,7 +35,7 @@ constexpr int kMaxSpiral = 4096; // (2r+1)^2 bound for the LDS spiral table (r <
 struct GraphWs {
     int32_t *cnt;       // [P+1]  per-pixel event counters; all-zero between builds (invariant)
     int32_t *start;     // [P+1]  exclusive scan of cnt
-    int32_t *scan_tmp;  // [scan_scratch_elems(P+1)]
+    int32_t *scan_tmp;  // [scan_chained_state_bytes(P+1) / 4]: ticket, tag and per-tile words of the one-launch scan
     int32_t *ev_xyb;    // [Nmax] x | y<<12 | b<<24  (denormalised ints)
     int32_t *ev_t;      // [Nmax] denormalised timestamp (us)
     int32_t *ev_rank;   // [Nmax] arrival rank inside the pixel (arbitrary order)
@@ -58,7 +58,7 @@ size_t carve(const dagr_graph_desc &d, char *base, GraphWs *ws) {
     };
     int32_t *cnt = (int32_t *)take((P + 1 + 8) * 4);
     int32_t *start = (int32_t *)take((P + 1 + 8) * 4);
-    int32_t *scan_tmp = (int32_t *)take(scan_scratch_elems(P + 1) * 4);
+    int32_t *scan_tmp = (int32_t *)take(scan_chained_state_bytes(P + 1));
     int32_t *ev_xyb = (int32_t *)take(d.max_events * 4);
     int32_t *ev_t = (int32_t *)take(d.max_events * 4);
     int32_t *ev_rank = (int32_t *)take(d.max_events * 4);
@@ -900,9 +900,11 @@ template <typename BatchT>
 __global__ __launch_bounds__(kBlock) void k_stage_window(const float *__restrict__ pos, const float *__restrict__ feat,
                                                         const BatchT *__restrict__ batch, int N,
                                                         float *__restrict__ pos_out, float *__restrict__ feat_out,
-                                                        int32_t *__restrict__ batch_out, int32_t *__restrict__ n_dev) {
+                                                        int32_t *__restrict__ batch_out, int32_t *__restrict__ n_dev,
+                                                        int32_t *__restrict__ status8) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i == 0) *n_dev = N;
+    if (status8 && i < 8) status8[i] = 0;     // the builder's status words start over (dagr_graph_build_window_dev)
     if (i < N) {
         feat_out[i] = feat[i];
         batch_out[i] = (int32_t)batch[i];
@@ -979,6 +981,7 @@ int dagr_graph_workspace_init(const dagr_graph_desc *desc, void *workspace, size
     DAGR_CHECK_HIP(hipMemsetAsync(ws.cnt, 0, (ws.P + 1 + 8) * 4, (hipStream_t)stream));
     DAGR_CHECK_HIP(hipMemsetAsync(ws.start, 0, (ws.P + 1 + 8) * 4, (hipStream_t)stream));
     DAGR_CHECK_HIP(hipMemsetAsync(ws.status, 0, 8 * 4, (hipStream_t)stream));
+    DAGR_CHECK_HIP(hipMemsetAsync(ws.scan_tmp, 0, scan_chained_state_bytes(ws.P + 1), (hipStream_t)stream));
     return DAGR_OK;
 }
 
@@ -1042,7 +1045,8 @@ static int build_window(const dagr_graph_desc *desc, void *workspace, const void
     const int n = (int)N;
     const unsigned gN = (unsigned)ceil_div(N, kBlock);
     const int W = desc->width, H = desc->height, B = desc->batch_size;
-    DAGR_CHECK_HIP(hipMemsetAsync(ws.status, 0, 8 * 4, stream));
+    // (device-count form: dagr_stage_window, the launch in front of the captured window, has cleared the status words)
+    if (!n_dev) DAGR_CHECK_HIP(hipMemsetAsync(ws.status, 0, 8 * 4, stream));
 #define DAGR_LAUNCH_COUNT(BT, IP)                                                                          \
     k_count<BT, IP><<<gN, kBlock, 0, stream>>>(pos, (const BT *)batch, n, n_dev, W, H, B, (float)W, (float)H, \
                                                (float)desc->time_window, ws.cnt, ws.ev_xyb, ws.ev_t,         \
@@ -1052,7 +1056,7 @@ static int build_window(const dagr_graph_desc *desc, void *workspace, const void
 #undef DAGR_LAUNCH_COUNT
     DAGR_CHECK_LAUNCH();
     // start = exclusive_scan(cnt); cnt is re-zeroed in the same pass (invariant for the next window)
-    DAGR_CHECK_HIP(exclusive_scan_i32(ws.cnt, ws.start, ws.P + 1, ws.scan_tmp, true, stream));
+    DAGR_CHECK_HIP(exclusive_scan_i32_chained(ws.cnt, ws.start, ws.P + 1, ws.scan_tmp, true, stream));
     k_scatter<<<gN, kBlock, 0, stream>>>(n, n_dev, W, H, ws.ev_xyb, ws.ev_rank, ws.start, ws.slot_tmp, ws.ev_slot);
     DAGR_CHECK_LAUNCH();
     // number of occupied CSR slots M = start[P] <= N (dropped events excluded); slots are a
@@ -1087,17 +1091,22 @@ const int32_t *dagr_graph_node_count_ptr(const dagr_graph_desc *desc, void *work
     return graph_ws_node_count(desc, workspace);
 }
 
-int dagr_stage_window(const float *pos, const float *feat, const void *batch, int32_t batch_is_int64, int64_t N,
-                      float *pos_out, float *feat_out, int32_t *batch_out, int32_t *n_dev, void *stream) {
-    DAGR_CHECK_ARG(N >= 0 && N < (1ll << 30) && pos_out && feat_out && batch_out && n_dev, "bad arguments");
+int dagr_stage_window(const dagr_graph_desc *desc, void *workspace, const float *pos, const float *feat, const void *batch,
+                      int32_t batch_is_int64, int64_t N, float *pos_out, float *feat_out, int32_t *batch_out,
+                      int32_t *n_dev, void *stream) {
+    int rc = validate(desc);
+    if (rc != DAGR_OK) return rc;
+    DAGR_CHECK_ARG(workspace && N >= 0 && N <= desc->max_events && pos_out && feat_out && batch_out && n_dev, "bad arguments");
     DAGR_CHECK_ARG(N == 0 || (pos && feat && batch), "NULL input");
+    GraphWs ws;
+    carve(*desc, (char *)workspace, &ws);
     const unsigned grid = (unsigned)std::max<int64_t>(1, ceil_div(N, kBlock));
     if (batch_is_int64)
         k_stage_window<int64_t><<<grid, kBlock, 0, (hipStream_t)stream>>>(pos, feat, (const int64_t *)batch, (int)N, pos_out,
-                                                                         feat_out, batch_out, n_dev);
+                                                                         feat_out, batch_out, n_dev, ws.status);
     else
         k_stage_window<int32_t><<<grid, kBlock, 0, (hipStream_t)stream>>>(pos, feat, (const int32_t *)batch, (int)N, pos_out,
-                                                                         feat_out, batch_out, n_dev);
+                                                                         feat_out, batch_out, n_dev, ws.status);
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;
 }

@@ -292,10 +292,92 @@ __global__ __launch_bounds__(kBlock) void k_decode_heads(const float *__restrict
         out[i] = r;
     }
 }
+
+// to_dense of both head scales + the CNN head's logits + collect_outputs / decode_outputs in ONE launch (spline_conv.py:
+// 80-107, dagr.py:219-222,230-234,283-312).  The head maps are tiny (B x 175 anchors): one workgroup keeps both winner
+// tables (highest node index per cell, csrc/dense.hip) in LDS, then every thread decodes output elements straight from the
+// winning node's predictor row (+ the image branch's logit) -- the dense maps exist only as an optional by-product for
+// traces.  Replaces k_dense_winner + k_dense_cells per scale, the concatenation / addition of the CNN maps and
+// k_decode_heads: 5 (events-only) to 9 launches at the very end of every window's dependency chain.
+struct HeadScale {
+    const int32_t *n_ptr; int n_max;
+    const float *pred; int ld;              // [n, ld]: reg 4 | obj 1 | cls C
+    const float *pos; const int32_t *batch;
+    float vx, vy, stride; int Hc, Wc;
+    const float *cnn[3]; int cb[3], cc[3], cy[3], cx[3];   // image-branch logits reg / obj / cls with their strides (or NULL)
+    float *dense;                           // optional [B, 5 + C, Hc, Wc]: the (fused) logit maps
+};
+
+__global__ __launch_bounds__(1024) void k_heads_finish(HeadScale h0, HeadScale h1, int n_scales, int B, int CH,
+                                                      float *__restrict__ out, int32_t *__restrict__ status) {
+    extern __shared__ int winner[];
+    const int A0 = h0.Hc * h0.Wc, A1 = n_scales > 1 ? h1.Hc * h1.Wc : 0, A = A0 + A1;
+    for (int i = threadIdx.x; i < B * A; i += blockDim.x) winner[i] = -1;
+    __syncthreads();
+    for (int s = 0; s < n_scales; s++) {
+        const HeadScale &h = s == 0 ? h0 : h1;
+        int32_t *w = winner + (s == 0 ? 0 : B * A0);
+        const int n_nodes = h.n_ptr ? min(*h.n_ptr, h.n_max) : h.n_max;
+        for (int n = threadIdx.x; n < n_nodes; n += blockDim.x) {
+            const int cx = (int)(h.pos[3 * n] / h.vx), cy = (int)(h.pos[3 * n + 1] / h.vy), b = h.batch[n];
+            if (cx < 0 || cx >= h.Wc || cy < 0 || cy >= h.Hc || b < 0 || b >= B) { atomicOr(status, 1); continue; }
+            atomicMax(&w[(b * h.Hc + cy) * h.Wc + cx], n);
+        }
+    }
+    __syncthreads();
+    const int total = B * A * CH;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        const int ch = i % CH, a = (i / CH) % A, b = i / (CH * A);
+        const bool first = a < A0;
+        const HeadScale &h = first ? h0 : h1;
+        const int cell = first ? a : a - A0;
+        const int HW = first ? A0 : A1;
+        const int n = (first ? winner : winner + B * A0)[b * HW + cell];
+        float v = n >= 0 ? h.pred[(size_t)n * h.ld + ch] : 0.0f;
+        const int k = ch < 4 ? 0 : (ch == 4 ? 1 : 2);
+        if (h.cnn[k]) {
+            const int cc_ = ch < 4 ? ch : (ch == 4 ? 0 : ch - 5);
+            const int y = cell / h.Wc, x = cell - y * h.Wc;
+            v = v + h.cnn[k][(size_t)b * h.cb[k] + (size_t)cc_ * h.cc[k] + (size_t)y * h.cy[k] + (size_t)x * h.cx[k]];
+        }
+        if (h.dense) h.dense[((size_t)b * CH + ch) * HW + cell] = v;
+        float r;
+        if (ch < 2) r = (v + (float)(ch == 0 ? cell % h.Wc : cell / h.Wc)) * h.stride;
+        else if (ch < 4) r = expf(v) * h.stride;
+        else r = 1.0f / (1.0f + expf(-v));
+        out[i] = r;
+    }
+}
 }  // namespace
 }  // namespace dagr
 
 using namespace dagr;
+
+extern "C" int dagr_heads_finish(const dagr_head_scale *scale0, const dagr_head_scale *scale1, int32_t batch_size,
+                                 int32_t channels, float *out, int32_t *status, void *stream) {
+    DAGR_CHECK_ARG(scale0 && out && status && batch_size > 0 && channels >= 5, "bad arguments");
+    HeadScale h[2] = {};
+    const dagr_head_scale *in[2] = {scale0, scale1};
+    int cells = 0;
+    for (int s = 0; s < (scale1 ? 2 : 1); s++) {
+        const dagr_head_scale &d = *in[s];
+        DAGR_CHECK_ARG(d.Hc > 0 && d.Wc > 0 && d.n_max >= 0 && d.ld >= channels && d.vx > 0 && d.vy > 0, "bad head scale");
+        DAGR_CHECK_ARG(d.n_max == 0 || (d.pred && d.pos && d.batch), "NULL head input");
+        h[s].n_ptr = d.n_ptr; h[s].n_max = d.n_max; h[s].pred = d.pred; h[s].ld = d.ld; h[s].pos = d.pos; h[s].batch = d.batch;
+        h[s].vx = d.vx; h[s].vy = d.vy; h[s].stride = d.stride; h[s].Hc = d.Hc; h[s].Wc = d.Wc; h[s].dense = d.dense;
+        for (int k = 0; k < 3; k++) {
+            h[s].cnn[k] = d.cnn[k];
+            h[s].cb[k] = d.cnn_stride[k][0]; h[s].cc[k] = d.cnn_stride[k][1];
+            h[s].cy[k] = d.cnn_stride[k][2]; h[s].cx[k] = d.cnn_stride[k][3];
+        }
+        cells += d.Hc * d.Wc;
+    }
+    const size_t lds = (size_t)batch_size * cells * 4;
+    DAGR_CHECK_ARG(lds <= 64 * 1024, "head maps too large for the one-workgroup finish kernel");
+    k_heads_finish<<<1, 1024, lds, (hipStream_t)stream>>>(h[0], h[1], scale1 ? 2 : 1, batch_size, channels, out, status);
+    DAGR_CHECK_LAUNCH();
+    return DAGR_OK;
+}
 
 extern "C" int dagr_nms_batched(const float *boxes, const float *scores, const int32_t *cls, const uint8_t *valid,
                                 int32_t B, int32_t A, float iou_threshold, float class_offset, int32_t *order_out,

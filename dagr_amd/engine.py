@@ -434,7 +434,6 @@ class WindowEngine:
                 stem=torch.zeros((T, self.n_reg), dtype=torch.float32, device=dev),
                 cr=torch.zeros((T, 2 * self.n_reg), dtype=torch.float32, device=dev),
                 pred=torch.zeros((T, 5 + self.num_classes), dtype=torch.float32, device=dev),
-                winner=torch.full((self.B * Hc * Wc,), -1, dtype=torch.int32, device=dev),   # armed: dagr_to_dense_armed
                 dense=torch.zeros((self.B, 5 + self.num_classes, Hc, Wc), dtype=torch.float32, device=dev)))
         self.status = torch.zeros((4,), dtype=torch.int32, device=dev)
         self.fused_passes_max_nodes = int(os.environ.get("DAGR_FUSED_PASSES_MAX_NODES", "1600"))
@@ -576,7 +575,7 @@ class WindowEngine:
                                                     P(self.deg), x, ldx, xskip, ldskip, P(w), P(s), 1, out, ldo, None,
                                                     _lib.cur_stream(self.device)), "conv_l0_tiles_rows")
 
-    def forward_append(self, pos, feat, batch):
+    def forward_append(self, pos, feat, batch, static_out=False):
         """``reset=False``: the n events of a micro-batch attach to the resident window (EV_TGN.forward, ev_tgn.py:45-56).
         Edges point from older to newer events, so the window's level-0 rows stand; the update
           1. links the events into their pixels' chains and searches their in-edges (dagr_async_graph_append),
@@ -620,8 +619,8 @@ class WindowEngine:
             self._n_rows = first + n
         self._pool1_stream(rebuild=False, first=first, n=n)
         if self.tail_graph and not self.use_image:
-            return self._replay_tail()
-        return self._decode(self._tail_and_head())
+            return self._replay_tail(static_out)
+        return self._tail_and_head()
 
     # ------------------------------------------------------------------------------- kernels
     def _conv_generic(self, lvl, pack, x, ldx, xskip, ldskip, out, ldo, dom, stream, code=None, scratch=None):
@@ -885,7 +884,9 @@ class WindowEngine:
                 self._stage_pool(k)
 
     def _stage_head_scale(self, i, scratch=None):
-        """GNNHead.process_feature of scale i + to_dense (dagr.py:179-190; spline_conv.py:80-118)."""
+        """GNNHead.process_feature of scale i (dagr.py:179-190): stem, cls_conv | reg_conv (one launch, shared input),
+        then reg_pred | obj_pred on the reg half and cls_pred on the cls half of that row as the two jobs of ONE paired
+        launch (dagr_spline_conv_fused_pair) -> the scale's predictor rows."""
         L, P = self.L, _lib.ptr
         stream = _lib.cur_stream(self.device)
         lvln = self.head_levels[i]
@@ -907,26 +908,60 @@ class WindowEngine:
         pred = hb["pred"]
         npred = pred.shape[1]
         # pred columns: [reg(4) | obj(1) | cls(num_classes)] = order of collect_outputs (dagr.py:300-302)
-        self._conv_generic(lvl, ro, ctypes.c_void_p(hb["cr"].data_ptr() + 4 * nr), 2 * nr, None, 0, P(pred), npred,
-                           dom, stream, code, scratch)
-        self._conv_generic(lvl, cls, P(hb["cr"]), 2 * nr, None, 0, ctypes.c_void_p(pred.data_ptr() + 4 * 5), npred,
-                           dom, stream, code, scratch)
-        Hc, Wc = self.out_sizes[i]
-        vox = self.head_vox[i]
-        _lib.check(L.dagr_to_dense_armed(P(lvl.counts), lvl.T, P(pred), npred, npred, P(lvl.pos), P(lvl.batch),
-                                   float(vox[0]), float(vox[1]), self.B, Hc, Wc, P(hb["winner"]), P(hb["dense"]),
-                                   P(self.status), stream), "to_dense")
-        return hb["dense"]
+        x_reg, x_cls = ctypes.c_void_p(hb["cr"].data_ptr() + 4 * nr), P(hb["cr"])
+        o_reg, o_cls = P(pred), ctypes.c_void_p(pred.data_ptr() + 4 * 5)
+        if self.fuse_convs and L.dagr_spline_conv_fused_passes(ro.cin, 0) >= 1 and \
+                (L.dagr_spline_conv_fused_passes(ro.cin, 0) == 1 or lvl.T <= self.fused_passes_max_nodes):
+            kcode = lvl.code if code is None else code
+            _lib.check(L.dagr_spline_conv_fused_pair(P(lvl.counts), lvl.T, P(lvl.rowptr), P(lvl.col), P(kcode), 2 * nr, ro.cin,
+                                                     dom["rx"], dom["ry"], dom["den_x"], dom["den_y"], npred, 0, x_reg,
+                                                     P(ro.Wq), P(ro.bias), o_reg, ro.N, x_cls, P(cls.Wq), P(cls.bias), o_cls,
+                                                     cls.N, stream), "spline_conv_fused_pair")
+        else:
+            self._conv_generic(lvl, ro, x_reg, 2 * nr, None, 0, o_reg, npred, dom, stream, code, scratch)
+            self._conv_generic(lvl, cls, x_cls, 2 * nr, None, 0, o_cls, npred, dom, stream, code, scratch)
+        return pred
+
+    def _heads_finish(self):
+        """to_dense of every scale (spline_conv.py:80-107) + the CNN head's logits (dagr.py:219-222,230-234) +
+        collect_outputs / decode_outputs (dagr.py:283-312): one launch (dagr_heads_finish).  The fused logit maps land in
+        ``head_buf[i]["dense"]`` as a by-product (traces, tests)."""
+        P = _lib.ptr
+        scales = []
+        for i, lvln in enumerate(self.head_levels):
+            lvl, hb = self.levels[lvln - 1], self.head_buf[i]
+            Hc, Wc = self.out_sizes[i]
+            vox = self.head_vox[i]
+            hs = _lib.HeadScale(n_ptr=lvl.counts.data_ptr(), n_max=lvl.T, pred=hb["pred"].data_ptr(), ld=hb["pred"].shape[1],
+                                pos=lvl.pos.data_ptr(), batch=lvl.batch.data_ptr(), vx=float(vox[0]), vy=float(vox[1]),
+                                stride=float(self.strides[i]), Hc=int(Hc), Wc=int(Wc), dense=hb["dense"].data_ptr())
+            if self._cnn_out is not None:
+                for k, name in enumerate(("reg_output", "obj_output", "cls_output")):
+                    t = self._cnn_out[name][i]
+                    hs.cnn[k] = t.data_ptr()
+                    for j in range(4):
+                        hs.cnn_stride[k][j] = int(t.stride(j))
+            scales.append(hs)
+        A = sum(int(h) * int(w) for h, w in self.out_sizes)
+        CH = 5 + self.num_classes
+        out = torch.empty((self.B, A, CH), dtype=torch.float32, device=self.device)
+        _lib.check(self.L.dagr_heads_finish(ctypes.byref(scales[0]), ctypes.byref(scales[1]) if len(scales) > 1 else None,
+                                            self.B, CH, P(out), P(self.status), _lib.cur_stream(self.device)), "heads_finish")
+        self._fused_dense = [hb["dense"] for hb in self.head_buf]
+        return out
 
     def stage_head(self):
-        """GNNHead.process_feature per scale + to_dense (dagr.py:179-236)."""
-        return [self._stage_head_scale(i) for i in range(len(self.head_levels))]
+        """GNNHead.process_feature per scale, then to_dense + fusion + decode in one launch (dagr.py:179-236,283-312)."""
+        for i in range(len(self.head_levels)):
+            self._stage_head_scale(i)
+        return self._heads_finish()
 
     def _tail_and_head(self, trace=None):
         """Levels 1..4 and both head scales with the dependency structure the graph has: head scale 1 only needs level 3
-        (out3), so it runs on a side stream next to pool4 -> layer5 -> head scale 2 (net.py:166-186, dagr.py:213-236)."""
+        (out3), so it runs on a side stream next to pool4 -> layer5 -> head scale 2 (net.py:166-186, dagr.py:213-236);
+        then to_dense + image-logit fusion + decode of both scales in one launch.  Returns the decoded outputs."""
         first = self.head_levels[0]                  # 3 when both scales exist, 4 with num_scales = 1
-        outs = [None] * len(self.head_levels)
+        done = [False] * len(self.head_levels)
         cur = torch.cuda.current_stream(self.device)
         forked = False
         for k in range(4):
@@ -938,26 +973,29 @@ class WindowEngine:
                 ev.record(cur)
                 self._head_stream.wait_event(ev)
                 with torch.cuda.stream(self._head_stream):
-                    outs[0] = self._stage_head_scale(0, scratch=self.A2)
+                    self._stage_head_scale(0, scratch=self.A2)
+                    done[0] = True
                     self._head_join = torch.cuda.Event()
                     self._head_join.record(self._head_stream)
                 forked = True
             if k < 3:
                 self._stage_pool(k)
         for i in range(len(self.head_levels)):
-            if outs[i] is None:
-                outs[i] = self._stage_head_scale(i)
+            if not done[i]:
+                self._stage_head_scale(i)
         if forked:
             cur.wait_event(self._head_join)
-        return outs
+        return self._heads_finish()
 
-    def forward_raw(self, pos, feat, batch, image=None, trace=None, image_handle=None):
+    def forward_raw(self, pos, feat, batch, image=None, trace=None, image_handle=None, static_out=False):
         """pos fp32[N,3] normalised (format_data), feat fp32[N,1], batch int32/int64[N] on the device;
         image fp32[B,3,H,W] in [0,1] when the model was built with --use_image.
-        Returns decoded head outputs [B, n_anchors, 5+num_classes] (GNNHead.forward eval)."""
+        Returns decoded head outputs [B, n_anchors, 5+num_classes] (GNNHead.forward eval).
+        ``static_out``: the caller consumes the outputs before the engine's next window (``DAGR.forward`` post-processes
+        them at once), so a captured window may hand out its own output buffer instead of a copy."""
         if trace is None and image_handle is None and self.window_graph and self.l0_tiles and not self.no_events \
                 and (image is not None or not self.use_image):
-            return self._forward_window_graph(pos, feat, batch, image)
+            return self._forward_window_graph(pos, feat, batch, image, static_out)
         self._cnn_out = None
         if self.use_image:
             if image_handle is not None:
@@ -987,10 +1025,10 @@ class WindowEngine:
         self.stage_pool1()
         if trace is None and self.tail_graph and not self.use_image:
             return self._replay_tail()
-        outs = self._tail_and_head(trace)
+        out = self._tail_and_head(trace)
         if trace is not None:
-            trace["head_dense"] = [o.clone() for o in outs]
-        return self._decode(outs)
+            trace["head_dense"] = [o.clone() for o in self._fused_dense]
+        return out
 
     def _forward_static(self):
         """One window on the engine's static input buffers with every launch sized for the event capacity and bounded by
@@ -1005,11 +1043,11 @@ class WindowEngine:
             self.stage_l0_conv1()
             self.stage_l0_conv2()
             self.stage_pool1()
-            return self._decode(self._tail_and_head())
+            return self._tail_and_head()
         finally:
             self._dev_mode = False
 
-    def _forward_window_graph(self, pos, feat, batch, image):
+    def _forward_window_graph(self, pos, feat, batch, image, static_out=False):
         """Latency mode: the caller's window is staged into the static buffers by ONE launch (which also writes the event
         count to device memory); everything else -- image branch, graph build, level 0, pooled levels, heads, decode: ~45
         launches events-only, several hundred with the ResNet-50 branch -- is one replayed HIP graph.  Until round 4 only the
@@ -1021,9 +1059,10 @@ class WindowEngine:
         pos = pos.float().contiguous()
         feat = feat.float().reshape(-1).contiguous()
         batch = batch.contiguous()
-        _lib.check(L.dagr_stage_window(P(pos), P(feat), P(batch), 1 if batch.dtype == torch.int64 else 0, N, P(self.in_pos),
-                                       P(self.in_feat), P(self.in_batch), P(self.n_dev), _lib.cur_stream(self.device)),
-                   "stage_window")
+        g = self.graph
+        _lib.check(L.dagr_stage_window(ctypes.byref(g.desc), P(g.workspace), P(pos), P(feat), P(batch),
+                                       1 if batch.dtype == torch.int64 else 0, N, P(self.in_pos), P(self.in_feat),
+                                       P(self.in_batch), P(self.n_dev), _lib.cur_stream(self.device)), "stage_window")
         if self.use_image:
             if self.in_image is None or self.in_image.shape != image.shape:
                 self.in_image = torch.empty(tuple(image.shape), dtype=torch.float32, device=self.device)
@@ -1050,9 +1089,9 @@ class WindowEngine:
         self._pos, self._batch = self.in_pos[:N], self.in_batch[:N]
         self._nbr = (self.nbr_src[:N], self.nbr_code[:N], self.deg[:N])
         self._x0 = self.x0buf[:N]
-        return out.clone()   # the graph's output buffer is rewritten by the next window
+        return out if static_out else out.clone()   # the graph's output buffer is rewritten by the next window
 
-    def _replay_tail(self):
+    def _replay_tail(self, static_out=False):
         """Everything after pool1 has launch shapes that do not depend on the window (node / edge counts stay on the
         device): ~70 small dependent launches, captured once as a HIP graph and replayed -- the host then issues ONE
         launch for them, which is what bounds single-window latency at small N.  (Events-only: with --use_image the tail
@@ -1060,24 +1099,13 @@ class WindowEngine:
         if self._graph is None:
             if self._graph_warm < 2:                 # lazy one-time work (function attributes, allocator) stays eager
                 self._graph_warm += 1
-                return self._decode(self._tail_and_head())
+                return self._tail_and_head()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                out = self._decode(self._tail_and_head())
+                out = self._tail_and_head()
             self._graph, self._graph_out = g, out
         self._graph.replay()
-        return self._graph_out.clone()   # the graph's output buffer is rewritten by the next window
-
-    def _decode(self, dense_maps):
-        """collect_outputs + decode_outputs (dagr.py:283-312) on the tiny dense maps (torch ops)."""
-        if self._cnn_out is not None:   # dagr.py:219-222,230-234: CNN-head logits are added to the GNN maps
-            fused = []
-            for k, o in enumerate(dense_maps):
-                c = self._cnn_out
-                fused.append(o + torch.cat([c["reg_output"][k], c["obj_output"][k], c["cls_output"][k]], 1))
-            dense_maps = fused
-            self._fused_dense = fused
-        return self._decode_maps(dense_maps)
+        return self._graph_out if static_out else self._graph_out.clone()   # rewritten by the next window
 
     def _decode_maps(self, dense_maps):
         """collect_outputs + decode_outputs (dagr.py:283-312) in one launch (dagr_decode_heads)."""
@@ -1148,10 +1176,11 @@ class WindowEngine:
                 if v != want:
                     raise RuntimeError(f"data.{name} = {v}, but the model was built for {want}")
 
-    def forward_data(self, data):
+    def forward_data(self, data, static_out=False):
         """``DAGR.forward`` input contract: ``data`` after ``format_data`` (pos fp32[N,3] normalised,
         x fp32[N,1], batch)."""
         batch = data.batch if getattr(data, "batch", None) is not None else \
             torch.zeros(data.pos.shape[0], dtype=torch.int64, device=data.pos.device)
         self.check_batch(data)
-        return self.forward_raw(data.pos.float(), data.x.float(), batch, image=getattr(data, "image", None))
+        return self.forward_raw(data.pos.float(), data.x.float(), batch, image=getattr(data, "image", None),
+                                static_out=static_out)

@@ -280,7 +280,7 @@ class DAGR(torch.nn.Module):
             self._window = None                  # a new window: the running one is gone
         if reset or self._window is None:
             # a window of its own (every evaluation script's call), or the first call of an asynchronous run
-            outputs = eng.forward_data(x)
+            outputs = eng.forward_data(x, static_out=filtering)      # post-processed below, before the next window
             # only remembered: a later reset=False call continues from it.  A running window keeps the FRAME of the call
             # that opened it (DSEC: the image at the start of the window, dsec_data.py:141-184); later micro-batches
             # bring events only, in the incremental and in the re-evaluating mode alike.
@@ -293,7 +293,7 @@ class DAGR(torch.nn.Module):
             # far -- the guarantee the reference's asynchronous model gives for its update (evaluate_flops.py:139-147).
             batch = x.batch if getattr(x, "batch", None) is not None else \
                 torch.zeros(x.pos.shape[0], dtype=torch.int64, device=x.pos.device)
-            outputs = eng.forward_append(x.pos, x.x, batch)
+            outputs = eng.forward_append(x.pos, x.x, batch, static_out=filtering)
             self._window.append(_window_part(x))
             if len(self._window) > 64:           # bounded bookkeeping on long streams: one concatenated part
                 _concat_window(self._window)

@@ -134,9 +134,11 @@ int dagr_graph_build_window_dev(const dagr_graph_desc *desc, void *workspace, co
  * that follow it in a captured window */
 const int32_t *dagr_graph_node_count_ptr(const dagr_graph_desc *desc, void *workspace);
 /* One launch that copies a caller's window (format_data output: pos fp32[N,3], feat fp32[N], batch int32/int64[N]) into
- * static buffers (batch as int32) and writes N to *n_dev: the only per-window launch in front of a captured window graph. */
-int dagr_stage_window(const float *pos, const float *feat, const void *batch, int32_t batch_is_int64, int64_t N,
-                      float *pos_out, float *feat_out, int32_t *batch_out, int32_t *n_dev, void *stream);
+ * static buffers (batch as int32), writes N to *n_dev and clears the builder's status words: the only per-window launch in
+ * front of a captured window graph (dagr_graph_build_window_dev relies on it for the status words). */
+int dagr_stage_window(const dagr_graph_desc *desc, void *workspace, const float *pos, const float *feat, const void *batch,
+                      int32_t batch_is_int64, int64_t N, float *pos_out, float *feat_out, int32_t *batch_out,
+                      int32_t *n_dev, void *stream);
 
 /* The neighbour search alone, again, on the pixel index the last dagr_graph_build_window left in `workspace` (same N):
  * rewrites nbr_src / nbr_code / deg and the edge count.  For measurement (bench.py times the search kernels on their own
@@ -259,6 +261,15 @@ int dagr_spline_conv_fused(const int32_t *n_nodes_ptr, int32_t n_nodes_max, cons
                            const float *xskip, int32_t ldskip, int32_t cskip, int32_t rx, int32_t ry,
                            float den_x, float den_y, const float *Wq, const float *bias, float *C, int32_t ldc,
                            int32_t N, int32_t relu, void *stream);
+/* Two fused convs over the SAME graph in one launch (gridDim.z = 2): same row shape (cin channels, no skip input, row
+ * stride ldx), each with its own input pointer, packed weights, bias, output pointer (row stride ldc) and width.  The
+ * detection head's predictors: cls_pred on the cls_conv half of the fused row and reg_pred | obj_pred on the reg_conv half
+ * (model/networks/dagr.py:183-189) -- on <= 1 260-row levels a launch is what a conv costs. */
+int dagr_spline_conv_fused_pair(const int32_t *n_nodes_ptr, int32_t n_nodes_max, const int32_t *rowptr,
+                                const int32_t *col, const int32_t *code, int32_t ldx, int32_t cin, int32_t rx, int32_t ry,
+                                float den_x, float den_y, int32_t ldc, int32_t relu, const float *x_a, const float *Wq_a,
+                                const float *bias_a, float *C_a, int32_t N_a, const float *x_b, const float *Wq_b,
+                                const float *bias_b, float *C_b, int32_t N_b, void *stream);
 /* generic step 2: C[M,N] = act(A[M,K] . Wm[K,N] + bias[N]); M = min(*m_ptr, m_max) */
 int dagr_gemm_bias_act(const int32_t *m_ptr, int32_t m_max, const float *A, int32_t lda,
                        const float *Wm, int32_t ldw, const float *bias, float *C, int32_t ldc,
@@ -373,11 +384,6 @@ int dagr_pool_counters(const dagr_pool_desc *desc, void *pool_ws, int32_t *out8_
 int dagr_to_dense(const int32_t *n_ptr, int32_t n_max, const float *x, int32_t ldx, int32_t channels,
                   const float *pos, const int32_t *batch, float vx, float vy, int32_t batch_size,
                   int32_t Hc, int32_t Wc, int32_t *winner_scratch, float *dense, int32_t *status, void *stream);
-/* same result, two launches instead of three: winner_armed must hold -1 in every entry on entry (fill it once after
- * allocation) and holds -1 again on return -- for callers that keep the scratch between windows (the engine). */
-int dagr_to_dense_armed(const int32_t *n_ptr, int32_t n_max, const float *x, int32_t ldx, int32_t channels,
-                        const float *pos, const int32_t *batch, float vx, float vy, int32_t batch_size,
-                        int32_t Hc, int32_t Wc, int32_t *winner_armed, float *dense, int32_t *status, void *stream);
 
 /* ------------------------------------------------------------------------ *
  * training path (scripts/train_ncaltech101.py:41-74): backward halves the reference gets from
@@ -436,6 +442,22 @@ int dagr_nms_batched(const float *boxes, const float *scores, const int32_t *cls
                      int32_t B, int32_t A, float iou_threshold, float class_offset,
                      int32_t *order_out, int32_t *keep_out, int32_t *n_keep, void *stream);
 
+/* to_dense of the head scales (model/layers/spline_conv.py:80-107: cell = trunc(pos_xy / voxel_xy), highest node index
+ * wins a shared cell) + the image branch's logits (model/networks/dagr.py:219-222,230-234) + collect_outputs /
+ * decode_outputs (dagr.py:283-312) in ONE launch.  Per scale: the predictor rows pred[n, ld] (reg 4 | obj 1 | cls C),
+ * node positions / samples, the map geometry, optionally the CNN head's reg / obj / cls maps (element strides for
+ * [b, c, y, x]; NULL = events only) and optionally a dense[B, 5 + C, Hc, Wc] buffer that receives the fused logit maps.
+ * out[B, A, 5 + C] as dagr_decode_heads.  scale1 may be NULL (num_scales = 1).  status bit0: node outside the map. */
+typedef struct dagr_head_scale {
+    const int32_t *n_ptr; int32_t n_max;
+    const float *pred; int32_t ld;
+    const float *pos; const int32_t *batch;
+    float vx, vy, stride; int32_t Hc, Wc;
+    const float *cnn[3]; int32_t cnn_stride[3][4];
+    float *dense;
+} dagr_head_scale;
+int dagr_heads_finish(const dagr_head_scale *scale0, const dagr_head_scale *scale1, int32_t batch_size, int32_t channels,
+                      float *out, int32_t *status, void *stream);
 /* collect_outputs + decode_outputs of the eval head (model/networks/dagr.py:283-312; grid/stride cache of
  * model/utils.py:119-134) for one or two scales in one launch: dense logit maps [B, channels = 5+C, Hs, Ws] (reg | obj |
  * cls) -> out[B, A, channels], A = H0*W0 (+ H1*W1), xy = (logit + cell) * stride, wh = exp(logit) * stride, the rest

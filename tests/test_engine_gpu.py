@@ -564,9 +564,9 @@ def test_window_graph_replay_matches_eager_launches():
 
 def test_window_graph_with_the_image_branch():
     """--use_image: the dense branch (ResNet + CNN head on PyTorch-ROCm) sits inside the captured window too, on a static
-    frame buffer.  Replayed windows are bit-identical from replay to replay (different frames and window sizes through the
-    same graph) and equal the launch-by-launch path to the library convolutions' rounding (MIOpen may pick another
-    solver between its first and later calls)."""
+    frame buffer.  Replayed windows (different frames and window sizes through the same graph) equal the launch-by-launch
+    path to the library kernels' rounding: MIOpen may pick another solver between its first and later calls, and the
+    library GEMMs behind the 1x1 convolutions may split K with atomics (low bits differ from run to run, eager or not)."""
     W, H, B = 320, 215, 2
     args, model, sd = _setup(W, H, B, seed=13, use_image=True, img_net="resnet18")
     eng = model.engine().set_low_latency(True)
@@ -578,10 +578,9 @@ def test_window_graph_with_the_image_branch():
     assert eng._wg is not None
     eng.check_status()
     for k in range(2):
-        assert _decoded_err(eng, runs[-1][k], eager[k].cpu()) < 1e-4, k
-        for rep in (3, 4):          # replays of the captured graph
-            assert torch.equal(runs[rep][k], runs[2][k]), (rep, k)
-    assert not torch.equal(runs[-1][0], runs[-1][1])
+        for rep in range(5):
+            assert _decoded_err(eng, runs[rep][k], eager[k].cpu()) < 1e-4, (rep, k)
+    assert _decoded_err(eng, runs[-1][0], runs[-1][1].cpu()) > 1e-3      # the two windows are different windows
 
 
 def test_tail_graph_replay_matches_eager_launches():
