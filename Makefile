@@ -12,7 +12,7 @@ all: $(LIB) oracle
 
 $(LIB): $(OBJ)
 	@mkdir -p dagr_amd/lib
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJ) -L/opt/rocm/lib -lhipblaslt
 
 build/%.o: dagr_amd/csrc/%.hip dagr_amd/csrc/common.hpp include/dagr_hip.h
 	@mkdir -p build

@@ -152,6 +152,9 @@ SIGNATURES = {
     "dagr_spline_conv_fused_pair": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32,
                                                    c_float, c_float, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_void_p,
                                                    c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_void_p]),
+    "dagr_gemm_epilogue_workspace_bytes": (c_size_t, []),
+    "dagr_gemm_epilogue": (ctypes.c_int, [c_void_p, c_i64, c_i32, c_i64, c_void_p, c_i32, c_void_p, c_void_p, c_i64, c_i32,
+                                          c_void_p, c_i64, c_void_p, c_size_t, c_void_p]),
     "dagr_add_relu": (ctypes.c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
     "dagr_bias_relu": (ctypes.c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p]),
     "dagr_bias_silu": (ctypes.c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p]),

@@ -120,13 +120,42 @@ class _Conv1x1Gemm(torch.nn.Module):
         self.register_buffer("wt", conv.weight.detach().reshape(cout, cin).t().contiguous())
         self.register_buffer("b", conv.bias.detach().clone() if conv.bias is not None else torch.zeros(cout, device=conv.weight.device))
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """``residual`` (a channels-last map of the output's shape): relu(conv(x) + bias + residual) in ONE library GEMM
+        (dagr_gemm_epilogue: hipBLASLt with beta = 1 on the residual, bias and ReLU in the epilogue) -- the join of a
+        bottleneck (net_img.py:47-48) without a pass of its own."""
         if self.stride != 1:
             x = x[:, :, ::self.stride, ::self.stride]
         B, C, H, W = x.shape
         a = x.permute(0, 2, 3, 1).reshape(-1, C)
+        if residual is not None:
+            N = self.wt.shape[1]
+            r = residual.permute(0, 2, 3, 1)
+            if _LT["ok"] and a.is_cuda and a.dtype == torch.float32 and r.is_contiguous() and a.stride(1) == 1 \
+                    and tuple(r.shape) == (B, H, W, N):
+                y = torch.empty((a.shape[0], N), dtype=torch.float32, device=a.device)
+                ws = _lt_workspace(a.device)
+                rc = _lib.lib().dagr_gemm_epilogue(_lib.ptr(a), a.shape[0], C, a.stride(0), _lib.ptr(self.wt), N,
+                                                   _lib.ptr(self.b), _lib.ptr(r), N, 1, _lib.ptr(y), N, _lib.ptr(ws),
+                                                   ws.numel(), _lib.cur_stream(a.device))
+                if rc == 0:
+                    return y.view(B, H, W, -1).permute(0, 3, 1, 2)
+                _LT["ok"] = False      # the library has no kernel for this epilogue here: two passes from now on
+            y = torch.addmm(self.b, a, self.wt).view(B, H, W, -1).permute(0, 3, 1, 2)
+            return _add_relu_(y, residual)
         y = torch._addmm_activation(self.b, a, self.wt) if self.relu else torch.addmm(self.b, a, self.wt)
         return y.view(B, H, W, -1).permute(0, 3, 1, 2)
+
+
+_LT = {"ok": os.environ.get("DAGR_LT_RESIDUAL", "1") != "0", "ws": {}}
+
+
+def _lt_workspace(device):
+    """Scratch for the library GEMMs of ``dagr_gemm_epilogue`` (allocated once per device, before any capture)."""
+    key = str(device)
+    if key not in _LT["ws"]:
+        _LT["ws"][key] = torch.empty(int(_lib.lib().dagr_gemm_epilogue_workspace_bytes()), dtype=torch.uint8, device=device)
+    return _LT["ws"][key]
 
 
 def _gemmify_1x1(module):
@@ -191,6 +220,8 @@ def _bottleneck_forward(blk, x):
     identity = x if blk.downsample is None else blk.downsample(x)
     out = _conv_bias_relu(blk, "conv1", x)
     out = _conv_bias_relu(blk, "conv2", out)
+    if isinstance(blk.conv3, _Conv1x1Gemm):
+        return blk.conv3(out, residual=identity)      # relu(conv3 + bias + identity): one GEMM
     return _add_relu_(blk.conv3(out), identity)
 
 

@@ -507,6 +507,16 @@ int dagr_downsample_events(const int32_t *order, const int32_t *run_cell, const 
                            const int8_t *polarity, int32_t fx, int32_t fy, float *change_map, uint8_t *keep,
                            void *stream);
 
+/* The 1x1 convolutions of the channels-last image branch (src/dagr/model/networks/net_img.py:42-48, BatchNorm folded) as
+ * library GEMMs (hipBLASLt, fp32 in / fp32 accumulate) with the whole epilogue in the kernel:
+ *   D[M, N] = act(A[M, K] . Wt[K, N] + bias[N] (+ R[M, N])),  row-major, row strides lda / ldr / ldd; act 0 = none, 1 = ReLU;
+ * bias and R may be NULL.  The residual join + ReLU of a bottleneck (relu(bn3(conv3(x)) + identity)) is one launch.
+ * workspace: device scratch of at least dagr_gemm_epilogue_workspace_bytes() bytes (caller-owned, no hidden allocation). */
+size_t dagr_gemm_epilogue_workspace_bytes(void);
+int dagr_gemm_epilogue(const float *A, int64_t M, int32_t K, int64_t lda, const float *Wt, int32_t N, const float *bias,
+                       const float *R, int64_t ldr, int32_t act, float *D, int64_t ldd, void *workspace,
+                       size_t workspace_bytes, void *stream);
+
 /* Host-side helper: first n offsets of the search spiral (spiral.h:1-15), the closed form the
  * search kernel uses.  dx/dy are HOST arrays.  Lets CPU-only tests pin the visiting order. */
 int dagr_spiral_offsets(int32_t n, int32_t *dx_host, int32_t *dy_host);
