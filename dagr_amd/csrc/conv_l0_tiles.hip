@@ -27,6 +27,7 @@ namespace dagr {
 namespace {
 
 using f32x4_t = __attribute__((ext_vector_type(4))) float;
+using f32x2_t = __attribute__((ext_vector_type(2))) float;
 
 template <int CM, int CE, int CS, int TX, int TY>
 struct L0Steps {
@@ -61,8 +62,8 @@ struct L0Steps {
 
 constexpr int kTileWaves = 4;   // waves per workgroup (each owns its tiles; they share the weight image in LDS)
 
-template <int CM, int CE, int CS, int TX, int TY>
-__global__ __launch_bounds__(kTileWaves * 64, 2) void k_conv_l0_tiles(
+template <int CM, int CE, int CS, int TX, int TY, bool LEAN>
+__global__ __launch_bounds__(kTileWaves * 64, LEAN ? 3 : 2) void k_conv_l0_tiles(
     int n_first, int N, const int32_t *__restrict__ n_ptr, int rx, int ry, float den_x, float den_y, int win_x, int win_y, const int32_t *__restrict__ nbr_src,
     const int16_t *__restrict__ nbr_code, const int32_t *__restrict__ deg, const float *__restrict__ x, int ldx,
     const float *__restrict__ xskip, int ldskip, const float *__restrict__ wpack, const float *__restrict__ shift,
@@ -129,8 +130,12 @@ __global__ __launch_bounds__(kTileWaves * 64, 2) void k_conv_l0_tiles(
     int d_nx;
     int4 s_nx[4];
     int2 c_nx[4];
-    if (n_begin + 16 * wv < n_end) load_meta(n_begin + 16 * wv, d_nx, s_nx, c_nx);
+    // LEAN: three waves per SIMD instead of two (<= 170 registers): the next tile's neighbour row is not held across the tile
+    // and the source rows come in two batches of 8 through the same registers -- the waits are hidden by the third wave
+    // instead of being shortened
+    if (!LEAN && n_begin + 16 * wv < n_end) load_meta(n_begin + 16 * wv, d_nx, s_nx, c_nx);
     for (int n0 = n_begin + 16 * wv; n0 < n_end; n0 += stride) {
+        if (LEAN) load_meta(n0, d_nx, s_nx, c_nx);
         const int n = n0 + c;
         const bool valid = n < n_end;
         const int nn = valid ? n : n0;                  // a row that exists, for the predicated-off lanes
@@ -146,20 +151,20 @@ __global__ __launch_bounds__(kTileWaves * 64, 2) void k_conv_l0_tiles(
 #pragma unroll
         for (int off = 1; off < 16; off <<= 1) dmax = max(dmax, __shfl_xor(dmax, off, 16));
         // source rows: first batch of 8, and the second one when any node of the tile has more than 8 in-edges
-        float4 xv[16];
-        float xe[16];
+        float4 xv[LEAN ? 8 : 16];
+        float xe[LEAN ? 8 : 16];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int src = (u < d) ? srcs[u] : nn;
             if (CM) xv[u] = *reinterpret_cast<const float4 *>(x + (size_t)src * ldx + 4 * q);
             if (CE) xe[u] = (q < CE) ? x[(size_t)src * ldx + CM + q] : 0.f;
         }
-        if (dmax > 8) {
+        if (!LEAN && dmax > 8) {
 #pragma unroll
             for (int u = 8; u < 16; u++) {
                 const int src = (u < d) ? srcs[u] : nn;
-                if (CM) xv[u] = *reinterpret_cast<const float4 *>(x + (size_t)src * ldx + 4 * q);
-                if (CE) xe[u] = (q < CE) ? x[(size_t)src * ldx + CM + q] : 0.f;
+                if (CM) xv[u % (LEAN ? 8 : 16)] = *reinterpret_cast<const float4 *>(x + (size_t)src * ldx + 4 * q);
+                if (CE) xe[u % (LEAN ? 8 : 16)] = (q < CE) ? x[(size_t)src * ldx + CM + q] : 0.f;
             }
         }
         // root / skip operands of phase 2 and the next tile's neighbour row: requested now, consumed later
@@ -169,12 +174,15 @@ __global__ __launch_bounds__(kTileWaves * 64, 2) void k_conv_l0_tiles(
         if (CE) xre = (q < CE) ? x[(size_t)nn * ldx + CM + q] : 0.f;
         if (S::SKF) xs = *reinterpret_cast<const float4 *>(xskip + (size_t)nn * ldskip + 4 * q);
         if (S::SKE) xse = (q < S::SKE) ? xskip[(size_t)nn * ldskip + 16 * S::SKF + q] : 0.f;
-        load_meta(n0 + stride, d_nx, s_nx, c_nx);
+        if (!LEAN) load_meta(n0 + stride, d_nx, s_nx, c_nx);
 
-        float acc[CM ? NT : 1][4];
+        // A[tap][4 channels] as two packed pairs: the 60 FMAs of an edge issue as 30 v_pk_fma_f32 (two fp32 FMAs per lane
+        // and instruction -- the rate the 157 TFLOP/s fp32 peak is quoted for; scalar v_fma_f32 tops out at half of it).
+        // Same fused multiply-adds, same order per accumulator: bit-identical results.
+        f32x2_t acc[CM ? NT : 1][2];
         float acce[CE ? NT : 1];
 #pragma unroll
-        for (int t = 0; t < (CM ? NT : 1); t++) acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0.f;
+        for (int t = 0; t < (CM ? NT : 1); t++) { acc[t][0] = f32x2_t{0.f, 0.f}; acc[t][1] = f32x2_t{0.f, 0.f}; }
 #pragma unroll
         for (int t = 0; t < (CE ? NT : 1); t++) acce[t] = 0.f;
 
@@ -198,13 +206,13 @@ __global__ __launch_bounds__(kTileWaves * 64, 2) void k_conv_l0_tiles(
                 for (int a = 0; a < TX; a++) {
                     const float w = wx[a] * wy[b];            // == the level-0 offset table entry (bx[a]*by[b])
                     const int t = a + TX * b;
+                    constexpr int NX = LEAN ? 8 : 16;
                     if (CM) {
-                        acc[t][0] = fmaf(w, xv[u].x, acc[t][0]);
-                        acc[t][1] = fmaf(w, xv[u].y, acc[t][1]);
-                        acc[t][2] = fmaf(w, xv[u].z, acc[t][2]);
-                        acc[t][3] = fmaf(w, xv[u].w, acc[t][3]);
+                        const f32x2_t w2 = {w, w};
+                        acc[t][0] = __builtin_elementwise_fma(w2, f32x2_t{xv[u % NX].x, xv[u % NX].y}, acc[t][0]);
+                        acc[t][1] = __builtin_elementwise_fma(w2, f32x2_t{xv[u % NX].z, xv[u % NX].w}, acc[t][1]);
                     }
-                    if (CE) acce[t] = fmaf(w, xe[u], acce[t]);
+                    if (CE) acce[t] = fmaf(w, xe[u % NX], acce[t]);
                 }
             __builtin_amdgcn_sched_barrier(0);   // one edge's weights live at a time (register pressure)
         };
@@ -212,6 +220,14 @@ __global__ __launch_bounds__(kTileWaves * 64, 2) void k_conv_l0_tiles(
         for (int u = 0; u < 8; u++)
             if (u < dmax) edge(u);               // group-uniform
         if (dmax > 8) {
+            if (LEAN) {       // second batch of source rows, through the registers of the first
+#pragma unroll
+                for (int u = 8; u < 16; u++) {
+                    const int src = (u < d) ? srcs[u] : nn;
+                    if (CM) xv[u - 8] = *reinterpret_cast<const float4 *>(x + (size_t)src * ldx + 4 * q);
+                    if (CE) xe[u - 8] = (q < CE) ? x[(size_t)src * ldx + CM + q] : 0.f;
+                }
+            }
 #pragma unroll
             for (int u = 8; u < 16; u++)
                 if (u < dmax) edge(u);
@@ -230,7 +246,7 @@ __global__ __launch_bounds__(kTileWaves * 64, 2) void k_conv_l0_tiles(
         if (CM) {
 #pragma unroll
             for (int t = 0; t < NT; t++) {
-                DAGR_STEP(acc[t][0]); DAGR_STEP(acc[t][1]); DAGR_STEP(acc[t][2]); DAGR_STEP(acc[t][3]);
+                DAGR_STEP(acc[t][0][0]); DAGR_STEP(acc[t][0][1]); DAGR_STEP(acc[t][1][0]); DAGR_STEP(acc[t][1][1]);
             }
         }
         if (CE) {
@@ -255,14 +271,14 @@ __global__ __launch_bounds__(kTileWaves * 64, 2) void k_conv_l0_tiles(
     }
 }
 
-template <int CM, int CE, int CS, int TX, int TY>
-int launch_tiles(int64_t n_first, int64_t N, const int32_t *n_ptr, int rx, int ry, float den_x, float den_y, int win_x, int win_y, const int32_t *nbr_src,
+template <int CM, int CE, int CS, int TX, int TY, bool LEAN>
+int launch_tiles_v(int64_t n_first, int64_t N, const int32_t *n_ptr, int rx, int ry, float den_x, float den_y, int win_x, int win_y, const int32_t *nbr_src,
                  const int16_t *nbr_code, const int32_t *deg, const float *x, int ldx, const float *xskip, int ldskip,
                  const float *wpack, const float *shift, int relu, float *out, int ldo, hipStream_t stream) {
     using S = L0Steps<CM, CE, CS, TX, TY>;
     const size_t lds_bytes = ((size_t)S::N * 64 + (size_t)(2 * rx + 1) * 4 + (size_t)(2 * ry + 1) * 8) * 4;
     DAGR_CHECK_ARG(lds_bytes <= 64 * 1024, "offset domain too large for the axis tables");
-    auto kern = k_conv_l0_tiles<CM, CE, CS, TX, TY>;
+    auto kern = k_conv_l0_tiles<CM, CE, CS, TX, TY, LEAN>;
     {
         static thread_local size_t set_for = 0;
         if (set_for < lds_bytes) {
@@ -277,6 +293,21 @@ int launch_tiles(int64_t n_first, int64_t N, const int32_t *n_ptr, int rx, int r
                                                        x, ldx, xskip, ldskip, wpack, shift, relu, out, ldo);
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;
+}
+
+template <int CM, int CE, int CS, int TX, int TY>
+int launch_tiles(int64_t n_first, int64_t N, const int32_t *n_ptr, int rx, int ry, float den_x, float den_y, int win_x, int win_y,
+                 const int32_t *nbr_src, const int16_t *nbr_code, const int32_t *deg, const float *x, int ldx,
+                 const float *xskip, int ldskip, const float *wpack, const float *shift, int relu, float *out, int ldo,
+                 hipStream_t stream) {
+    // three waves per SIMD (LEAN) wherever the kernel fits 170 registers without scratch: -4 % on the 16 -> 16 + skip and
+    // 3 -> 16 convs (0.179 -> 0.171, 0.090 -> 0.087 ms at 800 k nodes); the 19 -> 16 conv (main block + extras: 220
+    // registers) spills at that budget and is 7 % slower, so it keeps two waves.  PMC (profiles/r3_*_pmc_sq.csv): the SIMDs'
+    // issue slots are ~77 % busy at two waves -- the kernel is bound by instruction issue (packed FMAs already), which is
+    // why a third wave buys so little.
+    constexpr bool kLean = !(CM > 0 && CE > 0);
+    return launch_tiles_v<CM, CE, CS, TX, TY, kLean>(n_first, N, n_ptr, rx, ry, den_x, den_y, win_x, win_y, nbr_src, nbr_code,
+                                                     deg, x, ldx, xskip, ldskip, wpack, shift, relu, out, ldo, stream);
 }
 
 }  // namespace
