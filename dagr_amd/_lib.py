@@ -41,6 +41,24 @@ class HeadScale(ctypes.Structure):
                 ("cnn", c_void_p * 3), ("cnn_stride", (c_i32 * 4) * 3), ("dense", c_void_p)]
 
 
+class AsyncUpdateArgs(ctypes.Structure):
+    """``dagr_async_update_args`` (include/dagr_hip.h)."""
+    _fields_ = [("gdesc", ctypes.POINTER(GraphDesc)), ("graph_ws", c_void_p), ("n_static", c_i64), ("first_id", c_i64),
+                ("app_head", c_void_p), ("app_next", c_void_p), ("app_xytb", c_void_p), ("capacity", c_i64),
+                ("pos", c_void_p), ("batch", c_void_p), ("batch_is_int64", c_i32), ("n_new", c_i64),
+                ("nbr_src", c_void_p), ("nbr_code", c_void_p), ("deg", c_void_p), ("status", c_void_p),
+                ("feat", c_void_p), ("pos_nodes", c_void_p), ("batch_nodes", c_void_p), ("batch_events", c_void_p),
+                ("x0", c_void_p), ("ldx0", c_i32), ("col_feat", c_i32), ("col_pos", c_i32),
+                ("win_x", c_i32), ("tx", c_i32), ("win_y", c_i32), ("ty", c_i32), ("rx", c_i32), ("ry", c_i32),
+                ("den_x", c_float), ("den_y", c_float),
+                ("cin1", c_i32), ("w1", c_void_p), ("s1", c_void_p), ("h1", c_void_p), ("ldh1", c_i32),
+                ("w2", c_void_p), ("s2", c_void_p), ("hp0", c_void_p), ("ldhp0", c_i32),
+                ("pdesc", ctypes.POINTER(PoolDesc)), ("pool_ws", c_void_p), ("xlo", c_void_p), ("ylo", c_void_p),
+                ("x_out", c_void_p), ("ldo", c_i32), ("pos_out", c_void_p), ("batch_out", c_void_p), ("n_out", c_void_p),
+                ("rowptr_out", c_void_p), ("col_out", c_void_p), ("code_out", c_void_p), ("e_out", c_void_p),
+                ("e_cap", c_i32)]
+
+
 # name -> (restype, argtypes); the single source of truth for the symbols we bind.  The CPU-only
 # test-suite checks that every function declared in include/dagr_hip.h appears here and resolves.
 SIGNATURES = {
@@ -140,6 +158,7 @@ SIGNATURES = {
                                                c_void_p, c_i64, c_void_p, c_i32, c_void_p, c_i32, c_i64, c_void_p, c_void_p,
                                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32,
                                                c_i32, c_i32, c_void_p]),
+    "dagr_async_update": (ctypes.c_int, [ctypes.POINTER(AsyncUpdateArgs), c_void_p]),
     "dagr_pool_l0_stream": (ctypes.c_int, [ctypes.POINTER(PoolDesc), c_void_p, c_i32, ctypes.POINTER(GraphDesc), c_void_p,
                                            c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_void_p, c_i64, c_i64, c_i64,
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_void_p,

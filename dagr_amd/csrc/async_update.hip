@@ -241,4 +241,30 @@ int dagr_async_graph_append(const dagr_graph_desc *desc, void *graph_ws, int64_t
     return DAGR_OK;
 }
 
+int dagr_async_update(const dagr_async_update_args *a, void *stream) {
+    DAGR_CHECK_ARG(a && a->gdesc && a->pdesc, "NULL arguments");
+    DAGR_CHECK_ARG(a->cin1 >= 1 && a->cin1 <= 4, "events-only input rows expected (polarity | pos_xy)");
+    int rc = DAGR_OK;
+    if (a->n_new > 0) {
+        rc = dagr_async_graph_append(a->gdesc, a->graph_ws, a->n_static, a->first_id, a->app_head, a->app_next, a->app_xytb,
+                                     a->capacity, a->pos, 0, a->batch, a->batch_is_int64, a->n_new, a->nbr_src, a->nbr_code,
+                                     a->deg, a->status, a->feat, a->pos_nodes, a->batch_nodes, a->batch_events, a->x0, a->ldx0,
+                                     a->col_feat, a->col_pos, stream);
+        if (rc != DAGR_OK) return rc;
+        const int K = a->gdesc->max_neighbors;
+        rc = dagr_spline_conv_l0_tiles_rows(0, a->cin1, 0, a->win_x, a->tx, a->win_y, a->ty, a->rx, a->ry, a->den_x, a->den_y,
+                                            a->first_id, a->n_new, K, a->nbr_src, a->nbr_code, a->deg, a->x0, a->ldx0, nullptr,
+                                            0, a->w1, a->s1, 1, a->h1, a->ldh1, nullptr, stream);
+        if (rc != DAGR_OK) return rc;
+        rc = dagr_spline_conv_l0_tiles_rows(16, 0, a->cin1, a->win_x, a->tx, a->win_y, a->ty, a->rx, a->ry, a->den_x, a->den_y,
+                                            a->first_id, a->n_new, K, a->nbr_src, a->nbr_code, a->deg, a->h1, a->ldh1, a->x0,
+                                            a->ldx0, a->w2, a->s2, 1, a->hp0, a->ldhp0, nullptr, stream);
+        if (rc != DAGR_OK) return rc;
+    }
+    return dagr_pool_l0_stream(a->pdesc, a->pool_ws, 0, a->gdesc, a->graph_ws, a->xlo, a->ylo, a->hp0, a->ldhp0, a->pos_nodes,
+                               a->batch_events, a->n_static, a->first_id, a->n_new, a->nbr_src, a->nbr_code, a->deg, a->x_out,
+                               a->ldo, 0, a->pos_out, a->batch_out, a->n_out, a->rowptr_out, a->col_out, a->code_out, a->e_out,
+                               a->e_cap, stream);
+}
+
 }  // extern "C"

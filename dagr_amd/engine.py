@@ -577,6 +577,7 @@ class WindowEngine:
         for name in ("next", "xytb", "batch_ev"):
             if a[name].shape[0] < self.rows_cap:
                 a[name] = torch.zeros((self.rows_cap,) + tuple(a[name].shape[1:]), dtype=a[name].dtype, device=dev)
+        a.pop("args", None)                  # the argument block of dagr_async_update is rebuilt for this window
         a["head"].fill_(-1)
         a["status"].zero_()
         a["batch_ev"][:n0] = self._batch.to(torch.int32)
@@ -606,6 +607,35 @@ class WindowEngine:
                                                     P(self.deg), x, ldx, xskip, ldskip, P(w), P(s), 1, out, ldo, None,
                                                     _lib.cur_stream(self.device)), "conv_l0_tiles_rows")
 
+    def _async_call(self, a, first, n, pos, feat, batch, stream):
+        """Fill / refresh the argument block of ``dagr_async_update`` and issue the update."""
+        P = lambda t: None if t is None else t.data_ptr()
+        u = a.get("args")
+        g, l1, d0 = self.graph, self.levels[0], self.dom[0]
+        if u is None or a.get("args_rows_cap") != self.rows_cap:
+            u = _lib.AsyncUpdateArgs()
+            u.gdesc, u.graph_ws = ctypes.pointer(g.desc), P(g.workspace)
+            u.app_head, u.app_next, u.app_xytb = P(a["head"]), P(a["next"]), P(a["xytb"])
+            u.capacity = a["next"].shape[0]
+            u.nbr_src, u.nbr_code, u.deg, u.status = P(self.nbr_src), P(self.nbr_code), P(self.deg), P(a["status"])
+            u.pos_nodes, u.batch_nodes, u.batch_events = P(self.pos_n), P(self.batch_n), P(a["batch_ev"])
+            u.x0, u.ldx0, u.col_feat, u.col_pos = P(self.x0buf), self.x0_ld, self.x0_feat_col, self.x0_pos_col
+            u.win_x, u.tx, u.win_y, u.ty = self.win0
+            u.rx, u.ry, u.den_x, u.den_y = d0["rx"], d0["ry"], d0["den_x"], d0["den_y"]
+            cin1, _, w1, s1 = self.l0_conv1
+            _, _, w2, s2 = self.l0_conv2
+            u.cin1, u.w1, u.s1, u.h1, u.ldh1 = cin1, P(w1), P(s1), P(self.h1), 16
+            u.w2, u.s2, u.hp0, u.ldhp0 = P(w2), P(s2), P(self.hp0), self.hp0.shape[1]
+            u.pdesc, u.pool_ws, u.xlo, u.ylo = ctypes.pointer(self.pool_desc[0]), P(a["pool_ws"]), P(self.xlo), P(self.ylo)
+            u.x_out, u.ldo, u.pos_out, u.batch_out = P(l1.x), l1.x.shape[1], P(l1.pos), P(l1.batch)
+            u.n_out, u.rowptr_out, u.col_out, u.code_out = P(l1.counts), P(l1.rowptr), P(l1.col), P(l1.code)
+            u.e_out, u.e_cap = l1.counts.data_ptr() + 4, l1.e_cap
+            a["args"], a["args_rows_cap"] = u, self.rows_cap
+        u.n_static, u.first_id, u.n_new = self._N, first, n
+        u.pos, u.feat, u.batch = P(pos), P(feat), P(batch)
+        u.batch_is_int64 = 1 if (batch is not None and batch.dtype == torch.int64) else 0
+        _lib.check(self.L.dagr_async_update(ctypes.byref(u), stream), "async_update")
+
     def forward_append(self, pos, feat, batch, static_out=False):
         """``reset=False``: the n events of a micro-batch attach to the resident window (EV_TGN.forward, ev_tgn.py:45-56).
         Edges point from older to newer events, so the window's level-0 rows stand; the update
@@ -630,25 +660,30 @@ class WindowEngine:
             pos = pos.float().contiguous()
             feat = feat.float().reshape(-1).contiguous()
             batch = batch.contiguous()
-            b64 = 1 if batch.dtype == torch.int64 else 0
-            g = self.graph
-            _lib.check(L.dagr_async_graph_append(ctypes.byref(g.desc), P(g.workspace), self._N, first, P(a["head"]),
-                                                 P(a["next"]), P(a["xytb"]), a["next"].shape[0], P(pos), 0, P(batch), b64,
-                                                 n, P(self.nbr_src), P(self.nbr_code), P(self.deg), P(a["status"]), P(feat),
-                                                 P(self.pos_n), P(self.batch_n), P(a["batch_ev"]), P(self.x0buf),
-                                                 self.x0_ld, self.x0_feat_col, self.x0_pos_col, stream),
-                       "async_graph_append")
-            rows = slice(first, first + n)
-            if self.use_image:
+        if not self.use_image:
+            # events-only: graph append + both level-0 convs on the new rows + pool1's resident accumulators as ONE native
+            # call (dagr_async_update): same kernels, no host time between their launches
+            self._async_call(a, first, n, pos if n else None, feat if n else None, batch if n else None, stream)
+            self._n_rows = first + n
+        else:
+            if n:
+                b64 = 1 if batch.dtype == torch.int64 else 0
+                g = self.graph
+                _lib.check(L.dagr_async_graph_append(ctypes.byref(g.desc), P(g.workspace), self._N, first, P(a["head"]),
+                                                     P(a["next"]), P(a["xytb"]), a["next"].shape[0], P(pos), 0, P(batch), b64,
+                                                     n, P(self.nbr_src), P(self.nbr_code), P(self.deg), P(a["status"]), P(feat),
+                                                     P(self.pos_n), P(self.batch_n), P(a["batch_ev"]), P(self.x0buf),
+                                                     self.x0_ld, self.x0_feat_col, self.x0_pos_col, stream),
+                           "async_graph_append")
+                rows = slice(first, first + n)
                 self._sample(None, n, self.pos_n[rows], self.batch_n[rows], 0, self._img_feats[0], self.x0buf[rows],
                              self.x0_img_col)
-            self._conv_l0_rows(self.l0_conv1, first, n, P(self.x0buf), self.x0_ld, None, 0, P(self.h1), 16)
-            self._conv_l0_rows(self.l0_conv2, first, n, P(self.h1), 16, P(self.x0buf), self.x0_ld, P(self.hp0),
-                               self.hp0.shape[1])
-            if self.use_image:
+                self._conv_l0_rows(self.l0_conv1, first, n, P(self.x0buf), self.x0_ld, None, 0, P(self.h1), 16)
+                self._conv_l0_rows(self.l0_conv2, first, n, P(self.h1), 16, P(self.x0buf), self.x0_ld, P(self.hp0),
+                                   self.hp0.shape[1])
                 self._sample(None, n, self.pos_n[rows], self.batch_n[rows], 0, self._img_feats[1], self.hp0[rows], 16)
-            self._n_rows = first + n
-        self._pool1_stream(rebuild=False, first=first, n=n)
+                self._n_rows = first + n
+            self._pool1_stream(rebuild=False, first=first, n=n)
         if self.tail_graph and not self.use_image:
             return self._replay_tail(static_out)
         return self._tail_and_head()
@@ -1068,8 +1103,22 @@ class WindowEngine:
         try:
             self._cnn_out = None
             if self.use_image:
+                # the graph build needs nothing from the frame: it runs beside the image branch (a fork inside the captured
+                # window; the level-0 input rows are the first stage that needs both)
+                cur = torch.cuda.current_stream(self.device)
+                if self._head_stream is None:
+                    self._head_stream = torch.cuda.Stream(self.device)
+                fork = torch.cuda.Event()
+                fork.record(cur)
+                self._head_stream.wait_event(fork)
+                with torch.cuda.stream(self._head_stream):
+                    self.stage_graph(self.in_pos, self.in_batch)
+                    join = torch.cuda.Event()
+                    join.record(self._head_stream)
                 self.stage_image(self.in_image)
-            self.stage_graph(self.in_pos, self.in_batch)
+                cur.wait_event(join)
+            else:
+                self.stage_graph(self.in_pos, self.in_batch)
             self.stage_l0_input(self.in_feat)
             self.stage_l0_conv1()
             self.stage_l0_conv2()

@@ -336,6 +336,25 @@ int dagr_async_graph_append(const dagr_graph_desc *desc, void *graph_ws, int64_t
                              * dagr_graph_gather_inputs writes them for a window, and the sample index by event id */
                             const float *feat, float *pos_nodes, int32_t *batch_nodes, int32_t *batch_events, float *x0,
                             int32_t ldx0, int32_t col_feat, int32_t col_pos, void *stream);
+/* One asynchronous update as ONE call: dagr_async_graph_append (with the node-ordered inputs), conv_block1 on the n new rows
+ * (dagr_spline_conv_l0_tiles_rows twice) and dagr_pool_l0_stream, issued back to back from native code.  Same kernels, same
+ * arguments as the four calls; what it removes is the host time between their launches (an update of a few events is
+ * ~8 launches of a few microseconds each: issued one by one from the caller's language the GPU waits for the host).
+ * Events-only rows (polarity | pos_xy: cin1 = 3). */
+typedef struct dagr_async_update_args {
+    const dagr_graph_desc *gdesc; void *graph_ws; int64_t n_static, first_id;
+    int32_t *app_head, *app_next, *app_xytb; int64_t capacity;
+    const float *pos; const void *batch; int32_t batch_is_int64; int64_t n_new;
+    int32_t *nbr_src; int16_t *nbr_code; int32_t *deg; int32_t *status;
+    const float *feat; float *pos_nodes; int32_t *batch_nodes, *batch_events; float *x0; int32_t ldx0, col_feat, col_pos;
+    int32_t win_x, tx, win_y, ty, rx, ry; float den_x, den_y;
+    int32_t cin1; const float *w1, *s1; float *h1; int32_t ldh1;
+    const float *w2, *s2; float *hp0; int32_t ldhp0;
+    const dagr_pool_desc *pdesc; void *pool_ws; const int32_t *xlo, *ylo;
+    float *x_out; int32_t ldo; float *pos_out; int32_t *batch_out, *n_out, *rowptr_out, *col_out, *code_out, *e_out;
+    int32_t e_cap;
+} dagr_async_update_args;
+int dagr_async_update(const dagr_async_update_args *args, void *stream);
 /* Launch (A) of dagr_pool_l0 alone: the level-0 accumulation kernel over the window last built on `graph_ws`, into the
  * accumulators of `pool_ws` (max / fixed-point sums: repeating it leaves max accumulators unchanged and scales the sums;
  * the next dagr_pool_l0 call re-arms everything).  For measurement (bench.py times the kernel on its own with HIP
