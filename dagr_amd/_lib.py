@@ -168,6 +168,10 @@ SIGNATURES = {
     "dagr_spline_conv_fused": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32,
                                               c_void_p, c_i32, c_i32, c_i32, c_i32, c_float, c_float, c_void_p,
                                               c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p]),
+    "dagr_spline_conv_fused_pool": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32,
+                                                   c_void_p, c_i32, c_i32, c_i32, c_i32, c_float, c_float, c_void_p,
+                                                   c_void_p, c_void_p, c_i32, c_i32, c_i32, ctypes.POINTER(PoolDesc),
+                                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dagr_spline_conv_fused_pair": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32,
                                                    c_float, c_float, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_void_p,
                                                    c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_void_p]),

@@ -16,6 +16,7 @@
 #include <algorithm>
 
 #include "common.hpp"
+#include "pool_common.hpp"
 
 #ifndef DAGR_TRACE          // tools/microbench/conv_trace.hip defines it to time the stages of k_conv_fused
 #define DAGR_TRACE(i)
@@ -168,6 +169,17 @@ struct AxisF {
     int k0, k1;
     float b0, b1;
 };
+// launch (A) of the pooling step that consumes this conv's output, fused into the conv (dagr_spline_conv_fused_pool): the
+// epilogue merges every output element into its cluster's accumulator, wave w does the bookkeeping and the in-edges of
+// node w -- exactly k_pool_accumulate's work (pooling.hip), on the values the epilogue holds in registers.
+struct PoolFuse {
+    int on;
+    dagr_pool_desc d;
+    PoolWs ws;
+    const float *pos;
+    const int32_t *batch;
+    int32_t *cluster_raw_out;
+};
 struct ConvJob2 {       // what differs between the two convs of a paired launch
     const float *x, *Wq, *bias;
     float *C;
@@ -191,10 +203,12 @@ __global__ __launch_bounds__(kGemmThreads) void k_conv_fused(
     const int32_t *__restrict__ n_ptr, int n_max, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const int32_t *__restrict__ code, const float *__restrict__ x, int ldx, int cin, const float *__restrict__ xskip,
     int ldskip, int cskip, int rx, int ry, float den_x, float den_y, const float *__restrict__ Wq,
-    const float *__restrict__ bias, float *__restrict__ C, int ldc, int N, int relu, int KP, int NC, ConvJob2 second) {
+    const float *__restrict__ bias, float *__restrict__ C, int ldc, int N, int relu, int KP, int NC, ConvJob2 second,
+    PoolFuse pf) {
     // a second conv on the same graph, same shape of input row (dagr_spline_conv_fused_pair): gridDim.z = 2
     if (blockIdx.z == 1) { x = second.x; Wq = second.Wq; bias = second.bias; C = second.C; N = second.N; }
     extern __shared__ __align__(16) float fl[];
+    __shared__ int s_raw[16];                        // fused pooling: cluster (table slot) of the tile's nodes, -1 = none
     const int K = 26 * cin + cskip;
     float *At = fl;                                  // [16][KP], columns K..KP-1 zero
     float *red = fl + 16 * KP;                       // [KSPLIT][16][NB] split-K partials
@@ -208,6 +222,19 @@ __global__ __launch_bounds__(kGemmThreads) void k_conv_fused(
     const int e0 = rowptr[n_spec], e1s = rowptr[n_spec + 1];
     const int M = n_ptr ? min(*n_ptr, n_max) : n_max;
     if (m0 >= M) return;
+    int my_raw = -1;
+    if (pf.on) {
+        const int n = m0 + wv;
+        if (n < M) {
+            bool ok;
+            my_raw = cluster_raw(pf.pos[3 * n], pf.pos[3 * n + 1], pf.pos[3 * n + 2], pf.batch[n], pf.d, ok);
+            if (!ok) {
+                my_raw = -1;
+                if (lane == 0 && blockIdx.y == 0) { atomicOr(&pf.ws.status[0], 1); pf.cluster_raw_out[n] = -1; }
+            }
+        }
+        if (lane == 0) s_raw[wv] = my_raw;
+    }
     DAGR_TRACE(1);
     // ---- phase A: wave wv aggregates node m0 + wv (edge order and arithmetic of k_tap_aggregate)
     {
@@ -287,6 +314,9 @@ __global__ __launch_bounds__(kGemmThreads) void k_conv_fused(
             }
         }
     }
+    // fused pooling: the node's bookkeeping and in-edges (one column workgroup per node tile does it)
+    if (pf.on && my_raw >= 0 && blockIdx.y == 0)
+        pool_merge_node(pf.d, pf.ws, m0 + wv, my_raw, pf.pos, pf.batch, col, e0, e1s, lane, 64, pf.cluster_raw_out);
     DAGR_TRACE(3);
     __syncthreads();
     DAGR_TRACE(4);
@@ -379,6 +409,15 @@ __global__ __launch_bounds__(kGemmThreads) void k_conv_fused(
                 v += bias ? bias[ocol] : 0.f;
                 if (relu) v = fmaxf(v, 0.f);
                 C[(size_t)orow * ldc + ocol] = v;
+                if (pf.on) {
+                    const int raw = s_raw[idx / NBc];
+                    if (raw >= 0 && ocol < pf.d.channels) {
+                        long long *acc = pf.ws.xacc + (size_t)raw * pf.d.channels + ocol;
+                        if (pf.d.aggr == 0) atomicMax(reinterpret_cast<int *>(acc), enc_f(v));
+                        else atomicAdd(reinterpret_cast<unsigned long long *>(acc),
+                                       (unsigned long long)(long long)llrint((double)v * kFeatScale));
+                    }
+                }
             }
         }
         __syncthreads();
@@ -691,7 +730,7 @@ static int launch_conv_fused(const int32_t *n_nodes_ptr, int32_t n_nodes_max, co
                              const int32_t *code, const float *x, int32_t ldx, int32_t cin, const float *xskip,
                              int32_t ldskip, int32_t cskip, int32_t rx, int32_t ry, float den_x, float den_y,
                              const float *Wq, const float *bias, float *C, int32_t ldc, int32_t N, int32_t relu,
-                             const dagr::ConvJob2 *second, void *stream) {
+                             const dagr::ConvJob2 *second, const dagr::PoolFuse *pool, void *stream) {
     using namespace dagr;
     DAGR_CHECK_ARG(n_nodes_max >= 0 && cin >= 1 && N >= 1, "bad sizes");
     if (n_nodes_max == 0) return DAGR_OK;
@@ -705,6 +744,7 @@ static int launch_conv_fused(const int32_t *n_nodes_ptr, int32_t n_nodes_max, co
     }
     const size_t lds_bytes = ((size_t)16 * KP + (size_t)KSPLIT * 16 * NB) * 4;
     const bool mp = tp < 25;
+    DAGR_CHECK_ARG(!(pool && mp), "the fused pooling merge needs the single-pass form of the conv");
     static thread_local size_t set_max[2] = {0, 0};
     if (lds_bytes > set_max[mp]) {
         DAGR_CHECK_HIP(hipFuncSetAttribute(mp ? (const void *)k_conv_fused_mp : (const void *)k_conv_fused,
@@ -735,6 +775,8 @@ static int launch_conv_fused(const int32_t *n_nodes_ptr, int32_t n_nodes_max, co
     }
     const dim3 grid((unsigned)row_blocks, loop_cols ? 1u : (unsigned)ceil_div(Nmax, 16 * nc), (unsigned)jobs);
     const ConvJob2 job2 = second ? *second : ConvJob2{nullptr, nullptr, nullptr, nullptr, 0};
+    PoolFuse pf{};
+    if (pool) pf = *pool;
     if (mp)
         k_conv_fused_mp<<<grid, kGemmThreads, lds_bytes, (hipStream_t)stream>>>(
             n_nodes_ptr, n_nodes_max, rowptr, col, code, x, ldx, cin, xskip, ldskip, cskip, rx, ry, den_x, den_y, Wq, bias,
@@ -742,7 +784,7 @@ static int launch_conv_fused(const int32_t *n_nodes_ptr, int32_t n_nodes_max, co
     else
         k_conv_fused<<<grid, kGemmThreads, lds_bytes, (hipStream_t)stream>>>(
             n_nodes_ptr, n_nodes_max, rowptr, col, code, x, ldx, cin, xskip, ldskip, cskip, rx, ry, den_x, den_y, Wq, bias,
-            C, ldc, N, relu, KP, nc, job2);
+            C, ldc, N, relu, KP, nc, job2, pf);
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;
 }
@@ -753,7 +795,26 @@ extern "C" int dagr_spline_conv_fused(const int32_t *n_nodes_ptr, int32_t n_node
                                       float den_x, float den_y, const float *Wq, const float *bias, float *C,
                                       int32_t ldc, int32_t N, int32_t relu, void *stream) {
     return launch_conv_fused(n_nodes_ptr, n_nodes_max, rowptr, col, code, x, ldx, cin, xskip, ldskip, cskip, rx, ry, den_x,
-                             den_y, Wq, bias, C, ldc, N, relu, nullptr, stream);
+                             den_y, Wq, bias, C, ldc, N, relu, nullptr, nullptr, stream);
+}
+
+extern "C" int dagr_spline_conv_fused_pool(const int32_t *n_nodes_ptr, int32_t n_nodes_max, const int32_t *rowptr,
+                                           const int32_t *col, const int32_t *code, const float *x, int32_t ldx, int32_t cin,
+                                           const float *xskip, int32_t ldskip, int32_t cskip, int32_t rx, int32_t ry,
+                                           float den_x, float den_y, const float *Wq, const float *bias, float *C,
+                                           int32_t ldc, int32_t N, int32_t relu, const dagr_pool_desc *pdesc, void *pool_ws,
+                                           const float *pos, const int32_t *batch, int32_t *cluster_scratch, void *stream) {
+    using namespace dagr;
+    DAGR_CHECK_ARG(pdesc && pool_ws && pos && batch && cluster_scratch, "NULL pooling arguments");
+    DAGR_CHECK_ARG(pdesc->channels == N && pdesc->gx > 0 && pdesc->gy > 0 && pdesc->batch_size > 0 &&
+                       (pdesc->aggr == 0 || pdesc->aggr == 1), "the pooling consumes exactly this conv's N output columns");
+    PoolFuse pf{};
+    pf.on = 1;
+    pf.d = *pdesc;
+    pool_carve(*pdesc, (char *)pool_ws, &pf.ws);
+    pf.pos = pos; pf.batch = batch; pf.cluster_raw_out = cluster_scratch;
+    return launch_conv_fused(n_nodes_ptr, n_nodes_max, rowptr, col, code, x, ldx, cin, xskip, ldskip, cskip, rx, ry, den_x,
+                             den_y, Wq, bias, C, ldc, N, relu, nullptr, &pf, stream);
 }
 
 extern "C" int dagr_spline_conv_fused_pair(const int32_t *n_nodes_ptr, int32_t n_nodes_max, const int32_t *rowptr,
@@ -765,7 +826,7 @@ extern "C" int dagr_spline_conv_fused_pair(const int32_t *n_nodes_ptr, int32_t n
     DAGR_CHECK_ARG(x_b && Wq_b && C_b && N_b >= 1 && ((uintptr_t)Wq_b % 16) == 0, "bad second conv");
     const dagr::ConvJob2 second{x_b, Wq_b, bias_b, C_b, N_b};
     return launch_conv_fused(n_nodes_ptr, n_nodes_max, rowptr, col, code, x_a, ldx, cin, nullptr, 0, 0, rx, ry, den_x, den_y,
-                             Wq_a, bias_a, C_a, ldc, N_a, relu, &second, stream);
+                             Wq_a, bias_a, C_a, ldc, N_a, relu, &second, nullptr, stream);
 }
 
 extern "C" size_t dagr_spline_conv_fused_lds_bytes(int32_t cin, int32_t cskip) {

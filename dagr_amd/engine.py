@@ -310,6 +310,8 @@ class WindowEngine:
         self._net_f = self._cnn_f = None
         self.fuse_convs = os.environ.get("DAGR_FUSE_CONVS", "1") != "0"
         self.fast_coarse_edges = os.environ.get("DAGR_FAST_COARSE_EDGES", "1") != "0"
+        self.fuse_pool_accumulate = os.environ.get("DAGR_FUSE_POOL", "1") != "0"
+        self._pool_accumulated = [False] * 4
         self.fuse_image_epilogues = os.environ.get("DAGR_IMG_EPILOGUES", "1") != "0"
         # Latency mode (one window batch at a time, e.g. DAGR.forward): head scale 1 runs beside pool4 / layer5 / head scale
         # 2 and everything after pool1 is replayed as one HIP graph -- the host issues one launch instead of ~70.  When
@@ -922,7 +924,21 @@ class WindowEngine:
         ldx = lvl.x.shape[1]
         self._conv_generic(lvl, c1, P(lvl.x), ldx, None, 0, P(lvl.h1), c1.N, dom, stream)
         ldh = lvl.hp.shape[1]
-        self._conv_generic(lvl, c2, P(lvl.h1), c1.N, P(lvl.x), ldx, P(lvl.hp), ldh, dom, stream)
+        # events-only levels that are pooled next: launch (A) of that pooling (merge of every node into its cluster's
+        # accumulators, coarse-edge sets) rides in this conv's epilogue -- one launch less per level
+        fuse_pool = (k < 3 and not self.use_image and self.fuse_convs and self.fuse_pool_accumulate
+                     and L.dagr_spline_conv_fused_passes(c2.cin, c2.cskip) == 1
+                     and self.pool_desc[k + 1].channels == c2.N)
+        self._pool_accumulated[k] = fuse_pool
+        if fuse_pool:
+            d = self.pool_desc[k + 1]
+            _lib.check(L.dagr_spline_conv_fused_pool(P(lvl.counts), lvl.T, P(lvl.rowptr), P(lvl.col), P(lvl.code), P(lvl.h1),
+                                                     c1.N, c2.cin, P(lvl.x), ldx, c2.cskip, dom["rx"], dom["ry"],
+                                                     dom["den_x"], dom["den_y"], P(c2.Wq), P(c2.bias), P(lvl.hp), ldh, c2.N,
+                                                     1 if c2.relu else 0, ctypes.byref(d), P(self.pool_ws[k + 1]), P(lvl.pos),
+                                                     P(lvl.batch), P(lvl.cluster), stream), "spline_conv_fused_pool")
+        else:
+            self._conv_generic(lvl, c2, P(lvl.h1), c1.N, P(lvl.x), ldx, P(lvl.hp), ldh, dom, stream)
         if trace is not None:
             trace[f"pool{k + 1}"] = self._level_snapshot(lvl, lvl.x)
             trace[f"layer{k + 2}"] = self._level_snapshot(lvl, lvl.hp[:, :lvl.cout])
@@ -936,7 +952,9 @@ class WindowEngine:
         if self.use_image:
             self._sample(P(lvl.counts), lvl.T, lvl.pos, lvl.batch, 0, self._img_feats[k + 2], lvl.hp, lvl.cout)
         d = self.pool_desc[k + 1]
-        _lib.check(L.dagr_pool_csr(ctypes.byref(d), P(self.pool_ws[k + 1]), P(lvl.counts), lvl.T, P(lvl.hp),
+        # (n_max = 0: the accumulation already happened in the conv's epilogue -- scan + emit only)
+        _lib.check(L.dagr_pool_csr(ctypes.byref(d), P(self.pool_ws[k + 1]), P(lvl.counts),
+                                   0 if self._pool_accumulated[k] else lvl.T, P(lvl.hp),
                                    ldh, P(lvl.pos), P(lvl.batch), P(lvl.rowptr), P(lvl.col),
                                    P(lvl.cluster), P(nxt.x), nxt.x.shape[1], 0, P(nxt.pos), P(nxt.batch),
                                    P(nxt.counts), P(nxt.rowptr), P(nxt.col), P(nxt.code),
