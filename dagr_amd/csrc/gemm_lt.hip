@@ -79,16 +79,47 @@ extern "C" int dagr_gemm_epilogue(const float *A, int64_t M, int32_t K, int64_t 
         LT_OK(hipblasLtMatmulPreferenceCreate(&pref));
         const uint64_t max_ws = workspace ? (uint64_t)workspace_bytes : 0;
         LT_OK(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &max_ws, sizeof(max_ws)));
-        hipblasLtMatmulHeuristicResult_t res[4];
+        constexpr int kCand = 16;
+        hipblasLtMatmulHeuristicResult_t res[kCand];
         int found = 0;
-        const hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(h, p.desc, p.a, p.b, p.c, p.d, pref, 4, res, &found);
+        const hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(h, p.desc, p.a, p.b, p.c, p.d, pref, kCand, res, &found);
         hipblasLtMatmulPreferenceDestroy(pref);
         if (st != HIPBLAS_STATUS_SUCCESS || found < 1) {
             set_error("dagr_gemm_epilogue: the library offers no kernel for this GEMM + epilogue");
             return DAGR_ERR_UNSUPPORTED;
         }
-        p.algo = res[0].algo;
-        p.workspace = res[0].workspaceSize;
+        int best = 0;
+        // The library ranks its kernels by a model; the first time a shape is seen (a warm-up call, never inside a stream
+        // capture) the candidates are timed on the caller's own operands and the fastest is kept for the shape.
+        static const bool tune = [] { const char *e = getenv("DAGR_LT_TUNE"); return !(e && e[0] == '0'); }();
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing((hipStream_t)stream, &cap);
+        if (tune && found > 1 && cap == hipStreamCaptureStatusNone) {
+            hipEvent_t e0, e1;
+            if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+                const float alpha = 1.0f, beta = R ? 1.0f : 0.0f;
+                float best_ms = 0.f;
+                for (int c = 0; c < found; c++) {
+                    if (res[c].workspaceSize > workspace_bytes) continue;
+                    bool ok = true;
+                    float ms = 0.f;
+                    for (int rep = 0; rep < 3 && ok; rep++) {       // first repetition = warm-up (code load), last two timed
+                        if (rep == 1) (void)hipEventRecord(e0, (hipStream_t)stream);
+                        ok = hipblasLtMatmul(h, p.desc, &alpha, Wt, p.a, A, p.b, &beta, R ? (const void *)R : (const void *)D,
+                                             p.c, D, p.d, &res[c].algo, workspace, workspace_bytes,
+                                             (hipStream_t)stream) == HIPBLAS_STATUS_SUCCESS;
+                    }
+                    (void)hipEventRecord(e1, (hipStream_t)stream);
+                    if (hipEventSynchronize(e1) != hipSuccess || !ok) continue;
+                    (void)hipEventElapsedTime(&ms, e0, e1);
+                    if (best_ms == 0.f || ms < best_ms) { best_ms = ms; best = c; }
+                }
+                (void)hipEventDestroy(e0);
+                (void)hipEventDestroy(e1);
+            }
+        }
+        p.algo = res[best].algo;
+        p.workspace = res[best].workspaceSize;
         it = plans.emplace(key, p).first;
 #undef LT_OK
     }

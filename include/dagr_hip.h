@@ -261,17 +261,6 @@ int dagr_spline_conv_fused(const int32_t *n_nodes_ptr, int32_t n_nodes_max, cons
                            const float *xskip, int32_t ldskip, int32_t cskip, int32_t rx, int32_t ry,
                            float den_x, float den_y, const float *Wq, const float *bias, float *C, int32_t ldc,
                            int32_t N, int32_t relu, void *stream);
-/* dagr_spline_conv_fused + launch (A) of the pooling step that consumes its output (dagr_pool_csr's accumulation) in one
- * launch: the epilogue merges every output element into its cluster's accumulator (the values it holds in registers),
- * wave w does the bookkeeping and the in-edges of node w.  Single-pass form only (dagr_spline_conv_fused_passes == 1);
- * pdesc->channels must equal N.  Follow with dagr_pool_csr(..., n_max = 0, ...): scan + emit only.  pos / batch: the
- * level's node positions and samples; cluster_scratch int32[n_nodes_max]. */
-int dagr_spline_conv_fused_pool(const int32_t *n_nodes_ptr, int32_t n_nodes_max, const int32_t *rowptr,
-                                const int32_t *col, const int32_t *code, const float *x, int32_t ldx, int32_t cin,
-                                const float *xskip, int32_t ldskip, int32_t cskip, int32_t rx, int32_t ry,
-                                float den_x, float den_y, const float *Wq, const float *bias, float *C,
-                                int32_t ldc, int32_t N, int32_t relu, const dagr_pool_desc *pdesc, void *pool_ws,
-                                const float *pos, const int32_t *batch, int32_t *cluster_scratch, void *stream);
 /* Two fused convs over the SAME graph in one launch (gridDim.z = 2): same row shape (cin channels, no skip input, row
  * stride ldx), each with its own input pointer, packed weights, bias, output pointer (row stride ldc) and width.  The
  * detection head's predictors: cls_pred on the cls_conv half of the fused row and reg_pred | obj_pred on the reg_conv half
@@ -385,6 +374,17 @@ int dagr_pool_l0_stream(const dagr_pool_desc *desc, void *pool_ws, int32_t rebui
                         int32_t xoff, float *pos_out, int32_t *batch_out, int32_t *n_out, int32_t *rowptr_out,
                         int32_t *col_out, int32_t *code_out, int32_t *e_out, int32_t e_cap, void *stream);
 
+/* dagr_spline_conv_fused + launch (A) of the pooling step that consumes its output (dagr_pool_csr's accumulation) in one
+ * launch: the epilogue merges every output element into its cluster's accumulator (the values it holds in registers),
+ * wave w does the bookkeeping and the in-edges of node w.  Single-pass form only (dagr_spline_conv_fused_passes == 1);
+ * pdesc->channels must equal N.  Follow with dagr_pool_csr(..., n_max = 0, ...): scan + emit only.  pos / batch: the
+ * level's node positions and samples; cluster_scratch int32[n_nodes_max]. */
+int dagr_spline_conv_fused_pool(const int32_t *n_nodes_ptr, int32_t n_nodes_max, const int32_t *rowptr,
+                                const int32_t *col, const int32_t *code, const float *x, int32_t ldx, int32_t cin,
+                                const float *xskip, int32_t ldskip, int32_t cskip, int32_t rx, int32_t ry,
+                                float den_x, float den_y, const float *Wq, const float *bias, float *C,
+                                int32_t ldc, int32_t N, int32_t relu, const dagr_pool_desc *pdesc, void *pool_ws,
+                                const float *pos, const int32_t *batch, int32_t *cluster_scratch, void *stream);
 /* coarser levels: input graph in CSR; n_ptr (device) = number of valid input nodes (<= n_max) */
 int dagr_pool_csr(const dagr_pool_desc *desc, void *pool_ws, const int32_t *n_ptr, int32_t n_max, const float *x,
                   int32_t ldx, const float *pos, const int32_t *batch, const int32_t *rowptr, const int32_t *col,
