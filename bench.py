@@ -10,11 +10,14 @@ ranks itself and refuses to run on fewer devices; windows are independent so ran
 
   value / ms_per_step   BASELINE config 2 on the synthetic 640x480 stream (dagr-s + resnet50 image branch), K steps
   events_only           the same K steps on the events-only model (config 1 shape): the hand-written path alone
-  latency_ms            per-window latency (HIP events, one window batch at a time, 20 warm-up + 100 timed windows):
-                        median / p95 for B in {1, 8}, N in {25k..400k} events per window, S-uniform and S-edges
+  latency_ms            per-window latency (HIP events, one window batch at a time through the captured window graph, 20
+                        warm-up + 100 timed windows): median / p95 for B in {1, 8}, N in {25k..400k} events per window,
+                        S-uniform and S-edges
   async_update          f3: microseconds per reset=False update (1 / 10 / 100 events onto a 25 k-event window) vs re-evaluation
   roofline / stages     dominant kernel of the event path and per-stage timings (HIP events on the kernels' stream)
-  cpu_baseline          the CPU oracle (a port of the reference's op sequence) on the host cores: the SAME step (B windows)
+  cpu_baseline          the CPU oracle (a port of the reference's op sequence) on the host cores: median of 3 steps of a
+                        bounded sample of the step's windows, for the headline model and (events_only.cpu_baseline) the
+                        events-only one
   image_branch          the dense ResNet-50 branch's time, GFLOP and rate against the fp32 matrix peak (library code)
 """
 import argparse
@@ -677,8 +680,10 @@ def main():
 
     if rank == 0 and world == 1 and not a.no_latency:
         Ns = [int(v) for v in a.latency_n.split(",") if v]
-        lat = {"protocol": f"one window batch at a time on one engine in latency mode (tail + heads replayed as a HIP "
-                           f"graph), device idle at window start, HIP events around forward + post-processing; "
+        lat = {"protocol": f"one window batch at a time on one engine in latency mode (the caller's events staged by one "
+                           f"launch, the whole window -- image branch, graph build, level 0, tail, heads, decode -- replayed "
+                           f"as one captured HIP graph sized for the engine's event capacity, then the post-processing "
+                           f"launch), device idle at window start, HIP events around forward + post-processing; "
                            f"{a.latency_warmup} warm-up + {a.latency_windows} timed windows"}
         lat["events_only"] = latency_sweep(W, H, False, a.img_net, dev, Ns, a.latency_warmup, a.latency_windows)
         if use_image:

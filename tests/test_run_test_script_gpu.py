@@ -41,3 +41,18 @@ def test_run_test_interframe_script(tmp_path):
     want = {50000 * w + off for w in range(6) for off in (0, 25000, 50000)}
     assert set(np.unique(rec["t"])) <= want and (np.diff(rec["t"].astype(np.int64)) >= 0).all()
     assert "3 offsets x 6 windows" in stdout
+
+
+def test_run_test_script_scores_a_labelled_run(tmp_path):
+    """``--labelled``: synthetic windows with boxes through the real model -> ONE set of COCO-protocol metrics for the run
+    (scripts/run_test.py:61-65; under a process group detections and ground truth are gathered first:
+    tests/test_sharding_gloo.py holds world-2 == world-1)."""
+    import json
+    out = tmp_path / "out"
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "run_test.py"), "--labelled", "--windows", "6", "--batch_size", "2",
+           "--events_per_window", "4000", "--width", "240", "--height", "180", "--output_directory", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "metrics of the run (1 rank(s))" in r.stdout
+    m = json.load(open(out / "synthetic" / "detection" / "run_test" / "metrics.json"))
+    assert set(m) >= {"mAP", "mAP_50", "mAP_75"} and all(np.isfinite(v) for v in m.values())
