@@ -41,6 +41,20 @@ class HeadScale(ctypes.Structure):
                 ("cnn", c_void_p * 3), ("cnn_stride", (c_i32 * 4) * 3), ("dense", c_void_p)]
 
 
+class ConvJob(ctypes.Structure):
+    """``dagr_conv_job`` (include/dagr_hip.h)."""
+    _fields_ = [("n_nodes_ptr", c_void_p), ("n_nodes_max", c_i32), ("rowptr", c_void_p), ("col", c_void_p),
+                ("code", c_void_p), ("x", c_void_p), ("ldx", c_i32), ("cin", c_i32), ("xskip", c_void_p),
+                ("ldskip", c_i32), ("cskip", c_i32), ("rx", c_i32), ("ry", c_i32), ("den_x", c_float), ("den_y", c_float),
+                ("Wq", c_void_p), ("bias", c_void_p), ("C", c_void_p), ("ldc", c_i32), ("N", c_i32), ("relu", c_i32)]
+
+
+class L0Inputs(ctypes.Structure):
+    """``dagr_l0_inputs`` (include/dagr_hip.h)."""
+    _fields_ = [("feat", c_void_p), ("pos_nodes", c_void_p), ("batch_nodes", c_void_p), ("x0", c_void_p), ("ldx0", c_i32),
+                ("col_feat", c_i32), ("col_pos", c_i32)]
+
+
 class AsyncUpdateArgs(ctypes.Structure):
     """``dagr_async_update_args`` (include/dagr_hip.h)."""
     _fields_ = [("gdesc", ctypes.POINTER(GraphDesc)), ("graph_ws", c_void_p), ("n_static", c_i64), ("first_id", c_i64),
@@ -93,6 +107,8 @@ SIGNATURES = {
                                                  c_void_p]),
     "dagr_graph_build_window_dev": (ctypes.c_int, [ctypes.POINTER(GraphDesc), c_void_p, c_void_p, c_i32, c_void_p,
                                                    c_i32, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dagr_graph_build_window_inputs": (ctypes.c_int, [ctypes.POINTER(GraphDesc), c_void_p, c_void_p, c_void_p, c_i32, c_i64,
+                                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dagr_graph_node_count_ptr": (c_void_p, [ctypes.POINTER(GraphDesc), c_void_p]),
     "dagr_stage_window": (ctypes.c_int, [ctypes.POINTER(GraphDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i64,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -172,6 +188,7 @@ SIGNATURES = {
                                                    c_void_p, c_i32, c_i32, c_i32, c_i32, c_float, c_float, c_void_p,
                                                    c_void_p, c_void_p, c_i32, c_i32, c_i32, ctypes.POINTER(PoolDesc),
                                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dagr_spline_conv_fused_multi": (ctypes.c_int, [c_void_p, c_i32, c_void_p]),
     "dagr_spline_conv_fused_pair": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32,
                                                    c_float, c_float, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_void_p,
                                                    c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_void_p]),

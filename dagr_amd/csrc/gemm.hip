@@ -180,11 +180,31 @@ struct PoolFuse {
     const int32_t *batch;
     int32_t *cluster_raw_out;
 };
-struct ConvJob2 {       // what differs between the two convs of a paired launch
-    const float *x, *Wq, *bias;
+// Extra convs of a multi-job launch (dagr_spline_conv_fused_multi / _pair): blockIdx.z = 1 + index.  Jobs are independent
+// convs -- other graphs, row shapes and widths allowed -- that become ready at the same point of a window (a head scale's
+// convs beside the next level's): on levels of <= 1 260 rows a launch costs what a conv costs, and the chip has the CUs.
+constexpr int kMaxExtraJobs = 3;
+struct ConvJob {
+    const int32_t *n_ptr, *rowptr, *col, *code;
+    const float *x, *xskip, *Wq, *bias;
     float *C;
-    int N;
+    int n_max, ldx, cin, ldskip, cskip, rx, ry, ldc, N, relu, KP, NC, gy, tp;
+    float den_x, den_y;
 };
+struct ConvJobs {
+    int extra;
+    ConvJob j[kMaxExtraJobs];
+};
+// the parameters of job blockIdx.z replace the kernel's own (job 0); false: this workgroup lies outside the job's grid
+#define DAGR_CONV_PICK_JOB(TP_STMT)                                                                                      \
+    if (blockIdx.z > 0) {                                                                                                \
+        const ConvJob &jb = jobs.j[blockIdx.z - 1];                                                                      \
+        n_ptr = jb.n_ptr; n_max = jb.n_max; rowptr = jb.rowptr; col = jb.col; code = jb.code; x = jb.x; ldx = jb.ldx;    \
+        cin = jb.cin; xskip = jb.xskip; ldskip = jb.ldskip; cskip = jb.cskip; rx = jb.rx; ry = jb.ry; den_x = jb.den_x;  \
+        den_y = jb.den_y; Wq = jb.Wq; bias = jb.bias; C = jb.C; ldc = jb.ldc; N = jb.N; relu = jb.relu; KP = jb.KP;      \
+        NC = jb.NC; TP_STMT;                                                                                             \
+        if ((int)blockIdx.y >= jb.gy || (int)blockIdx.x * 16 >= jb.n_max) return;                                        \
+    } else if ((int)blockIdx.y >= gy0 || (int)blockIdx.x * 16 >= n_max) return;
 __device__ __forceinline__ AxisF spline_axis_f(int idx, int r, float den) {   // == spline_axis (spline_conv.hip)
     const float pseudo = (float)(idx - r) / den + 0.5f;
     const float v = pseudo * 4.0f;
@@ -203,10 +223,10 @@ __global__ __launch_bounds__(kGemmThreads) void k_conv_fused(
     const int32_t *__restrict__ n_ptr, int n_max, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const int32_t *__restrict__ code, const float *__restrict__ x, int ldx, int cin, const float *__restrict__ xskip,
     int ldskip, int cskip, int rx, int ry, float den_x, float den_y, const float *__restrict__ Wq,
-    const float *__restrict__ bias, float *__restrict__ C, int ldc, int N, int relu, int KP, int NC, ConvJob2 second,
+    const float *__restrict__ bias, float *__restrict__ C, int ldc, int N, int relu, int KP, int NC, int gy0, ConvJobs jobs,
     PoolFuse pf) {
-    // a second conv on the same graph, same shape of input row (dagr_spline_conv_fused_pair): gridDim.z = 2
-    if (blockIdx.z == 1) { x = second.x; Wq = second.Wq; bias = second.bias; C = second.C; N = second.N; }
+    DAGR_CONV_PICK_JOB((void)0)
+    if (blockIdx.z > 0) pf.on = 0;                   // the fused pooling merge belongs to job 0
     extern __shared__ __align__(16) float fl[];
     __shared__ int s_raw[16];                        // fused pooling: cluster (table slot) of the tile's nodes, -1 = none
     const int K = 26 * cin + cskip;
@@ -433,9 +453,9 @@ __global__ __launch_bounds__(kGemmThreads) void k_conv_fused_mp(
     const int32_t *__restrict__ n_ptr, int n_max, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const int32_t *__restrict__ code, const float *__restrict__ x, int ldx, int cin, const float *__restrict__ xskip,
     int ldskip, int cskip, int rx, int ry, float den_x, float den_y, const float *__restrict__ Wq,
-    const float *__restrict__ bias, float *__restrict__ C, int ldc, int N, int relu, int KP, int NC, int tp, ConvJob2 second) {
-    // a second conv on the same graph, same shape of input row (dagr_spline_conv_fused_pair): gridDim.z = 2
-    if (blockIdx.z == 1) { x = second.x; Wq = second.Wq; bias = second.bias; C = second.C; N = second.N; }
+    const float *__restrict__ bias, float *__restrict__ C, int ldc, int N, int relu, int KP, int NC, int tp, int gy0,
+    ConvJobs jobs) {
+    DAGR_CONV_PICK_JOB(tp = jb.tp)
     extern __shared__ __align__(16) float fl[];
     const int K = 26 * cin + cskip;
     float *At = fl;                                  // [16][KP]: the pass's columns, zero behind them
@@ -726,65 +746,104 @@ bool fused_plan(int cin, int cskip, int *tp_out, int *kp_out) {
 }  // namespace
 }  // namespace dagr
 
-static int launch_conv_fused(const int32_t *n_nodes_ptr, int32_t n_nodes_max, const int32_t *rowptr, const int32_t *col,
-                             const int32_t *code, const float *x, int32_t ldx, int32_t cin, const float *xskip,
-                             int32_t ldskip, int32_t cskip, int32_t rx, int32_t ry, float den_x, float den_y,
-                             const float *Wq, const float *bias, float *C, int32_t ldc, int32_t N, int32_t relu,
-                             const dagr::ConvJob2 *second, const dagr::PoolFuse *pool, void *stream) {
+namespace {
+struct HostConvJob {        // one fused conv as the C entry points describe it
+    const int32_t *n_ptr;
+    int32_t n_max;
+    const int32_t *rowptr, *col, *code;
+    const float *x;
+    int32_t ldx, cin;
+    const float *xskip;
+    int32_t ldskip, cskip, rx, ry;
+    float den_x, den_y;
+    const float *Wq, *bias;
+    float *C;
+    int32_t ldc, N, relu;
+};
+}  // namespace
+
+// 1 .. 4 independent fused convs in ONE launch (blockIdx.z = job).  All of them in the same form (single pass, or passes).
+static int launch_conv_jobs(const HostConvJob *hj, int count, const dagr::PoolFuse *pool, void *stream) {
     using namespace dagr;
-    DAGR_CHECK_ARG(n_nodes_max >= 0 && cin >= 1 && N >= 1, "bad sizes");
-    if (n_nodes_max == 0) return DAGR_OK;
-    DAGR_CHECK_ARG(rowptr && col && code && x && Wq && C, "NULL pointer");
-    DAGR_CHECK_ARG(cskip == 0 || xskip, "xskip is NULL");
-    DAGR_CHECK_ARG(((uintptr_t)Wq % 16) == 0, "packed weights must be 16-byte aligned");
-    int tp = 25, KP = 0;
-    if (!fused_plan(cin, cskip, &tp, &KP)) {
-        set_error("dagr_spline_conv_fused: one tap of the input row does not fit the LDS tile (use tap_aggregate + gemm)");
-        return DAGR_ERR_UNSUPPORTED;
+    DAGR_CHECK_ARG(count >= 1 && count <= 1 + kMaxExtraJobs, "1 .. 4 convs per launch");
+    ConvJob dev[1 + kMaxExtraJobs];
+    size_t lds_max = 0;
+    int mp_all = -1, live = 0;
+    unsigned gx = 1, gy = 1;
+    for (int i = 0; i < count; i++) {
+        const HostConvJob &h = hj[i];
+        DAGR_CHECK_ARG(h.n_max >= 0 && h.cin >= 1 && h.N >= 1, "bad sizes");
+        ConvJob &d = dev[i];
+        d = ConvJob{h.n_ptr, h.rowptr, h.col, h.code, h.x, h.xskip, h.Wq, h.bias, h.C, h.n_max, h.ldx, h.cin, h.ldskip,
+                    h.cskip, h.rx, h.ry, h.ldc, h.N, h.relu, 0, 4, 0, 25, h.den_x, h.den_y};
+        if (h.n_max == 0) continue;             // (gy = 0: every workgroup of the job leaves at once)
+        live++;
+        DAGR_CHECK_ARG(h.rowptr && h.col && h.code && h.x && h.Wq && h.C, "NULL pointer");
+        DAGR_CHECK_ARG(h.cskip == 0 || h.xskip, "xskip is NULL");
+        DAGR_CHECK_ARG(((uintptr_t)h.Wq % 16) == 0, "packed weights must be 16-byte aligned");
+        int tp = 25, KP = 0;
+        if (!fused_plan(h.cin, h.cskip, &tp, &KP)) {
+            set_error("dagr_spline_conv_fused: one tap of the input row does not fit the LDS tile (use tap_aggregate + gemm)");
+            return DAGR_ERR_UNSUPPORTED;
+        }
+        const int mp = tp < 25 ? 1 : 0;
+        if (mp_all >= 0 && mp != mp_all) {
+            set_error("dagr_spline_conv_fused_multi: single-pass and multi-pass convs cannot share a launch");
+            return DAGR_ERR_UNSUPPORTED;
+        }
+        mp_all = mp;
+        lds_max = std::max(lds_max, ((size_t)16 * KP + (size_t)KSPLIT * 16 * NB) * 4);
+        // Column tiles per workgroup (4, 2 or 1): the tile leaves room for one workgroup per CU, so the launch runs in
+        // ceil(workgroups / CUs) rounds.  A round costs the edge walk + prologue (~5 us, repeated by every workgroup of a
+        // node tile) plus ~1.5 us per column tile (measured, tools/microbench/conv_trace.hip); few nodes -> spread the
+        // columns over workgroups, but never into an extra round: 71 node tiles x 4 column workgroups ran 284 workgroups
+        // on 256 CUs, 18.5 us where 141 node tiles took 16.9.
+        const int row_blocks = ceil_div(h.n_max, 16);
+        const int passes = tp >= 25 ? 1 : (25 + tp - 1) / tp;
+        int nc = 4, loop_cols = passes == 1 ? 1 : 0;
+        float best = 0.0f;
+        for (int c = 4; c >= 1; c >>= 1) {
+            // single pass, 4 tiles: one workgroup per node tile walks all 64-column blocks over its tile; else gridDim.y
+            // workgroups of c tiles each
+            const int loop = (c == 4 && passes == 1) ? 1 : 0;
+            // (the job's own workgroups: the split -- and with it the summation order of the K partials -- must not
+            // depend on which other convs share the launch)
+            const int wgs = loop ? row_blocks : row_blocks * (int)ceil_div(h.N, 16 * c);
+            const float tiles = loop ? 4.0f * (float)ceil_div(h.N, 64) : (float)c;
+            // n_max is a capacity: a level's table has one sample plane more than the batch fills (QUIRK-1), and
+            // workgroups past the device-side count leave at once -- count 9 in 10 as live
+            const float cost = (float)ceil_div((int64_t)wgs * 9 / 10, device_cu_count()) * (5.0f * (float)passes + 1.5f * tiles);
+            if (best == 0.0f || cost < best) { best = cost; nc = c; loop_cols = loop; }
+        }
+        d.KP = KP; d.NC = nc; d.tp = tp;
+        d.gy = loop_cols ? 1 : (int)ceil_div(h.N, 16 * nc);
+        gx = std::max(gx, (unsigned)row_blocks);
+        gy = std::max(gy, (unsigned)d.gy);
     }
-    const size_t lds_bytes = ((size_t)16 * KP + (size_t)KSPLIT * 16 * NB) * 4;
-    const bool mp = tp < 25;
-    DAGR_CHECK_ARG(!(pool && mp), "the fused pooling merge needs the single-pass form of the conv");
+    if (live == 0) return DAGR_OK;
+    const bool mp = mp_all == 1;
+    DAGR_CHECK_ARG(!(pool && (mp || dev[0].gy == 0)), "the fused pooling merge needs the single-pass form of the conv");
     static thread_local size_t set_max[2] = {0, 0};
-    if (lds_bytes > set_max[mp]) {
+    if (lds_max > set_max[mp]) {
         DAGR_CHECK_HIP(hipFuncSetAttribute(mp ? (const void *)k_conv_fused_mp : (const void *)k_conv_fused,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        set_max[mp] = lds_bytes;
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+        set_max[mp] = lds_max;
     }
-    // Column tiles per workgroup (4, 2 or 1): the tile leaves room for one workgroup per CU, so the launch runs in
-    // ceil(workgroups / CUs) rounds.  A round costs the edge walk + prologue (~5 us, repeated by every workgroup of a
-    // node tile) plus ~1.5 us per column tile (measured, tools/microbench/conv_trace.hip); few nodes -> spread the
-    // columns over workgroups, but never into an extra round: 71 node tiles x 4 column workgroups ran 284 workgroups
-    // on 256 CUs, 18.5 us where 141 node tiles took 16.9.
-    const int row_blocks = ceil_div(n_nodes_max, 16);
-    const int passes = tp >= 25 ? 1 : (25 + tp - 1) / tp;
-    const int jobs = second ? 2 : 1;
-    const int Nmax = second ? std::max(N, second->N) : N;
-    int nc = 4, loop_cols = passes == 1 ? 1 : 0;
-    float best = 0.0f;
-    for (int c = 4; c >= 1; c >>= 1) {
-        // single pass, 4 tiles: one workgroup per node tile walks all 64-column blocks over its tile; else gridDim.y
-        // workgroups of c tiles each
-        const int loop = (c == 4 && passes == 1) ? 1 : 0;
-        const int wgs = jobs * (loop ? row_blocks : row_blocks * (int)ceil_div(Nmax, 16 * c));
-        const float tiles = loop ? 4.0f * (float)ceil_div(Nmax, 64) : (float)c;
-        // n_nodes_max is a capacity: a level's table has one sample plane more than the batch fills (QUIRK-1), and
-        // workgroups past the device-side count leave at once -- count 9 in 10 as live
-        const float cost = (float)ceil_div((int64_t)wgs * 9 / 10, device_cu_count()) * (5.0f * (float)passes + 1.5f * tiles);
-        if (best == 0.0f || cost < best) { best = cost; nc = c; loop_cols = loop; }
-    }
-    const dim3 grid((unsigned)row_blocks, loop_cols ? 1u : (unsigned)ceil_div(Nmax, 16 * nc), (unsigned)jobs);
-    const ConvJob2 job2 = second ? *second : ConvJob2{nullptr, nullptr, nullptr, nullptr, 0};
+    ConvJobs jobs{};
+    jobs.extra = count - 1;
+    for (int i = 1; i < count; i++) jobs.j[i - 1] = dev[i];
+    const ConvJob &a = dev[0];
+    const dim3 grid(gx, gy, (unsigned)count);
     PoolFuse pf{};
     if (pool) pf = *pool;
     if (mp)
-        k_conv_fused_mp<<<grid, kGemmThreads, lds_bytes, (hipStream_t)stream>>>(
-            n_nodes_ptr, n_nodes_max, rowptr, col, code, x, ldx, cin, xskip, ldskip, cskip, rx, ry, den_x, den_y, Wq, bias,
-            C, ldc, N, relu, KP, nc, tp, job2);
+        k_conv_fused_mp<<<grid, kGemmThreads, lds_max, (hipStream_t)stream>>>(
+            a.n_ptr, a.n_max, a.rowptr, a.col, a.code, a.x, a.ldx, a.cin, a.xskip, a.ldskip, a.cskip, a.rx, a.ry, a.den_x,
+            a.den_y, a.Wq, a.bias, a.C, a.ldc, a.N, a.relu, a.KP, a.NC, a.tp, a.gy, jobs);
     else
-        k_conv_fused<<<grid, kGemmThreads, lds_bytes, (hipStream_t)stream>>>(
-            n_nodes_ptr, n_nodes_max, rowptr, col, code, x, ldx, cin, xskip, ldskip, cskip, rx, ry, den_x, den_y, Wq, bias,
-            C, ldc, N, relu, KP, nc, job2, pf);
+        k_conv_fused<<<grid, kGemmThreads, lds_max, (hipStream_t)stream>>>(
+            a.n_ptr, a.n_max, a.rowptr, a.col, a.code, a.x, a.ldx, a.cin, a.xskip, a.ldskip, a.cskip, a.rx, a.ry, a.den_x,
+            a.den_y, a.Wq, a.bias, a.C, a.ldc, a.N, a.relu, a.KP, a.NC, a.gy, jobs, pf);
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;
 }
@@ -794,8 +853,9 @@ extern "C" int dagr_spline_conv_fused(const int32_t *n_nodes_ptr, int32_t n_node
                                       const float *xskip, int32_t ldskip, int32_t cskip, int32_t rx, int32_t ry,
                                       float den_x, float den_y, const float *Wq, const float *bias, float *C,
                                       int32_t ldc, int32_t N, int32_t relu, void *stream) {
-    return launch_conv_fused(n_nodes_ptr, n_nodes_max, rowptr, col, code, x, ldx, cin, xskip, ldskip, cskip, rx, ry, den_x,
-                             den_y, Wq, bias, C, ldc, N, relu, nullptr, nullptr, stream);
+    const HostConvJob j{n_nodes_ptr, n_nodes_max, rowptr, col, code, x, ldx, cin, xskip, ldskip, cskip, rx, ry, den_x, den_y,
+                        Wq, bias, C, ldc, N, relu};
+    return launch_conv_jobs(&j, 1, nullptr, stream);
 }
 
 extern "C" int dagr_spline_conv_fused_pool(const int32_t *n_nodes_ptr, int32_t n_nodes_max, const int32_t *rowptr,
@@ -808,13 +868,15 @@ extern "C" int dagr_spline_conv_fused_pool(const int32_t *n_nodes_ptr, int32_t n
     DAGR_CHECK_ARG(pdesc && pool_ws && pos && batch && cluster_scratch, "NULL pooling arguments");
     DAGR_CHECK_ARG(pdesc->channels == N && pdesc->gx > 0 && pdesc->gy > 0 && pdesc->batch_size > 0 &&
                        (pdesc->aggr == 0 || pdesc->aggr == 1), "the pooling consumes exactly this conv's N output columns");
+    if (n_nodes_max == 0) return DAGR_OK;
     PoolFuse pf{};
     pf.on = 1;
     pf.d = *pdesc;
     pool_carve(*pdesc, (char *)pool_ws, &pf.ws);
     pf.pos = pos; pf.batch = batch; pf.cluster_raw_out = cluster_scratch;
-    return launch_conv_fused(n_nodes_ptr, n_nodes_max, rowptr, col, code, x, ldx, cin, xskip, ldskip, cskip, rx, ry, den_x,
-                             den_y, Wq, bias, C, ldc, N, relu, nullptr, &pf, stream);
+    const HostConvJob j{n_nodes_ptr, n_nodes_max, rowptr, col, code, x, ldx, cin, xskip, ldskip, cskip, rx, ry, den_x, den_y,
+                        Wq, bias, C, ldc, N, relu};
+    return launch_conv_jobs(&j, 1, &pf, stream);
 }
 
 extern "C" int dagr_spline_conv_fused_pair(const int32_t *n_nodes_ptr, int32_t n_nodes_max, const int32_t *rowptr,
@@ -824,9 +886,23 @@ extern "C" int dagr_spline_conv_fused_pair(const int32_t *n_nodes_ptr, int32_t n
                                            const float *x_b, const float *Wq_b, const float *bias_b, float *C_b,
                                            int32_t N_b, void *stream) {
     DAGR_CHECK_ARG(x_b && Wq_b && C_b && N_b >= 1 && ((uintptr_t)Wq_b % 16) == 0, "bad second conv");
-    const dagr::ConvJob2 second{x_b, Wq_b, bias_b, C_b, N_b};
-    return launch_conv_fused(n_nodes_ptr, n_nodes_max, rowptr, col, code, x_a, ldx, cin, nullptr, 0, 0, rx, ry, den_x, den_y,
-                             Wq_a, bias_a, C_a, ldc, N_a, relu, &second, nullptr, stream);
+    const HostConvJob j[2] = {
+        {n_nodes_ptr, n_nodes_max, rowptr, col, code, x_a, ldx, cin, nullptr, 0, 0, rx, ry, den_x, den_y, Wq_a, bias_a, C_a,
+         ldc, N_a, relu},
+        {n_nodes_ptr, n_nodes_max, rowptr, col, code, x_b, ldx, cin, nullptr, 0, 0, rx, ry, den_x, den_y, Wq_b, bias_b, C_b,
+         ldc, N_b, relu}};
+    return launch_conv_jobs(j, 2, nullptr, stream);
+}
+
+extern "C" int dagr_spline_conv_fused_multi(const dagr_conv_job *jobs, int32_t count, void *stream) {
+    DAGR_CHECK_ARG(jobs && count >= 1 && count <= 4, "1 .. 4 jobs");
+    HostConvJob j[4];
+    for (int i = 0; i < count; i++) {
+        const dagr_conv_job &q = jobs[i];
+        j[i] = HostConvJob{q.n_nodes_ptr, q.n_nodes_max, q.rowptr, q.col, q.code, q.x, q.ldx, q.cin, q.xskip, q.ldskip,
+                           q.cskip, q.rx, q.ry, q.den_x, q.den_y, q.Wq, q.bias, q.C, q.ldc, q.N, q.relu};
+    }
+    return launch_conv_jobs(j, count, nullptr, stream);
 }
 
 extern "C" size_t dagr_spline_conv_fused_lds_bytes(int32_t cin, int32_t cskip) {

@@ -67,7 +67,7 @@ size_t carve(const dagr_graph_desc &d, char *base, GraphWs *ws) {
     int32_t *slot_xyb = (int32_t *)take(d.max_events * 4);
     int32_t *ev_slot = (int32_t *)take(d.max_events * 4);
     int32_t *long_list = (int32_t *)take((d.max_events / kShortSeg + 2) * 4);
-    int32_t *status = (int32_t *)take(8 * 4);
+    int32_t *status = (int32_t *)take(16 * 4);     // (8, 9: the staging launch's flag words)
     if (ws) *ws = GraphWs{cnt, start, scan_tmp, ev_xyb, ev_t, ev_rank, slot_tmp, slot_it, slot_xyb, ev_slot, long_list, status, P};
     return off;
 }
@@ -90,15 +90,14 @@ int validate(const dagr_graph_desc *d) {
 // K1: denormalise (ev_tgn.py:11-16) + per-pixel count.  One thread per event.
 //   int(pos * [W,H,T] + 1e-3): fp32 multiply, fp32 add (separately rounded -- this TU is built with
 //   -ffp-contract=off), truncation toward zero.
+// `flags`: where the two conditions an event can raise are recorded -- the builder's status words (flags[1] |= 1: outside
+// the sensor / batch; flags[6] = 1: timestamps not sorted), or the staging launch's own two words (see k_stage_window).
 template <typename BatchT, bool kIntPos>
-__global__ __launch_bounds__(kBlock) void k_count(const void *__restrict__ pos_, const BatchT *__restrict__ batch,
-                                                 int N, const int32_t *__restrict__ n_dev, int W, int H, int B, float fW,
-                                                 float fH, float fT, int32_t *__restrict__ cnt,
-                                                 int32_t *__restrict__ ev_xyb, int32_t *__restrict__ ev_t,
-                                                 int32_t *__restrict__ ev_rank, int32_t *__restrict__ status) {
-    const int e = blockIdx.x * kBlock + threadIdx.x;
-    // n_dev: the window's event count in device memory (launches sized for a capacity N: captured HIP graphs)
-    if (e >= N || (n_dev && e >= *n_dev)) return;
+__device__ __forceinline__ void count_event(int e, const void *__restrict__ pos_, const BatchT *__restrict__ batch, int W,
+                                            int H, int B, float fW, float fH, float fT, int32_t *__restrict__ cnt,
+                                            int32_t *__restrict__ ev_xyb, int32_t *__restrict__ ev_t,
+                                            int32_t *__restrict__ ev_rank, int32_t *__restrict__ flag_fov,
+                                            int32_t *__restrict__ flag_time) {
     int x, y, t;
     if (kIntPos) {  // already-denormalised int32 [N,3] (SlidingWindowGraph.forward's own input contract)
         const int32_t *pos = static_cast<const int32_t *>(pos_);
@@ -112,18 +111,18 @@ __global__ __launch_bounds__(kBlock) void k_count(const void *__restrict__ pos_,
     }
     const int b = (int)batch[e];
     ev_t[e] = t;
-    // status[6]: set when timestamps are not non-decreasing in event order inside a sample.  Ids then do not order time,
+    // time flag: set when timestamps are not non-decreasing in event order inside a sample.  Ids then do not order time,
     // and the search kernels fall back from the two binary searches per pixel to the reference's linear FIFO walk.
     if (e > 0 && (int)batch[e - 1] == b) {
         int tp;
         if (kIntPos) tp = static_cast<const int32_t *>(pos_)[3 * (int64_t)(e - 1) + 2];
         else tp = (int)(fT * static_cast<const float *>(pos_)[3 * (int64_t)(e - 1) + 2] + 1e-3f);
-        if (tp > t) status[6] = 1;
+        if (tp > t) *flag_time = 1;
     }
     if (x < 0 || x >= W || y < 0 || y >= H || b < 0 || b >= B) {
         // The reference would index its FIFO volume out of bounds here; we flag and drop the
         // event from the pixel index (it keeps its self loop).
-        atomicOr(&status[1], 1);
+        atomicOr(flag_fov, 1);
         ev_xyb[e] = -1;
         ev_rank[e] = 0;
         return;
@@ -133,13 +132,31 @@ __global__ __launch_bounds__(kBlock) void k_count(const void *__restrict__ pos_,
     ev_rank[e] = atomicAdd(&cnt[p], 1);
 }
 
+template <typename BatchT, bool kIntPos>
+__global__ __launch_bounds__(kBlock) void k_count(const void *__restrict__ pos_, const BatchT *__restrict__ batch,
+                                                 int N, int W, int H, int B, float fW,
+                                                 float fH, float fT, int32_t *__restrict__ cnt,
+                                                 int32_t *__restrict__ ev_xyb, int32_t *__restrict__ ev_t,
+                                                 int32_t *__restrict__ ev_rank, int32_t *__restrict__ status) {
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= N) return;
+    count_event<BatchT, kIntPos>(e, pos_, batch, W, H, B, fW, fH, fT, cnt, ev_xyb, ev_t, ev_rank, status + 1, status + 6);
+}
+
 // K3: scatter event ids into their pixel segment (arrival order).
+// n_dev: the window's event count in device memory (launches sized for a capacity N: captured HIP graphs); K1 then ran
+// inside the staging launch, whose two flag words (status[8], status[9]) this launch moves into the builder's and re-arms.
 __global__ __launch_bounds__(kBlock) void k_scatter(int N, const int32_t *__restrict__ n_dev, int W, int H,
                                                    const int32_t *__restrict__ ev_xyb,
                                                    const int32_t *__restrict__ ev_rank,
                                                    const int32_t *__restrict__ start,
-                                                   int32_t *__restrict__ slot_tmp, int32_t *__restrict__ ev_slot) {
+                                                   int32_t *__restrict__ slot_tmp, int32_t *__restrict__ ev_slot,
+                                                   int32_t *__restrict__ status) {
     const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (n_dev && e == 0) {
+        if (status[8]) { atomicOr(&status[1], 1); status[8] = 0; }
+        if (status[9]) { status[6] = 1; status[9] = 0; }
+    }
     if (e >= N || (n_dev && e >= *n_dev)) return;
     const int c = ev_xyb[e];
     if (c < 0) { ev_slot[e] = -1; return; }
@@ -394,6 +411,27 @@ __global__ __launch_bounds__(kBlock) void k_search(const int32_t *__restrict__ m
         atomicAdd(reinterpret_cast<unsigned long long *>(status + 2), (unsigned long long)blk_edges);
 }
 
+// level-0 inputs in node (slot) order -- pos, sample index and the [polarity | ... | pos_xy] feature row -- written by the
+// LAST launch of the graph build (dagr_graph_build_window_inputs) instead of a launch of their own
+struct GatherArgs {
+    const float *pos, *feat;
+    float *pos_s;
+    int32_t *batch_s;
+    float *x0;
+    int ldx0, col_feat, col_pos;
+};
+__device__ __forceinline__ void gather_node(const GatherArgs &g, int n, const int2 *__restrict__ slot_it,
+                                            const int32_t *__restrict__ slot_xyb) {
+    const int e = slot_it[n].x;
+    const float px = g.pos[3 * (size_t)e], py = g.pos[3 * (size_t)e + 1], pt = g.pos[3 * (size_t)e + 2];
+    g.pos_s[3 * (size_t)n] = px; g.pos_s[3 * (size_t)n + 1] = py; g.pos_s[3 * (size_t)n + 2] = pt;
+    g.batch_s[n] = (slot_xyb[n] >> 24) & 127;
+    float *row = g.x0 + (size_t)n * g.ldx0;
+    row[g.col_feat] = g.feat[e];
+    row[g.col_pos] = px;
+    row[g.col_pos + 1] = py;
+}
+
 // ---------------------------------------------------------------------------------------------
 // K6 (r <= 7): LDS-tiled, persistent variant of k_search<true>.  Same cut semantics, fewer
 // instructions per probed pixel:
@@ -434,8 +472,12 @@ __global__ __launch_bounds__(kBlock) void k_search_tiled(const int32_t *__restri
                                                         int16_t *__restrict__ nbr_code, int32_t *__restrict__ deg,
                                                         int32_t *__restrict__ status,
                                                         const int32_t *__restrict__ node_list,
-                                                        const int32_t *__restrict__ node_list_count) {
+                                                        const int32_t *__restrict__ node_list_count, GatherArgs gather) {
     __shared__ int tile[(kBlock / 16) * 16 * 17];
+    if (gather.pos) {       // (independent of the search: the pixel index is final since k_order_long)
+        const int m = *m_ptr;
+        for (int n = blockIdx.x * kBlock + threadIdx.x; n < m; n += gridDim.x * kBlock) gather_node(gather, n, slot_it, slot_xyb);
+    }
     // list mode (the usual call): most windows defer nothing -- leave before the per-lane spiral constants are built
     // (an empty sweep of the persistent grid cost 10 us per window)
     if (node_list && *node_list_count <= 0) return;
@@ -874,40 +916,34 @@ __global__ __launch_bounds__(kBlock) void k_node_order(int N, const int2 *__rest
     if (event_slot) event_slot[i] = ev_slot[i];
 }
 
-// level-0 inputs in node (slot) order: pos, sample index, and the [polarity | ... | pos_xy] feature row
 __global__ __launch_bounds__(kBlock) void k_gather_inputs(const int32_t *__restrict__ m_ptr, int N,
                                                          const int2 *__restrict__ slot_it,
-                                                         const int32_t *__restrict__ slot_xyb,
-                                                         const float *__restrict__ pos,
-                                                         const float *__restrict__ feat,
-                                                         float *__restrict__ pos_s, int32_t *__restrict__ batch_s,
-                                                         float *__restrict__ x0, int ldx0, int col_feat,
-                                                         int col_pos) {
+                                                         const int32_t *__restrict__ slot_xyb, GatherArgs g) {
     const int n = blockIdx.x * kBlock + threadIdx.x;
     if (n >= N || n >= *m_ptr) return;
-    const int e = slot_it[n].x;
-    const float px = pos[3 * (size_t)e], py = pos[3 * (size_t)e + 1], pt = pos[3 * (size_t)e + 2];
-    pos_s[3 * (size_t)n] = px; pos_s[3 * (size_t)n + 1] = py; pos_s[3 * (size_t)n + 2] = pt;
-    batch_s[n] = (slot_xyb[n] >> 24) & 127;
-    float *row = x0 + (size_t)n * ldx0;
-    row[col_feat] = feat[e];
-    row[col_pos] = px;
-    row[col_pos + 1] = py;
+    gather_node(g, n, slot_it, slot_xyb);
 }
 
-// the caller's window -> the engine's static input buffers + the event count in device memory (captured-graph mode)
+// the caller's window -> the engine's static input buffers + the event count in device memory (captured-graph mode), and K1
+// of the graph build (denormalise + per-pixel count) on the way: the launch in front of the captured window does what the
+// window's first launch would (one launch less on the window's dependent chain).  The builder's status words are cleared
+// here, so what K1 has to report goes to two words of its own (status[8], status[9]; k_scatter moves them over).
 template <typename BatchT>
 __global__ __launch_bounds__(kBlock) void k_stage_window(const float *__restrict__ pos, const float *__restrict__ feat,
                                                         const BatchT *__restrict__ batch, int N,
                                                         float *__restrict__ pos_out, float *__restrict__ feat_out,
                                                         int32_t *__restrict__ batch_out, int32_t *__restrict__ n_dev,
-                                                        int32_t *__restrict__ status8) {
+                                                        int32_t *__restrict__ status8, int W, int H, int B, float fT,
+                                                        int32_t *__restrict__ cnt, int32_t *__restrict__ ev_xyb,
+                                                        int32_t *__restrict__ ev_t, int32_t *__restrict__ ev_rank) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i == 0) *n_dev = N;
-    if (status8 && i < 8) status8[i] = 0;     // the builder's status words start over (dagr_graph_build_window_dev)
+    if (i < 8) status8[i] = 0;     // the builder's status words start over (dagr_graph_build_window_dev)
     if (i < N) {
         feat_out[i] = feat[i];
         batch_out[i] = (int32_t)batch[i];
+        count_event<BatchT, false>(i, pos, batch, W, H, B, (float)W, (float)H, fT, cnt, ev_xyb, ev_t, ev_rank, status8 + 8,
+                                   status8 + 9);
     }
     if (i < 3 * N) pos_out[i] = pos[i];
     if (i + gridDim.x * kBlock < 3 * N) pos_out[i + gridDim.x * kBlock] = pos[i + gridDim.x * kBlock];
@@ -980,13 +1016,14 @@ int dagr_graph_workspace_init(const dagr_graph_desc *desc, void *workspace, size
     }
     DAGR_CHECK_HIP(hipMemsetAsync(ws.cnt, 0, (ws.P + 1 + 8) * 4, (hipStream_t)stream));
     DAGR_CHECK_HIP(hipMemsetAsync(ws.start, 0, (ws.P + 1 + 8) * 4, (hipStream_t)stream));
-    DAGR_CHECK_HIP(hipMemsetAsync(ws.status, 0, 8 * 4, (hipStream_t)stream));
+    DAGR_CHECK_HIP(hipMemsetAsync(ws.status, 0, 16 * 4, (hipStream_t)stream));
     DAGR_CHECK_HIP(hipMemsetAsync(ws.scan_tmp, 0, scan_chained_state_bytes(ws.P + 1), (hipStream_t)stream));
     return DAGR_OK;
 }
 
 static int launch_search(const dagr_graph_desc *desc, const GraphWs &ws, int64_t N, int32_t *nbr_src, int16_t *nbr_code,
-                         int32_t *deg, hipStream_t stream) {
+                         int32_t *deg, hipStream_t stream, const GatherArgs *gather = nullptr) {
+    const GatherArgs ga = gather ? *gather : GatherArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
     const int W = desc->width, H = desc->height;
     const unsigned gS = (unsigned)ceil_div(N * 16, kBlock);
     if (2 * desc->radius + 2 <= 16) {
@@ -1017,11 +1054,16 @@ static int launch_search(const dagr_graph_desc *desc, const GraphWs &ws, int64_t
         k_search_tiled<<<gT, kBlock, 0, stream>>>(ws.start + ws.P, W, H, desc->max_neighbors, desc->queue_size,
                                                   desc->radius, (float)desc->delta_t_us, ws.slot_xyb, ws.start,
                                                   ws.slot_it, nbr_src, nbr_code, deg, ws.status, ws.ev_rank,
-                                                  ws.status + 5);
+                                                  ws.status + 5, ga);
     } else {
         k_search<<<gS, kBlock, 0, stream>>>(ws.start + ws.P, W, H, desc->max_neighbors, desc->queue_size, desc->radius,
                                             (float)desc->delta_t_us, ws.slot_xyb, ws.start, ws.slot_it, nbr_src,
                                             nbr_code, deg, ws.status);
+        if (gather) {
+            DAGR_CHECK_LAUNCH();
+            k_gather_inputs<<<(unsigned)ceil_div(N, kBlock), kBlock, 0, stream>>>(ws.start + ws.P, (int)N, ws.slot_it,
+                                                                                 ws.slot_xyb, ga);
+        }
     }
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;
@@ -1029,7 +1071,7 @@ static int launch_search(const dagr_graph_desc *desc, const GraphWs &ws, int64_t
 
 static int build_window(const dagr_graph_desc *desc, void *workspace, const void *pos, int32_t pos_is_int32,
                         const void *batch, int32_t batch_is_int64, int64_t N, const int32_t *n_dev, int32_t *nbr_src,
-                        int16_t *nbr_code, int32_t *deg, void *stream_) {
+                        int16_t *nbr_code, int32_t *deg, void *stream_, const GatherArgs *gather = nullptr) {
     int rc = validate(desc);
     if (rc != DAGR_OK) return rc;
     DAGR_CHECK_ARG(workspace != nullptr, "workspace is NULL");
@@ -1045,19 +1087,22 @@ static int build_window(const dagr_graph_desc *desc, void *workspace, const void
     const int n = (int)N;
     const unsigned gN = (unsigned)ceil_div(N, kBlock);
     const int W = desc->width, H = desc->height, B = desc->batch_size;
-    // (device-count form: dagr_stage_window, the launch in front of the captured window, has cleared the status words)
-    if (!n_dev) DAGR_CHECK_HIP(hipMemsetAsync(ws.status, 0, 8 * 4, stream));
+    // (device-count form: dagr_stage_window, the launch in front of the captured window, has cleared the status words and
+    // run K1 on the window it staged)
+    if (!n_dev) {
+        DAGR_CHECK_HIP(hipMemsetAsync(ws.status, 0, 8 * 4, stream));
 #define DAGR_LAUNCH_COUNT(BT, IP)                                                                          \
-    k_count<BT, IP><<<gN, kBlock, 0, stream>>>(pos, (const BT *)batch, n, n_dev, W, H, B, (float)W, (float)H, \
+    k_count<BT, IP><<<gN, kBlock, 0, stream>>>(pos, (const BT *)batch, n, W, H, B, (float)W, (float)H,        \
                                                (float)desc->time_window, ws.cnt, ws.ev_xyb, ws.ev_t,         \
                                                ws.ev_rank, ws.status)
-    if (batch_is_int64) { if (pos_is_int32) DAGR_LAUNCH_COUNT(int64_t, true); else DAGR_LAUNCH_COUNT(int64_t, false); }
-    else                { if (pos_is_int32) DAGR_LAUNCH_COUNT(int32_t, true); else DAGR_LAUNCH_COUNT(int32_t, false); }
+        if (batch_is_int64) { if (pos_is_int32) DAGR_LAUNCH_COUNT(int64_t, true); else DAGR_LAUNCH_COUNT(int64_t, false); }
+        else                { if (pos_is_int32) DAGR_LAUNCH_COUNT(int32_t, true); else DAGR_LAUNCH_COUNT(int32_t, false); }
 #undef DAGR_LAUNCH_COUNT
-    DAGR_CHECK_LAUNCH();
+        DAGR_CHECK_LAUNCH();
+    }
     // start = exclusive_scan(cnt); cnt is re-zeroed in the same pass (invariant for the next window)
     DAGR_CHECK_HIP(exclusive_scan_i32_chained(ws.cnt, ws.start, ws.P + 1, ws.scan_tmp, true, stream));
-    k_scatter<<<gN, kBlock, 0, stream>>>(n, n_dev, W, H, ws.ev_xyb, ws.ev_rank, ws.start, ws.slot_tmp, ws.ev_slot);
+    k_scatter<<<gN, kBlock, 0, stream>>>(n, n_dev, W, H, ws.ev_xyb, ws.ev_rank, ws.start, ws.slot_tmp, ws.ev_slot, ws.status);
     DAGR_CHECK_LAUNCH();
     // number of occupied CSR slots M = start[P] <= N (dropped events excluded); slots are a
     // prefix [0, M) so launching N threads with an in-kernel bound read would need M on the host.
@@ -1070,7 +1115,7 @@ static int build_window(const dagr_graph_desc *desc, void *workspace, const void
                                             ws.slot_tmp, ws.slot_it,
                                             ws.long_list, long_cap, ws.status);
     DAGR_CHECK_LAUNCH();
-    return launch_search(desc, ws, N, nbr_src, nbr_code, deg, stream);
+    return launch_search(desc, ws, N, nbr_src, nbr_code, deg, stream, gather);
 }
 
 int dagr_graph_build_window(const dagr_graph_desc *desc, void *workspace, const void *pos, int32_t pos_is_int32,
@@ -1084,6 +1129,18 @@ int dagr_graph_build_window_dev(const dagr_graph_desc *desc, void *workspace, co
                                 int32_t *nbr_src, int16_t *nbr_code, int32_t *deg, void *stream) {
     DAGR_CHECK_ARG(n_dev != nullptr && n_cap > 0, "n_dev is NULL / empty capacity");
     return build_window(desc, workspace, pos, pos_is_int32, batch, batch_is_int64, n_cap, n_dev, nbr_src, nbr_code, deg, stream);
+}
+
+int dagr_graph_build_window_inputs(const dagr_graph_desc *desc, void *workspace, const float *pos, const void *batch,
+                                   int32_t batch_is_int64, int64_t N, const int32_t *n_dev, int32_t *nbr_src,
+                                   int16_t *nbr_code, int32_t *deg, const dagr_l0_inputs *in, void *stream) {
+    DAGR_CHECK_ARG(in != nullptr, "inputs is NULL");
+    if (N == 0) return build_window(desc, workspace, pos, 0, batch, batch_is_int64, N, n_dev, nbr_src, nbr_code, deg, stream);
+    DAGR_CHECK_ARG(pos && in->feat && in->pos_nodes && in->batch_nodes && in->x0 && in->ldx0 >= in->col_pos + 2 &&
+                       in->col_pos >= 0 && in->col_feat >= 0 && in->col_feat < in->ldx0 && in->col_feat != in->col_pos &&
+                       in->col_feat != in->col_pos + 1, "bad level-0 input description");
+    const GatherArgs ga{pos, in->feat, in->pos_nodes, in->batch_nodes, in->x0, in->ldx0, in->col_feat, in->col_pos};
+    return build_window(desc, workspace, pos, 0, batch, batch_is_int64, N, n_dev, nbr_src, nbr_code, deg, stream, &ga);
 }
 
 const int32_t *dagr_graph_node_count_ptr(const dagr_graph_desc *desc, void *workspace) {
@@ -1101,12 +1158,15 @@ int dagr_stage_window(const dagr_graph_desc *desc, void *workspace, const float 
     GraphWs ws;
     carve(*desc, (char *)workspace, &ws);
     const unsigned grid = (unsigned)std::max<int64_t>(1, ceil_div(N, kBlock));
+    const int W = desc->width, H = desc->height, B = desc->batch_size;
     if (batch_is_int64)
-        k_stage_window<int64_t><<<grid, kBlock, 0, (hipStream_t)stream>>>(pos, feat, (const int64_t *)batch, (int)N, pos_out,
-                                                                         feat_out, batch_out, n_dev, ws.status);
+        k_stage_window<int64_t><<<grid, kBlock, 0, (hipStream_t)stream>>>(
+            pos, feat, (const int64_t *)batch, (int)N, pos_out, feat_out, batch_out, n_dev, ws.status, W, H, B,
+            (float)desc->time_window, ws.cnt, ws.ev_xyb, ws.ev_t, ws.ev_rank);
     else
-        k_stage_window<int32_t><<<grid, kBlock, 0, (hipStream_t)stream>>>(pos, feat, (const int32_t *)batch, (int)N, pos_out,
-                                                                         feat_out, batch_out, n_dev, ws.status);
+        k_stage_window<int32_t><<<grid, kBlock, 0, (hipStream_t)stream>>>(
+            pos, feat, (const int32_t *)batch, (int)N, pos_out, feat_out, batch_out, n_dev, ws.status, W, H, B,
+            (float)desc->time_window, ws.cnt, ws.ev_xyb, ws.ev_t, ws.ev_rank);
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;
 }
@@ -1221,8 +1281,9 @@ int dagr_graph_gather_inputs(const dagr_graph_desc *desc, void *workspace, const
                        col_feat >= 0 && col_feat < ldx0 && col_feat != col_pos && col_feat != col_pos + 1, "bad arguments");
     GraphWs ws;
     carve(*desc, (char *)workspace, &ws);
-    k_gather_inputs<<<(unsigned)ceil_div(N, kBlock), kBlock, 0, (hipStream_t)stream>>>(
-        ws.start + ws.P, (int)N, ws.slot_it, ws.slot_xyb, pos, feat, pos_nodes, batch_nodes, x0, ldx0, col_feat, col_pos);
+    const GatherArgs ga{pos, feat, pos_nodes, batch_nodes, x0, ldx0, col_feat, col_pos};
+    k_gather_inputs<<<(unsigned)ceil_div(N, kBlock), kBlock, 0, (hipStream_t)stream>>>(ws.start + ws.P, (int)N, ws.slot_it,
+                                                                                     ws.slot_xyb, ga);
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;
 }

@@ -312,6 +312,10 @@ class WindowEngine:
         self._img_stream = None
         self._net_f = self._cnn_f = None
         self.fuse_convs = os.environ.get("DAGR_FUSE_CONVS", "1") != "0"
+        # head scale 1's convs ride in the launches of layer5 / head scale 2 (dagr_spline_conv_fused_multi)
+        self.merge_heads = os.environ.get("DAGR_MERGE_HEADS", "1") != "0"
+        self._tail_jobs = None
+        self._inputs_gathered = False
         self.fast_coarse_edges = os.environ.get("DAGR_FAST_COARSE_EDGES", "1") != "0"
         self.fuse_pool_accumulate = os.environ.get("DAGR_FUSE_POOL", "1") != "0"
         self._pool_accumulated = [False] * 4
@@ -716,14 +720,23 @@ class WindowEngine:
                                         out, ldo, pack.K, pack.N, 1 if pack.relu else 0, stream), "gemm")
 
     # -------------------------------------------------------------------------------- stages
-    def stage_graph(self, pos, batch):
-        """events -> neighbour lists (EV_TGN.forward, layers/ev_tgn.py:39-58)."""
+    def stage_graph(self, pos, batch, feat=None):
+        """events -> neighbour lists (EV_TGN.forward, layers/ev_tgn.py:39-58).  With ``feat`` (the events' features) the
+        build's last launch also writes the node-ordered level-0 inputs (``stage_l0_input`` then only samples the image
+        features): one launch less per window."""
         N = int(pos.shape[0])
         self._alloc_events(N)
         self._N = N
         self._pos, self._batch = pos, batch
         self._nbr = (self.nbr_src[:N], self.nbr_code[:N], self.deg[:N])
-        self.graph.build(pos, batch, out=self._nbr, n_dev=self.n_dev if self._dev_mode else None)
+        inputs = None
+        if feat is not None and pos.dtype == torch.float32:
+            self._feat_flat = feat.float().reshape(-1).contiguous()      # (kept alive until the launch has run)
+            inputs = _lib.L0Inputs(feat=self._feat_flat.data_ptr(), pos_nodes=self.pos_n.data_ptr(),
+                                   batch_nodes=self.batch_n.data_ptr(), x0=self.x0buf.data_ptr(), ldx0=self.x0_ld,
+                                   col_feat=self.x0_feat_col, col_pos=self.x0_pos_col)
+        self.graph.build(pos, batch, out=self._nbr, n_dev=self.n_dev if self._dev_mode else None, inputs=inputs)
+        self._inputs_gathered = inputs is not None
         self._n_rows = N              # a new window: the asynchronous state of the previous one is gone
         self._async_on = False
 
@@ -843,13 +856,14 @@ class WindowEngine:
     def stage_l0_input(self, feat):
         """Level-0 inputs in node order: x = cat(x, [image feats,] pos[:, :2]) (net.py:118,124-125)."""
         N = self._N
-        f = feat.float().reshape(-1).contiguous()
         x0 = self.x0buf[:N]
         g = self.graph
-        _lib.check(self.L.dagr_graph_gather_inputs(ctypes.byref(g.desc), _lib.ptr(g.workspace), _lib.ptr(self._pos),
-                                                   _lib.ptr(f), N, _lib.ptr(self.pos_n), _lib.ptr(self.batch_n),
-                                                   _lib.ptr(x0), self.x0_ld, self.x0_feat_col, self.x0_pos_col,
-                                                   _lib.cur_stream(self.device)), "graph_gather_inputs")
+        if not self._inputs_gathered:
+            f = feat.float().reshape(-1).contiguous()
+            _lib.check(self.L.dagr_graph_gather_inputs(ctypes.byref(g.desc), _lib.ptr(g.workspace), _lib.ptr(self._pos),
+                                                       _lib.ptr(f), N, _lib.ptr(self.pos_n), _lib.ptr(self.batch_n),
+                                                       _lib.ptr(x0), self.x0_ld, self.x0_feat_col, self.x0_pos_col,
+                                                       _lib.cur_stream(self.device)), "graph_gather_inputs")
         if self.use_image:
             self._sample(self._nptr(), N, self.pos_n, self.batch_n, 0, self._img_feats[0], x0, self.x0_img_col)
         self._x0 = x0
@@ -970,6 +984,77 @@ class WindowEngine:
             if k < 3:
                 self._stage_pool(k)
 
+    def _head_recode(self, i):
+        """Edge codes of head scale i's graph in the head convs' own offset domain, when that differs from the level's
+        (num_scales = 1: the head's table covers pool3's domain, dagr.py:52-62)."""
+        code = self.head_code[i]
+        if code is None:
+            return
+        L, P = self.L, _lib.ptr
+        lvln = self.head_levels[i]
+        lvl = self.levels[lvln - 1]
+        dom = self.head_dom[i]
+        rm = dom["remap"]
+        _lib.check(L.dagr_pool_recode(P(lvl.counts), lvl.T, P(lvl.rowptr), P(lvl.col), P(lvl.pos),
+                                      self.pool_desc[lvln - 1].two_max, float(rm[0, 0]), float(rm[0, 2]),
+                                      float(rm[1, 1]), float(rm[1, 2]), dom["rx"], dom["ry"], P(code),
+                                      lvl.e_cap, ctypes.c_void_p(self.status.data_ptr() + 4), _lib.cur_stream(self.device)),
+                   "pool_recode")
+
+    def _conv_job(self, lvl, pack, x, ldx, xskip, ldskip, out, ldo, dom, code=None):
+        """One entry of a multi-job launch: the arguments ``_conv_generic`` would pass (device addresses as ints)."""
+        code = lvl.code if code is None else code
+        return _lib.ConvJob(n_nodes_ptr=lvl.counts.data_ptr(), n_nodes_max=lvl.T, rowptr=lvl.rowptr.data_ptr(),
+                            col=lvl.col.data_ptr(), code=code.data_ptr(), x=x, ldx=ldx, cin=pack.cin, xskip=xskip,
+                            ldskip=ldskip, cskip=pack.cskip, rx=dom["rx"], ry=dom["ry"], den_x=dom["den_x"],
+                            den_y=dom["den_y"], Wq=pack.Wq.data_ptr(), bias=pack.bias.data_ptr(), C=out, ldc=ldo, N=pack.N,
+                            relu=1 if pack.relu else 0)
+
+    def _build_tail_jobs(self):
+        """Launch plan of layer5 + both head scales when both exist (net.py:166-186, dagr.py:179-236): head scale 1 needs
+        level 3 only, so its convs share the launches of pool4's consumers --
+            [layer5.conv1 | stem_1]  [layer5.conv2 | cls_conv,reg_conv_1]  [stem_2 | reg,obj_pred_1 | cls_pred_1]
+            [cls_conv,reg_conv_2]  [reg,obj_pred_2 | cls_pred_2]
+        five launches where the stream fork ran eight (three of them beside the others, + a fork and a join).  None when
+        a conv of the plan needs the pass form (dagr-m / dagr-l heads) or a single scale exists."""
+        L = self.L
+        if not (self.fuse_convs and self.merge_heads and len(self.head_levels) == 2 and self.head_levels[0] == 3):
+            return None
+        c1, c2 = self.packs[3]
+        packs = [c1, c2] + [p for hp in self.head_packs for p in hp]
+        if any(L.dagr_spline_conv_fused_passes(p.cin, p.cskip) != 1 for p in packs):
+            return None
+        nr = self.n_reg
+        lvl4 = self.levels[3]
+        dom4 = self.dom[4]
+        ldx4, ldh4 = lvl4.x.shape[1], lvl4.hp.shape[1]
+        layer5 = [self._conv_job(lvl4, c1, lvl4.x.data_ptr(), ldx4, None, 0, lvl4.h1.data_ptr(), c1.N, dom4),
+                  self._conv_job(lvl4, c2, lvl4.h1.data_ptr(), c1.N, lvl4.x.data_ptr(), ldx4, lvl4.hp.data_ptr(), ldh4, dom4)]
+        heads = []
+        for i in range(2):
+            lvl = self.levels[self.head_levels[i] - 1]
+            stem, cr, cls, ro = self.head_packs[i]
+            hb, dom, code = self.head_buf[i], self.head_dom[i], self.head_code[i]
+            pred = hb["pred"]
+            npred = pred.shape[1]
+            heads.append([
+                [self._conv_job(lvl, stem, lvl.hp.data_ptr(), lvl.hp.shape[1], None, 0, hb["stem"].data_ptr(), nr, dom, code)],
+                [self._conv_job(lvl, cr, hb["stem"].data_ptr(), nr, None, 0, hb["cr"].data_ptr(), 2 * nr, dom, code)],
+                # pred columns: [reg(4) | obj(1) | cls(num_classes)] = order of collect_outputs (dagr.py:300-302)
+                [self._conv_job(lvl, ro, hb["cr"].data_ptr() + 4 * nr, 2 * nr, None, 0, pred.data_ptr(), npred, dom, code),
+                 self._conv_job(lvl, cls, hb["cr"].data_ptr(), 2 * nr, None, 0, pred.data_ptr() + 4 * 5, npred, dom, code)]])
+        plan = [[layer5[0]] + heads[0][0], [layer5[1]] + heads[0][1], heads[1][0] + heads[0][2], heads[1][1], heads[1][2]]
+        return [((_lib.ConvJob * len(jobs))(*jobs), len(jobs)) for jobs in plan]
+
+    def _stage_level5_and_heads(self):
+        """layer5 and both head scales by the launch plan of ``_build_tail_jobs``."""
+        stream = _lib.cur_stream(self.device)
+        self._pool_accumulated[3] = False
+        for i in range(2):
+            self._head_recode(i)
+        for arr, count in self._tail_jobs:
+            _lib.check(self.L.dagr_spline_conv_fused_multi(arr, count, stream), "spline_conv_fused_multi")
+
     def _stage_head_scale(self, i, scratch=None):
         """GNNHead.process_feature of scale i (dagr.py:179-190): stem, cls_conv | reg_conv (one launch, shared input),
         then reg_pred | obj_pred on the reg half and cls_pred on the cls half of that row as the two jobs of ONE paired
@@ -982,13 +1067,7 @@ class WindowEngine:
         hb = self.head_buf[i]
         dom = self.head_dom[i]
         code = self.head_code[i]
-        if code is not None:
-            rm = dom["remap"]
-            _lib.check(L.dagr_pool_recode(P(lvl.counts), lvl.T, P(lvl.rowptr), P(lvl.col), P(lvl.pos),
-                                          self.pool_desc[lvln - 1].two_max, float(rm[0, 0]), float(rm[0, 2]),
-                                          float(rm[1, 1]), float(rm[1, 2]), dom["rx"], dom["ry"], P(code),
-                                          lvl.e_cap, ctypes.c_void_p(self.status.data_ptr() + 4), stream),
-                       "pool_recode")
+        self._head_recode(i)
         nr = self.n_reg
         self._conv_generic(lvl, stem, P(lvl.hp), lvl.hp.shape[1], None, 0, P(hb["stem"]), nr, dom, stream, code, scratch)
         self._conv_generic(lvl, cr, P(hb["stem"]), nr, None, 0, P(hb["cr"]), 2 * nr, dom, stream, code, scratch)
@@ -1048,6 +1127,15 @@ class WindowEngine:
         (out3), so it runs on a side stream next to pool4 -> layer5 -> head scale 2 (net.py:166-186, dagr.py:213-236);
         then to_dense + image-logit fusion + decode of both scales in one launch.  Returns the decoded outputs."""
         first = self.head_levels[0]                  # 3 when both scales exist, 4 with num_scales = 1
+        if trace is None:
+            if self._tail_jobs is None:
+                self._tail_jobs = self._build_tail_jobs() or False
+            if self._tail_jobs:
+                for k in range(3):
+                    self._stage_level(k)
+                    self._stage_pool(k)
+                self._stage_level5_and_heads()
+                return self._heads_finish()
         done = [False] * len(self.head_levels)
         cur = torch.cuda.current_stream(self.device)
         forked = False
@@ -1097,7 +1185,7 @@ class WindowEngine:
             c = self._cnn_out
             return self._decode_maps([torch.cat([c["reg_output"][k], c["obj_output"][k], c["cls_output"][k]], 1)
                                       for k in range(self.num_scales)])
-        self.stage_graph(pos.contiguous(), batch.contiguous())
+        self.stage_graph(pos.contiguous(), batch.contiguous(), feat)
         self.stage_l0_input(feat)
         self.stage_l0_conv1()
         self.stage_l0_conv2()
@@ -1133,13 +1221,13 @@ class WindowEngine:
                 fork.record(cur)
                 self._head_stream.wait_event(fork)
                 with torch.cuda.stream(self._head_stream):
-                    self.stage_graph(self.in_pos, self.in_batch)
+                    self.stage_graph(self.in_pos, self.in_batch, self.in_feat)
                     join = torch.cuda.Event()
                     join.record(self._head_stream)
                 self.stage_image(self.in_image)
                 cur.wait_event(join)
             else:
-                self.stage_graph(self.in_pos, self.in_batch)
+                self.stage_graph(self.in_pos, self.in_batch, self.in_feat)
             self.stage_l0_input(self.in_feat)
             self.stage_l0_conv1()
             self.stage_l0_conv2()

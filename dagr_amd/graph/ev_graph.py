@@ -60,7 +60,7 @@ class WindowGraphBuilder:
         import ctypes as _c
         return _c.c_void_p(_lib.lib().dagr_graph_node_count_ptr(ctypes.byref(self.desc), _lib.ptr(self.workspace)))
 
-    def build(self, pos, batch, out=None, n_dev=None):
+    def build(self, pos, batch, out=None, n_dev=None, inputs=None):
         """``n_dev`` (int32[1] on the device): the event count lives in device memory -- ``pos`` / ``batch`` are capacity-sized
         buffers and every launch is bounded by ``*n_dev`` on the device (a window captured once as a HIP graph then serves
         windows of any size)."""
@@ -81,6 +81,14 @@ class WindowGraphBuilder:
         else:
             nbr_src, nbr_code, deg = out
         L = _lib.lib()
+        if inputs is not None:
+            # ``inputs`` (_lib.L0Inputs): the node-ordered level-0 inputs come out of the build's last launch
+            _lib.check(L.dagr_graph_build_window_inputs(ctypes.byref(self.desc), _lib.ptr(self.workspace), _lib.ptr(pos),
+                                                        _lib.ptr(batch), 1 if batch.dtype == torch.int64 else 0, N,
+                                                        _lib.ptr(n_dev) if n_dev is not None else None, _lib.ptr(nbr_src),
+                                                        _lib.ptr(nbr_code), _lib.ptr(deg), ctypes.byref(inputs),
+                                                        _lib.cur_stream(self.device)), "graph_build_window_inputs")
+            return nbr_src, nbr_code, deg
         if n_dev is not None:
             _lib.check(L.dagr_graph_build_window_dev(ctypes.byref(self.desc), _lib.ptr(self.workspace), _lib.ptr(pos),
                                                      1 if pos.dtype == torch.int32 else 0, _lib.ptr(batch),

@@ -126,7 +126,8 @@ int dagr_graph_build_window(const dagr_graph_desc *desc, void *workspace,
 
 /* dagr_graph_build_window with the event count in DEVICE memory: every launch is sized for `n_cap` events and bounded by
  * *n_dev (<= n_cap) on the device, so the call can be captured in a HIP graph once and replayed for windows of any size.
- * pos / batch must hold n_cap entries' worth of storage (entries past *n_dev are not read). */
+ * pos / batch: the static buffers dagr_stage_window filled -- that launch has already run the build's first step
+ * (denormalise + per-pixel count) on them and cleared the status words; this call continues from there. */
 int dagr_graph_build_window_dev(const dagr_graph_desc *desc, void *workspace, const void *pos, int32_t pos_is_int32,
                                 const void *batch, int32_t batch_is_int64, int64_t n_cap, const int32_t *n_dev,
                                 int32_t *nbr_src, int16_t *nbr_code, int32_t *deg, void *stream);
@@ -134,8 +135,9 @@ int dagr_graph_build_window_dev(const dagr_graph_desc *desc, void *workspace, co
  * that follow it in a captured window */
 const int32_t *dagr_graph_node_count_ptr(const dagr_graph_desc *desc, void *workspace);
 /* One launch that copies a caller's window (format_data output: pos fp32[N,3], feat fp32[N], batch int32/int64[N]) into
- * static buffers (batch as int32), writes N to *n_dev and clears the builder's status words: the only per-window launch in
- * front of a captured window graph (dagr_graph_build_window_dev relies on it for the status words). */
+ * static buffers (batch as int32), writes N to *n_dev, clears the builder's status words and runs the build's first step
+ * (denormalise_pos + the per-pixel count, ev_tgn.py:11-16): the only per-window launch in front of a captured window graph
+ * (dagr_graph_build_window_dev continues from its results). */
 int dagr_stage_window(const dagr_graph_desc *desc, void *workspace, const float *pos, const float *feat, const void *batch,
                       int32_t batch_is_int64, int64_t N, float *pos_out, float *feat_out, int32_t *batch_out,
                       int32_t *n_dev, void *stream);
@@ -176,6 +178,19 @@ int dagr_graph_node_order(const dagr_graph_desc *desc, void *workspace, int64_t 
 int dagr_graph_gather_inputs(const dagr_graph_desc *desc, void *workspace, const float *pos, const float *feat,
                              int64_t N, float *pos_nodes, int32_t *batch_nodes, float *x0, int32_t ldx0,
                              int32_t col_feat, int32_t col_pos, void *stream);
+
+/* dagr_graph_build_window (n_dev NULL) / dagr_graph_build_window_dev (n_dev given) on normalised fp32 positions that ALSO
+ * writes the node-ordered level-0 inputs of dagr_graph_gather_inputs, from its last launch: one launch less per window. */
+typedef struct dagr_l0_inputs {
+    const float *feat;          /* fp32[N] per event (polarity)                       */
+    float *pos_nodes;           /* fp32[N,3]                                          */
+    int32_t *batch_nodes;       /* int32[N]                                           */
+    float *x0;                  /* level-0 feature rows, row stride ldx0              */
+    int32_t ldx0, col_feat, col_pos;
+} dagr_l0_inputs;
+int dagr_graph_build_window_inputs(const dagr_graph_desc *desc, void *workspace, const float *pos, const void *batch,
+                                   int32_t batch_is_int64, int64_t N, const int32_t *n_dev, int32_t *nbr_src,
+                                   int16_t *nbr_code, int32_t *deg, const dagr_l0_inputs *inputs, void *stream);
 
 /* ------------------------------------------------------------------------ *
  * SplineConv (degree-1 open B-spline, 5x5 kernel, sum aggregation)
@@ -270,6 +285,25 @@ int dagr_spline_conv_fused_pair(const int32_t *n_nodes_ptr, int32_t n_nodes_max,
                                 float den_x, float den_y, int32_t ldc, int32_t relu, const float *x_a, const float *Wq_a,
                                 const float *bias_a, float *C_a, int32_t N_a, const float *x_b, const float *Wq_b,
                                 const float *bias_b, float *C_b, int32_t N_b, void *stream);
+/* 1 .. 4 INDEPENDENT fused convs in one launch (gridDim.z = job): each job is a full dagr_spline_conv_fused argument set
+ * (its own graph, row shape, weights, output).  What a window offers at one point of its dependency graph -- head scale 1's
+ * stem beside the first conv of layer5, its cls_conv | reg_conv beside the second, its predictors beside head scale 2's
+ * stem (model/networks/net.py:166-186, dagr.py:213-236) -- costs one launch instead of a stream fork + join.  All jobs must
+ * take the same form (dagr_spline_conv_fused_passes == 1 for all, or > 1 for all); DAGR_ERR_UNSUPPORTED otherwise. */
+typedef struct dagr_conv_job {
+    const int32_t *n_nodes_ptr;
+    int32_t n_nodes_max;
+    const int32_t *rowptr, *col, *code;
+    const float *x;
+    int32_t ldx, cin;
+    const float *xskip;
+    int32_t ldskip, cskip, rx, ry;
+    float den_x, den_y;
+    const float *Wq, *bias;
+    float *C;
+    int32_t ldc, N, relu;
+} dagr_conv_job;
+int dagr_spline_conv_fused_multi(const dagr_conv_job *jobs, int32_t count, void *stream);
 /* generic step 2: C[M,N] = act(A[M,K] . Wm[K,N] + bias[N]); M = min(*m_ptr, m_max) */
 int dagr_gemm_bias_act(const int32_t *m_ptr, int32_t m_max, const float *A, int32_t lda,
                        const float *Wm, int32_t ldw, const float *bias, float *C, int32_t ldc,

@@ -115,3 +115,91 @@ def test_format_events_bit_exact_vs_reference_golden():
     d = format_data(d)
     assert np.array_equal(d.pos.cpu().numpy(), syn.format_data_np(x, y, t, 640, 480))
     assert np.array_equal(d.x.cpu().numpy(), p.astype(np.float32).reshape(-1, 1))
+
+
+def _float_case(case):
+    from dagr_amd.utils.synthetic import format_data_np
+    dev = torch.device("cuda:0")
+    pos = torch.from_numpy(format_data_np(case["x"], case["y"], case["t"], case["W"], case["H"])).to(dev)
+    batch = torch.from_numpy(case["b"].astype(np.int64)).to(dev)
+    feat = torch.from_numpy(np.where(np.arange(len(case["x"])) % 3 == 0, -1.0, 1.0).astype(np.float32)).to(dev)
+    return pos, batch, feat
+
+
+def _builder(case, N):
+    from dagr_amd.graph.ev_graph import WindowGraphBuilder
+    return WindowGraphBuilder(case["W"], case["H"], case["B"], case["K"], case["Q"], case["r"], case["dt"],
+                              max_events=max(N, 16), device=torch.device("cuda:0"))
+
+
+@pytest.mark.parametrize("case", medium_cases()[:2] + small_cases()[:4], ids=lambda c: c["name"])
+def test_build_with_level0_inputs_equals_build_then_gather(case):
+    """dagr_graph_build_window_inputs (the node-ordered level-0 inputs written by the build's last launch) ==
+    dagr_graph_build_window + dagr_graph_gather_inputs, bit for bit: neighbour lists, pos / sample of every node, the
+    feature row's own columns; the columns left for image features stay untouched."""
+    import ctypes
+    from dagr_amd import _lib
+    L, P = _lib.lib(), _lib.ptr
+    dev = torch.device("cuda:0")
+    pos, batch, feat = _float_case(case)
+    N = int(pos.shape[0])
+    if N == 0:
+        pytest.skip("empty case")
+    g = _builder(case, N)
+    ld, col_feat, col_pos = 6, 4, 1
+    a = g.build(pos, batch)
+    pos_a = torch.full((N, 3), -5.0, device=dev); b_a = torch.full((N,), -5, dtype=torch.int32, device=dev)
+    x_a = torch.full((N, ld), -5.0, device=dev)
+    _lib.check(L.dagr_graph_gather_inputs(ctypes.byref(g.desc), P(g.workspace), P(pos), P(feat), N, P(pos_a), P(b_a), P(x_a), ld,
+                                          col_feat, col_pos, _lib.cur_stream(dev)), "gather")
+    ne_a = g.status()
+    pos_b = torch.full((N, 3), -5.0, device=dev); b_b = torch.full((N,), -5, dtype=torch.int32, device=dev)
+    x_b = torch.full((N, ld), -5.0, device=dev)
+    inputs = _lib.L0Inputs(feat=feat.data_ptr(), pos_nodes=pos_b.data_ptr(), batch_nodes=b_b.data_ptr(), x0=x_b.data_ptr(),
+                           ldx0=ld, col_feat=col_feat, col_pos=col_pos)
+    b = g.build(pos, batch, inputs=inputs)
+    assert g.status() == ne_a
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    assert torch.equal(pos_a, pos_b) and torch.equal(b_a, b_b) and torch.equal(x_a, x_b)
+    assert bool((x_b[:, [0, 3, 5]] == -5.0).all()) and not bool((x_b[:, col_feat] == -5.0).any())
+
+
+@pytest.mark.parametrize("mutate", ["plain", "out_of_range", "unsorted_time"])
+def test_staged_device_count_build_equals_host_count_build(mutate):
+    """The captured-window form: dagr_stage_window (copy + event count to device memory + the build's first step) followed by
+    dagr_graph_build_window_dev on capacity-sized buffers == dagr_graph_build_window on the window itself -- neighbour
+    lists, edge count and the status flags (an event outside the sensor, timestamps out of order), also when the same
+    buffers then serve a smaller window."""
+    import ctypes
+    from dagr_amd import _lib
+    L, P = _lib.lib(), _lib.ptr
+    dev = torch.device("cuda:0")
+    case = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in medium_cases()[0].items()}
+    if mutate == "out_of_range":
+        case["x"][5] = case["W"] + 2
+    if mutate == "unsorted_time":
+        i = len(case["t"]) // 2
+        case["t"][i], case["t"][i + 1] = case["t"][i + 1] + 7, case["t"][i]
+    pos, batch, feat = _float_case(case)
+    N = int(pos.shape[0])
+    cap = N + 1000
+    K = case["K"]
+    for n in (N, N // 3):
+        g1 = _builder(case, cap)
+        want = g1.build(pos[:n].contiguous(), batch[:n].contiguous())
+        want_status = g1.status()
+        g2 = _builder(case, cap)
+        in_pos = torch.zeros((cap, 3), device=dev); in_feat = torch.zeros((cap,), device=dev)
+        in_batch = torch.zeros((cap,), dtype=torch.int32, device=dev); n_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
+        out = (torch.zeros((cap, K), dtype=torch.int32, device=dev), torch.zeros((cap, K), dtype=torch.int16, device=dev),
+               torch.zeros((cap,), dtype=torch.int32, device=dev))
+        for rep in range(2):        # twice: the staging launch re-arms what the previous window left
+            _lib.check(L.dagr_stage_window(ctypes.byref(g2.desc), P(g2.workspace), P(pos), P(feat), P(batch), 1, n, P(in_pos),
+                                           P(in_feat), P(in_batch), P(n_dev), _lib.cur_stream(dev)), "stage_window")
+            g2.build(in_pos, in_batch, out=out, n_dev=n_dev)
+        assert g2.status() == want_status, (mutate, n)
+        if mutate == "out_of_range":
+            assert want_status[1] & 1
+        for u, v in zip(want, out):
+            assert torch.equal(u, v[:n]), (mutate, n)

@@ -129,3 +129,79 @@ def test_fused_rejects_oversized_k():
     rc = L.dagr_spline_conv_fused(None, 1, _lib.ptr(z), _lib.ptr(z), _lib.ptr(z), _lib.ptr(f), 2400, 2400, None, 0, 0, 7, 7,
                                   14.0, 14.0, _lib.ptr(f), None, _lib.ptr(f), 64, 64, 1, _lib.cur_stream(dev))
     assert rc != 0 and b"does not fit" in L.dagr_last_error()
+
+
+def _random_job(rng, dev, T, cin, cskip, N, max_deg, relu, live=None):
+    """Device buffers + the dagr_conv_job of one random conv; returns (job, out tensor, keep-alive list)."""
+    from dagr_amd import _lib
+    r, den = 7, (14.0, 17.5)
+    deg = rng.integers(0, max_deg + 1, size=T)
+    rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    E = max(1, int(rowptr[-1]))
+    t = lambda a: torch.from_numpy(a).to(dev)
+    col = t(rng.integers(0, T, size=E).astype(np.int32))
+    code = t((rng.integers(0, 2 * r + 1, size=E) | (rng.integers(0, 2 * r + 1, size=E) << 16)).astype(np.int32))
+    x = t(rng.standard_normal((T, cin)).astype(np.float32))
+    xs = t(rng.standard_normal((T, cskip)).astype(np.float32)) if cskip else None
+    K = 26 * cin + cskip
+    Wq = _pack_wq(t((rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)))
+    bias = t(rng.standard_normal(N).astype(np.float32))
+    n_ptr = torch.tensor([T if live is None else live], dtype=torch.int32, device=dev)
+    d_rowptr = t(rowptr)
+    out = torch.full((T, N), 7.0, dtype=torch.float32, device=dev)
+    job = _lib.ConvJob(n_nodes_ptr=n_ptr.data_ptr(), n_nodes_max=T, rowptr=d_rowptr.data_ptr(), col=col.data_ptr(),
+                       code=code.data_ptr(), x=x.data_ptr(), ldx=cin, cin=cin, xskip=xs.data_ptr() if cskip else None,
+                       ldskip=cskip, cskip=cskip, rx=r, ry=r, den_x=den[0], den_y=den[1], Wq=Wq.data_ptr(),
+                       bias=bias.data_ptr(), C=out.data_ptr(), ldc=N, N=N, relu=int(relu))
+    return job, out, [n_ptr, d_rowptr, col, code, x, xs, Wq, bias]
+
+
+MULTI = [  # jobs of one launch: (T, cin, cskip, N, max_deg, relu, live rows or None)
+    [(70, 66, 0, 64, 6, True, 36), (280, 64, 0, 64, 7, True, 141)],                               # layer5.conv1 | stem_1
+    [(70, 64, 66, 64, 6, True, 36), (280, 64, 0, 128, 7, True, 141)],                             # layer5.conv2 | cls,reg conv_1
+    [(70, 64, 0, 64, 6, True, None), (280, 64, 0, 5, 7, False, 141), (280, 64, 0, 2, 7, False, 141)],   # stem_2 | preds_1
+    [(1300, 32, 0, 200, 9, True, 1122), (16, 3, 5, 7, 0, True, None), (37, 64, 64, 128, 70, False, None),
+     (5000, 82, 0, 64, 8, True, 4482)],                                                           # four very different jobs
+    [(300, 128, 0, 256, 9, True, None), (150, 256, 0, 7, 70, False, None)],                       # pass form for all jobs
+]
+
+
+@pytest.mark.parametrize("specs", MULTI)
+def test_multi_job_launch_equals_single_launches_bit_for_bit(specs):
+    """dagr_spline_conv_fused_multi: every job's output equals what dagr_spline_conv_fused writes for it alone (same
+    column split, same K partial order), rows past a job's device-side count untouched."""
+    from dagr_amd import _lib
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(len(specs) * 977 + specs[0][0])
+    S = _lib.cur_stream(dev)
+    jobs, outs, keep = [], [], []
+    for sp in specs:
+        j, o, k = _random_job(rng, dev, *sp)
+        jobs.append(j); outs.append(o); keep.append(k)
+    arr = (_lib.ConvJob * len(jobs))(*jobs)
+    _lib.check(L.dagr_spline_conv_fused_multi(arr, len(jobs), S), "multi")
+    torch.cuda.synchronize()
+    got = [o.clone() for o in outs]
+    for j, o, sp in zip(jobs, outs, specs):
+        o.fill_(7.0)
+        _lib.check(L.dagr_spline_conv_fused(j.n_nodes_ptr, j.n_nodes_max, j.rowptr, j.col, j.code, j.x, j.ldx, j.cin, j.xskip,
+                                            j.ldskip, j.cskip, j.rx, j.ry, j.den_x, j.den_y, j.Wq, j.bias, j.C, j.ldc, j.N,
+                                            j.relu, S), "single")
+    torch.cuda.synchronize()
+    for g, o, sp in zip(got, outs, specs):
+        assert torch.equal(g, o), sp
+        live = sp[0] if sp[6] is None else sp[6]
+        assert bool((g[live:] == 7.0).all()) and not bool((g[:live] == 7.0).all()), sp
+
+
+def test_multi_job_launch_rejects_mixed_forms():
+    from dagr_amd import _lib
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    a = _random_job(rng, dev, 64, 64, 0, 64, 5, True)
+    b = _random_job(rng, dev, 64, 128, 0, 64, 5, True)          # needs passes
+    arr = (_lib.ConvJob * 2)(a[0], b[0])
+    rc = L.dagr_spline_conv_fused_multi(arr, 2, _lib.cur_stream(dev))
+    assert rc != 0 and b"cannot share a launch" in L.dagr_last_error()
