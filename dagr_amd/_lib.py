@@ -110,6 +110,8 @@ SIGNATURES = {
     "dagr_graph_build_window_inputs": (ctypes.c_int, [ctypes.POINTER(GraphDesc), c_void_p, c_void_p, c_void_p, c_i32, c_i64,
                                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dagr_graph_node_count_ptr": (c_void_p, [ctypes.POINTER(GraphDesc), c_void_p]),
+    "dagr_graph_csr_codes": (ctypes.c_int, [ctypes.POINTER(GraphDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i32,
+                                            c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
     "dagr_stage_window": (ctypes.c_int, [ctypes.POINTER(GraphDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i64,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dagr_spiral_offsets": (ctypes.c_int, [c_i32, c_void_p, c_void_p]),
@@ -141,6 +143,7 @@ SIGNATURES = {
     "dagr_pool_recode": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
                                         c_float, c_i32, c_i32, c_void_p, c_i32, c_void_p, c_void_p]),
     "dagr_pool_status": (ctypes.c_int, [ctypes.POINTER(PoolDesc), c_void_p, ctypes.POINTER(c_i32), c_void_p]),
+    "dagr_pool_status_ptr": (c_void_p, [ctypes.POINTER(PoolDesc), c_void_p]),
     "dagr_pool_counters": (ctypes.c_int, [ctypes.POINTER(PoolDesc), c_void_p, c_void_p, c_void_p]),
     "dagr_to_dense": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_i32, c_i32, c_void_p, c_void_p, c_float, c_float,
                                      c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -905,6 +905,36 @@ __global__ __launch_bounds__(kBlock) void k_edge_index(int N, int K, const int32
     edge_index[row_stride + o] = e;
 }
 
+// the same rows as k_edge_index, as what the convolutions consume: source event id and offset code per edge
+// (dx + bias) | (dy + bias) << 16 with (dx, dy) = pixel of the source - pixel of the destination
+__global__ __launch_bounds__(kBlock) void k_csr_codes(int N, int K, int side, int r, int bias,
+                                                     const int32_t *__restrict__ ev_slot,
+                                                     const int2 *__restrict__ slot_it,
+                                                     const int32_t *__restrict__ nbr_src,
+                                                     const int16_t *__restrict__ nbr_code,
+                                                     const int32_t *__restrict__ deg,
+                                                     const int32_t *__restrict__ rowptr, int32_t *__restrict__ col,
+                                                     int32_t *__restrict__ code, int64_t e_cap) {
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int e = (int)(gid / K);
+    const int j = (int)(gid % K);
+    if (e >= N) return;
+    const int s = ev_slot[e];
+    const int d = s >= 0 ? deg[s] : 1;
+    if (j >= d) return;
+    const int64_t o = (int64_t)rowptr[e] + j;
+    if (o >= e_cap) return;
+    int src = e, dx = 0, dy = 0;                 // an event outside the sensor keeps its self loop only
+    if (s >= 0) {
+        src = slot_it[nbr_src[(int64_t)s * K + j]].x;
+        const int c = nbr_code[(int64_t)s * K + j];
+        dx = c / side - r;
+        dy = c % side - r;
+    }
+    col[o] = src;
+    code[o] = (dx + bias) | ((dy + bias) << 16);
+}
+
 __global__ __launch_bounds__(kBlock) void k_node_order(int N, const int2 *__restrict__ slot_it,
                                                       const int32_t *__restrict__ ev_slot,
                                                       const int32_t *__restrict__ m_ptr,
@@ -1252,6 +1282,31 @@ int dagr_graph_edge_index(const dagr_graph_desc *desc, void *workspace, const in
                                                                               row_stride);
         DAGR_CHECK_LAUNCH();
     }
+    return DAGR_OK;
+}
+
+int dagr_graph_csr_codes(const dagr_graph_desc *desc, void *workspace, const int32_t *nbr_src, const int16_t *nbr_code,
+                         const int32_t *deg, int64_t N, int32_t code_bias, int32_t *rowptr, int32_t *scan_scratch,
+                         int32_t *col, int32_t *code, int64_t e_cap, void *stream_) {
+    int rc = validate(desc);
+    if (rc != DAGR_OK) return rc;
+    DAGR_CHECK_ARG(workspace && N >= 0 && rowptr && scan_scratch && code_bias >= 0 && code_bias < (1 << 15), "bad arguments");
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N == 0) {
+        DAGR_CHECK_HIP(hipMemsetAsync(rowptr, 0, 4, stream));
+        return DAGR_OK;
+    }
+    DAGR_CHECK_ARG(nbr_src && nbr_code && deg && col && code && e_cap >= 0, "NULL pointer");
+    GraphWs ws;
+    carve(*desc, (char *)workspace, &ws);
+    const int K = desc->max_neighbors;
+    k_deg_by_event<<<(unsigned)ceil_div(N + 1, kBlock), kBlock, 0, stream>>>((int)N, ws.ev_slot, deg, rowptr);
+    DAGR_CHECK_LAUNCH();
+    DAGR_CHECK_HIP(exclusive_scan_i32(rowptr, rowptr, N + 1, scan_scratch, false, stream));
+    k_csr_codes<<<(unsigned)ceil_div(N * K, kBlock), kBlock, 0, stream>>>((int)N, K, 2 * desc->radius + 1, desc->radius,
+                                                                         code_bias, ws.ev_slot, ws.slot_it, nbr_src,
+                                                                         nbr_code, deg, rowptr, col, code, e_cap);
+    DAGR_CHECK_LAUNCH();
     return DAGR_OK;
 }
 

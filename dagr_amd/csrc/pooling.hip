@@ -1219,6 +1219,13 @@ int dagr_pool_status(const dagr_pool_desc *desc, void *pool_ws, int32_t *flags_h
     return DAGR_OK;
 }
 
+const int32_t *dagr_pool_status_ptr(const dagr_pool_desc *desc, void *pool_ws) {
+    if (validate_pool(desc) != DAGR_OK || !pool_ws) return nullptr;
+    PoolWs ws;
+    pool_carve(*desc, (char *)pool_ws, &ws);
+    return ws.status;
+}
+
 int dagr_pool_counters(const dagr_pool_desc *desc, void *pool_ws, int32_t *out8_host, void *stream) {
     int rc = validate_pool(desc);
     if (rc != DAGR_OK) return rc;

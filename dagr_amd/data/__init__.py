@@ -12,10 +12,31 @@ class Data:
             setattr(self, k, v)
 
     def keys(self):
-        return [k for k in self.__dict__.keys() if not k.startswith("_")]
+        lazy = self.__dict__.get("_lazy") or {}
+        return [k for k in self.__dict__.keys() if not k.startswith("_")] + [k for k in lazy if k not in self.__dict__]
 
     def __contains__(self, key):
-        return key in self.__dict__
+        return key in self.__dict__ or key in (self.__dict__.get("_lazy") or {})
+
+    # Attributes that are derived from others and cost launches to build (the reference-shaped ``edge_index`` /
+    # ``edge_attr`` of a graph the kernels hold as CSR + offset codes) can be registered as recipes: they are built on
+    # first access and behave like plain attributes from then on; assigning the attribute replaces the recipe.
+    def set_lazy(self, name, fn):
+        self.__dict__.pop(name, None)
+        lazy = dict(self.__dict__.get("_lazy") or {})        # (never shared with the object this one was copied from)
+        lazy[name] = fn
+        self.__dict__["_lazy"] = lazy
+
+    def is_lazy(self, name):
+        return name not in self.__dict__ and name in (self.__dict__.get("_lazy") or {})
+
+    def __getattr__(self, name):                              # reached only when the normal lookup fails
+        lazy = self.__dict__.get("_lazy")
+        if lazy is not None and name in lazy:
+            value = lazy[name](self)
+            self.__dict__[name] = value
+            return value
+        raise AttributeError(f"{type(self).__name__!r} object has no attribute {name!r}")
 
     def _apply(self, fn):
         out = copy.copy(self)
@@ -78,6 +99,11 @@ class Batch(Data):
                 setattr(out, k, list(vals))
         out.batch = torch.cat([torch.full((n,), i, dtype=torch.long) for i, n in enumerate(n_nodes)])
         out._num_graphs = len(data_list)
+        d0 = data_list[0]
+        if all(hasattr(d0, k) for k in ("width", "height", "time_window")):
+            # the sensor geometry as python ints: format_data / EV_TGN read it per batch, and the collated tensors move to
+            # the device with the batch (a read-back there is a host synchronisation per scalar)
+            out._geometry = tuple(int(getattr(d0, k)) for k in ("width", "height", "time_window"))
         return out
 
 

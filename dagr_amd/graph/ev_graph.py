@@ -127,6 +127,23 @@ class WindowGraphBuilder:
                                                     _lib.cur_stream(self.device)), "graph_node_order")
         return slot_event, event_slot
 
+    def csr_codes(self, nbr_src, nbr_code, deg, code_bias):
+        """(rowptr int32[N+1] by destination event, col int32[N*K] source event ids, code int32[N*K] offset codes
+        (dx + code_bias) | (dy + code_bias) << 16): the graph as the convolutions consume it, no host synchronisation
+        (entries past rowptr[N] are unused capacity)."""
+        N = int(deg.shape[0])
+        L = _lib.lib()
+        rowptr = torch.empty((N + 1,), dtype=torch.int32, device=self.device)
+        cap = max(1, N * self.K)
+        col = torch.empty((cap,), dtype=torch.int32, device=self.device)
+        code = torch.empty((cap,), dtype=torch.int32, device=self.device)
+        scratch = torch.empty((L.dagr_scan_scratch_elems(N + 1),), dtype=torch.int32, device=self.device)
+        _lib.check(L.dagr_graph_csr_codes(ctypes.byref(self.desc), _lib.ptr(self.workspace), _lib.ptr(nbr_src),
+                                          _lib.ptr(nbr_code), _lib.ptr(deg), N, int(code_bias), _lib.ptr(rowptr),
+                                          _lib.ptr(scratch), _lib.ptr(col), _lib.ptr(code), cap,
+                                          _lib.cur_stream(self.device)), "graph_csr_codes")
+        return rowptr, col, code
+
     def edge_index(self, nbr_src, deg):
         """Reference-shaped ``int64[2,E]`` in event ids (synchronises to learn E) + rowptr int32[N+1]."""
         N = int(deg.shape[0])

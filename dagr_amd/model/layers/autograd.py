@@ -122,7 +122,11 @@ class PoolFeatFn(torch.autograd.Function):
             _lib.check(L.dagr_pool_argmax(P(cluster), n, P(xc), C, C, P(pooled), pooled.stride(0), nc, P(arg), stream),
                        "pool_argmax")
         else:
-            count = torch.bincount(cluster[cluster >= 0].long(), minlength=max(nc, 1)).int()
+            # members per cluster; nodes outside the grid (-1) go to a spare slot (no mask indexing: no host sync)
+            count = torch.zeros((max(nc, 1) + 1,), dtype=torch.int32, device=x.device)
+            count.scatter_add_(0, torch.where(cluster >= 0, cluster, torch.full_like(cluster, max(nc, 1))).long(),
+                               torch.ones_like(cluster))
+            count = count[:max(nc, 1)].contiguous()
         ctx.save_for_backward(cluster, arg if arg is not None else count)
         ctx.meta = (n, C, aggr)
         return pooled

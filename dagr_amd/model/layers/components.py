@@ -35,6 +35,11 @@ class Cartesian(torch.nn.Module):
 
     def forward(self, data):                                    # components.py:30-35
         from . import _ops
-        data.edge_attr = _ops.cartesian(data.pos, data.edge_index, self.max)
+        if getattr(data, "is_lazy", None) is not None and data.is_lazy("edge_index"):
+            # the graph is held as CSR + integer pixel offsets (EV_TGN's training graph): the attribute tensor is a recipe,
+            # like edge_index itself -- the training-mode convs read the offsets, not the attributes
+            data.set_lazy("edge_attr", lambda d, m=self.max: _ops.cartesian(d.pos, d.edge_index, m))
+        else:
+            data.edge_attr = _ops.cartesian(data.pos, data.edge_index, self.max)
         data.edge_attr_max = self.max       # read by the training-mode conv to recover exact pixel offsets
         return data

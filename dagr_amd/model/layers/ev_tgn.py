@@ -14,6 +14,9 @@ from ...graph.ev_graph import SlidingWindowGraph, WindowGraphBuilder
 
 
 def _get_value_as_int(obj, key):
+    geo = getattr(obj, "_geometry", None)        # (width, height, time_window) as read once by format_data
+    if geo is not None and key in ("width", "height", "time_window"):
+        return geo[("width", "height", "time_window").index(key)]
     val = getattr(obj, key)
     return int(val) if isinstance(val, (int, float)) else int(val[0])
 
@@ -66,11 +69,16 @@ class EV_TGN(torch.nn.Module):
                                                      device=events.pos.device)
             self._train_key = key
         b = self._train_builder
-        nbr_src, _, deg = b.build(events.pos.float().contiguous(), events.batch.contiguous())
-        ei, rowptr = b.edge_index(nbr_src, deg)
-        events.edge_index = ei
-        # CSR by destination for model/layers/_ops.graph_csr (perm None: the edges already are in CSR order)
-        events._dagr_csr = (rowptr, ei[0].int().contiguous(), None, (int(events.pos.shape[0]), ei.data_ptr(), int(ei.shape[1])))
+        from . import _ops
+        nbr_src, nbr_code, deg = b.build(events.pos.float().contiguous(), events.batch.contiguous())
+        # the graph as the convolutions consume it -- CSR by destination + the integer pixel offset of every edge (what
+        # its Cartesian attribute encodes) -- straight from the builder, without a host round trip; the reference-shaped
+        # ``edge_index`` is built from it on first access (nothing in the training forward reads it)
+        rowptr, col, code = b.csr_codes(nbr_src, nbr_code, deg, _ops.EXACT_R)
+        n = int(events.pos.shape[0])
+        events._dagr_csr = (rowptr, col, None, ("csr", n))
+        events._dagr_pixel_codes = (code, width, height)
+        events.set_lazy("edge_index", _ops.edge_index_from_csr)
         return events
 
     def forward(self, events, reset=True):

@@ -84,7 +84,16 @@ class Net(torch.nn.Module):
         if self.use_image:
             data.x = with_image(data, 0)
         data = self.edge_attrs(data)
-        data.edge_attr = torch.clamp(data.edge_attr, min=0, max=1)
+        if getattr(data, "is_lazy", None) is not None and data.is_lazy("edge_attr"):
+            recipe = data.__dict__["_lazy"]["edge_attr"]
+            data.set_lazy("edge_attr", lambda d, f=recipe: torch.clamp(f(d), min=0, max=1))
+            # the clamp never binds while every edge's pixel offset lies inside the Cartesian range (|d| <= search radius
+            # <= max * size on both axes: r_eff above); should a configuration break that, the convs go by the attributes
+            rpx = int(self.events_to_graph.radius * self.width + 1)
+            if not (rpx <= self.edge_attrs.max * self.width and rpx <= self.edge_attrs.max * self.height):
+                data._dagr_pixel_codes = None
+        else:
+            data.edge_attr = torch.clamp(data.edge_attr, min=0, max=1)
         outputs = []
         for k, name in enumerate(self.LAYER_NAMES):
             data.x = torch.cat((data.x, data.pos[:, :2]), dim=1)
@@ -105,4 +114,9 @@ class Net(torch.nn.Module):
         return outputs[-self.num_scales:]
 
     def get_output_sizes(self):  # net.py:103-106
-        return [(1 / p.voxel_size[:2] + 1e-3).cpu().int().numpy().tolist()[::-1] for p in (self.pool3, self.pool4)]
+        key = tuple((p.voxel_size.data_ptr(), p.voxel_size._version) for p in (self.pool3, self.pool4))
+        cached = getattr(self, "_output_sizes", None)
+        if cached is None or cached[0] != key:      # (a read-back per call would synchronise every training step)
+            cached = self._output_sizes = (key, [(1 / p.voxel_size[:2] + 1e-3).cpu().int().numpy().tolist()[::-1]
+                                                 for p in (self.pool3, self.pool4)])
+        return [list(v) for v in cached[1]]

@@ -167,11 +167,16 @@ def detection_losses(labels, outputs, grids, strides, num_classes):
     reg_t = rows[..., 1:5]
     cls_t = F.one_hot(rows[..., 0].long().clamp(0, num_classes - 1), num_classes).to(dt) * m_iou.unsqueeze(2)
     num_fg = fgf.sum().clamp(min=1.0)
-    sel = fg.view(-1)
-    loss_iou = iou_loss(box.reshape(-1, 4)[sel], reg_t.reshape(-1, 4)[sel]).sum() / num_fg
+    # sums over the matched anchors written as masked sums over all anchors (boolean-mask indexing would synchronise with
+    # the host, here and again in its backward): an unmatched anchor's boxes are replaced by a unit box on both sides
+    # (IoU 1 -> loss exactly 0, and `where` routes its gradient to the constant), its class term is multiplied away
+    sel = fg.view(-1, 1)
+    unit = torch.ones((1, 4), device=dev, dtype=dt)
+    loss_iou = (iou_loss(torch.where(sel, box.reshape(-1, 4), unit), torch.where(sel, reg_t.reshape(-1, 4), unit))
+                * fgf.view(-1)).sum() / num_fg
     loss_obj = F.binary_cross_entropy_with_logits(obj.reshape(-1, 1), fgf.view(-1, 1), reduction="none").sum() / num_fg
-    loss_cls = F.binary_cross_entropy_with_logits(cls.reshape(-1, num_classes)[sel], cls_t.reshape(-1, num_classes)[sel],
-                                                  reduction="none").sum() / num_fg
+    loss_cls = (F.binary_cross_entropy_with_logits(cls.reshape(-1, num_classes), cls_t.reshape(-1, num_classes),
+                                                   reduction="none") * fgf.view(-1, 1)).sum() / num_fg
     loss_l1 = 0.0
     total = REG_WEIGHT * loss_iou + loss_obj + loss_cls + loss_l1
     return total, REG_WEIGHT * loss_iou, loss_obj, loss_cls, loss_l1, num_fg / num_gts.clamp(min=1.0)

@@ -83,8 +83,8 @@ def convert_to_training_format(bbox, batch, batch_size):
     # running index of every box inside its sample (boxes of a sample are contiguous, samples ascending)
     first = torch.ones_like(batch, dtype=torch.bool)
     first[1:] = batch[1:] != batch[:-1]
-    start = torch.arange(len(batch), device=batch.device)[first]
-    counter = torch.arange(len(batch), device=batch.device) - start[torch.cumsum(first.long(), 0) - 1]
+    idx = torch.arange(len(batch), device=batch.device)
+    counter = idx - torch.cummax(torch.where(first, idx, torch.zeros_like(idx)), 0).values     # (no mask indexing: no host sync)
     rows = bbox[:, :5].clone().float()
     rows[:, :2] += rows[:, 2:4] * .5                       # corner -> centre
     targets[batch, counter] = torch.roll(rows, shifts=1, dims=1)
@@ -96,7 +96,7 @@ def shallow_copy(data):
     cached CSR of the graph is shared, the reference's ``adj_t`` is not carried over -- it is recomputed there)."""
     out = data.__class__()
     keep = ("edge_index", "edge_attr", "pos", "batch", "pooling", "num_image_channels", "skipped", "pooled", "width",
-            "height", "time_window", "edge_attr_max", "_dagr_csr", "_dagr_exact")
+            "height", "time_window", "edge_attr_max", "_dagr_csr", "_dagr_exact", "_dagr_pixel_codes", "_lazy")
     for k in keep:
         if k in data.__dict__:
             out.__dict__[k] = data.__dict__[k]

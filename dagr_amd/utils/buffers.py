@@ -10,7 +10,17 @@ from .. import _lib
 
 
 def format_data(data, normalizer=None):
-    W, H, T = int(data.width[0]), int(data.height[0]), int(data.time_window[0])
+    geo = getattr(data, "_geometry", None)
+    if geo is None:
+        # one read-back for the three scalars (they sit on the device once the batch does); kept on the batch for the
+        # layers that ask again (EV_TGN)
+        w, h, tw = data.width, data.height, data.time_window
+        if torch.is_tensor(w) and w.is_cuda:
+            geo = tuple(int(v) for v in torch.stack((w.reshape(-1)[0], h.reshape(-1)[0], tw.reshape(-1)[0])).tolist())
+        else:
+            geo = (int(w[0]), int(h[0]), int(tw[0]))
+        data._geometry = geo
+    W, H, T = geo
     if hasattr(data, "image"):
         data.image = data.image.float() / 255.0
     pos, t, x = data.pos, data.t, data.x

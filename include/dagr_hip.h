@@ -168,6 +168,14 @@ size_t dagr_scan_scratch_elems(int64_t n);
 int dagr_graph_edge_index(const dagr_graph_desc *desc, void *workspace, const int32_t *nbr_src, const int32_t *deg,
                           int64_t N, int32_t *rowptr, int32_t *scan_scratch,
                           int64_t *edge_index, int64_t row_stride, void *stream);
+/* The same edges as dagr_graph_edge_index, in the form the convolutions consume, without a host round trip for E:
+ * rowptr int32[N+1] by destination EVENT, col int32[e_cap] source event ids, code int32[e_cap] = (dx + code_bias) |
+ * (dy + code_bias) << 16 with (dx, dy) = source pixel - destination pixel (what T.Cartesian's attribute of the edge
+ * encodes, transforms/cartesian in ev_tgn.py:39-58 + net.py:118-121); row e holds deg(e) entries, self loop first.
+ * e_cap >= N * max_neighbors always suffices.  Asynchronous. */
+int dagr_graph_csr_codes(const dagr_graph_desc *desc, void *workspace, const int32_t *nbr_src, const int16_t *nbr_code,
+                         const int32_t *deg, int64_t N, int32_t code_bias, int32_t *rowptr, int32_t *scan_scratch,
+                         int32_t *col, int32_t *code, int64_t e_cap, void *stream);
 /* slot_event[n] = event id of node n, event_slot[e] = node of event e (either may be NULL) */
 int dagr_graph_node_order(const dagr_graph_desc *desc, void *workspace, int64_t N, int32_t *slot_event,
                           int32_t *event_slot, void *stream);
@@ -436,6 +444,9 @@ int dagr_pool_recode(const int32_t *n_ptr, int32_t n_max, const int32_t *rowptr,
 /* flags bit0: node outside the voxel grid; bit1: > 64 distinct sources for one cluster;
  * bit2: edge capacity exceeded; bit3: LUT coordinate out of range.  Synchronises `stream`. */
 int dagr_pool_status(const dagr_pool_desc *desc, void *pool_ws, int32_t *flags_host, void *stream);
+/* device address of that status word (inside pool_ws): a caller that reads other results back anyway (the training path
+ * reads the two output counts of dagr_pool_csr) fetches it in the same transfer instead of a synchronisation of its own */
+const int32_t *dagr_pool_status_ptr(const dagr_pool_desc *desc, void *pool_ws);
 /* All eight status words (synchronises `stream`): [0] the flags above, [4] accumulator epoch, [5] level-0 nodes merged
  * through the global path so far (outside the streaming kernel's LDS window, or t == 1.0 nodes; cumulative). */
 int dagr_pool_counters(const dagr_pool_desc *desc, void *pool_ws, int32_t *out8_host, void *stream);
