@@ -127,6 +127,9 @@ SIGNATURES = {
     "dagr_spline_tap_scatter_grad": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32,
                                                     c_i32, c_i32, c_float, c_float, c_void_p, c_void_p, c_void_p, c_i32,
                                                     c_void_p]),
+    "dagr_spline_tap_scatter_grad_w": (ctypes.c_int, [c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_i32,
+                                                      c_void_p, c_i32, c_i32, c_i32, c_i32, c_float, c_float, c_void_p,
+                                                      c_void_p, c_void_p, c_i32, c_void_p]),
     "dagr_pool_workspace_bytes": (c_size_t, [ctypes.POINTER(PoolDesc)]),
     "dagr_pool_workspace_init": (ctypes.c_int, [ctypes.POINTER(PoolDesc), c_void_p, c_size_t, c_void_p]),
     "dagr_pool_l0": (ctypes.c_int, [ctypes.POINTER(PoolDesc), c_void_p, ctypes.POINTER(GraphDesc), c_void_p,

@@ -127,6 +127,73 @@ __global__ __launch_bounds__(kBlock) void k_tap_scatter_grad(const int32_t *__re
     }
 }
 
+// The same scatter for the narrow convs of the event level (cin, cout <= 16; 400 k rows in a training step) WITHOUT the
+// gA matrix: gA[n] = g[n] . Wm^T is 26 cin values per node -- 16 lanes rebuild the row in LDS from g[n] (16 values) and the
+// weights (<= 26 KB, staged once per workgroup), then walk the node's edges exactly as k_tap_scatter_grad<16> does.  The
+// [n, 26 cin] matrix (0.67 GB for the 16 -> 16 conv) was written by a library GEMM, read by a max-norm reduction and read
+// again here.  `amax` must bound |gA| (the caller passes max|g| * max_k sum_co |Wm[k, co]|).
+__global__ __launch_bounds__(kBlock) void k_tap_scatter_grad_w(const int32_t *__restrict__ n_nodes_ptr, int n_nodes_max,
+                                                              const int32_t *__restrict__ rowptr,
+                                                              const int32_t *__restrict__ col,
+                                                              const int32_t *__restrict__ code,
+                                                              const float *__restrict__ g, int ldg, int cout,
+                                                              const float *__restrict__ Wm, int ldw, int cin, int rx,
+                                                              int ry, float den_x, float den_y,
+                                                              const float *__restrict__ amax,
+                                                              long long *__restrict__ acc) {
+    extern __shared__ __align__(16) float lds[];
+    constexpr int LPN = 16, NPB = kBlock / LPN;
+    const int K = 26 * cin;
+    float *Ws = lds;                                  // [K][16], columns >= cout zero
+    float *rows = lds + (size_t)K * 16;               // [NPB][K]
+    for (int i = threadIdx.x; i < K * 16; i += kBlock) {
+        const int k = i >> 4, co = i & 15;
+        Ws[i] = co < cout ? Wm[(size_t)k * ldw + co] : 0.0f;
+    }
+    const int lane = threadIdx.x & (LPN - 1), slot = threadIdx.x / LPN;
+    const int n = blockIdx.x * NPB + slot;
+    const int n_nodes = n_nodes_ptr ? min(*n_nodes_ptr, n_nodes_max) : n_nodes_max;
+    const bool active = n < n_nodes;
+    const float gl = (active && lane < cout) ? g[(size_t)n * ldg + lane] : 0.0f;
+    float gv[16];
+#pragma unroll
+    for (int co = 0; co < 16; co++) gv[co] = __shfl(gl, co, LPN);
+    __syncthreads();
+    float *row = rows + (size_t)slot * K;
+    for (int k = lane; k < K; k += LPN) {
+        const float4 *w = reinterpret_cast<const float4 *>(Ws + (size_t)k * 16);
+        float a = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float4 wq = w[q];
+            a += gv[4 * q] * wq.x; a += gv[4 * q + 1] * wq.y; a += gv[4 * q + 2] * wq.z; a += gv[4 * q + 3] * wq.w;
+        }
+        row[k] = a;
+    }
+    __syncthreads();
+    if (!active) return;
+    const float m = *amax;
+    const double scale = m > 0.0f ? kFixedOne / (double)m : 0.0;
+    auto add = [&](size_t at, float v) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(acc + at), (unsigned long long)__double2ll_rn((double)v * scale));
+    };
+    for (int i = lane; i < cin; i += LPN) add((size_t)n * cin + i, row[25 * cin + i]);
+    const int e0 = rowptr[n], e1 = rowptr[n + 1];
+    for (int e = e0; e < e1; e++) {
+        const int src = col[e];
+        const int c = code[e];
+        const Axis ax = spline_axis(c & 0xffff, rx, den_x);
+        const Axis ay = spline_axis(c >> 16, ry, den_y);
+        const float b00 = ax.b0 * ay.b0, b10 = ax.b1 * ay.b0, b01 = ax.b0 * ay.b1, b11 = ax.b1 * ay.b1;
+        const float *a00 = row + (ax.k0 + 5 * ay.k0) * cin;
+        const float *a10 = row + (ax.k1 + 5 * ay.k0) * cin;
+        const float *a01 = row + (ax.k0 + 5 * ay.k1) * cin;
+        const float *a11 = row + (ax.k1 + 5 * ay.k1) * cin;
+        for (int i = lane; i < cin; i += LPN)
+            add((size_t)src * cin + i, b00 * a00[i] + b10 * a10[i] + b01 * a01[i] + b11 * a11[i]);
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_fixed_to_float(const int32_t *__restrict__ n_nodes_ptr, int n_nodes_max, int cin,
                                                           const float *__restrict__ amax,
                                                           const long long *__restrict__ acc, float *__restrict__ gx,
@@ -510,6 +577,27 @@ int dagr_spline_tap_scatter_grad(const int32_t *n_nodes_ptr, int32_t n_nodes_max
     DAGR_CHECK_LAUNCH();
     k_fixed_to_float<<<(unsigned)ceil_div((int64_t)n_nodes_max * cin, kBlock), kBlock, 0, (hipStream_t)stream>>>(
         n_nodes_ptr, n_nodes_max, cin, grad_A_absmax, (const long long *)acc, grad_x, ldg);
+    DAGR_CHECK_LAUNCH();
+    return DAGR_OK;
+}
+
+int dagr_spline_tap_scatter_grad_w(const int32_t *n_nodes_ptr, int32_t n_nodes_max, const int32_t *rowptr,
+                                   const int32_t *col, const int32_t *code, const float *grad_out, int32_t ldg, int32_t cout,
+                                   const float *Wm, int32_t ldw, int32_t cin, int32_t rx, int32_t ry, float den_x,
+                                   float den_y, const float *grad_A_bound, int64_t *acc, float *grad_x, int32_t ldgx,
+                                   void *stream) {
+    DAGR_CHECK_ARG(n_nodes_max >= 0, "n_nodes_max < 0");
+    if (n_nodes_max == 0) return DAGR_OK;
+    DAGR_CHECK_ARG(rowptr && col && code && grad_out && Wm && grad_x && grad_A_bound && acc, "NULL pointer");
+    DAGR_CHECK_ARG(cin >= 1 && cin <= 16 && cout >= 1 && cout <= 16 && ldg >= cout && ldw >= cout && ldgx >= cin,
+                   "the fused form covers cin, cout <= 16 (use dagr_spline_tap_scatter_grad)");
+    const size_t lds_bytes = ((size_t)26 * cin * 16 + (size_t)(kBlock / 16) * 26 * cin) * 4;     // <= 53 KB
+    k_tap_scatter_grad_w<<<(unsigned)ceil_div(n_nodes_max, kBlock / 16), kBlock, lds_bytes, (hipStream_t)stream>>>(
+        n_nodes_ptr, n_nodes_max, rowptr, col, code, grad_out, ldg, cout, Wm, ldw, cin, rx, ry, den_x, den_y, grad_A_bound,
+        (long long *)acc);
+    DAGR_CHECK_LAUNCH();
+    k_fixed_to_float<<<(unsigned)ceil_div((int64_t)n_nodes_max * cin, kBlock), kBlock, 0, (hipStream_t)stream>>>(
+        n_nodes_ptr, n_nodes_max, cin, grad_A_bound, (const long long *)acc, grad_x, ldgx);
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;
 }

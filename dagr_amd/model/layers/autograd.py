@@ -16,19 +16,20 @@ import torch
 from ... import _lib
 
 
-def _at_g(A, g):
-    """A^T . g for a tall A [n, K] and g [n, cout] (the weight gradient of a SplineConv).  The library picks a kernel without
+def _at_g(A, g, K=None):
+    """A[:, :K]^T . g for a tall A [n, lda >= K] and g [n, cout] (the weight gradient of a SplineConv).  The library picks a kernel without
     split-K for this shape -- 0.6 - 0.9 ms at n = 400 k, a seventh of HBM peak -- so the long dimension is cut into a batch
     of P blocks (one batched product, then a fixed-order sum of the P partial results): 0.05 - 0.15 ms
     (tools/skinny_gemm_bench.py).  Deterministic; only the summation order differs from the plain product."""
-    n, K = A.shape
+    n, lda = A.shape
+    K = lda if K is None else K
     P = 64 if n >= 131072 else (16 if n >= 8192 else 1)
     m = n // P * P
     if P == 1 or m == 0:
-        return A.t() @ g
-    r = torch.bmm(A[:m].view(P, m // P, K).transpose(1, 2), g[:m].view(P, m // P, g.shape[1])).sum(0)
+        return A[:, :K].t() @ g
+    r = torch.bmm(A[:m].view(P, m // P, lda)[:, :, :K].transpose(1, 2), g[:m].view(P, m // P, g.shape[1])).sum(0)
     if m < n:
-        r = r + A[m:].t() @ g[m:]
+        r = r + A[m:, :K].t() @ g[m:]
     return r
 
 
@@ -55,16 +56,26 @@ class SplineConvFn(torch.autograd.Function):
         n, cin = x.shape
         cout = weight.shape[2]
         K = 26 * cin
-        lda = K                 # dense rows: the matrix is read by library GEMMs only, and the aggregation writes every entry
+        # the event level's products go through the library's own skinny GEMM, which wants 16-byte aligned rows (the pad
+        # columns are never read); elsewhere dense rows: library GEMMs read the matrix and the aggregation writes every entry
+        own_gemm = n >= 65536 and cout in (8, 16)
+        lda = (K + 3) // 4 * 4 if own_gemm else K
         x = x.float().contiguous()
         A = torch.empty((n, lda), dtype=torch.float32, device=x.device)
         if n:
             _lib.check(L.dagr_spline_tap_aggregate(None, n, P(rowptr), P(col), P(code), P(x), cin, cin, None, 0, 0, rx,
                                                    ry, den_x, den_y, P(A), lda, _lib.cur_stream(x.device)), "tap_aggregate")
         Wm = torch.cat([weight.reshape(25 * cin, cout), root.t()], 0)
-        out = A[:, :K] @ Wm
-        if bias is not None:
-            out = out + bias
+        if own_gemm:
+            # the event level: a [400 k, 416] . [416, 16] product for which the library picks a kernel at a seventh of HBM
+            # speed (0.94 ms); the library's own skinny GEMM streams A once (bias in its epilogue)
+            out = torch.empty((n, cout), dtype=torch.float32, device=x.device)
+            _lib.check(L.dagr_gemm_bias_act(None, n, P(A), lda, P(Wm), cout, P(bias.float().contiguous()) if bias is not None
+                                            else None, P(out), cout, K, cout, 0, _lib.cur_stream(x.device)), "gemm")
+        elif bias is not None:
+            out = torch.addmm(bias, A[:, :K], Wm)
+        else:
+            out = A[:, :K] @ Wm
         ctx.save_for_backward(A, Wm, rowptr, col, code)
         ctx.dom = (rx, ry, den_x, den_y)
         ctx.shape = (n, cin, cout, K, lda, bias is not None)
@@ -77,17 +88,27 @@ class SplineConvFn(torch.autograd.Function):
         n, cin, cout, K, lda, has_bias = ctx.shape
         rx, ry, den_x, den_y = ctx.dom
         g = g.float().contiguous()
-        gWm = _at_g(A, g)
+        gWm = _at_g(A, g, K)
         gW = gWm[:25 * cin].reshape(25, cin, cout)
         groot = gWm[25 * cin:].t().contiguous()
-        gA = _g_wt(g, Wm.t().contiguous())                # [n, K] = [n, lda]: no zero fill, no copy
-        gx = torch.zeros((n, cin), dtype=torch.float32, device=g.device)
-        if n:
+        # (the first conv of the network consumes the events' own features: no input gradient is asked for)
+        gx = torch.zeros((n, cin), dtype=torch.float32, device=g.device) if ctx.needs_input_grad[0] else None
+        if n and cin <= 16 and cout <= 16 and ctx.needs_input_grad[0]:
+            # narrow convs (the event level): the node's row of gA = g . Wm^T is rebuilt inside the scatter kernel -- no
+            # [n, 26 cin] matrix (0.67 GB for 16 -> 16 at 400 k rows), no reduction over it; the fixed-point scale is the
+            # bound max|g| * max_k sum_co |Wm[k, co]| >= max|gA| (device scalars, no host sync)
+            bound = (torch.linalg.vector_norm(g, ord=float("inf")) * Wm.abs().sum(1).amax()).reshape(1).contiguous()
+            acc = torch.zeros((n, cin), dtype=torch.int64, device=g.device)
+            _lib.check(L.dagr_spline_tap_scatter_grad_w(None, n, P(rowptr), P(col), P(code), P(g), cout, cout, P(Wm), cout,
+                                                        cin, rx, ry, den_x, den_y, P(bound), P(acc), P(gx), cin,
+                                                        _lib.cur_stream(g.device)), "tap_scatter_grad_w")
+        elif n and ctx.needs_input_grad[0]:
+            gA = _g_wt(g, Wm.t().contiguous())                # [n, K]: no zero fill, no copy
             # deterministic scatter: 64-bit fixed-point sums scaled by max |gA| (a device scalar, no host sync; one
             # reduction pass, no |gA| temporary)
             amax = torch.linalg.vector_norm(gA, ord=float("inf")).reshape(1).contiguous()
             acc = torch.zeros((n, cin), dtype=torch.int64, device=g.device)
-            _lib.check(L.dagr_spline_tap_scatter_grad(None, n, P(rowptr), P(col), P(code), P(gA), lda, cin, rx, ry,
+            _lib.check(L.dagr_spline_tap_scatter_grad(None, n, P(rowptr), P(col), P(code), P(gA), gA.shape[1], cin, rx, ry,
                                                       den_x, den_y, P(amax), P(acc), P(gx), cin,
                                                       _lib.cur_stream(g.device)), "tap_scatter_grad")
         gb = g.sum(0) if has_bias else None

@@ -267,6 +267,15 @@ int dagr_spline_tap_scatter_grad(const int32_t *n_nodes_ptr, int32_t n_nodes_max
                                  const int32_t *col, const int32_t *code, const float *grad_A, int32_t lda, int32_t cin,
                                  int32_t rx, int32_t ry, float den_x, float den_y, const float *grad_A_absmax,
                                  int64_t *acc, float *grad_x, int32_t ldg, void *stream);
+/* The same gradient for narrow convs (cin, cout <= 16: the event level, 400 k rows per training step) straight from
+ * grad_out[n, cout] and the weight matrix Wm[26 cin, cout] (rows: 25 taps x cin, then the root rows): grad_A's row of a
+ * node is rebuilt in LDS instead of being written by a GEMM (0.67 GB for the 16 -> 16 conv), reduced for its maximum and
+ * read back.  *grad_A_bound: a device scalar >= max |grad_out . Wm^T|, e.g. max|grad_out| * max_k sum_co |Wm[k, co]|. */
+int dagr_spline_tap_scatter_grad_w(const int32_t *n_nodes_ptr, int32_t n_nodes_max, const int32_t *rowptr,
+                                   const int32_t *col, const int32_t *code, const float *grad_out, int32_t ldg, int32_t cout,
+                                   const float *Wm, int32_t ldw, int32_t cin, int32_t rx, int32_t ry, float den_x,
+                                   float den_y, const float *grad_A_bound, int64_t *acc, float *grad_x, int32_t ldgx,
+                                   void *stream);
 /* fused steps 1+2: 16 aggregated rows live in LDS, no A matrix in HBM, one launch.  K = 26*cin + cskip beyond the tile
  * (~2270 floats) is cut at tap boundaries into passes over the same edges, the accumulators staying in registers;
  * dagr_spline_conv_fused_lds_bytes(cin, cskip) = the tile of the scheme chosen, > 160 KiB when a single tap

@@ -126,12 +126,9 @@ def _float_case(case):
     return pos, batch, feat
 
 
-def _assert_same_lists(a, b, n):
-    """neighbour lists equal on their live entries (columns past a node's degree are unspecified)."""
-    (src_a, code_a, deg_a), (src_b, code_b, deg_b) = a, b
-    assert torch.equal(deg_a[:n], deg_b[:n])
-    live = torch.arange(src_a.shape[1], device=src_a.device)[None, :] < deg_a[:n, None]
-    assert torch.equal(src_a[:n][live], src_b[:n][live]) and torch.equal(code_a[:n][live], code_b[:n][live])
+def _edges(g, lists, n):
+    """edge_index (event ids; slot numbering inside a long pixel segment is not specified, event ids are)."""
+    return g.edge_index(lists[0][:n], lists[2][:n])[0]
 
 
 def _builder(case, N):
@@ -156,20 +153,26 @@ def test_build_with_level0_inputs_equals_build_then_gather(case):
     g = _builder(case, N)
     ld, col_feat, col_pos = 6, 4, 1
     a = g.build(pos, batch)
-    pos_a = torch.full((N, 3), -5.0, device=dev); b_a = torch.full((N,), -5, dtype=torch.int32, device=dev)
-    x_a = torch.full((N, ld), -5.0, device=dev)
-    _lib.check(L.dagr_graph_gather_inputs(ctypes.byref(g.desc), P(g.workspace), P(pos), P(feat), N, P(pos_a), P(b_a), P(x_a), ld,
-                                          col_feat, col_pos, _lib.cur_stream(dev)), "gather")
-    ne_a = g.status()
+    ei_a, st_a = _edges(g, a, N), g.status()
     pos_b = torch.full((N, 3), -5.0, device=dev); b_b = torch.full((N,), -5, dtype=torch.int32, device=dev)
     x_b = torch.full((N, ld), -5.0, device=dev)
     inputs = _lib.L0Inputs(feat=feat.data_ptr(), pos_nodes=pos_b.data_ptr(), batch_nodes=b_b.data_ptr(), x0=x_b.data_ptr(),
                            ldx0=ld, col_feat=col_feat, col_pos=col_pos)
     b = g.build(pos, batch, inputs=inputs)
-    assert g.status() == ne_a
-    _assert_same_lists(a, b, N)
+    assert g.status() == st_a and torch.equal(_edges(g, b, N), ei_a)
+    # every node carries its own event's inputs
+    slot_event, event_slot = g.node_order(N)
+    assert bool((event_slot >= 0).all())
+    s_ = event_slot.long()
+    assert torch.equal(pos_b[s_], pos) and torch.equal(b_b[s_].long(), batch) and torch.equal(x_b[s_, col_feat], feat)
+    assert torch.equal(x_b[s_][:, col_pos:col_pos + 2], pos[:, :2])
+    assert bool((x_b[:, [0, 3, 5]] == -5.0).all())
+    # ... which is what the separate launch writes
+    pos_a = torch.full((N, 3), -5.0, device=dev); b_a = torch.full((N,), -5, dtype=torch.int32, device=dev)
+    x_a = torch.full((N, ld), -5.0, device=dev)
+    _lib.check(L.dagr_graph_gather_inputs(ctypes.byref(g.desc), P(g.workspace), P(pos), P(feat), N, P(pos_a), P(b_a), P(x_a), ld,
+                                          col_feat, col_pos, _lib.cur_stream(dev)), "gather")
     assert torch.equal(pos_a, pos_b) and torch.equal(b_a, b_b) and torch.equal(x_a, x_b)
-    assert bool((x_b[:, [0, 3, 5]] == -5.0).all()) and not bool((x_b[:, col_feat] == -5.0).any())
 
 
 @pytest.mark.parametrize("mutate", ["plain", "out_of_range", "unsorted_time"])
@@ -208,4 +211,4 @@ def test_staged_device_count_build_equals_host_count_build(mutate):
         assert g2.status() == want_status, (mutate, n)
         if mutate == "out_of_range":
             assert want_status[1] & 1
-        _assert_same_lists(want, out, n)
+        assert torch.equal(_edges(g1, want, n), _edges(g2, out, n)), (mutate, n)

@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("mode", ["train_exact_offsets", "eval_lut_domain"])
-@pytest.mark.parametrize("n,cin,cout,max_deg", [(300, 8, 6, 9), (1000, 66, 64, 12), (40, 3, 16, 30)])
+@pytest.mark.parametrize("n,cin,cout,max_deg", [(300, 8, 6, 9), (1000, 66, 64, 12), (40, 3, 16, 30),
+                                                 (66000, 16, 16, 4)])     # event-level shape: skinny-GEMM forward, gA rebuilt in the scatter
 def test_spline_conv_gradients_match_float64_autograd(n, cin, cout, max_deg, mode):
     from dagr_amd.model.layers.spline_conv import MySplineConv
     rng = np.random.default_rng(n + cin)
