@@ -219,7 +219,12 @@ __device__ __forceinline__ AxisF spline_axis_f(int idx, int r, float den) {   //
     return a;
 }
 
-__global__ __launch_bounds__(kGemmThreads) void k_conv_fused(
+// U = weight groups in flight per wave.  4: the form tuned for the small levels (72 registers, one 16-wave workgroup per
+// CU).  3: 62 registers = 8 waves per SIMD, so that TWO workgroups share a CU when their tiles fit (<= 80 KB each): on
+// levels that take several rounds of workgroups (level 1 - 2 of a B = 8 batch) one's edge walk overlaps the other's
+// contraction, which a single resident workgroup runs back to back.
+template <int U>
+__global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(U == 4 ? 4 : 8, U == 4 ? 7 : 8))) void k_conv_fused(
     const int32_t *__restrict__ n_ptr, int n_max, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const int32_t *__restrict__ code, const float *__restrict__ x, int ldx, int cin, const float *__restrict__ xskip,
     int ldskip, int cskip, int rx, int ry, float den_x, float den_y, const float *__restrict__ Wq,
@@ -235,7 +240,6 @@ __global__ __launch_bounds__(kGemmThreads) void k_conv_fused(
     const int m0 = blockIdx.x * 16;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: loop bounds below stay in SGPRs
-    constexpr int U = 4;
     DAGR_TRACE(0);
     // rowptr has n_max + 1 entries: read it before the device-side bound is known (one latency, not two)
     const int n_spec = min(m0 + wv, n_max - 1);
@@ -823,11 +827,16 @@ static int launch_conv_jobs(const HostConvJob *hj, int count, const dagr::PoolFu
     if (live == 0) return DAGR_OK;
     const bool mp = mp_all == 1;
     DAGR_CHECK_ARG(!(pool && (mp || dev[0].gy == 0)), "the fused pooling merge needs the single-pass form of the conv");
-    static thread_local size_t set_max[2] = {0, 0};
-    if (lds_max > set_max[mp]) {
-        DAGR_CHECK_HIP(hipFuncSetAttribute(mp ? (const void *)k_conv_fused_mp : (const void *)k_conv_fused,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-        set_max[mp] = lds_max;
+    // two workgroups per CU (the 62-register form) when the launch takes more than one round of workgroups and two tiles
+    // fit the LDS; builder knob DAGR_CONV_DENSE=0: never
+    static const bool dense_ok = [] { const char *e = getenv("DAGR_CONV_DENSE"); return !(e && atoi(e) == 0); }();
+    const bool dense = dense_ok && !mp && lds_max <= 80 * 1024 && (int64_t)gx * gy * count > device_cu_count();
+    const int which = mp ? 1 : (dense ? 2 : 0);
+    static thread_local size_t set_max[3] = {0, 0, 0};
+    if (lds_max > set_max[which]) {
+        const void *fn = mp ? (const void *)k_conv_fused_mp : (dense ? (const void *)k_conv_fused<3> : (const void *)k_conv_fused<4>);
+        DAGR_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+        set_max[which] = lds_max;
     }
     ConvJobs jobs{};
     jobs.extra = count - 1;
@@ -840,8 +849,12 @@ static int launch_conv_jobs(const HostConvJob *hj, int count, const dagr::PoolFu
         k_conv_fused_mp<<<grid, kGemmThreads, lds_max, (hipStream_t)stream>>>(
             a.n_ptr, a.n_max, a.rowptr, a.col, a.code, a.x, a.ldx, a.cin, a.xskip, a.ldskip, a.cskip, a.rx, a.ry, a.den_x,
             a.den_y, a.Wq, a.bias, a.C, a.ldc, a.N, a.relu, a.KP, a.NC, a.tp, a.gy, jobs);
+    else if (dense)
+        k_conv_fused<3><<<grid, kGemmThreads, lds_max, (hipStream_t)stream>>>(
+            a.n_ptr, a.n_max, a.rowptr, a.col, a.code, a.x, a.ldx, a.cin, a.xskip, a.ldskip, a.cskip, a.rx, a.ry, a.den_x,
+            a.den_y, a.Wq, a.bias, a.C, a.ldc, a.N, a.relu, a.KP, a.NC, a.gy, jobs, pf);
     else
-        k_conv_fused<<<grid, kGemmThreads, lds_max, (hipStream_t)stream>>>(
+        k_conv_fused<4><<<grid, kGemmThreads, lds_max, (hipStream_t)stream>>>(
             a.n_ptr, a.n_max, a.rowptr, a.col, a.code, a.x, a.ldx, a.cin, a.xskip, a.ldskip, a.cskip, a.rx, a.ry, a.den_x,
             a.den_y, a.Wq, a.bias, a.C, a.ldc, a.N, a.relu, a.KP, a.NC, a.gy, jobs, pf);
     DAGR_CHECK_LAUNCH();

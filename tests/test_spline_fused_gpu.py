@@ -46,6 +46,8 @@ CASES = [  # T, cin, cskip, N, max_deg, relu
     (5000, 82, 0, 64, 8, True),       # cin > 64 (two channel chunks), K = 2132
     (16, 3, 5, 7, 0, True),           # no edges at all
     (200, 64, 0, 200, 6, False),      # N > 128: four column blocks
+    (6000, 18, 0, 32, 9, True),       # level 1 of a B = 8 batch: more workgroups than CUs, two tiles per CU (62-register form)
+    (6000, 32, 18, 32, 9, True),
     # rows beyond the LDS tile: K cut at tap boundaries into passes (accumulators stay in registers across them)
     (300, 128, 0, 256, 9, True),      # head conv pair of dagr-s (cls_conv | reg_conv): 2 passes of 13 / 12 + root
     (1200, 130, 130, 64, 7, True),    # --use_image level >= 2: K = 3510, tap split must be a multiple of 8
