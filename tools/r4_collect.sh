@@ -20,3 +20,7 @@ cp $G/r4_final/timeline_b8_100k.txt profiles/r4_timeline_b8_100k.txt
 cp $G/r4_final/pool_probe.jsonl profiles/r4_pool_probe.jsonl
 cp $G/r4_final/img_branch_probe.jsonl profiles/r4_img_branch_probe.jsonl
 tail -1 $G/r4_final/train_probe.json > profiles/r4_train_probe.json
+cp $G/r4_final/train_syncs.txt profiles/r4_train_syncs.txt
+cp $G/r4_final/tail_probe.jsonl profiles/r4_tail_probe.jsonl
+cp $G/r4_final/lat_probe.json profiles/r4_lat_probe.json
+

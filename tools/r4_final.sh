@@ -30,3 +30,7 @@ tail -c 400 "$OUT/bench_default.json"; tail -2 "$OUT/bench_default.err"
 timeout 200 python tools/pool_probe.py uniform:8:100000:0 uniform:8:100000:1 edges:8:100000:0 edges:8:100000:1 uniform:1:25000:0 2>&1 | grep spec > "$OUT/pool_probe.jsonl"
 timeout 200 python tools/img_branch_probe.py 2>&1 | grep lt_residual > "$OUT/img_branch_probe.jsonl"
 timeout 200 python tools/train_probe.py 8 50000 10 > "$OUT/train_probe.json" 2>&1; tail -1 "$OUT/train_probe.json" | cut -c1-300
+timeout 200 python tools/train_syncs.py 2>/dev/null | head -24 > "$OUT/train_syncs.txt"; head -3 "$OUT/train_syncs.txt"
+timeout 200 python tools/tail_probe.py uniform:8:100000 uniform:1:25000 2>&1 | grep spec > "$OUT/tail_probe.jsonl"
+ASYNC=1 timeout 300 python tools/lat_probe.py 25000 > "$OUT/lat_probe.json" 2>/dev/null; tail -c 700 "$OUT/lat_probe.json"
+
