@@ -69,6 +69,30 @@ class GNNHead(YOLOXHeadParams):
         obj_output = obj_pred(reg_feat, batch_size=batch_size)
         return cls_output, reg_output, obj_output
 
+    def _graphed_losses(self, fn, lab, flat, tag):
+        """The YOLOX loss (SimOTA assignment + three terms: ~150 small torch launches forward, ~200 backward, all on
+        shapes that depend only on the configuration) as two replayed HIP graphs (``torch.cuda.make_graphed_callables``);
+        the training step is host-bound, and this is a quarter of its launches.  Captured once per (shapes, device);
+        ``DAGR_GRAPH_LOSS=0`` or a capture that fails falls back to the launch-by-launch form (same kernels, same bits)."""
+        import os
+        if not lab.is_cuda or os.environ.get("DAGR_GRAPH_LOSS", "1") == "0" or not torch.is_grad_enabled() \
+                or not all(t.requires_grad for t in flat):
+            return fn
+        # (one capture per call site: a graphed callable owns its input / output buffers, and the image branch's loss and
+        # the hybrid loss of a --use_image step are both alive until backward)
+        key = (tag, str(lab.device), tuple(lab.shape), tuple(tuple(t.shape) for t in flat), flat[0].dtype)
+        cache = self.__dict__.setdefault("_loss_graphs", {})
+        if key not in cache:
+            try:
+                sample = (torch.zeros_like(lab),) + tuple(torch.randn_like(t).requires_grad_(True) for t in flat)
+                sample[0][:, 0, 1:] = torch.tensor([40.0, 40.0, 30.0, 30.0], device=lab.device)      # one box per image
+                cache[key] = torch.cuda.make_graphed_callables(fn, sample)
+            except Exception as exc:                    # capture not possible here: keep the eager form
+                import warnings
+                warnings.warn(f"loss graph capture failed ({exc}); using the launch-by-launch form")
+                cache[key] = fn
+        return cache[key]
+
     def forward(self, xin, labels=None, imgs=None, output_sizes=None):
         """Eval: decoded ``[B, n_anchors, 5 + num_classes]`` from the backbone outputs (and the image outputs with
         ``--use_image``); ``--no_events`` returns the image branch's own detections (dagr.py:283-284).
@@ -101,13 +125,25 @@ class GNNHead(YOLOXHeadParams):
         if self.training:
             from .yolox_loss import detection_losses, output_and_grid
 
-            def losses(maps, lab):
+            def losses_eager(lab, *flat):
+                maps = [flat[3 * k:3 * k + 3] for k in range(len(flat) // 3)]
                 outs, grids = zip(*(output_and_grid(torch.cat(m, 1), st) for m, st in zip(maps, self.strides)))
-                return detection_losses(lab, torch.cat(outs, 1), list(grids), self.strides[:len(maps)], self.num_classes)
+                r = detection_losses(lab, torch.cat(outs, 1), list(grids), self.strides[:len(maps)], self.num_classes)
+                return r[0], r[1], r[2], r[3], r[5]          # (r[4]: the L1 term, 0.0 with use_l1 = False, dagr.py:168)
+
+            def losses(maps, lab, tag="events"):
+                flat = [t for m in maps for t in m]
+                fn = self._graphed_losses(losses_eager, lab, flat, tag)
+                total, iou, obj, cls, ratio = fn(lab, *flat)
+                if fn is not losses_eager:
+                    # a replayed graph hands out ITS buffers, rewritten by the next step: the caller gets values of its own
+                    # (one small launch for the five scalars; `total` keeps its link to the graph's backward)
+                    total, iou, obj, cls, ratio = torch.stack((total, iou, obj, cls, ratio)).unbind(0)
+                return total, iou, obj, cls, 0.0, ratio
             if self.use_image:
                 # dagr.py:241-268: CNNHead always yields both scales; the image branch learns to detect on its own
                 both = [(out_cnn["reg_output"][k], out_cnn["obj_output"][k], out_cnn["cls_output"][k]) for k in (0, 1)]
-                loss_image = list(losses(both, image_labels))
+                loss_image = list(losses(both, image_labels, "image"))
                 if not self.pretrain_cnn:
                     loss_events = losses(raw, labels)
                     for i in range(5):

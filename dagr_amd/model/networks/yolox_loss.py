@@ -49,9 +49,11 @@ def iou_loss(pred, target):
     """yolox IOUloss(reduction='none', loss_type='iou'): 1 - IoU^2 per row, boxes as (cx, cy, w, h)."""
     lo = torch.max(pred[:, :2] - pred[:, 2:] / 2, target[:, :2] - target[:, 2:] / 2)
     hi = torch.min(pred[:, :2] + pred[:, 2:] / 2, target[:, :2] + target[:, 2:] / 2)
-    overlap = (lo < hi).to(pred.dtype).prod(dim=1)
-    inter = (hi - lo).prod(dim=1) * overlap
-    union = pred[:, 2:].prod(1) + target[:, 2:].prod(1) - inter
+    # (two-factor products written out: ``prod(dim)``'s backward counts zeros with a host read-back)
+    overlap = ((lo[:, 0] < hi[:, 0]) & (lo[:, 1] < hi[:, 1])).to(pred.dtype)
+    d = hi - lo
+    inter = d[:, 0] * d[:, 1] * overlap
+    union = pred[:, 2] * pred[:, 3] + target[:, 2] * target[:, 3] - inter
     iou = inter / (union + 1e-16)
     return 1 - iou ** 2
 

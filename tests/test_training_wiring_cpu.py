@@ -167,6 +167,8 @@ def test_training_forward_wiring_with_the_image_branch(oracle_kernels):
         if v.requires_grad and v.grad is not None:
             g = params[k].grad
             assert g is not None, k
-            assert float((g - v.grad).abs().max()) <= 2e-4 * max(1e-6, float(v.grad.abs().max())), k
+            # (+ 5e-7: a conv bias in front of a BatchNorm has a gradient that is zero in exact arithmetic -- both sides hold
+            # 1e-8-sized rounding noise there, and a relative bar on noise compares nothing)
+            assert float((g - v.grad).abs().max()) <= 2e-4 * float(v.grad.abs().max()) + 5e-7, k
             n_img += k.startswith("backbone.net.") or "cnn_head" in k
     assert n_img >= 60
