@@ -1359,8 +1359,9 @@ class WindowEngine:
         ng = getattr(data, "num_graphs", None)
         if ng is not None and int(ng) > self.B:
             raise RuntimeError(f"batch of {int(ng)} windows, but the model was built with batch_size = {self.B}")
-        for name, want in (("width", self.W), ("height", self.H), ("time_window", self.time_window)):
-            v = getattr(data, name, None)
+        geo = getattr(data, "_geometry", None)          # python ints stashed by the collation (data/__init__.py)
+        for k, (name, want) in enumerate((("width", self.W), ("height", self.H), ("time_window", self.time_window))):
+            v = geo[k] if geo is not None else getattr(data, name, None)
             if v is not None and not (torch.is_tensor(v) and v.is_cuda):   # no device read-back on the hot path
                 v = int(v[0]) if hasattr(v, "__len__") else int(v)
                 if v != want:
