@@ -72,19 +72,46 @@ __global__ __launch_bounds__(kTileWaves * 64, LEAN ? 3 : 2) void k_conv_l0_tiles
     constexpr int NT = S::NT;
     extern __shared__ __align__(16) float lds[];
     float *w_l = lds;                            // [S::N][64]  B operands in [k-step][lane] order
-    float *ax_l = w_l + S::N * 64;               // [2rx+1][4]  per-axis basis weights of the TX-wide tap window
-    float *ay_l = ax_l + (2 * rx + 1) * 4;       // [2ry+1][8]
+    // [(2rx+1)(2ry+1) + 1][WS]: the NT tap weights bx[a] * by[b] of every offset code (row = the code the graph builder
+    // stores: ix * (2ry+1) + iy), the last row all zero (absent edges).  Until round 4 the kernel kept the two per-axis
+    // tables and rebuilt the products per edge: code decode + three table rows + 8 packed multiplies + 5 selects = 17 of
+    // the 51 VALU instructions an edge cost on a kernel that is bound by instruction issue; now an edge reads its row.
+    // Row stride = NT rounded up to 4, + 4: consecutive rows start 5 (or 3) 16-byte slots apart, so the 16 rows a
+    // ds_read_b128 group touches spread over the bank slots instead of piling onto four.
+    // Measured (800 k nodes): 16 -> 16 + skip 0.173 -> 0.162 ms (image), 0.168 -> 0.155 ms (events-only); 19 -> 16 conv
+    // 0.226 -> 0.222 ms (with the freed registers it fits three waves per SIMD without scratch); the 3 -> 16 conv, whose
+    // edge is 15 scalar FMAs, becomes LDS-bound on the four row reads (0.085 -> 0.150 ms) and keeps the per-axis tables.
+    constexpr bool PRE = CM > 0;
+    constexpr int WS = (NT + 3) / 4 * 4 + 4;
+    float *wt_l = w_l + S::N * 64;
+    float *ax_l = wt_l;                          // !PRE: [2rx+1][4]  per-axis basis weights of the TX-wide tap window
+    float *ay_l = ax_l + (2 * rx + 1) * 4;       //       [2ry+1][8]
+    const int sy = 2 * ry + 1;
+    const int n_codes = (2 * rx + 1) * sy;
     for (int i = threadIdx.x; i < S::N * 64; i += blockDim.x) {
         const int s = i >> 6, lq = (i >> 4) & 3, c = i & 15;
         const int r = S::row(s, lq);
         w_l[i] = r >= 0 ? wpack[r * 16 + c] : 0.0f;
     }
-    for (int i = threadIdx.x; i < (2 * rx + 1) * 4; i += blockDim.x) {
+    for (int i = threadIdx.x; PRE && i < (n_codes + 1) * WS; i += blockDim.x) {
+        const int o = i / WS, t = i - o * WS;
+        float w = 0.0f;
+        if (o < n_codes && t < NT) {
+            const Axis ax = spline_axis(o / sy, rx, den_x);
+            const Axis ay = spline_axis(o % sy, ry, den_y);
+            const int ta = t % TX + win_x, tb = t / TX + win_y;     // taps of the 5-tap kernel this column stands for
+            const float wx = (ta == ax.k0 ? ax.b0 : 0.0f) + (ta == ax.k1 ? ax.b1 : 0.0f);
+            const float wy = (tb == ay.k0 ? ay.b0 : 0.0f) + (tb == ay.k1 ? ay.b1 : 0.0f);
+            w = wx * wy;                                            // == the level-0 offset table entry (bx[a]*by[b])
+        }
+        wt_l[i] = w;
+    }
+    for (int i = threadIdx.x; !PRE && i < (2 * rx + 1) * 4; i += blockDim.x) {
         const Axis a = spline_axis(i >> 2, rx, den_x);
         const int t = (i & 3) + win_x;           // tap of the 5-tap kernel this column stands for
         ax_l[i] = (i & 3) < TX ? ((t == a.k0 ? a.b0 : 0.0f) + (t == a.k1 ? a.b1 : 0.0f)) : 0.0f;
     }
-    for (int i = threadIdx.x; i < (2 * ry + 1) * 8; i += blockDim.x) {
+    for (int i = threadIdx.x; !PRE && i < (2 * ry + 1) * 8; i += blockDim.x) {
         const Axis a = spline_axis(i >> 3, ry, den_y);
         const int t = (i & 7) + win_y;
         ay_l[i] = (i & 7) < TY ? ((t == a.k0 ? a.b0 : 0.0f) + (t == a.k1 ? a.b1 : 0.0f)) : 0.0f;
@@ -97,7 +124,6 @@ __global__ __launch_bounds__(kTileWaves * 64, LEAN ? 3 : 2) void k_conv_l0_tiles
     const int c = l & 15, q = l >> 4;
     const float my_shift = shift[c];
     const float inv_sy = 1.0f / (float)(2 * ry + 1);
-    const int sy = 2 * ry + 1;
     // XCD x = blockIdx % 8 owns the x-th eighth of the nodes (one sample of a B = 8 batch); its workgroups sweep that range
     // TOGETHER: workgroup lb takes the 64-node groups lb, lb + bpx, lb + 2 bpx ... (one 16-node tile per wave).  The source
     // rows a tile gathers lie within +-r pixel rows of it, so the rows all workgroups of the XCD need at one time form a band
@@ -140,13 +166,19 @@ __global__ __launch_bounds__(kTileWaves * 64, LEAN ? 3 : 2) void k_conv_l0_tiles
         const bool valid = n < n_end;
         const int nn = valid ? n : n0;                  // a row that exists, for the predicated-off lanes
         const int d = d_nx;
-        int srcs[16], codes[16];
+        // offset codes: with a main channel block (register-bound instantiations) they stay packed two per register until
+        // their edge; the 3 -> 16 conv has registers to spare and unpacks them once (measured: 0.085 vs 0.090 ms)
+        int srcs[16], cpk[8], cun[CM ? 1 : 16];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             srcs[4 * k] = s_nx[k].x; srcs[4 * k + 1] = s_nx[k].y; srcs[4 * k + 2] = s_nx[k].z; srcs[4 * k + 3] = s_nx[k].w;
-            codes[4 * k] = c_nx[k].x & 0xffff; codes[4 * k + 1] = (c_nx[k].x >> 16) & 0xffff;
-            codes[4 * k + 2] = c_nx[k].y & 0xffff; codes[4 * k + 3] = (c_nx[k].y >> 16) & 0xffff;
+            cpk[2 * k] = c_nx[k].x; cpk[2 * k + 1] = c_nx[k].y;
+            if (!CM) {
+                cun[(4 * k) % (CM ? 1 : 16)] = c_nx[k].x & 0xffff; cun[(4 * k + 1) % (CM ? 1 : 16)] = (c_nx[k].x >> 16) & 0xffff;
+                cun[(4 * k + 2) % (CM ? 1 : 16)] = c_nx[k].y & 0xffff; cun[(4 * k + 3) % (CM ? 1 : 16)] = (c_nx[k].y >> 16) & 0xffff;
+            }
         }
+        auto code_of = [&](int u) { return CM ? ((cpk[u >> 1] >> (16 * (u & 1))) & 0xffff) : cun[u % (CM ? 1 : 16)]; };
         int dmax = d;
 #pragma unroll
         for (int off = 1; off < 16; off <<= 1) dmax = max(dmax, __shfl_xor(dmax, off, 16));
@@ -189,31 +221,43 @@ __global__ __launch_bounds__(kTileWaves * 64, LEAN ? 3 : 2) void k_conv_l0_tiles
         // ---- phase 1: this lane's node, its <= 16 in-edges.  (Requesting the basis rows of edge u+1 before the FMAs of edge
         // u was measured: 3-10 % slower -- more live registers, no shorter chain.)
         auto edge = [&](int u) {
-            const bool ok = u < d;
-            const int code = ok ? codes[u] : 0;
-            const int ix = (int)(((float)code + 0.5f) * inv_sy);
-            const int iy = code - ix * sy;
-            const float4 wx4 = *reinterpret_cast<const float4 *>(ax_l + 4 * ix);
-            const float4 wy4 = *reinterpret_cast<const float4 *>(ay_l + 8 * iy);
-            const float4 wy5 = *reinterpret_cast<const float4 *>(ay_l + 8 * iy + 4);
-            const float wx[4] = {wx4.x, wx4.y, wx4.z, wx4.w};
-            float wy[8] = {wy4.x, wy4.y, wy4.z, wy4.w, wy5.x, wy5.y, wy5.z, wy5.w};
-#pragma unroll
-            for (int b = 0; b < TY; b++) wy[b] = ok ? wy[b] : 0.f;
-#pragma unroll
-            for (int b = 0; b < TY; b++)
-#pragma unroll
-                for (int a = 0; a < TX; a++) {
-                    const float w = wx[a] * wy[b];            // == the level-0 offset table entry (bx[a]*by[b])
-                    const int t = a + TX * b;
-                    constexpr int NX = LEAN ? 8 : 16;
-                    if (CM) {
-                        const f32x2_t w2 = {w, w};
-                        acc[t][0] = __builtin_elementwise_fma(w2, f32x2_t{xv[u % NX].x, xv[u % NX].y}, acc[t][0]);
-                        acc[t][1] = __builtin_elementwise_fma(w2, f32x2_t{xv[u % NX].z, xv[u % NX].w}, acc[t][1]);
-                    }
-                    if (CE) acce[t] = fmaf(w, xe[u % NX], acce[t]);
+            constexpr int NX = LEAN ? 8 : 16;
+            auto tap = [&](int t, float w) {
+                if (CM) {
+                    const f32x2_t w2 = {w, w};
+                    acc[t][0] = __builtin_elementwise_fma(w2, f32x2_t{xv[u % NX].x, xv[u % NX].y}, acc[t][0]);
+                    acc[t][1] = __builtin_elementwise_fma(w2, f32x2_t{xv[u % NX].z, xv[u % NX].w}, acc[t][1]);
                 }
+                if (CE) acce[t] = fmaf(w, xe[u % NX], acce[t]);
+            };
+            if constexpr (PRE) {
+                const int code = (u < d) ? code_of(u) : n_codes;      // absent edge: the all-zero row
+                const float *wr = wt_l + code * WS;
+#pragma unroll
+                for (int k = 0; k < (NT + 3) / 4; k++) {
+                    const float4 w4 = *reinterpret_cast<const float4 *>(wr + 4 * k);
+                    const float w[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (4 * k + j < NT) tap(4 * k + j, w[j]);
+                }
+            } else {
+                const bool ok = u < d;
+                const int code = ok ? code_of(u) : 0;
+                const int ix = (int)(((float)code + 0.5f) * inv_sy);
+                const int iy = code - ix * sy;
+                const float4 wx4 = *reinterpret_cast<const float4 *>(ax_l + 4 * ix);
+                const float4 wy4 = *reinterpret_cast<const float4 *>(ay_l + 8 * iy);
+                const float4 wy5 = *reinterpret_cast<const float4 *>(ay_l + 8 * iy + 4);
+                const float wx[4] = {wx4.x, wx4.y, wx4.z, wx4.w};
+                float wy[8] = {wy4.x, wy4.y, wy4.z, wy4.w, wy5.x, wy5.y, wy5.z, wy5.w};
+#pragma unroll
+                for (int b = 0; b < TY; b++) wy[b] = ok ? wy[b] : 0.f;
+#pragma unroll
+                for (int b = 0; b < TY; b++)
+#pragma unroll
+                    for (int a = 0; a < TX; a++) tap(a + TX * b, wx[a] * wy[b]);   // == the level-0 offset table entry (bx[a]*by[b])
+            }
             __builtin_amdgcn_sched_barrier(0);   // one edge's weights live at a time (register pressure)
         };
 #pragma unroll
@@ -276,8 +320,11 @@ int launch_tiles_v(int64_t n_first, int64_t N, const int32_t *n_ptr, int rx, int
                  const int16_t *nbr_code, const int32_t *deg, const float *x, int ldx, const float *xskip, int ldskip,
                  const float *wpack, const float *shift, int relu, float *out, int ldo, hipStream_t stream) {
     using S = L0Steps<CM, CE, CS, TX, TY>;
-    const size_t lds_bytes = ((size_t)S::N * 64 + (size_t)(2 * rx + 1) * 4 + (size_t)(2 * ry + 1) * 8) * 4;
-    DAGR_CHECK_ARG(lds_bytes <= 64 * 1024, "offset domain too large for the axis tables");
+    constexpr int WS = (S::NT + 3) / 4 * 4 + 4;
+    constexpr bool PRE = CM > 0;     // per-offset weight rows / per-axis tables (see the kernel)
+    const size_t lds_bytes = ((size_t)S::N * 64 + (PRE ? ((size_t)(2 * rx + 1) * (2 * ry + 1) + 1) * WS
+                                                       : (size_t)(2 * rx + 1) * 4 + (size_t)(2 * ry + 1) * 8)) * 4;
+    DAGR_CHECK_ARG(lds_bytes <= 64 * 1024, "offset domain too large for the per-offset weight table");
     auto kern = k_conv_l0_tiles<CM, CE, CS, TX, TY, LEAN>;
     {
         static thread_local size_t set_for = 0;
@@ -300,12 +347,12 @@ int launch_tiles(int64_t n_first, int64_t N, const int32_t *n_ptr, int rx, int r
                  const int32_t *nbr_src, const int16_t *nbr_code, const int32_t *deg, const float *x, int ldx,
                  const float *xskip, int ldskip, const float *wpack, const float *shift, int relu, float *out, int ldo,
                  hipStream_t stream) {
-    // three waves per SIMD (LEAN) wherever the kernel fits 170 registers without scratch: -4 % on the 16 -> 16 + skip and
-    // 3 -> 16 convs (0.179 -> 0.171, 0.090 -> 0.087 ms at 800 k nodes); the 19 -> 16 conv (main block + extras: 220
-    // registers) spills at that budget and is 7 % slower, so it keeps two waves.  PMC (profiles/r3_*_pmc_sq.csv): the SIMDs'
-    // issue slots are ~77 % busy at two waves -- the kernel is bound by instruction issue (packed FMAs already), which is
-    // why a third wave buys so little.
-    constexpr bool kLean = !(CM > 0 && CE > 0);
+    // three waves per SIMD (LEAN: <= 168 registers, source rows in two batches of 8): -4 % on the 16 -> 16 + skip and
+    // 3 -> 16 convs (0.179 -> 0.171, 0.090 -> 0.087 ms at 800 k nodes).  The 19 -> 16 conv (main block + extras) used to
+    // spill at that budget (+7 %) and ran at two waves until the per-offset weight rows and the packed offset codes freed
+    // the registers (166, no scratch).  PMC (profiles/r3_*_pmc_sq.csv): the SIMDs' issue slots are ~77 % busy at two waves
+    // -- the kernel is bound by instruction issue (packed FMAs already), which is why a third wave buys so little.
+    constexpr bool kLean = true;
     return launch_tiles_v<CM, CE, CS, TX, TY, kLean>(n_first, N, n_ptr, rx, ry, den_x, den_y, win_x, win_y, nbr_src, nbr_code,
                                                      deg, x, ldx, xskip, ldskip, wpack, shift, relu, out, ldo, stream);
 }

@@ -1324,8 +1324,7 @@ class WindowEngine:
         if self.l0_tiles:
             tx, ty = self.win0[1], self.win0[3]
             cm = 16 if c0 >= 16 else 0
-            lean = lambda m, e: "false" if (m > 0 and e > 0) else "true"     # csrc/conv_l0_tiles.hip:launch_tiles
-            return {"l0_conv1": f"k_conv_l0_tiles<{cm}, {c0 - cm}, 0, {tx}, {ty}, {lean(cm, c0 - cm)}>",
+            return {"l0_conv1": f"k_conv_l0_tiles<{cm}, {c0 - cm}, 0, {tx}, {ty}, true>",     # (LEAN: csrc/conv_l0_tiles.hip:launch_tiles)
                     "l0_conv2": f"k_conv_l0_tiles<16, 0, {c0}, {tx}, {ty}, true>"}
         return {"l0_conv1": f"k_conv_l0<{c0}, 0, {nt}>", "l0_conv2": f"k_conv_l0<16, {c0}, {nt}>"}
 
