@@ -297,15 +297,21 @@ _DENSE_CONSTS = {}
 
 
 def _dense_consts(pooling):
-    """(Wc, Hc, vx, vy) of a voxel-size tensor as python numbers, read back once per tensor (version)."""
-    key = (pooling.data_ptr(), pooling._version, str(pooling.device))
-    c = _DENSE_CONSTS.get(key)
-    if c is None:
-        if len(_DENSE_CONSTS) > 64:
-            _DENSE_CONSTS.clear()
-        p = pooling.detach().float().cpu()
-        Wc, Hc = [int(v) for v in (1 / p[:2] + 1e-3).long()]
-        c = _DENSE_CONSTS[key] = (Wc, Hc, float(p[0]), float(p[1]))
+    """(Wc, Hc, vx, vy) of a voxel-size tensor as python numbers, read back once per buffer (and version of it): the
+    entry is tied to the buffer OBJECT the (possibly sliced) argument views -- an address alone could be reused by another
+    model's buffer after this one is gone."""
+    import weakref
+    base = pooling._base if pooling._base is not None else pooling
+    key = (id(base), pooling.data_ptr(), pooling._version, str(pooling.device))
+    hit = _DENSE_CONSTS.get(key)
+    if hit is not None and hit[0]() is base:
+        return hit[1]
+    if len(_DENSE_CONSTS) > 64:
+        _DENSE_CONSTS.clear()
+    p = pooling.detach().float().cpu()
+    Wc, Hc = [int(v) for v in (1 / p[:2] + 1e-3).long()]
+    c = (Wc, Hc, float(p[0]), float(p[1]))
+    _DENSE_CONSTS[key] = (weakref.ref(base), c)
     return c
 
 

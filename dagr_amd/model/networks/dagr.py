@@ -73,7 +73,10 @@ class GNNHead(YOLOXHeadParams):
         """The YOLOX loss (SimOTA assignment + three terms: ~150 small torch launches forward, ~200 backward, all on
         shapes that depend only on the configuration) as two replayed HIP graphs (``torch.cuda.make_graphed_callables``);
         the training step is host-bound, and this is a quarter of its launches.  Captured once per (shapes, device);
-        ``DAGR_GRAPH_LOSS=0`` or a capture that fails falls back to the launch-by-launch form (same kernels, same bits)."""
+        ``DAGR_GRAPH_LOSS=0`` or a capture that fails falls back to the launch-by-launch form (same kernels, same bits).
+        A replayed graph owns its input / output buffers: every forward must be followed by its backward before the next
+        forward of the same call site (the training scripts' loop; a loop that sums the losses of several forwards and
+        calls backward once needs ``DAGR_GRAPH_LOSS=0``)."""
         import os
         if not lab.is_cuda or os.environ.get("DAGR_GRAPH_LOSS", "1") == "0" or not torch.is_grad_enabled() \
                 or not all(t.requires_grad for t in flat):
