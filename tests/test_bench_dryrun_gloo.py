@@ -92,3 +92,22 @@ def test_world_size_must_match_gpus_flag():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], capture_output=True, text=True,
                        env=env, timeout=120)
     assert p.returncode != 0 and "--gpus 1 but the launcher started 2" in p.stderr
+
+
+def test_eight_ranks_as_the_driver_launches_them():
+    """The driver's scaling run: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1
+    --master-port P bench.py --gpus 8 ...` -- here with the stand-in rig on gloo: eight ranks rendezvous, every rank takes
+    part in the collectives, rank 0 prints ONE line whose value is the whole job's."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "8", "--dry-run-gloo", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["world"] == 8 and line["ranks_seen"] == 8 and len(line["per_rank"]) == 8
+    assert line["scaling"] == "weak" and line["steps"] == 3
+    assert all(set(r) == {"compute_ms", "gather_ms"} for r in line["per_rank"])
+    assert line["gather"]["detections"] == sum((r + i + b) % 4 for r in range(8) for i in range(3) for b in range(3))
