@@ -24,6 +24,10 @@ def _at_g(A, g, K=None):
     n, lda = A.shape
     K = lda if K is None else K
     P = 64 if n >= 131072 else (16 if n >= 8192 else 1)
+    if P > 1 and K < 128:
+        # a narrow A (the network's first conv: K = 26) gives the batched kernel one 16-row tile per batch -- 64 workgroups,
+        # 0.94 ms for 42 MB (rocprofv3, profiles/r4_train_step_kernel_stats.md); more, shorter batches fill the chip
+        P = min(1024, P * (128 // max(16, (K + 15) // 16 * 16)) * 2)
     m = n // P * P
     if P == 1 or m == 0:
         return A[:, :K].t() @ g
@@ -47,6 +51,32 @@ def _g_wt(g, WmT):
     if m < n:
         torch.mm(g[m:], WmT, out=out[m:])
     return out
+
+
+class TallLinearFn(torch.autograd.Function):
+    """y = x . W^T for a tall x [n, cin] (the skip Linear of the event level: 400 k rows, 3 -> 16).  torch's backward forms the
+    weight gradient g^T x as ONE product reduced over n with no split -- 0.94 ms at n = 400 k, the largest kernel of a
+    training step (rocprofv3, profiles/r4_train_step_kernel_stats.md); ``_at_g`` cuts n into a batch of partial products."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return x @ weight.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        gx = g @ weight if ctx.needs_input_grad[0] else None
+        gw = _at_g(g, x.contiguous()) if ctx.needs_input_grad[1] else None       # [cout, cin] = g^T . x
+        return gx, gw
+
+
+def tall_linear(mlp, x):
+    """``mlp(x)`` (a bias-free ``torch.nn.Linear``) with the weight gradient of ``TallLinearFn`` on tall inputs."""
+    if mlp.bias is None and x.shape[0] >= 131072 and x.is_cuda and torch.is_grad_enabled():
+        return TallLinearFn.apply(x, mlp.weight)
+    return mlp(x)
 
 
 class SplineConvFn(torch.autograd.Function):

@@ -54,7 +54,8 @@ class ConvBlockWithSkip(ConvBlock):
     def forward(self, data, data_skip):                         # conv.py:47-56
         if self.training:
             data = self.conv(data)
-            skip = _bn(self.norm_skip, self.lin.mlp(data_skip.x))
+            from .autograd import tall_linear
+            skip = _bn(self.norm_skip, tall_linear(self.lin.mlp, data_skip.x))
             data.x = torch.relu(_bn(self.norm, data.x) + skip)
             return data
         data.x = _ops.conv_on_data(self.conv, data, norm=self.norm, skip=(self.lin, self.norm_skip), xskip=data_skip.x,
