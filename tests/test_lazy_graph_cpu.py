@@ -140,3 +140,23 @@ def test_masked_loss_sums_equal_the_indexed_form_in_value_and_gradient():
         assert abs(float(g_.detach()) - float(w_.detach())) <= 1e-5 * max(1.0, abs(float(w_.detach())))
     assert float((a.grad - b.grad).abs().max()) <= 1e-6 * max(1.0, float(b.grad.abs().max()))
     assert bool(torch.isfinite(a.grad).all())
+
+
+def test_tall_linear_and_batched_weight_gradient_equal_the_plain_forms():
+    """TallLinearFn (the event level's skip Linear) and _at_g (A^T g as a batch of partial products over the long dimension,
+    any batch count, padded rows) against torch's own Linear / matmul."""
+    from dagr_amd.model.layers.autograd import TallLinearFn, _at_g
+    torch.manual_seed(1)
+    x = torch.randn(9000, 3, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(16, 3, dtype=torch.float64, requires_grad=True)
+    y = TallLinearFn.apply(x, w)
+    g = torch.randn_like(y)
+    y.backward(g)
+    x2, w2 = x.detach().clone().requires_grad_(True), w.detach().clone().requires_grad_(True)
+    y2 = torch.nn.functional.linear(x2, w2)
+    y2.backward(g)
+    assert torch.equal(y.detach(), y2.detach()) and torch.allclose(x.grad, x2.grad) and torch.allclose(w.grad, w2.grad, rtol=1e-12)
+    for n, K, lda in ((140000, 26, 28), (140001, 26, 26), (9000, 416, 416), (100, 5, 8)):
+        A = torch.randn(n, lda, dtype=torch.float64)
+        gg = torch.randn(n, 16, dtype=torch.float64)
+        assert torch.allclose(_at_g(A, gg, K), A[:, :K].t() @ gg, rtol=1e-10, atol=1e-9), (n, K, lda)
