@@ -190,8 +190,9 @@ def main(argv=None, model_factory=None, preset="ncaltech101"):
     ddp = world > 1 or (os.environ.get("DAGR_FORCE_DDP") == "1" and torch.distributed.is_initialized())
     net = parallel.data_parallel(model, dev) if ddp else model
     lr = float(args.l_r * np.sqrt(a.batch_size) / np.sqrt(64))                    # :132-133, nominal batch 64
+    # (fused: one multi-tensor launch per step instead of a dozen -- the step is bound by the host issuing launches)
     optimizer = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=lr,
-                                  weight_decay=args.weight_decay)
+                                  weight_decay=args.weight_decay, fused=(dev.type == "cuda"))
     schedule = LRSchedule(warmup_epochs=.3, num_iters_per_epoch=len(train_loader), tot_num_epochs=args.tot_num_epochs)
     scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer=optimizer, lr_lambda=schedule)
     out_dir = set_up_logging_directory(preset, "detection", a.output_directory, exp_name=a.exp_name)

@@ -24,7 +24,7 @@ ds = SyntheticObjects(B * 4, N, seed=3)
 model = DAGR(args, height=ds.height, width=ds.width).to(dev)
 model.cache_luts(width=ds.width, height=ds.height, radius=args.radius)
 ema = ModelEMA(model)
-opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-5)
+opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-5, fused=True)
 batches = [b.to(dev) for b in DataLoader(ds, batch_size=B, follow_batch=["bbox"])]
 model.train()
 
