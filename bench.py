@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--stream", choices=["uniform", "edges"], default="uniform")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the per-window latency sweep")
+    ap.add_argument("--no-rccl", action="store_true", help="world 1: no one-rank process group (plain barriers, local gather)")
     ap.add_argument("--no-events-only-leg", action="store_true", help="skip the events-only sub-measurement")
     ap.add_argument("--events-only", action="store_true",
                     help="make the events-only model (BASELINE config 1 shape) the headline instead of config 2")
@@ -391,6 +392,17 @@ def stage_timings(rig, slots, n_events_step):
     kernels = {k: dict(ms=round(v, 4), alg_MB=round(ab[k] / 1e6, 2) if k in ab else None,
                        alg_GBs=round(ab[k] / 1e9 / (v / 1e3), 1) if k in ab else None)
                for k, v in stages.items()}
+    if "l0_sample1" in kernels:
+        # 8(d) charges four taps per (node, channel); on this layout (nodes in pixel order) four of every five of those reads
+        # are cache hits, so the formula's bytes over the time is not an HBM rate (it printed > 8 TB/s).  Charged instead:
+        # what the kernel has to move once -- the feature map in, one row of Cf floats per node out; the formula's figure
+        # stays beside it as `formula_MB`.
+        fmap = eng._img_feats[1]
+        cf = 64
+        comp_b = fmap.numel() * fmap.element_size() + 4 * cf * n_events_step + 16 * n_events_step
+        kernels["l0_sample1"] = dict(ms=kernels["l0_sample1"]["ms"], alg_MB=round(comp_b / 1e6, 2),
+                                     alg_GBs=round(comp_b / 1e9 / (stages["l0_sample1"] / 1e3), 1),
+                                     formula_MB=round(ab["l0_sample1"] / 1e6, 2), bytes="compulsory (map once + rows out)")
     # the dominant kernel of the event path: the longest single-kernel stage among ALL of them (the other stages are
     # sequences of short launches, reported as stages)
     N_ = n_events_step
@@ -606,9 +618,28 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    rccl_note = None
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
+    elif not a.no_rccl:
+        # one rank: a one-rank RCCL group all the same (under torch.distributed.run: the launcher's rendezvous; alone: a
+        # local TCP store), so that the barriers and the detection gather of the timed region are the code -- and the
+        # library -- of the N > 1 runs, and the line's `gather` is an RCCL number at every N
+        import torch.distributed as tdist
+        try:
+            if "MASTER_ADDR" in os.environ and "MASTER_PORT" in os.environ and "RANK" in os.environ:
+                tdist.init_process_group("nccl", device_id=dev)
+            else:
+                import socket
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    port = sk.getsockname()[1]
+                tdist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+            dist = tdist
+            rccl_note = "one-rank nccl group"
+        except Exception as exc:                      # the bench line must not depend on it
+            rccl_note = f"no process group at world 1 ({type(exc).__name__}: {exc})"[:200]
     from dagr_amd.utils import synthetic as syn
 
     W, H, B, NPW = a.width, a.height, a.batch, a.events_per_window
@@ -651,7 +682,8 @@ def main():
                        # below; the measured per-window latency is `latency_ms`)
                        "stage_sum_ms": st["batch_latency_ms"]},
             "gather": {"detections": run["n_detections"], "gather_ms_rank0": round(1e3 * run["t_gather"], 3),
-                       "compute_ms_rank0": round(1e3 * run["t_compute"], 3)},
+                       "compute_ms_rank0": round(1e3 * run["t_compute"], 3),
+                       "backend": ("nccl (RCCL)" if dist is not None else "none"), "note": rccl_note},
             "roofline": st["roofline"], "stages": st["stages"],
         }
         if st["image_branch"] is not None:

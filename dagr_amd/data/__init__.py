@@ -38,12 +38,21 @@ class Data:
             return value
         raise AttributeError(f"{type(self).__name__!r} object has no attribute {name!r}")
 
+    def __setattr__(self, name, value):
+        # ``edge_index`` assigned by the caller replaces the graph: the kernel-side forms derived from the OLD graph (CSR by
+        # destination, integer pixel offsets, exact-offset cache) must not outlive it (set_lazy's contract: assigning the
+        # attribute replaces the recipe).  The producers of those forms set them AFTER the graph they belong to.
+        if name == "edge_index":
+            for k in ("_dagr_csr", "_dagr_pixel_codes", "_dagr_exact"):
+                self.__dict__.pop(k, None)
+        object.__setattr__(self, name, value)
+
     def _apply(self, fn):
         out = copy.copy(self)
         for k in self.keys():
             v = getattr(self, k)
             if torch.is_tensor(v):
-                setattr(out, k, fn(v))
+                out.__dict__[k] = fn(v)          # (the same graph on another device / in another dtype: caches stay)
         return out
 
     def to(self, device, non_blocking=False):
@@ -144,6 +153,18 @@ class DataLoader:
                 per = len(idx) // world
                 idx = idx[rank * per:(rank + 1) * per]
             yield Batch.from_data_list([self._fetch(i) for i in idx], follow_batch=self.follow_batch)
+
+    def image_ids(self, step):
+        """Global positions, in the run, of the images of the ``step``-th batch THIS loader yields: batch k of the run
+        holds positions [k*B, (k+1)*B); a ``batches`` loader yields whole batches of its own list, a ``shard`` loader the
+        rank's slice of every batch.  The ids ``DetectionBuffer.update`` needs for one evaluation over all ranks."""
+        B, k = self.batch_size, self.batches[step]
+        ids = list(range(k * B, min((k + 1) * B, len(self.order))))
+        if self.shard is not None:
+            rank, world = self.shard
+            per = len(ids) // world
+            ids = ids[rank * per:(rank + 1) * per]
+        return ids
 
     def _fetch(self, i):
         """Sample i of this epoch.  Shuffled (training) loaders draw the sample's random augmentations from a generator

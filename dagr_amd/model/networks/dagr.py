@@ -74,13 +74,15 @@ class GNNHead(YOLOXHeadParams):
         shapes that depend only on the configuration) as two replayed HIP graphs (``torch.cuda.make_graphed_callables``);
         the training step is host-bound, and this is a quarter of its launches.  Captured once per (shapes, device);
         ``DAGR_GRAPH_LOSS=0`` or a capture that fails falls back to the launch-by-launch form (same kernels, same bits).
-        A replayed graph owns its input / output buffers: every forward must be followed by its backward before the next
-        forward of the same call site (the training scripts' loop; a loop that sums the losses of several forwards and
-        calls backward once needs ``DAGR_GRAPH_LOSS=0``)."""
+        A replayed graph owns its input / output buffers, so a call site's graph serves ONE forward at a time: ``losses``
+        below keeps a "backward pending" mark per call site (set by the forward, cleared when the backward has run through
+        the graph or the loss tensor has been dropped), and a forward that arrives while the mark is set -- gradient
+        accumulation, several micro-batches summed before one backward -- takes the launch-by-launch form instead of
+        overwriting the first forward's buffers.  Returns (callable, key); key is None for the launch-by-launch form."""
         import os
         if not lab.is_cuda or os.environ.get("DAGR_GRAPH_LOSS", "1") == "0" or not torch.is_grad_enabled() \
                 or not all(t.requires_grad for t in flat):
-            return fn
+            return fn, None
         # (one capture per call site: a graphed callable owns its input / output buffers, and the image branch's loss and
         # the hybrid loss of a --use_image step are both alive until backward)
         key = (tag, str(lab.device), tuple(lab.shape), tuple(tuple(t.shape) for t in flat), flat[0].dtype)
@@ -93,8 +95,14 @@ class GNNHead(YOLOXHeadParams):
             except Exception as exc:                    # capture not possible here: keep the eager form
                 import warnings
                 warnings.warn(f"loss graph capture failed ({exc}); using the launch-by-launch form")
-                cache[key] = fn
-        return cache[key]
+                cache[key] = None                       # (a sentinel: the fallback is the caller's own eager closure)
+        if cache[key] is None:
+            return fn, None
+        pending = self.__dict__.setdefault("_loss_graph_pending", {})
+        mark = pending.get(key)
+        if mark is not None and not mark[1] and mark[0]() is not None:
+            return fn, None                             # the previous forward of this call site still awaits its backward
+        return cache[key], key
 
     def forward(self, xin, labels=None, imgs=None, output_sizes=None):
         """Eval: decoded ``[B, n_anchors, 5 + num_classes]`` from the backbone outputs (and the image outputs with
@@ -136,12 +144,20 @@ class GNNHead(YOLOXHeadParams):
 
             def losses(maps, lab, tag="events"):
                 flat = [t for m in maps for t in m]
-                fn = self._graphed_losses(losses_eager, lab, flat, tag)
+                fn, key = self._graphed_losses(losses_eager, lab, flat, tag)
                 total, iou, obj, cls, ratio = fn(lab, *flat)
-                if fn is not losses_eager:
+                if key is not None:
                     # a replayed graph hands out ITS buffers, rewritten by the next step: the caller gets values of its own
                     # (one small launch for the five scalars; `total` keeps its link to the graph's backward)
                     total, iou, obj, cls, ratio = torch.stack((total, iou, obj, cls, ratio)).unbind(0)
+                    import weakref
+                    mark = [weakref.ref(total), False]           # [the loss of this forward, its backward has run]
+                    self._loss_graph_pending[key] = mark
+
+                    def _done(grad, mark=mark):
+                        mark[1] = True
+                        return grad
+                    total.register_hook(_done)
                 return total, iou, obj, cls, 0.0, ratio
             if self.use_image:
                 # dagr.py:241-268: CNNHead always yields both scales; the image branch learns to detect on its own

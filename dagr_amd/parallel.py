@@ -47,8 +47,9 @@ def gather_evaluation(detections, ground_truth, image_ids, group=None):
     def host(v):
         return np.asarray(v.detach().cpu() if torch.is_tensor(v) else v)
     order = sorted(range(len(image_ids)), key=lambda i: int(image_ids[i]))
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_available() or not dist.is_initialized():
         return [detections[i] for i in order], [ground_truth[i] for i in order], [int(image_ids[i]) for i in order]
+    # (a one-rank group goes through the collective too: the same code path whatever the world size)
     rows = []
     for i in order:
         d, g, iid = detections[i], ground_truth[i], float(image_ids[i])
@@ -64,18 +65,25 @@ def gather_evaluation(detections, ground_truth, image_ids, group=None):
     mine = torch.from_numpy(np.concatenate(rows, 0) if rows else np.zeros((0, 8)))
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
     allrows = gather_detections(mine.to(dev), group=group).cpu().numpy()
+    # one stable sort by (image id, row kind) groups every image's rows (ground truth, detections, header; each kind in
+    # the order its rank sent it) -- a mask per image was quadratic in the images of a full test split
+    allrows = allrows[np.lexsort((allrows[:, 1], allrows[:, 0]))]
     heads = allrows[allrows[:, 1] == 2.0]
-    ids = sorted(int(v) for v in heads[:, 0])
+    ids = [int(v) for v in heads[:, 0]]
     if len(set(ids)) != len(ids):
         raise RuntimeError("gather_evaluation: an image id arrived from two ranks")
     dets, gts = [], []
-    for iid in ids:
-        r = allrows[allrows[:, 0] == iid]
-        g, d = r[r[:, 1] == 0.0], r[r[:, 1] == 1.0]
+    pos = 0
+    for h in heads:                                   # rows of one image: n_gt x kind 0, n_det x kind 1, the header
+        n_gt, n_det = int(h[2]), int(h[3])
+        g, d = allrows[pos:pos + n_gt], allrows[pos + n_gt:pos + n_gt + n_det]
+        pos += n_gt + n_det + 1
         gts.append(dict(boxes=torch.from_numpy(g[:, 2:6].astype(np.float32)), labels=torch.from_numpy(g[:, 7].astype(np.int64))))
         dets.append(dict(boxes=torch.from_numpy(d[:, 2:6].astype(np.float32)),
                          scores=torch.from_numpy(d[:, 6].astype(np.float32)),
                          labels=torch.from_numpy(d[:, 7].astype(np.int64))))
+    if pos != len(allrows):
+        raise RuntimeError("gather_evaluation: rows without a header")
     return dets, gts, ids
 
 

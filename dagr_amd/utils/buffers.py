@@ -114,6 +114,8 @@ class DetectionBuffer:
         """``image_ids``: the GLOBAL index of every image of the batch in the run (sharded runs: the images of a rank are
         a subset); default: a running count, i.e. the order of arrival."""
         n0 = len(self.detections)
+        if image_ids is not None and len(image_ids) != len(detections):
+            raise ValueError(f"DetectionBuffer.update: {len(image_ids)} image ids for {len(detections)} images")
         self.detections.extend({k: v.cpu() for k, v in d.items()} for d in detections)
         self.ground_truth.extend({k: v.cpu() for k, v in d.items()} for d in groundtruth)
         self.image_ids.extend(image_ids if image_ids is not None else range(n0, n0 + len(detections)))
@@ -127,14 +129,20 @@ class DetectionBuffer:
             return {k: np.concatenate(v) for k, v in out.items()}
         return by_sequence(self.detections), by_sequence(self.ground_truth)
 
-    def compute(self):
+    def compute(self, gather=True, group=None):
         """mAP & co over everything collected since the last call (buffers.py:113-122).  Under a process group (window
         batches sharded over the GPUs of a node) the ranks' images are gathered first -- detections AND ground truth, in
         global image order -- and every rank evaluates the whole run: ONE mAP, the number the reference's single process
-        prints (run_test.py:61-65)."""
+        prints (run_test.py:61-65).  That makes this call a COLLECTIVE over ``group`` (default group when None): every
+        rank has to make it, with image ids that are unique over the ranks (``update(image_ids=...)``).
+        ``gather=False``: this rank's images only, no communication (a caller that scores on one rank)."""
         from .coco_eval import evaluate_detection
         from ..parallel import gather_evaluation
-        dets, gts, _ = gather_evaluation(self.detections, self.ground_truth, self.image_ids)
+        if gather:
+            dets, gts, _ = gather_evaluation(self.detections, self.ground_truth, self.image_ids, group=group)
+        else:
+            order = sorted(range(len(self.image_ids)), key=lambda i: int(self.image_ids[i]))
+            dets, gts = [self.detections[i] for i in order], [self.ground_truth[i] for i in order]
         out = evaluate_detection(gts, dets, height=self.height, width=self.width, classes=self.classes)
         self.detections, self.ground_truth, self.image_ids = [], [], []
         return {k.replace("AP", "mAP"): v for k, v in out.items()}

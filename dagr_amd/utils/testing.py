@@ -35,8 +35,8 @@ def run_test_with_visualization(loader, model, dataset: str, log_every_n_batch=-
         ds = loader.dataset
         scorer = DetectionBuffer(height=ds.height, width=ds.width, classes=ds.classes)
     collected = [] if compile_detections else None
-    # global index of an image in the run: batch k of the (possibly sharded) loader holds images [k*B, (k+1)*B)
-    batch_ids = getattr(loader, "batches", None)
+    # global index of an image in the run (``DataLoader.image_ids``: right for both ways of sharding a loader); a foreign
+    # loader numbers its images in order of arrival
     for step, data in enumerate(loader):
         if torch.cuda.is_available():
             data = data.cuda(non_blocking=True)
@@ -49,8 +49,7 @@ def run_test_with_visualization(loader, model, dataset: str, log_every_n_batch=-
         if scorer is not None:
             if len(out) < 2:
                 raise RuntimeError("evaluation needs ground-truth boxes (data.bbox); pass no_eval=True without them")
-            first = (batch_ids[step] if batch_ids is not None else step) * getattr(loader, "batch_size", len(detections))
-            scorer.update(detections, out[1], dataset, data.height[0], data.width[0],
-                          image_ids=range(first, first + len(detections)))
+            ids = loader.image_ids(step) if hasattr(loader, "image_ids") else None
+            scorer.update(detections, out[1], dataset, data.height[0], data.width[0], image_ids=ids)
     metrics = scorer.compute() if scorer is not None else None
     return (metrics, collected) if compile_detections else metrics

@@ -55,10 +55,27 @@ def distributed():
         dev = torch.device("cuda", local_rank)
     else:
         dev = torch.device("cpu")
-    if world > 1 and not torch.distributed.is_initialized():
+    # a launcher's rendezvous is honoured at every world size (one rank under ``torch.distributed.run`` is a one-rank RCCL
+    # group: the gathers at the end of the run are then the collectives an 8-rank run makes)
+    launched = all(k in os.environ for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"))
+    if (world > 1 or launched) and not torch.distributed.is_initialized():
         torch.distributed.init_process_group("nccl" if dev.type == "cuda" else "gloo",
                                              **({"device_id": dev} if dev.type == "cuda" else {}))
+        global _OWNS_GROUP
+        _OWNS_GROUP = True
     return world, rank, dev
+
+
+_OWNS_GROUP = False
+
+
+def finish(world):
+    """End of a script: ranks leave together; the process group goes if this script made it (or the run is sharded)."""
+    global _OWNS_GROUP
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and (world > 1 or _OWNS_GROUP):
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+        _OWNS_GROUP = False
 
 
 def dataset_and_loader(a, world, rank):

@@ -42,9 +42,7 @@ def main(argv=None, model_factory=None):
     if rank == 0:
         print(f"{a.num_interframe_steps} offsets x {len(ds) // a.batch_size * a.batch_size} windows on {world} GPU(s) in "
               f"{time.perf_counter() - t0:.2f} s -> {out_dir}: {files}")
-    if world > 1:
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
+    C.finish(world)
     return out_dir
 
 

@@ -95,8 +95,8 @@ def train_epoch(loader, net, module, ema, scheduler, optimizer, clip, dev, log, 
 @torch.no_grad()
 def validate(loader, net, dev, dry_run_steps=-1, detections=True):
     """``run_test`` of the training script (:76-99): ``ema.ema`` in eval mode through the window engine, detections and
-    targets into the mAP buffer; every rank evaluates its slice of the validation batches and the buffers are merged on
-    all ranks before ``compute``.  ``detections=False`` (stand-in models without an eval branch): the mean training-mode
+    targets into the mAP buffer under their global image ids; every rank runs its slice of the validation batches and
+    ``compute`` gathers the slices (one collective, ``parallel.gather_evaluation``): the same mAP on every rank.  ``detections=False`` (stand-in models without an eval branch): the mean training-mode
     loss of the validation batches instead, reported as a negative "mAP" so that the best-checkpoint logic still works."""
     from dagr.utils.buffers import DetectionBuffer
     if detections:
@@ -105,14 +105,10 @@ def validate(loader, net, dev, dry_run_steps=-1, detections=True):
         for i, data in enumerate(loader):
             data = format_data(data.to(dev))
             dets, targets = net(data)
-            buf.update(dets, targets, "ncaltech101", data.height[0], data.width[0])
+            buf.update(dets, targets, "ncaltech101", data.height[0], data.width[0],
+                       image_ids=loader.image_ids(i) if hasattr(loader, "image_ids") else None)
             if 0 < dry_run_steps == i:
                 break
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            parts = [None] * torch.distributed.get_world_size()
-            torch.distributed.all_gather_object(parts, (buf.detections, buf.ground_truth))
-            buf.detections = [d for p in parts for d in p[0]]
-            buf.ground_truth = [g for p in parts for g in p[1]]
         return buf.compute()
     was = net.training
     net.train()

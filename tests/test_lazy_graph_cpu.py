@@ -160,3 +160,22 @@ def test_tall_linear_and_batched_weight_gradient_equal_the_plain_forms():
         A = torch.randn(n, lda, dtype=torch.float64)
         gg = torch.randn(n, 16, dtype=torch.float64)
         assert torch.allclose(_at_g(A, gg, K), A[:, :K].t() @ gg, rtol=1e-10, atol=1e-9), (n, K, lda)
+
+
+def test_assigning_edge_index_drops_the_kernel_side_forms_of_the_old_graph():
+    """``Data.set_lazy``'s contract (assigning the attribute replaces the recipe) includes what was derived from the old
+    graph: the cached CSR, the integer pixel offsets and the exact-offset cache.  Moving the SAME graph
+    (``to`` / ``clone``) keeps them, and materialising the lazy ``edge_index`` is not an assignment."""
+    from dagr_amd.model.layers import _ops
+    rowptr, col = torch.tensor([0, 1, 3], dtype=torch.int32), torch.tensor([0, 0, 1], dtype=torch.int32)
+    d = Data(x=torch.zeros(2, 1), pos=torch.zeros(2, 3))
+    d._dagr_csr = (rowptr, col, None, ("csr", 2))
+    d._dagr_pixel_codes = (torch.zeros(3, dtype=torch.int32), 8, 8)
+    d.set_lazy("edge_index", _ops.edge_index_from_csr)
+    assert d.edge_index.tolist() == [[0, 0, 1], [0, 1, 1]] and "_dagr_csr" in d.__dict__     # materialised: caches stay
+    moved = d.to("cpu")
+    assert "_dagr_csr" in moved.__dict__ and "_dagr_pixel_codes" in moved.__dict__
+    d.edge_index = torch.tensor([[1], [0]])
+    assert "_dagr_csr" not in d.__dict__ and "_dagr_pixel_codes" not in d.__dict__
+    r, c, _ = _ops.graph_csr(d)                                     # rebuilt from the new edge_index
+    assert r.tolist() == [0, 1, 1] and c.tolist() == [1]

@@ -80,10 +80,13 @@ def _script_worker(rank, world, port, out_dir):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "scripts"))
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank))
     if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          LOCAL_RANK=str(rank))
         dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:       # no launcher: the script runs without a process group
+        for k in ("MASTER_ADDR", "MASTER_PORT", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            os.environ.pop(k, None)
     import run_test
     factory = lambda a, ds, dev: (type("A", (), {"note": "stand-in"})(), _StandInNet())
     run_test.main(["--windows", "10", "--batch_size", "2", "--events_per_window", "203", "--width", "64", "--height", "48",
@@ -135,10 +138,13 @@ def _labelled_worker(rank, world, port, out_dir, script):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "scripts"))
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank))
     if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          LOCAL_RANK=str(rank))
         dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:       # no launcher: the script runs without a process group
+        for k in ("MASTER_ADDR", "MASTER_PORT", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            os.environ.pop(k, None)
     mod = __import__(script)
     factory = lambda a, ds, dev: (type("A", (), {"note": "stand-in"})(), _LabelledStandInNet())
     extra = ["--num_interframe_steps", "2"] if script == "run_test_interframe" else []
@@ -184,3 +190,84 @@ def test_gather_evaluation_orders_by_image_id_without_a_process_group():
     g = [dict(boxes=torch.zeros((1, 4)), labels=torch.zeros(1, dtype=torch.long)) for _ in range(3)]
     dets, gts, ids = parallel.gather_evaluation(d, g, [5, 1, 3])
     assert ids == [1, 3, 5] and [len(x["boxes"]) for x in dets] == [2, 3, 1]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# a launcher's ONE-rank rendezvous is a process group too (scripts/_common.py:distributed): the evaluation gather then runs
+# as a collective -- the code path of an 8-rank run -- and gives the numbers of the run without a group
+def _one_rank_launched_worker(rank, port, out_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "scripts"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    import run_test
+    factory = lambda a, ds, dev: (type("A", (), {"note": "stand-in"})(), _LabelledStandInNet())
+    run_test.main(["--labelled", "--windows", "14", "--batch_size", "2", "--events_per_window", "400", "--width", "240",
+                   "--height", "180", "--output_directory", out_dir], model_factory=factory)
+    assert not dist.is_initialized()                     # the script made the group, the script took it down
+
+
+def test_one_rank_launch_goes_through_the_collectives(tmp_path):
+    import json
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    _labelled_worker(0, 1, 0, str(tmp_path / "plain"), "run_test")
+    mp.spawn(_one_rank_launched_worker, args=(_free_port(), str(tmp_path / "launched")), nprocs=1, join=True)
+    a, b = (json.load(open(tmp_path / d / "synthetic" / "detection" / "run_test" / "metrics.json")) for d in ("plain", "launched"))
+    assert a == b and 0.0 < a["mAP"] < 1.0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the training script's validation pass with a DETECTING model under a process group: every rank runs its
+# slice of each validation batch (DataLoader(shard=(rank, world))), the buffer carries global image ids and compute()
+# gathers once -- the mAP of the whole validation split on every rank, equal to the single-process number
+def _validate_worker(rank, world, port, out_dir):
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "scripts"))
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          LOCAL_RANK=str(rank), CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    import train_ncaltech101 as T
+    from dagr.data import DataLoader
+    from dagr.data.augment import Augmentations
+    from dagr.data.synthetic_data import SyntheticObjects
+    ds = SyntheticObjects(12, 400, 240, 180, transform=Augmentations.transform_testing)
+    loader = DataLoader(ds, follow_batch=["bbox", "bbox0"], batch_size=4, shuffle=False, drop_last=True,
+                        shard=(rank, world) if world > 1 else None)
+    assert loader.image_ids(1) == list(range(4, 8))[rank * (4 // world):(rank + 1) * (4 // world)]
+    metrics = T.validate(loader, _LabelledStandInNet(), torch.device("cpu"), detections=True)
+    with open(os.path.join(out_dir, f"val_w{world}_r{rank}.json"), "w") as f:
+        json.dump(metrics, f)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_training_validation_with_detections_is_one_map_over_all_ranks(tmp_path):
+    import json
+    _validate_worker(0, 1, 0, str(tmp_path))
+    mp.spawn(_validate_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    one = json.load(open(tmp_path / "val_w1_r0.json"))
+    two = [json.load(open(tmp_path / f"val_w2_r{r}.json")) for r in (0, 1)]
+    assert 0.0 < one["mAP"] < 1.0
+    assert two[0] == one and two[1] == one, (one, two)
+
+
+def test_compute_without_gather_scores_this_ranks_images_only():
+    from dagr_amd.utils.buffers import DetectionBuffer
+    buf = DetectionBuffer(height=180, width=240, classes=["a", "b"])
+    box = torch.tensor([[10.0, 10.0, 60.0, 50.0]])
+    det = [dict(boxes=box, scores=torch.tensor([0.9]), labels=torch.tensor([0]))]
+    gt = [dict(boxes=box, labels=torch.tensor([0]))]
+    buf.update(det, gt, image_ids=[7])
+    m = buf.compute(gather=False)
+    assert abs(m["mAP"] - 1.0) < 1e-9 and buf.image_ids == []
+    try:
+        buf.update(det + det, gt + gt, image_ids=[1])
+        raise AssertionError("a wrong number of image ids must be refused")
+    except ValueError:
+        pass

@@ -164,6 +164,47 @@ def test_training_backward_is_deterministic():
         assert torch.equal(snaps[0][1][k], snaps[1][1][k]), k
 
 
+def test_two_forwards_before_one_backward_do_not_share_the_loss_graph():
+    """Gradient accumulation: two forwards of the same call site, ONE backward over the sum.  The graphed YOLOX loss owns
+    static buffers, so the second forward must not replay it while the first one's backward is pending (it
+    silently produced wrong gradients); it takes the launch-by-launch form, and the result equals the all-eager run."""
+    import os
+    W, H, B = 240, 180, 2
+    args, model, _, batch, _, _ = _training_case(W, H, B, 3000, seed=6)
+
+    def accumulate():
+        model.zero_grad(set_to_none=True)
+        o1 = model(format_data(batch.clone().cuda()))
+        o2 = model(format_data(batch.clone().cuda()))
+        (o1["total_loss"] + o2["total_loss"]).backward()
+        return float(o1["total_loss"]), float(o2["total_loss"]), \
+            {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    old = os.environ.pop("DAGR_GRAPH_LOSS", None)
+    try:
+        a1, a2, ga = accumulate()                 # graph for the first forward, launch-by-launch for the second
+        b1, b2, gb = accumulate()                 # again: the mark of the first round was cleared by its backward
+        os.environ["DAGR_GRAPH_LOSS"] = "0"
+        e1, e2, ge = accumulate()
+    finally:
+        os.environ.pop("DAGR_GRAPH_LOSS", None)
+        if old is not None:
+            os.environ["DAGR_GRAPH_LOSS"] = old
+    assert a1 == b1 and a2 == b2 and e1 == e2
+    assert abs(a1 - e1) <= 1e-6 * max(1.0, abs(e1)) and abs(a2 - e2) <= 1e-6 * max(1.0, abs(e2))
+    assert ga.keys() == ge.keys() and len(ga) >= 60
+    for k in ga:
+        assert torch.equal(ga[k], gb[k]), k
+        assert _rel(ga[k], ge[k]) < 1e-6, (k, _rel(ga[k], ge[k]))
+    # and a forward whose loss was dropped without a backward does not block the graph for good
+    model.zero_grad(set_to_none=True)
+    model(format_data(batch.clone().cuda()))
+    import gc
+    gc.collect()
+    head = model.head
+    marks = list(head.__dict__.get("_loss_graph_pending", {}).values())
+    assert marks and all(m[0]() is None or m[1] for m in marks)
+
+
 def test_a_few_optimizer_steps_reduce_the_loss():
     W, H, B = 240, 180, 2
     args, model, _, batch, _, _ = _training_case(W, H, B, 2000, seed=4)
