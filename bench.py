@@ -600,6 +600,20 @@ def async_update_leg(W, H, dev, n_window=25000, sizes=(1, 10, 100), n_updates=10
     return out
 
 
+def _claim_stdout():
+    """The run's ONE JSON line goes to the process's real stdout; everything else that writes to file descriptor 1 on the way
+    (RCCL prints its version banner there when a communicator is made) is sent to stderr.  Returns the real stdout's fd."""
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+    return real
+
+
+def _emit(real_fd, text):
+    sys.stdout.flush()
+    os.write(real_fd, (text + "\n").encode())
+
+
 def main():
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -612,6 +626,7 @@ def main():
     if a.dry_run_gloo:
         return dry_run(a, world, rank)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    real_out = _claim_stdout()
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"bench.py: rank {rank} has no device ({torch.cuda.device_count()} visible, local rank {local_rank})")
     torch.backends.cudnn.benchmark = True   # MIOpen picks its fastest fp32 conv kernels for the image branch
@@ -622,22 +637,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
-    elif not a.no_rccl:
-        # one rank: a one-rank RCCL group all the same (under torch.distributed.run: the launcher's rendezvous; alone: a
-        # local TCP store), so that the barriers and the detection gather of the timed region are the code -- and the
-        # library -- of the N > 1 runs, and the line's `gather` is an RCCL number at every N
+    elif not a.no_rccl and all(k in os.environ for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")):
+        # one rank under a launcher (python -m torch.distributed.run --nproc-per-node 1): a one-rank RCCL group all the same,
+        # so that the barriers and the detection gather of the timed region are the code -- and the library -- of the
+        # N > 1 runs.  Without a launcher (python bench.py) there is no group: plain barriers, local gather.
         import torch.distributed as tdist
         try:
-            if "MASTER_ADDR" in os.environ and "MASTER_PORT" in os.environ and "RANK" in os.environ:
-                tdist.init_process_group("nccl", device_id=dev)
-            else:
-                import socket
-                with socket.socket() as sk:
-                    sk.bind(("127.0.0.1", 0))
-                    port = sk.getsockname()[1]
-                tdist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+            tdist.init_process_group("nccl", device_id=dev)
             dist = tdist
-            rccl_note = "one-rank nccl group"
+            rccl_note = "one-rank nccl group (launcher rendezvous)"
         except Exception as exc:                      # the bench line must not depend on it
             rccl_note = f"no process group at world 1 ({type(exc).__name__}: {exc})"[:200]
     from dagr_amd.utils import synthetic as syn
@@ -732,7 +740,7 @@ def main():
             result["events_only"]["cpu_baseline"] = cpu_baseline(None, ev_sd_cpu, W, H, Bc, NPW, a.cpu_steps, a.stream,
                                                                  False, a.img_net)
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        _emit(real_out, json.dumps(result))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

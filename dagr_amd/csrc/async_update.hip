@@ -6,13 +6,14 @@
 // min_index = number of events already in the graph.  Edges point from older to newer events, so the rows of the
 // events already in the window do not change: an update only APPENDS level-0 rows.
 //
-// Here there is no FIFO volume.  The window's events stay where dagr_graph_build_window left them -- the CSR-by-pixel
-// index, newest last inside a pixel -- and the events appended since hang off per-pixel chains, newest first:
+// Here there is no FIFO volume.  The window's events stay where dagr_graph_build_window left them -- the index keyed
+// (sample, y, time bucket, x), newest last inside a segment -- and the events appended since hang off per-pixel chains,
+// newest first:
 //   app_head[p]  newest appended event of pixel p (-1: none)           int32[B*H*W]
 //   app_next[k]  next older appended event of the same pixel           int32[capacity], k = id - n_static
 //   app_xytb[k]  {x, y, t, b} of appended event k                      int32[capacity][4]
-// The FIFO column of pixel p, newest first, is then: its chain, followed by the tail of its CSR segment read backwards,
-// cut at depth Q -- which is all the reference's walk looks at (ev_graph.cu:58-76).
+// The FIFO column of pixel p, newest first, is then: its chain, followed by its segments read backwards (newest bucket
+// first), cut at depth Q -- which is all the reference's walk looks at (ev_graph.cu:58-76).
 //   k_async_insert  one workgroup per chunk of <= 1024 new events: denormalise (ev_tgn.py:11-16), link every event to
 //                   the previous new event of its pixel (or the old head), publish the new heads.  No atomics: the
 //                   order inside a pixel is the event order, as the reference's stable sort gives it.
@@ -25,8 +26,7 @@
 #include "common.hpp"
 
 namespace dagr {
-// views into the builder workspace (graph_build.hip)
-void graph_ws_views(const dagr_graph_desc *desc, void *workspace, const int32_t **start, const int2 **slot_it);
+// (the builder's index: PixelIndex / graph_ws_index, common.hpp)
 
 namespace {
 
@@ -114,9 +114,45 @@ __global__ __launch_bounds__(kChunk) void k_async_insert(const void *__restrict_
     if (p >= 0 && last) app_head[p] = first_id + i;
 }
 
+// The window events of pixel (xn, yb), newest (largest id) first: fn(slot) until it returns false.  The pixel's events are
+// its nb segments (one per time bucket, ids ascending inside a segment); sorted timestamps make "newest bucket first, each
+// segment backwards" the order by id.  Unsorted timestamps (ids no longer follow the buckets): the next entry is the
+// largest id below the last one over all segments, found by one binary search per segment and step -- slow, rare, exact.
+template <typename Fn>
+__device__ __forceinline__ void walk_window_pixel(const PixelIndex &ix, bool unsorted, int xn, int yb, Fn fn) {
+    if (!unsorted) {
+        for (int j = ix.nb - 1; j >= 0; j--) {
+            const int key = ix.segment(xn, j, yb);
+            const int a0 = ix.start[key], a1 = ix.start[key + 1];
+            for (int k = a1 - 1; k >= a0; k--)
+                if (!fn(k)) return;
+        }
+        return;
+    }
+    int last = 0x7fffffff;
+    for (;;) {
+        int best = -1, bk = -1;
+        for (int j = 0; j < ix.nb; j++) {
+            const int key = ix.segment(xn, j, yb);
+            int a = ix.start[key], b = ix.start[key + 1];
+            const int a0 = a;
+            while (a < b) {                      // first slot of the segment with id >= last
+                const int m = (a + b) >> 1;
+                if (ix.slot_it[m].x < last) a = m + 1; else b = m;
+            }
+            if (a - 1 >= a0) {
+                const int id = ix.slot_it[a - 1].x;
+                if (id > best) { best = id; bk = a - 1; }
+            }
+        }
+        if (bk < 0) return;
+        last = best;
+        if (!fn(bk)) return;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_async_fill(int n, int first_id, int n_static, int W, int H, int B, int K, int Q, int r,
-                                                      float delta_t, const int32_t *__restrict__ start,
-                                                      const int2 *__restrict__ slot_it,
+                                                      float delta_t, const PixelIndex ix,
                                                       const int32_t *__restrict__ app_head,
                                                       const int32_t *__restrict__ app_next,
                                                       const int4 *__restrict__ app_xytb, int32_t *__restrict__ nbr_src,
@@ -124,6 +160,8 @@ __global__ __launch_bounds__(kBlock) void k_async_fill(int n, int first_id, int 
     const int l = threadIdx.x & 15;
     const int i = (blockIdx.x * kBlock + threadIdx.x) >> 4;
     if (i >= n) return;
+    const int2 *__restrict__ slot_it = ix.slot_it;
+    const bool unsorted = *ix.unsorted != 0;
     const int own = first_id + i;
     const int4 me = app_xytb[own - n_static];
     const int x = me.x, y = me.y, ts = me.z, b = me.w;
@@ -138,18 +176,17 @@ __global__ __launch_bounds__(kBlock) void k_async_fill(int n, int first_id, int 
     const bool inside = x >= 0 && x < W && y >= 0 && y < H && b >= 0 && b < B;
     for (int s0 = 0; s0 < S && total < K && inside; s0 += 16) {
         const int s = s0 + l;
-        int v = 0, head = -1, a0 = 0, a1 = 0, code = 0;
+        int v = 0, head = -1, xn = 0, yb = 0, code = 0;
         bool probe = false;
         if (s < S) {
             int sx, sy;
             spiral_offset_a(s, sx, sy);
-            const int xn = x + sx, yn = y + sy;
+            xn = x + sx;
+            const int yn = y + sy;
             code = (sx + r) * side + (sy + r);
             if (xn >= 0 && yn >= 0 && xn < W && yn < H) {          // out of FOV: skip this pixel only
-                const int p = xn + W * (yn + H * b);
-                head = app_head[p];
-                a0 = start[p];
-                a1 = start[p + 1];
+                yb = yn + H * b;
+                head = app_head[xn + W * yb];
                 probe = true;
             }
         }
@@ -162,10 +199,12 @@ __global__ __launch_bounds__(kBlock) void k_async_fill(int n, int first_id, int 
                     v++;
                 }
             }
-            for (int k = a1 - 1; k >= a0 && depth < Q && v < K; k--, depth++) {
-                if ((float)(ts - slot_it[k].y) > delta_t) continue;               // window events: always older than own
-                v++;
-            }
+            if (depth < Q && v < K)
+                walk_window_pixel(ix, unsorted, xn, yb, [&](int k) {
+                    if (!((float)(ts - slot_it[k].y) > delta_t)) v++;             // window events: always older than own
+                    depth++;
+                    return depth < Q && v < K;
+                });
         }
         const int incl = scan16a(v);
         int slot = total + incl - v;
@@ -180,12 +219,16 @@ __global__ __launch_bounds__(kBlock) void k_async_fill(int n, int first_id, int 
                     slot++;
                 }
             }
-            for (int k = a1 - 1; k >= a0 && depth < Q && slot < K; k--, depth++) {
-                if ((float)(ts - slot_it[k].y) > delta_t) continue;
-                nbr_src[row + slot] = k;                       // a window event's node is its CSR slot
-                nbr_code[row + slot] = (int16_t)code;
-                slot++;
-            }
+            if (depth < Q && slot < K)
+                walk_window_pixel(ix, unsorted, xn, yb, [&](int k) {
+                    if (!((float)(ts - slot_it[k].y) > delta_t)) {
+                        nbr_src[row + slot] = k;               // a window event's node is its CSR slot
+                        nbr_code[row + slot] = (int16_t)code;
+                        slot++;
+                    }
+                    depth++;
+                    return depth < Q && slot < K;
+                });
         }
     }
     if (l == 0) deg[own] = min(total, K);
@@ -216,9 +259,8 @@ int dagr_async_graph_append(const dagr_graph_desc *desc, void *graph_ws, int64_t
                        "level-0 input rows: normalised fp32 pos and all row arrays are needed");
     }
     hipStream_t stream = (hipStream_t)stream_;
-    const int32_t *start;
-    const int2 *slot_it;
-    graph_ws_views(desc, graph_ws, &start, &slot_it);
+    PixelIndex ix;
+    graph_ws_index(desc, graph_ws, &ix);
     const int W = desc->width, H = desc->height, B = desc->batch_size;
     for (int64_t c0 = 0; c0 < n_new; c0 += kChunk) {        // chunks in event order: a chunk's heads are in place before the next
         const int n = (int)std::min<int64_t>(kChunk, n_new - c0);
@@ -236,7 +278,7 @@ int dagr_async_graph_append(const dagr_graph_desc *desc, void *graph_ws, int64_t
     // the reference pushes the whole micro-batch into the queue before it searches (ev_graph.py:84-93): all chains first
     k_async_fill<<<(unsigned)ceil_div(n_new * 16, kBlock), kBlock, 0, stream>>>(
         (int)n_new, (int)first_id, (int)n_static, W, H, desc->batch_size, desc->max_neighbors, desc->queue_size, desc->radius,
-        (float)desc->delta_t_us, start, slot_it, app_head, app_next, (const int4 *)app_xytb, nbr_src, nbr_code, deg);
+        (float)desc->delta_t_us, ix, app_head, app_next, (const int4 *)app_xytb, nbr_src, nbr_code, deg);
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;
 }

@@ -156,7 +156,21 @@ hipError_t exclusive_scan_i32_chained(int32_t *in, int32_t *out, int64_t n, void
 hipError_t launch_gemm_mfma(const int32_t *m_ptr, int m_max, const float *A, int lda, const float *Wm, int ldw,
                             const float *bias, float *C, int ldc, int K, int N, int relu, hipStream_t stream);
 const int32_t *graph_ws_node_count(const dagr_graph_desc *desc, void *workspace);
-void graph_ws_views(const dagr_graph_desc *desc, void *workspace, const int32_t **start, const int2 **slot_it);
-const int32_t *graph_ws_slot_xyb(const dagr_graph_desc *desc, void *workspace);
+// The window builder's event index as the other kernels see it (graph_build.hip).  Events are CSR slots in
+// (sample, y, time bucket, x) order, ids ascending inside a segment (one pixel, one bucket); key of a segment:
+// x + W * (bucket + nb * (y + H * sample)); start[key] .. start[key + 1] are its slots.  All events of a range of pixel
+// rows of one sample are ONE contiguous run of slots (rows(y0) .. rows(y1)); a pixel's events, oldest bucket first, are its
+// nb segments (when the window's timestamps are sorted -- *unsorted == 0 -- that is also oldest event first).
+struct PixelIndex {
+    const int32_t *start;
+    const int2 *slot_it;        // {event id, t} per slot
+    const int32_t *slot_xyb;    // x | y << 12 | sample << 24 | visible << 31 per slot
+    const int32_t *n_nodes;     // number of indexed events (device)
+    const int32_t *unsorted;    // != 0: timestamps were not non-decreasing in event order inside a sample (device)
+    int W, H, nb;
+    __host__ __device__ int segment(int x, int bucket, int yb) const { return x + W * (bucket + nb * yb); }   // yb = y + H * sample
+    __host__ __device__ int row_begin(int yb) const { return W * nb * yb; }    // key of the first segment of pixel row yb
+};
+void graph_ws_index(const dagr_graph_desc *desc, void *workspace, PixelIndex *out);
 
 }  // namespace dagr

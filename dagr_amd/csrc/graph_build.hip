@@ -7,21 +7,25 @@
 // -1-padded int64 edge buffer.
 //
 // What this file does instead (same edge set, same order, bit-exact):
-//   * events are bucketed by linear pixel p = x + W*(y + H*b) into a CSR-by-pixel array
-//     (per-pixel counters -> exclusive scan -> scatter -> in-segment order fix-up).  After all N
-//     events of a reset window are inserted, the FIFO column of pixel p holds exactly the newest
-//     min(count_p, Q) events of that pixel, newest first -- i.e. the tail of its CSR segment read
-//     backwards.  The 157 MB volume and its refill disappear; the search touches a (P+1)-int
-//     offset array (1.2 MB/sample, L2-resident) plus {id, t} pairs that sit contiguously per pixel.
-//   * the search runs 16 lanes per destination event (4 events per wave64): each lane owns one
-//     spiral position of the current 16-position chunk, counts its admissible sources, a 16-lane
-//     prefix sum reproduces the reference's sequential "first K in spiral order, newest first
-//     inside a pixel" cut exactly, and the chunk loop exits as soon as K slots are filled (dense
-//     scenes finish in the first chunk, like the reference's early break).
+//   * events are bucketed by the key (sample, y, TIME BUCKET, x) into a CSR array (per-key counters -> exclusive scan ->
+//     scatter -> in-segment order fix-up).  A time bucket is delta_t wide (a hair more), so every admissible source of
+//     a destination (older, dt <= delta_t: ev_graph.cu:64,69) lies in the destination's own bucket or the one before,
+//     and in slot order the events of one pixel row of one bucket are ONE contiguous range: a destination fetches
+//     2 x (2r+1) row ranges that hold ~0.4 of the window's events in its (2r+1)^2 pixels (a 50 ms window, delta_t = 10 ms),
+//     where an index without the time dimension (rounds 1-4: CSR by pixel) handed it every event of those pixels and
+//     four in five failed the dt test.  After all N events of a reset window are inserted, the FIFO column of a pixel
+//     holds exactly the newest min(count, Q) events of that pixel, newest first -- its segments read backwards, newest
+//     bucket first; the 157 MB volume and its refill disappear.
+//   * the search is candidate-centric (k_search_rows): the row ranges' events are tested 16 at a time and keyed by
+//     (spiral rank of their pixel, recency); the reference's sequential "first K in spiral order, newest first inside a
+//     pixel" cut is "the K-1 smallest keys in key order".  Event-dense neighbourhoods go to a position-centric walk
+//     (k_search_dense), unsorted timestamps and radii beyond 7 pixels to its generic form.
 //   * output is a fixed-stride neighbour list [N, K] (int32 source + int16 offset code) + deg[N]:
 //     no -1 fill, no compaction pass, no host sync; the offset code is the SplineConv LUT index.
 #include "common.hpp"
 
+#include <algorithm>
+#include <stdlib.h>
 #include <type_traits>
 
 namespace dagr {
@@ -30,35 +34,116 @@ namespace {
 constexpr int kVisBit = (int)0x80000000;  // slot_xyb bit 31: among the newest Q events of its pixel
 constexpr int kShortSeg = 64;    // segments up to this length are ordered by per-slot rank counting
 constexpr int kMaxQueue = 1024;  // LDS staging bound for the long-segment path
-constexpr int kMaxSpiral = 4096; // (2r+1)^2 bound for the LDS spiral table (r <= 31)
+constexpr int kMaxSpiral = 4096; // (2r+1)^2 bound for the LDS spiral tables (r <= 31)
+constexpr int kMaxBuckets = 16;
+
+// Time buckets.  bucket(t) = clamp(floor((t - t_base) / wb), 0, nb - 1): monotone in t, so for ANY timestamps the sources
+// with t - delta <= ts <= t lie in the buckets bucket(t - delta) .. bucket(t), and wb >= delta makes that {tb - 1, tb}.
+// The nb buckets end at the window's normaliser T (the datasets shift a window so that its last event sits at T,
+// dsec_data.py:145); everything older shares bucket 0, everything later the last one -- slower, never wrong.
+struct TimeKey {
+    int t_base;         // start of bucket 0
+    int t_end;          // t_base + nb * wb
+    int wb;             // bucket width, us (>= delta_t_us + float-rounding slack)
+    float inv_wb;
+    int nb;             // number of buckets (1: the index of rounds 1-4)
+};
+
+TimeKey time_key(const dagr_graph_desc &d) {
+    // builder knobs: DAGR_TIME_BUCKETS (5 covers a 50 ms window at delta_t = 10 ms), DAGR_BUCKET_US (>= delta_t)
+    static const int env_nb = [] { const char *e = getenv("DAGR_TIME_BUCKETS"); return e ? atoi(e) : 0; }();
+    static const long long env_wb = [] { const char *e = getenv("DAGR_BUCKET_US"); return e ? atoll(e) : 0ll; }();
+    const long long delta = std::max<long long>(1, d.delta_t_us);
+    // the admissibility test is made in fp32 ((float)(t - ts) > delta_t, ev_graph.cu:69): beyond 2^24 us a difference of
+    // delta + 1 can round onto delta, hence the slack
+    long long wb = delta + (delta >> 22) + 1;
+    if (env_wb > wb) wb = env_wb;
+    // Default: ONE bucket (the index keyed by pixel of rounds 1-4).  Measured in round 5 (profiles/r5_search_buckets.md,
+    // 640x480, delta_t = 10 ms, 50 ms windows): with five buckets a destination examines 0.4 of the candidates but fetches
+    // 2 x (2r+1) row ranges instead of (2r+1), and the search kernel's time goes into exactly those scattered offset
+    // loads (one L1 line per lane: ~1 line per cycle and CU; 104 us of a 220-us launch with the candidate work removed) --
+    // a wash on sparse windows, a gain only on dense UNIFORM streams (-23 % of the build at 8 x 400 k events), a loss on
+    // clustered ones (S-edges 8 x 200 k: 1.79 ms against 1.65), which is what real recordings look like.  DAGR_DENSE_EVENTS
+    // = n switches buckets on for workspaces sized for >= n events per sample.
+    static const long long dense_thr = [] { const char *e = getenv("DAGR_DENSE_EVENTS"); return e ? atoll(e) : 0ll; }();
+    int nb = env_nb > 0 ? env_nb : (dense_thr > 0 && d.max_events / std::max(1, d.batch_size) >= dense_thr ? 5 : 1);
+    nb = std::min(std::max(nb, 1), kMaxBuckets);
+    const long long P = (long long)d.width * d.height * d.batch_size;
+    while (nb > 1 && (P * nb >= (1ll << 31) - 16 || P * nb > (1ll << 28))) nb--;   // table: 8 bytes per key
+    if (wb >= (1ll << 30)) { wb = 1ll << 30; nb = 1; }
+    while (nb > 1 && (long long)nb * wb >= (1ll << 31) - 1) nb--;                   // every quantity below fits int32
+    TimeKey k;
+    k.wb = (int)wb;
+    k.inv_wb = 1.0f / (float)wb;
+    k.nb = nb;
+    k.t_end = d.time_window;
+    k.t_base = (int)((long long)d.time_window - (long long)nb * wb);
+    return k;
+}
+
+__device__ __forceinline__ int bucket_of(const TimeKey &k, int t) {
+    if (k.nb == 1) return 0;
+    // t - t_base cannot overflow where it is taken: t_base <= t < t_end = t_base + nb * wb < t_base + 2^31
+    const int d = t < k.t_base ? 0 : (t >= k.t_end ? k.t_end - 1 - k.t_base : t - k.t_base);
+    int q = (int)((float)d * k.inv_wb);          // within one of the quotient (q < 16, fp32 relative error 2^-22)
+    q = min(q, k.nb - 1);
+    if (q * k.wb > d) q--;
+    else if ((q + 1) * k.wb <= d) q++;
+    return q;
+}
+
+// 16-lane rows by DPP (a lane group of the search kernels is one DPP row): no LDS round trip, one VALU per step
+template <int CTRL>
+__device__ __forceinline__ int dpp_row(int v) {      // bound_ctrl: lanes without a source read 0
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+__device__ __forceinline__ int row16_inclusive_scan(int v) {
+    v += dpp_row<0x111>(v);     // row_shr:1
+    v += dpp_row<0x112>(v);
+    v += dpp_row<0x114>(v);
+    v += dpp_row<0x118>(v);
+    return v;
+}
+__device__ __forceinline__ int row16_sum(int v) {    // every lane of the row gets the row's total
+    v += dpp_row<0x128>(v);     // row_ror:8
+    v += dpp_row<0x124>(v);
+    v += dpp_row<0x122>(v);
+    v += dpp_row<0x121>(v);
+    return v;
+}
 
 struct GraphWs {
-    int32_t *cnt;       // [P+1]  per-pixel event counters; all-zero between builds (invariant)
-    int32_t *start;     // [P+1]  exclusive scan of cnt
-    int32_t *scan_tmp;  // [scan_chained_state_bytes(P+1) / 4]: ticket, tag and per-tile words of the one-launch scan
+    int32_t *cnt;       // [PK+1]  per-key event counters; all-zero between builds (invariant)
+    int32_t *start;     // [PK+1]  exclusive scan of cnt
+    int32_t *scan_tmp;  // [scan_chained_state_bytes(PK+1) / 4]: ticket, tag and per-tile words of the one-launch scan
     int32_t *ev_xyb;    // [Nmax] x | y<<12 | b<<24  (denormalised ints)
     int32_t *ev_t;      // [Nmax] denormalised timestamp (us)
-    int32_t *ev_rank;   // [Nmax] arrival rank inside the pixel (arbitrary order)
+    int32_t *ev_rank;   // [Nmax] arrival rank inside the key's segment (arbitrary order)
     int32_t *slot_tmp;  // [Nmax] event id per CSR slot, arrival order
-    int2 *slot_it;      // [Nmax] {event id, t} per CSR slot, ascending id inside a pixel
+    int2 *slot_it;      // [Nmax] {event id, t} per CSR slot, ascending id inside a segment
     int32_t *slot_xyb;  // [Nmax] x | y<<12 | b<<24 per CSR slot
     int32_t *ev_slot;   // [Nmax] CSR slot of every event (-1: dropped)
-    int32_t *long_list; // [Nmax/kShortSeg + 1] pixels whose segment is longer than kShortSeg
-    int32_t *status;    // [8]: 0 n_long, 1 flags, 2..3 num_edges (uint64), 5 / 7 deferral list lengths, 6 unsorted timestamps
-    int64_t P;
+    int32_t *hot_list;  // [Nmax + 1] pixels with a segment beyond kShortSeg / Q / nb events (k_fix_pixels)
+    int32_t *status;    // [16]: 0 listed pixels, 1 flags, 2..3 num_edges (uint64), 4 pixels beyond the FIFO depth,
+                        //       5 deferral list length, 6 unsorted timestamps, 8 / 9 the staging launch's flag words
+    int64_t P;          // pixels: B * H * W
+    int64_t PK;         // keys: P * nb
+    TimeKey tk;
 };
 
 size_t carve(const dagr_graph_desc &d, char *base, GraphWs *ws) {
     const int64_t P = (int64_t)d.width * d.height * d.batch_size;
+    const TimeKey tk = time_key(d);
+    const int64_t PK = P * tk.nb;
     size_t off = 0;
     auto take = [&](size_t bytes) {
         size_t o = off;
         off = align_up(off + bytes, 256);
         return base ? base + o : nullptr;
     };
-    int32_t *cnt = (int32_t *)take((P + 1 + 8) * 4);
-    int32_t *start = (int32_t *)take((P + 1 + 8) * 4);
-    int32_t *scan_tmp = (int32_t *)take(scan_chained_state_bytes(P + 1));
+    int32_t *cnt = (int32_t *)take((PK + 1 + 8) * 4);
+    int32_t *start = (int32_t *)take((PK + 1 + 8) * 4);
+    int32_t *scan_tmp = (int32_t *)take(scan_chained_state_bytes(PK + 1));
     int32_t *ev_xyb = (int32_t *)take(d.max_events * 4);
     int32_t *ev_t = (int32_t *)take(d.max_events * 4);
     int32_t *ev_rank = (int32_t *)take(d.max_events * 4);
@@ -66,9 +151,9 @@ size_t carve(const dagr_graph_desc &d, char *base, GraphWs *ws) {
     int2 *slot_it = (int2 *)take(d.max_events * 8);
     int32_t *slot_xyb = (int32_t *)take(d.max_events * 4);
     int32_t *ev_slot = (int32_t *)take(d.max_events * 4);
-    int32_t *long_list = (int32_t *)take((d.max_events / kShortSeg + 2) * 4);
-    int32_t *status = (int32_t *)take(16 * 4);     // (8, 9: the staging launch's flag words)
-    if (ws) *ws = GraphWs{cnt, start, scan_tmp, ev_xyb, ev_t, ev_rank, slot_tmp, slot_it, slot_xyb, ev_slot, long_list, status, P};
+    int32_t *hot_list = (int32_t *)take((d.max_events + 2) * 4);
+    int32_t *status = (int32_t *)take(16 * 4);
+    if (ws) *ws = GraphWs{cnt, start, scan_tmp, ev_xyb, ev_t, ev_rank, slot_tmp, slot_it, slot_xyb, ev_slot, hot_list, status, P, PK, tk};
     return off;
 }
 
@@ -87,14 +172,15 @@ int validate(const dagr_graph_desc *d) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// K1: denormalise (ev_tgn.py:11-16) + per-pixel count.  One thread per event.
+// K1: denormalise (ev_tgn.py:11-16) + per-key count.  One thread per event.
 //   int(pos * [W,H,T] + 1e-3): fp32 multiply, fp32 add (separately rounded -- this TU is built with
 //   -ffp-contract=off), truncation toward zero.
 // `flags`: where the two conditions an event can raise are recorded -- the builder's status words (flags[1] |= 1: outside
 // the sensor / batch; flags[6] = 1: timestamps not sorted), or the staging launch's own two words (see k_stage_window).
 template <typename BatchT, bool kIntPos>
 __device__ __forceinline__ void count_event(int e, const void *__restrict__ pos_, const BatchT *__restrict__ batch, int W,
-                                            int H, int B, float fW, float fH, float fT, int32_t *__restrict__ cnt,
+                                            int H, int B, float fW, float fH, float fT, const TimeKey tk,
+                                            int32_t *__restrict__ cnt,
                                             int32_t *__restrict__ ev_xyb, int32_t *__restrict__ ev_t,
                                             int32_t *__restrict__ ev_rank, int32_t *__restrict__ flag_fov,
                                             int32_t *__restrict__ flag_time) {
@@ -111,8 +197,8 @@ __device__ __forceinline__ void count_event(int e, const void *__restrict__ pos_
     }
     const int b = (int)batch[e];
     ev_t[e] = t;
-    // time flag: set when timestamps are not non-decreasing in event order inside a sample.  Ids then do not order time,
-    // and the search kernels fall back from the two binary searches per pixel to the reference's linear FIFO walk.
+    // time flag: set when timestamps are not non-decreasing in event order inside a sample.  Ids then do not order time:
+    // the search takes its generic form (every later bucket examined, ids instead of positions as recency).
     if (e > 0 && (int)batch[e - 1] == b) {
         int tp;
         if (kIntPos) tp = static_cast<const int32_t *>(pos_)[3 * (int64_t)(e - 1) + 2];
@@ -121,33 +207,37 @@ __device__ __forceinline__ void count_event(int e, const void *__restrict__ pos_
     }
     if (x < 0 || x >= W || y < 0 || y >= H || b < 0 || b >= B) {
         // The reference would index its FIFO volume out of bounds here; we flag and drop the
-        // event from the pixel index (it keeps its self loop).
+        // event from the index (it keeps its self loop).
         atomicOr(flag_fov, 1);
         ev_xyb[e] = -1;
         ev_rank[e] = 0;
         return;
     }
     ev_xyb[e] = x | (y << 12) | (b << 24);
-    const int p = x + W * (y + H * b);
-    ev_rank[e] = atomicAdd(&cnt[p], 1);
+    const int key = x + W * (bucket_of(tk, t) + tk.nb * (y + H * b));
+    ev_rank[e] = atomicAdd(&cnt[key], 1);
 }
 
 template <typename BatchT, bool kIntPos>
 __global__ __launch_bounds__(kBlock) void k_count(const void *__restrict__ pos_, const BatchT *__restrict__ batch,
                                                  int N, int W, int H, int B, float fW,
-                                                 float fH, float fT, int32_t *__restrict__ cnt,
+                                                 float fH, float fT, const TimeKey tk, int32_t *__restrict__ cnt,
                                                  int32_t *__restrict__ ev_xyb, int32_t *__restrict__ ev_t,
                                                  int32_t *__restrict__ ev_rank, int32_t *__restrict__ status) {
     const int e = blockIdx.x * kBlock + threadIdx.x;
     if (e >= N) return;
-    count_event<BatchT, kIntPos>(e, pos_, batch, W, H, B, fW, fH, fT, cnt, ev_xyb, ev_t, ev_rank, status + 1, status + 6);
+    count_event<BatchT, kIntPos>(e, pos_, batch, W, H, B, fW, fH, fT, tk, cnt, ev_xyb, ev_t, ev_rank, status + 1, status + 6);
 }
 
-// K3: scatter event ids into their pixel segment (arrival order).
+__device__ __forceinline__ int key_of_event(int c, int t, int W, int H, const TimeKey &tk) {
+    return (c & 4095) + W * (bucket_of(tk, t) + tk.nb * (((c >> 12) & 4095) + H * (c >> 24)));
+}
+
+// K3: scatter event ids into their key's segment (arrival order).
 // n_dev: the window's event count in device memory (launches sized for a capacity N: captured HIP graphs); K1 then ran
 // inside the staging launch, whose two flag words (status[8], status[9]) this launch moves into the builder's and re-arms.
-__global__ __launch_bounds__(kBlock) void k_scatter(int N, const int32_t *__restrict__ n_dev, int W, int H,
-                                                   const int32_t *__restrict__ ev_xyb,
+__global__ __launch_bounds__(kBlock) void k_scatter(int N, const int32_t *__restrict__ n_dev, int W, int H, const TimeKey tk,
+                                                   const int32_t *__restrict__ ev_xyb, const int32_t *__restrict__ ev_t,
                                                    const int32_t *__restrict__ ev_rank,
                                                    const int32_t *__restrict__ start,
                                                    int32_t *__restrict__ slot_tmp, int32_t *__restrict__ ev_slot,
@@ -160,91 +250,127 @@ __global__ __launch_bounds__(kBlock) void k_scatter(int N, const int32_t *__rest
     if (e >= N || (n_dev && e >= *n_dev)) return;
     const int c = ev_xyb[e];
     if (c < 0) { ev_slot[e] = -1; return; }
-    const int p = (c & 4095) + W * (((c >> 12) & 4095) + H * (c >> 24));
-    slot_tmp[start[p] + ev_rank[e]] = e;
+    slot_tmp[start[key_of_event(c, ev_t[e], W, H, tk)] + ev_rank[e]] = e;
 }
 
-// K4: order each pixel segment by ascending event id (== the reference's stable sort by pixel,
-// graph/utils.py:10).  One thread per CSR slot; segments longer than kShortSeg are deferred.
-__global__ __launch_bounds__(kBlock) void k_order(int N, int64_t P, int W, int H, int Q, const int32_t *__restrict__ ev_xyb,
+// K4: order each segment by ascending event id (== the reference's stable sort by pixel, graph/utils.py:10, restricted
+// to one time bucket).  One thread per CSR slot; every event starts out visible (kVisBit), and the first slot of a segment
+// that MAY belong to a pixel with more than Q events in the window (segment longer than Q / nb: all segments at or below
+// that bound sum to <= Q), or that is too long for the rank counting, lists its pixel for k_fix_pixels.
+__global__ __launch_bounds__(kBlock) void k_order(int N, int64_t PK, int W, int H, const TimeKey tk, int hot_thr,
+                                                 const int32_t *__restrict__ ev_xyb,
                                                  const int32_t *__restrict__ ev_t,
                                                  const int32_t *__restrict__ start,
                                                  const int32_t *__restrict__ slot_tmp, int2 *__restrict__ slot_it,
                                                  int32_t *__restrict__ slot_xyb, int32_t *__restrict__ ev_slot,
-                                                 int32_t *__restrict__ long_list, int long_cap,
+                                                 int32_t *__restrict__ hot_list, int hot_cap,
                                                  int32_t *__restrict__ status) {
     const int s = blockIdx.x * kBlock + threadIdx.x;
-    if (s >= N || s >= start[P]) return;  // start[P] = number of indexed events (<= N)
+    if (s >= N || s >= start[PK]) return;  // start[PK] = number of indexed events (<= N)
     const int e = slot_tmp[s];
     const int c = ev_xyb[e];
-    const int p = (c & 4095) + W * (((c >> 12) & 4095) + H * (c >> 24));
-    const int a = start[p];
-    const int n = start[p + 1] - a;
+    const int t = ev_t[e];
+    const int key = key_of_event(c, t, W, H, tk);
+    const int a = start[key];
+    const int n = start[key + 1] - a;
     if (n <= kShortSeg) {
         int rank = 0;
         for (int k = 0; k < n; k++) rank += (slot_tmp[a + k] < e) ? 1 : 0;
-        slot_it[a + rank] = make_int2(e, ev_t[e]);
-        slot_xyb[a + rank] = c | ((n - rank <= Q) ? kVisBit : 0);   // FIFO depth (ev_graph.cu:201-211)
+        slot_it[a + rank] = make_int2(e, t);
+        slot_xyb[a + rank] = c | kVisBit;
         ev_slot[e] = a + rank;
-    } else if (s == a) {
-        const int i = atomicAdd(&status[0], 1);
-        if (i < long_cap) long_list[i] = p; else atomicOr(&status[1], 2);
+    }
+    if (s == a && n > hot_thr) {
+        // (listed once: by the oldest of the pixel's segments that are over the bound -- a few loads, on few threads)
+        const int j = bucket_of(tk, t);
+        bool first = true;
+        for (int q = 0; q < j && first; q++) {
+            const int kq = key - W * (j - q);
+            first = start[kq + 1] - start[kq] <= hot_thr;
+        }
+        if (first) {
+            const int i = atomicAdd(&status[0], 1);
+            if (i < hot_cap) hot_list[i] = (c & 4095) + W * (((c >> 12) & 4095) + H * (c >> 24));
+            else atomicOr(&status[1], 2);
+        }
     }
 }
 
-// K5: long segments (> kShortSeg events on one pixel).  Only the newest m = min(n, Q) events of a
-// pixel are ever visible to the search (FIFO depth Q, ev_graph.cu:201-211), so: radix-select the
-// m-th largest id, gather the m newest into LDS, rank-sort them into the tail of the segment.
-__global__ __launch_bounds__(kBlock) void k_order_long(int Q, const int32_t *__restrict__ ev_xyb,
+// the k-th largest of a set of (distinct) event ids, by 8-bit radix selection; `each(f)` calls f(id) for this thread's
+// share of the set.  All threads of the block call it; hist: int[256]; sh: int[4].  The ids of a pixel lie in a narrow
+// range (one sample's events), so the digits are taken from id - min, starting at the range's top bits: the first
+// histogram is spread over its 256 bins (on the raw ids every element of a pass over the top byte hit ONE bin -- an
+// LDS atomic serialised over all lanes, 0.24 ms for one clipped border pixel of an S-edges window) and a 2^20 range takes
+// three passes, not four.
+template <typename Each>
+__device__ __forceinline__ unsigned select_kth_largest(int k, int *hist, int *sh, Each each) {
+    if (threadIdx.x == 0) { sh[0] = 0; sh[1] = k; sh[2] = 0x7fffffff; sh[3] = 0; }
+    __syncthreads();
+    {
+        unsigned lo = 0x7fffffffu, hi = 0u;
+        each([&](unsigned v) { lo = min(lo, v); hi = max(hi, v); });
+        if (lo <= hi) { atomicMin(&sh[2], (int)lo); atomicMax(&sh[3], (int)hi); }
+    }
+    __syncthreads();
+    const unsigned vmin = (unsigned)sh[2];
+    const unsigned range = (unsigned)sh[3] - vmin;
+    const int bits = 32 - __clz((int)(range | 1u));
+    unsigned mask = 0;
+    for (int shift = max(bits - 8, 0);; shift = max(shift - 8, 0)) {
+        hist[threadIdx.x] = 0;
+        __syncthreads();
+        const unsigned prefix = (unsigned)sh[0];
+        each([&](unsigned v) {
+            const unsigned u = v - vmin;
+            if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255], 1);
+        });
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int rem = sh[1], d = 255;
+            for (; d > 0; d--) {
+                if (hist[d] >= rem) break;
+                rem -= hist[d];
+            }
+            sh[1] = rem;
+            sh[0] = (int)(prefix | ((unsigned)d << shift));     // (a digit that overlaps the previous one repeats its bits)
+        }
+        mask |= 255u << shift;
+        __syncthreads();
+        if (shift == 0) break;
+    }
+    return (unsigned)sh[0] + vmin;
+}
+
+// K5: the listed pixels.  Only the newest Q events of a PIXEL -- over all of its time buckets -- are visible to the
+// search (FIFO depth Q, ev_graph.cu:201-211; "newest" = largest ids: the FIFO is filled in event order), and segments
+// longer than kShortSeg are ordered here.  Sorted timestamps (the usual case): buckets follow the ids, so the pixel's
+// segments are walked newest first with the FIFO's remaining depth -- a segment is entirely visible (long: rank-sorted),
+// entirely invisible (long: copied as it lies, any order: it can never be a source) or, for ONE segment of the pixel, cut
+// at its (remaining depth)-th largest id (radix selection; the visible ids rank-sorted into its tail).  Unsorted
+// timestamps: the Q-th largest id of the whole pixel is the threshold of all segments, and every long segment gets its
+// min(n, Q) largest ids sorted into its tail (the rest is invisible whatever the threshold).
+__global__ __launch_bounds__(kBlock) void k_fix_pixels(int Q, int W, const TimeKey tk, const int32_t *__restrict__ ev_xyb,
                                                       int32_t *__restrict__ slot_xyb, int32_t *__restrict__ ev_slot,
                                                       const int32_t *__restrict__ ev_t,
                                                       const int32_t *__restrict__ start,
                                                       const int32_t *__restrict__ slot_tmp,
                                                       int2 *__restrict__ slot_it,
-                                                      const int32_t *__restrict__ long_list, int long_cap,
-                                                      const int32_t *__restrict__ status) {
+                                                      const int32_t *__restrict__ hot_list, int hot_cap,
+                                                      int32_t *__restrict__ status) {
     __shared__ int hist[256];
     __shared__ int sel[kMaxQueue];
-    __shared__ int sh_prefix, sh_remaining, sh_nsel, sh_nrest;
-    int n_long = status[0];
-    if (n_long > long_cap) n_long = long_cap;
-    for (int li = blockIdx.x; li < n_long; li += gridDim.x) {
-        const int p = long_list[li];
-        const int a = start[p];
-        const int n = start[p + 1] - a;
-        const int m = n < Q ? n : Q;
-        unsigned thr = 0;
-        if (n > m) {
-            if (threadIdx.x == 0) { sh_prefix = 0; sh_remaining = m; }
-            unsigned mask = 0;
-            for (int shift = 24; shift >= 0; shift -= 8) {
-                hist[threadIdx.x] = 0;
-                __syncthreads();
-                const unsigned prefix = (unsigned)sh_prefix;
-                for (int k = threadIdx.x; k < n; k += kBlock) {
-                    const unsigned v = (unsigned)slot_tmp[a + k];
-                    if ((v & mask) == prefix) atomicAdd(&hist[(v >> shift) & 255], 1);
-                }
-                __syncthreads();
-                if (threadIdx.x == 0) {
-                    int rem = sh_remaining, d = 255;
-                    for (; d > 0; d--) {
-                        if (hist[d] >= rem) break;
-                        rem -= hist[d];
-                    }
-                    sh_remaining = rem;
-                    sh_prefix = (int)(prefix | ((unsigned)d << shift));
-                }
-                mask |= 255u << shift;
-                __syncthreads();
-            }
-            thr = (unsigned)sh_prefix;
-        }
+    __shared__ int sh_sel[4], sh_nsel, sh_nrest;
+    int n_hot = status[0];
+    if (n_hot > hot_cap) n_hot = hot_cap;
+    const int nb = tk.nb;
+    const bool sorted_t = status[6] == 0;
+    // a long segment: its m ids >= thr_sel rank-sorted into the tail, visible from thr_vis on; the rest into the head
+    auto order_long = [&](int a, int n, int m, unsigned thr_sel, unsigned thr_vis) {
         if (threadIdx.x == 0) { sh_nsel = 0; sh_nrest = 0; }
         __syncthreads();
         for (int k = threadIdx.x; k < n; k += kBlock) {
             const int v = slot_tmp[a + k];
-            if ((unsigned)v >= thr) sel[atomicAdd(&sh_nsel, 1)] = v;
+            if ((unsigned)v >= thr_sel) sel[atomicAdd(&sh_nsel, 1)] = v;
             // older events are invisible to the search (beyond the FIFO depth) but remain graph nodes:
             // keep them, in any order, in the head of the segment (voxel pooling walks the segment)
             else {
@@ -259,12 +385,85 @@ __global__ __launch_bounds__(kBlock) void k_order_long(int Q, const int32_t *__r
         for (int i = threadIdx.x; i < m; i += kBlock) {
             const int v = sel[i];
             int rank = 0;
-            for (int j = 0; j < m; j++) rank += (sel[j] < v) ? 1 : 0;
+            for (int q = 0; q < m; q++) rank += (sel[q] < v) ? 1 : 0;
             slot_it[a + (n - m) + rank] = make_int2(v, ev_t[v]);
-            slot_xyb[a + (n - m) + rank] = ev_xyb[v] | kVisBit;
+            slot_xyb[a + (n - m) + rank] = ev_xyb[v] | ((unsigned)v >= thr_vis ? kVisBit : 0);
             ev_slot[v] = a + (n - m) + rank;
         }
         __syncthreads();
+    };
+    for (int li = blockIdx.x; li < n_hot; li += gridDim.x) {
+        const int p = hot_list[li];
+        const int x = p % W, yb = p / W;
+        const int key0 = x + W * nb * yb;              // bucket j of the pixel: key0 + W * j
+        if (sorted_t) {
+            int newer = 0;
+            bool cut = false;
+            for (int j = nb - 1; j >= 0; j--) {
+                const int a = start[key0 + W * j];
+                const int n = start[key0 + W * j + 1] - a;
+                if (n == 0) continue;
+                const int budget = Q - newer;          // what is left of the FIFO's depth for this segment
+                newer = min(newer + n, Q);
+                if (budget >= n) {                     // all visible
+                    if (n > kShortSeg) order_long(a, n, n, 0u, 0u);
+                } else if (budget <= 0) {              // all invisible
+                    cut = true;
+                    if (n <= kShortSeg) {
+                        for (int i = threadIdx.x; i < n; i += kBlock) slot_xyb[a + i] &= ~kVisBit;
+                    } else {
+                        for (int k = threadIdx.x; k < n; k += kBlock) {
+                            const int v = slot_tmp[a + k];
+                            slot_it[a + k] = make_int2(v, ev_t[v]);
+                            slot_xyb[a + k] = ev_xyb[v];
+                            ev_slot[v] = a + k;
+                        }
+                    }
+                } else {                               // the newest `budget` of the segment
+                    cut = true;
+                    if (n <= kShortSeg) {              // ordered by k_order: ids ascend along the slots
+                        for (int i = threadIdx.x; i < n - budget; i += kBlock) slot_xyb[a + i] &= ~kVisBit;
+                    } else {
+                        const unsigned thr = select_kth_largest(budget, hist, sh_sel, [&](auto f) {
+                            for (int k = threadIdx.x; k < n; k += kBlock) f((unsigned)slot_tmp[a + k]);
+                        });
+                        order_long(a, n, budget, thr, thr);
+                    }
+                }
+            }
+            if (cut && threadIdx.x == 0) atomicAdd(&status[4], 1);
+            continue;
+        }
+        int total = 0;
+        for (int j = 0; j < nb; j++) total += start[key0 + W * j + 1] - start[key0 + W * j];
+        unsigned thr_pix = 0;
+        if (total > Q) {
+            thr_pix = select_kth_largest(Q, hist, sh_sel, [&](auto f) {
+                for (int j = 0; j < nb; j++) {
+                    const int a = start[key0 + W * j], n = start[key0 + W * j + 1] - a;
+                    for (int k = threadIdx.x; k < n; k += kBlock) f((unsigned)slot_tmp[a + k]);
+                }
+            });
+            if (threadIdx.x == 0) atomicAdd(&status[4], 1);
+        }
+        for (int j = 0; j < nb; j++) {
+            const int a = start[key0 + W * j];
+            const int n = start[key0 + W * j + 1] - a;
+            if (n == 0) continue;
+            if (n <= kShortSeg) {       // ordered by k_order: only the visibility may change
+                if (thr_pix)
+                    for (int i = threadIdx.x; i < n; i += kBlock)
+                        if ((unsigned)slot_it[a + i].x < thr_pix) slot_xyb[a + i] &= ~kVisBit;
+                continue;
+            }
+            const int m = n < Q ? n : Q;
+            unsigned thr = 0;
+            if (n > m)
+                thr = select_kth_largest(m, hist, sh_sel, [&](auto f) {
+                    for (int k = threadIdx.x; k < n; k += kBlock) f((unsigned)slot_tmp[a + k]);
+                });
+            order_long(a, n, m, thr, thr_pix);
+        }
     }
 }
 
@@ -284,7 +483,6 @@ __host__ __device__ inline void spiral_offset(int s, int &sx, int &sy) {
     else { sx = -rho + 1 + (k - 6 * rho); sy = -rho; }
 }
 
-// K6: spiral radius search, 16 lanes per destination event.
 __device__ __forceinline__ int group16_inclusive_scan(int v) {
     const int l = threadIdx.x & 15;
 #pragma unroll
@@ -295,121 +493,11 @@ __device__ __forceinline__ int group16_inclusive_scan(int v) {
     return v;
 }
 
-// Level-0 node numbering.  The graph is emitted in *slot space*: node n is CSR slot n, i.e. events
-// ordered by (sample, y, x) and by time inside a pixel.  Spatially adjacent destinations then sit next
-// to each other in every level-0 array, so the segment-offset rows, the {id,t} candidates and (in the
-// SplineConv) the source feature rows they touch are shared through L1/L2 instead of being re-fetched
-// per event, and voxel pooling streams its members.  Event-order views (edge_index, permutations) are
+// Level-0 node numbering.  The graph is emitted in *slot space*: node n is CSR slot n, i.e. events ordered by
+// (sample, y, time bucket, x) and by time inside a segment.  All events of a band of pixel rows are one contiguous run of
+// nodes (voxel pooling streams its members), destinations that follow each other share the row ranges they fetch, and
+// the source rows of a tile of nodes sit in a few narrow runs of memory.  Event-order views (edge_index, permutations) are
 // produced on demand by dagr_graph_edge_index / dagr_graph_node_order.
-//
-// Generic search (any radius): probes go to global memory, 16 lanes per destination, batches of 8 rounds.
-__global__ __launch_bounds__(kBlock) void k_search(const int32_t *__restrict__ m_ptr, int W, int H, int K, int Q, int r,
-                                                  float delta_t, const int32_t *__restrict__ slot_xyb,
-                                                  const int32_t *__restrict__ start,
-                                                  const int2 *__restrict__ slot_it,
-                                                  int32_t *__restrict__ nbr_src, int16_t *__restrict__ nbr_code,
-                                                  int32_t *__restrict__ deg, int32_t *__restrict__ status) {
-    __shared__ int16_t sp_tab[kMaxSpiral];  // (sx + 64) | (sy + 64) << 8, spiral.h:1-15 order
-    __shared__ int blk_edges;
-    const int side = 2 * r + 1;
-    const int S = side * side;
-    for (int s = threadIdx.x; s < S; s += kBlock) {
-        int sx, sy;
-        spiral_offset(s, sx, sy);
-        sp_tab[s] = (int16_t)((sx + 64) | ((sy + 64) << 8));
-    }
-    if (threadIdx.x == 0) blk_edges = 0;
-    __syncthreads();
-    const int M = *m_ptr;
-    const int l = threadIdx.x & 15;
-    const int n = (blockIdx.x * kBlock + threadIdx.x) >> 4;   // destination slot
-    int total = 0;
-    if (n < M) {
-        const int2 me = slot_it[n];
-        const int e = me.x, t = me.y;
-        const int c = slot_xyb[n];
-        const int64_t row = (int64_t)n * K;
-        total = 1;
-        if (l == 0) {
-            nbr_src[row] = n;  // self loop first (ev_graph.cu:44-46)
-            nbr_code[row] = (int16_t)(r * side + r);
-        }
-        const int x = c & 4095, y = (c >> 12) & 4095, b = (c >> 24) & 127;
-        const int plane = W * H * b;
-        constexpr int kRounds = 8;
-        for (int s0 = 0; s0 < S && total < K;) {
-            const int rounds = (s0 == 0) ? 1 : min(kRounds, (S - s0 + 15) >> 4);
-            int bnd[kRounds], vis[kRounds], ecode[kRounds];
-#pragma unroll
-            for (int m = 0; m < kRounds; m++) {
-                bnd[m] = 0; vis[m] = 0; ecode[m] = 0;
-                const int s = s0 + 16 * m + l;
-                if (m < rounds && s < S) {
-                    const int code = sp_tab[s];
-                    const int sx = (code & 255) - 64, sy = ((code >> 8) & 255) - 64;
-                    ecode[m] = (sx + r) * side + (sy + r);
-                    const int xn = x + sx, yn = y + sy;
-                    if (xn >= 0 && yn >= 0 && xn < W && yn < H) {  // out of FOV: skip this pixel only
-                        const int p = plane + yn * W + xn;
-                        const int a = start[p];
-                        bnd[m] = start[p + 1];
-                        vis[m] = min(bnd[m] - a, Q);                // FIFO depth
-                    }
-                }
-            }
-            int2 it0[kRounds];
-#pragma unroll
-            for (int m = 0; m < kRounds; m++) {
-                it0[m] = make_int2(0x7fffffff, 0);
-                if (vis[m] > 0) it0[m] = slot_it[bnd[m] - 1];
-            }
-            // admissible sources per position, newest first:
-            //   skip ids >= e (newer or self, ev_graph.cu:64); skip dt > delta (continue, :69)
-            int v[kRounds];
-#pragma unroll
-            for (int m = 0; m < kRounds; m++) {
-                int cnt = 0;
-                if (vis[m] > 0) {
-                    cnt = (it0[m].x < e && !((float)(t - it0[m].y) > delta_t)) ? 1 : 0;
-                    for (int k = 1; k < vis[m] && cnt < K; k++) {
-                        const int2 it = slot_it[bnd[m] - 1 - k];
-                        if (it.x >= e) continue;
-                        if ((float)(t - it.y) > delta_t) continue;
-                        cnt++;
-                    }
-                }
-                v[m] = cnt;
-            }
-            // sequential cut in spiral order: round by round, lane by lane
-#pragma unroll
-            for (int m = 0; m < kRounds; m++) {
-                if (m < rounds) {   // uniform across the 16-lane group
-                    const int incl = group16_inclusive_scan(v[m]);
-                    int slot = total + incl - v[m];
-                    total += __shfl(incl, 15, 16);
-                    if (v[m] > 0 && slot < K) {
-                        for (int k = 0; k < vis[m] && slot < K; k++) {
-                            const int2 it = (k == 0) ? it0[m] : slot_it[bnd[m] - 1 - k];
-                            if (it.x >= e) continue;
-                            if ((float)(t - it.y) > delta_t) continue;
-                            nbr_src[row + slot] = bnd[m] - 1 - k;   // source node = its CSR slot
-                            nbr_code[row + slot] = (int16_t)ecode[m];
-                            slot++;
-                        }
-                    }
-                }
-            }
-            s0 += 16 * rounds;
-        }
-        if (total > K) total = K;
-        if (l == 0) deg[n] = total;
-    }
-    // window edge count (status[2..3] as uint64)
-    if (l == 0 && n < M) atomicAdd(&blk_edges, total);
-    __syncthreads();
-    if (threadIdx.x == 0 && blk_edges)
-        atomicAdd(reinterpret_cast<unsigned long long *>(status + 2), (unsigned long long)blk_edges);
-}
 
 // level-0 inputs in node (slot) order -- pos, sample index and the [polarity | ... | pos_xy] feature row -- written by the
 // LAST launch of the graph build (dagr_graph_build_window_inputs) instead of a launch of their own
@@ -432,241 +520,96 @@ __device__ __forceinline__ void gather_node(const GatherArgs &g, int n, const in
     row[g.col_pos + 1] = py;
 }
 
-// ---------------------------------------------------------------------------------------------
-// K6 (r <= 7): LDS-tiled, persistent variant of k_search<true>.  Same cut semantics, fewer
-// instructions per probed pixel:
-//   * a 16-lane group loops over events; the spiral position of (round m, lane l) does not depend on
-//     the event, so its tile offset and offset code live in registers for the whole kernel;
-//   * most pixels hold 0 or 1 visible events: a round in which no lane has more than one takes a
-//     ballot/popcount cut (the sequential "first K in spiral order" becomes a prefix popcount);
-//     rounds with a multi-event pixel fall back to the exact prefix-sum walk.
-
-// Admissible sources of one pixel for destination (e, t): the visible FIFO entries are the slots [lo_vis, bnd) of the
-// pixel's segment, ids ascending.  "Older than the destination" (ev_graph.cu:64) is a prefix [lo_vis, hi); when ids
-// order time (status[6] == 0) "dt <= delta" (ev_graph.cu:69) is a suffix [lo, hi) of it: two binary searches instead of
-// the reference's newest-first walk over up to Q entries.  Returns [lo, hi); the walk order newest-first is hi-1 .. lo.
-__device__ __forceinline__ void admissible_range(const int2 *__restrict__ slot_it, int lo_vis, int bnd, int e, int t,
-                                                 float delta_t, int &lo, int &hi) {
-    int a = lo_vis, b = bnd;                 // first slot in [a, b) with id >= e
-    while (a < b) {
-        const int m = (a + b) >> 1;
-        if (slot_it[m].x < e) a = m + 1; else b = m;
+// Admissible sources of one segment (one pixel, one time bucket; ids and -- timestamps being sorted -- times ascend along
+// its slots) for destination (e, t): "older than the destination" (ev_graph.cu:64) is a prefix [a, hi), "dt <= delta"
+// (ev_graph.cu:69) a suffix of it, "inside the FIFO depth" a suffix too: binary searches instead of the reference's
+// newest-first walk over up to Q entries.  Returns [lo, hi); the walk order newest-first is hi-1 .. lo.
+// own: the destination's own bucket (the bucket before it holds older events only).  hot: some pixel of the window
+// holds more than Q events (status[4]) -- otherwise every slot is visible and the third search is skipped.
+__device__ __forceinline__ void admissible_range(const int2 *__restrict__ slot_it, const int32_t *__restrict__ slot_xyb,
+                                                 int a, int b, int e, int t, float delta_t, bool own, bool hot, int &lo,
+                                                 int &hi) {
+    const int a0 = a, b0 = b;
+    if (b0 - a0 == 1) {                       // one entry (most segments): tested directly
+        const int2 it = slot_it[a0];
+        bool ok = (!own || it.x < e) && !((float)(t - it.y) > delta_t);
+        if (ok && hot) ok = slot_xyb[a0] < 0;
+        lo = a0;
+        hi = ok ? b0 : a0;
+        return;
     }
-    hi = a;
-    a = lo_vis; b = hi;                      // first slot in [a, b) with dt <= delta
+    hi = b0;
+    if (own) {                                // first slot in [a, b) with id >= e
+        while (a < b) {
+            const int m = (a + b) >> 1;
+            if (slot_it[m].x < e) a = m + 1; else b = m;
+        }
+        hi = a;
+    }
+    a = a0; b = hi;                           // first slot in [a, hi) with dt <= delta
     while (a < b) {
         const int m = (a + b) >> 1;
         if ((float)(t - slot_it[m].y) > delta_t) a = m + 1; else b = m;
     }
     lo = a;
-}
-
-constexpr int kTileRounds = 15;  // ceil(15*15 / 16)
-
-__global__ __launch_bounds__(kBlock) void k_search_tiled(const int32_t *__restrict__ m_ptr, int W, int H, int K, int Q,
-                                                        int r, float delta_t,
-                                                        const int32_t *__restrict__ slot_xyb,
-                                                        const int32_t *__restrict__ start,
-                                                        const int2 *__restrict__ slot_it,
-                                                        int32_t *__restrict__ nbr_src,
-                                                        int16_t *__restrict__ nbr_code, int32_t *__restrict__ deg,
-                                                        int32_t *__restrict__ status,
-                                                        const int32_t *__restrict__ node_list,
-                                                        const int32_t *__restrict__ node_list_count, GatherArgs gather) {
-    __shared__ int tile[(kBlock / 16) * 16 * 17];
-    if (gather.pos) {       // (independent of the search: the pixel index is final since k_order_long)
-        const int m = *m_ptr;
-        for (int n = blockIdx.x * kBlock + threadIdx.x; n < m; n += gridDim.x * kBlock) gather_node(gather, n, slot_it, slot_xyb);
-    }
-    // list mode (the usual call): most windows defer nothing -- leave before the per-lane spiral constants are built
-    // (an empty sweep of the persistent grid cost 10 us per window)
-    if (node_list && *node_list_count <= 0) return;
-    const int side = 2 * r + 1;
-    const int S = side * side;
-    const int l = threadIdx.x & 15;
-    const int grp = threadIdx.x >> 4;
-    const int gshift = threadIdx.x & 48;  // bit offset of this group inside the wave ballot
-    int *my_tile = tile + grp * 16 * 17;
-    // per-lane constants: position s = 16*m + l -> (tile offset | offset code << 16), -1 if s >= S
-    int pc[kTileRounds];
-#pragma unroll
-    for (int m = 0; m < kTileRounds; m++) {
-        const int s = 16 * m + l;
-        int sx, sy;
-        spiral_offset(s, sx, sy);
-        pc[m] = (s < S) ? (((sy + r) * 17 + (sx + r)) | (((sx + r) * side + (sy + r)) << 16)) : -1;
-    }
-    long long edges_acc = 0;
-    const bool sorted_t = status[6] == 0;    // ids order time: per-pixel binary searches are exact
-    // every block sweeps a contiguous range of slots (= a run of pixels along image rows): consecutive
-    // destinations share most of their neighbourhood, so offsets and candidates come out of L1/L2
-    const int M = node_list ? *node_list_count : *m_ptr;   // list mode: only the nodes the row kernel deferred
-    // XCD x = blockIdx % 8 owns the x-th eighth of the slots (one sample for B = 8), its blocks split it
-    // into contiguous strips: vertical neighbours of a strip live in the same XCD's L2
-    const int G = gridDim.x, nx = (G % 8 == 0) ? 8 : 1;
-    const int xcd = blockIdx.x % nx, lb = blockIdx.x / nx, bpx = G / nx;
-    const int chunk = (M + nx - 1) / nx;
-    const int per_block = (chunk + bpx - 1) / bpx;
-    const int n_begin = xcd * chunk + lb * per_block;
-    const int n_end = min(min(M, (xcd + 1) * chunk), n_begin + per_block);
-    for (int ni = n_begin + grp; ni < n_end; ni += kBlock / 16) {
-        const int n = node_list ? node_list[ni] : ni;
-        const int2 me = slot_it[n];
-        const int e = me.x, t = me.y;
-        const int c = slot_xyb[n];
-        const int64_t row = (int64_t)n * K;
-        int total = 1;
-        if (l == 0) {
-            nbr_src[row] = n;  // self loop first (ev_graph.cu:44-46)
-            nbr_code[row] = (int16_t)(r * side + r);
+    if (hot && slot_xyb[a0] >= 0) {           // the segment has invisible entries: its first visible slot
+        a = a0 + 1; b = b0;
+        while (a < b) {
+            const int m = (a + b) >> 1;
+            if (slot_xyb[m] >= 0) a = m + 1; else b = m;
         }
-        {
-            const int x = c & 4095, y = (c >> 12) & 4095, b = (c >> 24) & 127;
-            const int plane = W * H * b;
-            const int lo = max(x - r, 0), hi = min(x + r, W - 1) + 1;
-            const int col = plane + min(max(x - r + l, lo), hi);
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const int yn = y + i - r;
-                int val = 0;
-                if (i < side && yn >= 0 && yn < H) val = start[col + yn * W];
-                my_tile[i * 17 + l] = val;
-            }
-            __builtin_amdgcn_wave_barrier();
-
-            auto batch = [&](auto first_c, auto count_c) {
-                constexpr int m0 = decltype(first_c)::value, nr = decltype(count_c)::value;
-                int bnd[nr], vis[nr];
-                int2 it0[nr];
-#pragma unroll
-                for (int j = 0; j < nr; j++) {
-                    const int p = pc[m0 + j];
-                    bnd[j] = 0; vis[j] = 0;
-                    if (p >= 0) {
-                        const int cur = my_tile[p & 0xffff];
-                        bnd[j] = my_tile[(p & 0xffff) + 1];
-                        vis[j] = min(bnd[j] - cur, Q);   // FIFO depth
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < nr; j++) {
-                    it0[j] = make_int2(0x7fffffff, 0);
-                    if (vis[j] > 0) it0[j] = slot_it[bnd[j] - 1];
-                }
-#pragma unroll
-                for (int j = 0; j < nr; j++) {
-                    if (total >= K) break;                               // group-uniform
-                    if (16 * (m0 + j) >= S) break;
-                    // newest entry: skip ids >= e (ev_graph.cu:64), skip dt > delta (:69)
-                    const bool ok0 = vis[j] > 0 && it0[j].x < e && !((float)(t - it0[j].y) > delta_t);
-                    const unsigned multi = (unsigned)(__ballot(vis[j] > 1) >> gshift) & 0xffffu;
-                    const int ecode = pc[m0 + j] >> 16;
-                    if (multi == 0) {
-                        const unsigned bits = (unsigned)(__ballot(ok0) >> gshift) & 0xffffu;
-                        const int slot = total + __popc(bits & ((1u << l) - 1u));
-                        if (ok0 && slot < K) {
-                            nbr_src[row + slot] = bnd[j] - 1;   // source node = its CSR slot
-                            nbr_code[row + slot] = (int16_t)ecode;
-                        }
-                        total += __popc(bits);
-                    } else if (sorted_t) {
-                        int v = 0, lo = 0, hi = 0;
-                        if (vis[j] > 1) {
-                            admissible_range(slot_it, bnd[j] - vis[j], bnd[j], e, t, delta_t, lo, hi);
-                            v = min(hi - lo, K);
-                        } else if (vis[j] == 1) {
-                            v = ok0 ? 1 : 0;
-                            hi = bnd[j]; lo = hi - v;
-                        }
-                        const int incl = group16_inclusive_scan(v);
-                        int slot = total + incl - v;
-                        total += __shfl(incl, 15, 16);
-                        for (int k = 0; k < v && slot < K; k++, slot++) {
-                            nbr_src[row + slot] = hi - 1 - k;          // newest first
-                            nbr_code[row + slot] = (int16_t)ecode;
-                        }
-                    } else {
-                        int v = 0;
-                        if (vis[j] > 0) {
-                            v = ok0 ? 1 : 0;
-                            for (int k = 1; k < vis[j] && v < K; k++) {
-                                const int2 it = slot_it[bnd[j] - 1 - k];
-                                if (it.x >= e) continue;
-                                if ((float)(t - it.y) > delta_t) continue;
-                                v++;
-                            }
-                        }
-                        const int incl = group16_inclusive_scan(v);
-                        int slot = total + incl - v;
-                        total += __shfl(incl, 15, 16);
-                        if (v > 0 && slot < K) {
-                            for (int k = 0; k < vis[j] && slot < K; k++) {
-                                const int2 it = (k == 0) ? it0[j] : slot_it[bnd[j] - 1 - k];
-                                if (it.x >= e) continue;
-                                if ((float)(t - it.y) > delta_t) continue;
-                                nbr_src[row + slot] = bnd[j] - 1 - k;
-                                nbr_code[row + slot] = (int16_t)ecode;
-                                slot++;
-                            }
-                        }
-                    }
-                }
-            };
-            batch(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
-            if (total < K && S > 16) batch(std::integral_constant<int, 1>{}, std::integral_constant<int, 7>{});
-            if (total < K && S > 128) batch(std::integral_constant<int, 8>{}, std::integral_constant<int, 7>{});
-            if (total > K) total = K;
-            __builtin_amdgcn_wave_barrier();  // tile reads of this event precede the next event's writes
-        }
-        if (l == 0) { deg[n] = total; edges_acc += total; }
+        lo = max(lo, a);
     }
-    {   // one atomic per wave instead of one per lane group (same single-counter drain as in k_search_rows)
-        unsigned long long v = (l == 0) ? (unsigned long long)edges_acc : 0ull;
-        v += __shfl_down(v, 32, 64);
-        v += __shfl_down(v, 16, 64);
-        if ((threadIdx.x & 63) == 0 && v) atomicAdd(reinterpret_cast<unsigned long long *>(status + 2), v);
-    }
+    if (lo > hi) lo = hi;
 }
 
 // ---------------------------------------------------------------------------------------------
-// K6 fast path (r <= 7): candidate-centric search.  In slot order the events of one pixel row of the
-// neighbourhood are ONE contiguous slot range [start(row, x-r), start(row, x+r+1)), so
-//   1. 15 lanes fetch the 15 row ranges (2 offsets each), a 16-lane scan concatenates them;
+// K6 fast path (r <= 7, timestamps sorted): candidate-centric search.  In slot order the events of one pixel row of the
+// neighbourhood inside one time bucket are ONE contiguous slot range [start(row, bucket, x-r), start(row, bucket, x+r+1)),
+// and every admissible source lies in the destination's bucket tb or in tb - 1 (TimeKey), so
+//   1. 2 x 15 lanes fetch the row ranges of the two buckets (2 offsets each), two 16-lane scans concatenate them and
+//      every range lane writes (range, position) of its events into the group's candidate list in LDS;
 //   2. the C candidates are read 16 at a time, coalesced ({id,t} + packed x|y|visible): each lane
 //      tests its candidate (older than the destination, dt <= delta, inside the FIFO depth) and
-//      keys it with (spiral rank of its pixel, recency inside the pixel);
+//      keys it with (spiral rank of its pixel, recency inside the pixel: bucket tb before tb - 1, then position);
 //   3. the reference's sequential walk "spiral order, newest first, stop at K" is exactly "the K-1
 //      smallest keys in key order": valid candidates are compacted into LDS (ballot/popcount) and
 //      each takes the slot given by the number of smaller keys.
-// Work is proportional to the events actually present in the neighbourhood (~0.33/pixel in the
-// benchmark stream) instead of to its (2r+1)^2 pixels.  Neighbourhoods with more than kRowCap
-// candidates (dense scenes, where the position-centric kernel exits after the first ring anyway) are
-// appended to a list that k_search_tiled processes afterwards.
-// kRowCap candidates per neighbourhood: the key list is the kernel's LDS footprint (20 KiB per workgroup); 320 covers
-// uniform streams up to ~430 k events per 640x480 window.  Denser neighbourhoods go to the position-centric kernel.
-// (LIST_IN re-sweeps a deferral list; kept for experiments.)
+// Work is proportional to the events present in the neighbourhood during the last ~2 delta_t (0.4 of a 50 ms window at
+// delta_t = 10 ms) instead of to its (2r+1)^2 pixels or to the whole window.  Neighbourhoods with more than `defer_cap`
+// (<= kRowCap) candidates (event-dense scenes, where the position-centric walk exits after the first rings anyway) are
+// appended to a list that k_search_dense processes afterwards; the list is the kernel's LDS footprint (20 KiB per
+// workgroup).  The kernel is bound by VALU issue (rocprofv3: ~80 % of the SIMDs' cycles); what the round-5 form removed
+// from a destination's ~130 instructions: the 64-bit bucket arithmetic, the LDS round trips of the 16-lane scans
+// (ds_bpermute -> DPP row operations), the binary search that mapped a flat candidate index to its range (five LDS reads
+// per candidate -> one, the ranges expand themselves into the list), the LDS loop of the rank counting (-> 15 DPP
+// rotations when a neighbourhood keeps <= 16 admissible candidates, the usual case).
 constexpr int kRowCap = 320;
+struct alignas(4) Pair { int a, b; };
 
 // ROUNDS x 16 candidates are requested before the first is examined; WAVES per SIMD = the register budget (512 / WAVES)
-template <int CAP, bool LIST_IN, int ROUNDS = 4, int WAVES = 7>
+// TWO: the index has time buckets (ranges of two buckets per destination; the ranges expand themselves into the candidate
+// list).  One bucket (the index of a sparse workspace): 15 ranges, a candidate finds its range by binary search over the
+// ranges' bases -- cheaper than the expansion when a range holds ~5 events instead of ~1.
+template <int CAP, int ROUNDS, int WAVES, bool TWO>
 __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__restrict__ m_ptr, int W, int H, int K, int r,
-                                                       float delta_t, const int32_t *__restrict__ slot_xyb,
+                                                       float delta_t, const TimeKey tk, int defer_cap,
+                                                       const int32_t *__restrict__ slot_xyb,
                                                        const int32_t *__restrict__ start,
                                                        const int2 *__restrict__ slot_it,
                                                        int32_t *__restrict__ nbr_src, int16_t *__restrict__ nbr_code,
                                                        int32_t *__restrict__ deg, int32_t *__restrict__ status,
                                                        int32_t *__restrict__ node_list,
-                                                       int32_t *__restrict__ node_list_count,
-                                                       const int32_t *__restrict__ node_in,
-                                                       const int32_t *__restrict__ node_in_count) {
+                                                       int32_t *__restrict__ node_list_count) {
     constexpr int G = kBlock / 16;
     __shared__ unsigned char sp_rank[256];      // spiral index of offset (dy + r) * 16 + (dx + r)
     __shared__ unsigned short sp_dec[256];      // spiral index -> offset code (dx + r) * side + (dy + r) | (dy + r) << 12
-    __shared__ int row_lo[G][16], row_base[G][17];
-    // candidate keys, (spiral rank << 20) | (0xFFFFF - position in its row range): the source slot follows from the key.
-    // Dynamic LDS on purpose: with the size visible the compiler's occupancy estimate (made against 64 KiB) drops to 4
-    // waves per SIMD at CAP = 320 and it stops holding the kernel to the 72 registers that 7 waves need; the hardware
-    // has 160 KiB per CU and runs 6 workgroups of this kernel.
+    __shared__ int row_lo[G][TWO ? 32 : 16];    // first slot of the ranges 0..15 (bucket tb) and 16..31 (bucket tb - 1)
+    __shared__ int row_base[TWO ? 1 : G][TWO ? 1 : 17];   // one bucket: the ranges' positions in the concatenation
+    // the group's list: first the candidates as (range << 16 | position in the range), then -- compacted in place behind
+    // the reads -- the keys of the admissible ones, (spiral rank << 20) | (older bucket << 19) | (0x7FFFF - position): the
+    // source slot follows from the key.  Dynamic LDS on purpose: with the size visible the compiler's occupancy estimate
+    // (made against 64 KiB) drops and it stops holding the kernel to its register budget; the hardware has 160 KiB per CU.
     extern __shared__ int v_key_dyn[];
     __shared__ int def_buf[kBlock / 64][64];
     __shared__ unsigned long long blk_edges;   // the block's edge count: ONE global atomic per workgroup at the end
@@ -683,12 +626,13 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
     __syncthreads();
     const int l = threadIdx.x & 15;
     const int grp = threadIdx.x >> 4;
-    int *const v_keys = v_key_dyn + grp * CAP;
+    int *const v_keys = v_key_dyn + grp * (CAP + 4);       // (+ the rank counting's three sentinels)
     const int gshift = threadIdx.x & 48;
     const unsigned lt_mask = (1u << l) - 1u;
     long long edges_acc = 0;
-    const int M = LIST_IN ? *node_in_count : *m_ptr;     // list mode: only the nodes the first sweep deferred
-    if (M <= 0) return;
+    const int M = *m_ptr;
+    // timestamps out of order: sources may sit in any later bucket -- k_search_dense takes every node in its generic form
+    if (M <= 0 || status[6] != 0) return;
     const int Gd = gridDim.x, nx = (Gd % 8 == 0) ? 8 : 1;
     const int xcd = blockIdx.x % nx, lb = blockIdx.x / nx, bpx = Gd / nx;
     const int chunk = (M + nx - 1) / nx;
@@ -696,50 +640,55 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
     const int n_begin = xcd * chunk + lb * per_block;
     const int n_end = min(min(M, (xcd + 1) * chunk), n_begin + per_block);
     // Software pipeline over this lane group's destinations: the dependent chain {id,t | x,y,b} -> row bounds ->
-    // candidates is three HBM latencies; the first two are issued one and two destinations ahead.
-    auto node_of = [&](int i) { return LIST_IN ? node_in[min(i, M - 1)] : min(i, M - 1); };
+    // candidates is three memory latencies; the first two are issued one and two destinations ahead.
     auto load_node = [&](int i, int2 &me, int &c) {
-        const int nn = node_of(i);
+        const int nn = min(i, M - 1);
         me = slot_it[nn];
         c = slot_xyb[nn];
     };
-    auto load_rows = [&](int c, int &lo, int &len) {
+    auto load_rows = [&](int c, int t, int &lo0, int &len0, int &lo1, int &len1) {
         const int x = c & 4095, y = (c >> 12) & 4095, b = (c >> 24) & 127;
         const int yn = y + l - r;
-        lo = 0;
-        len = 0;
+        lo0 = 0; len0 = 0; lo1 = 0; len1 = 0;
         if (l < side && yn >= 0 && yn < H) {
-            const int base = W * (yn + H * b);
-            lo = start[base + max(x - r, 0)];
-            len = start[base + min(x + r, W - 1) + 1] - lo;
+            const int tb = bucket_of(tk, t);
+            const int base = W * (tb + tk.nb * (yn + H * b));
+            const int xl = max(x - r, 0), xh = min(x + r, W - 1) + 1;
+            lo0 = start[base + xl];
+            len0 = start[base + xh] - lo0;
+            if (TWO && tb > 0) {
+                lo1 = start[base - W + xl];
+                len1 = start[base - W + xh] - lo1;
+            }
         }
     };
     int2 me, me1;
-    int c, c1, lo, len;
+    int c, c1, lo0, len0, lo1, len1;
     if (n_begin + grp < n_end) {
         load_node(n_begin + grp, me, c);
         load_node(n_begin + grp + G, me1, c1);
-        load_rows(c, lo, len);
+        load_rows(c, me.y, lo0, len0, lo1, len1);
     }
     for (int ni = n_begin + grp; ni < n_end; ni += G) {
-        const int n = node_of(ni);
+        const int n = ni;
         // next destinations' loads (results are used one iteration later)
         int2 me2;
-        int c2, lo1, len1;
+        int c2, nlo0, nlen0, nlo1, nlen1;
         load_node(ni + 2 * G, me2, c2);
-        load_rows(c1, lo1, len1);
+        load_rows(c1, me1.y, nlo0, nlen0, nlo1, nlen1);
         const int e = me.x, t = me.y;
         const int x = c & 4095;
         const int64_t row = (int64_t)n * K;
-        // 1. row ranges: 15 lanes hold the 15 row ranges, a 16-lane scan concatenates them
-        const int incl = group16_inclusive_scan(len);
-        const int C = __shfl(incl, 15, 16);
-        const int lo_cur = lo, len_cur = len;
-        me = me1; c = c1; me1 = me2; c1 = c2; lo = lo1; len = len1;   // rotate the pipeline
+        // 1. row ranges: 2 x 15 lanes hold the row ranges of the two buckets, two 16-lane scans concatenate them
+        const int C0 = row16_sum(len0);
+        const int C = TWO ? C0 + row16_sum(len1) : C0;
+        const int cb0 = row16_inclusive_scan(len0) - len0, cb1 = TWO ? C0 + row16_inclusive_scan(len1) - len1 : 0;
+        const int clo0 = lo0, clo1 = lo1, cl0 = len0, cl1 = len1;
+        me = me1; c = c1; me1 = me2; c1 = c2; lo0 = nlo0; len0 = nlen0; lo1 = nlo1; len1 = nlen1;   // rotate the pipeline
         // Dense neighbourhoods are deferred to the position-centric kernel.  The list append is aggregated per wave
         // (LDS buffer, one global atomic per ~48 entries): one atomicAdd per destination on a single counter
         // serialises at ~350 M/s and was the whole cost of this kernel on dense windows (4.5 ms at 1.6 M deferrals).
-        const bool defer = C > CAP;
+        const bool defer = C > defer_cap;
         {
             const unsigned long long dmask = __ballot(defer && l == 0);
             if (dmask) {
@@ -761,55 +710,68 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
             }
         }
         if (defer) continue;
-        row_lo[grp][l] = lo_cur;
-        row_base[grp][l] = incl - len_cur;
-        if (l == 15) row_base[grp][16] = C;
+        row_lo[grp][l] = clo0;
+        if constexpr (TWO) {
+            row_lo[grp][16 + l] = clo1;
+            // every range writes its events into the candidate list: (range << 16) | position in the range
+            const int mx = max(cl0, cl1);
+            for (int k = 0; k < mx; k++) {
+                if (k < cl0) v_keys[cb0 + k] = (l << 16) | k;
+                if (k < cl1) v_keys[cb1 + k] = ((16 + l) << 16) | k;
+            }
+        } else {
+            row_base[grp][l] = cb0;
+            if (l == 15) row_base[grp][16] = C;
+        }
         __builtin_amdgcn_wave_barrier();
-        // 2. candidates, 16 per round, 4 rounds of loads in flight.  (Skipping the rounds no lane group of the wave needs
-        //    -- a wave-uniform break out of the batch -- was tried in round 3: same time, and the break cost 19 more
-        //    spilled registers, i.e. 2.6 x the kernel's HBM traffic in scratch.)
+        // 2. candidates, 16 per round, ROUNDS rounds of loads in flight.  The admissible ones are compacted into the SAME
+        //    list: their number never exceeds the number of candidates read so far, and a batch reads all of its list
+        //    entries before it writes any key.
         int V = 0;
         for (int c0 = 0; c0 < C; c0 += 16 * ROUNDS) {
             int2 it[ROUNDS];
-            int cxv[ROUNDS], rpv[ROUNDS];     // rpv: position in its row range (20 bits) | row << 20 -- one register, not two:
-                                              // the kernel sits exactly at its 72-register budget (7 waves per SIMD)
+            int cxv[ROUNDS], rpv[ROUNDS];     // rpv: (range << 16) | position in the range
 #pragma unroll
             for (int q = 0; q < ROUNDS; q++) {
                 const int ci = c0 + 16 * q + l;
                 it[q] = make_int2(0, 0);
                 cxv[q] = 0; rpv[q] = 0;
                 if (ci < C) {
-                    int rr = 0;
-                    if (row_base[grp][rr + 8] <= ci) rr += 8;
-                    if (row_base[grp][rr + 4] <= ci) rr += 4;
-                    if (row_base[grp][rr + 2] <= ci) rr += 2;
-                    if (row_base[grp][rr + 1] <= ci) rr += 1;
-                    const int rel = ci - row_base[grp][rr];
-                    rpv[q] = rel | (rr << 20);
-                    const int sv = row_lo[grp][rr] + rel;
+                    if constexpr (TWO) {
+                        rpv[q] = v_keys[ci];
+                    } else {
+                        int rr = 0;
+                        if (row_base[grp][rr + 8] <= ci) rr += 8;
+                        if (row_base[grp][rr + 4] <= ci) rr += 4;
+                        if (row_base[grp][rr + 2] <= ci) rr += 2;
+                        if (row_base[grp][rr + 1] <= ci) rr += 1;
+                        rpv[q] = (rr << 16) | (ci - row_base[grp][rr]);
+                    }
+                    const int sv = row_lo[grp][rpv[q] >> 16] + (rpv[q] & 0xffff);
                     it[q] = slot_it[sv];
                     cxv[q] = slot_xyb[sv];
                 }
             }
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int q = 0; q < ROUNDS; q++) {
-                const int ci = c0 + 16 * q + l;
-                bool valid = false;
-                int key = 0;
-                if (ci < C) {
-                    // visible in the FIFO; older than the destination (ev_graph.cu:64); dt <= delta (:69)
-                    valid = (cxv[q] < 0) && it[q].x < e && !((float)(t - it[q].y) > delta_t);
-                    const int dx = (cxv[q] & 4095) - x;
-                    const int rank = sp_rank[(rpv[q] >> 20) * 16 + (dx + r)];
-                    // spiral rank first, then newest first inside the pixel (larger slot = newer)
-                    key = (rank << 20) | (0xFFFFF - (rpv[q] & 0xFFFFF));
+                if (c0 + 16 * q < C) {        // (group-uniform: a round no group of the wave needs is skipped as a whole)
+                    const int ci = c0 + 16 * q + l;
+                    int valid = 0, key = 0;
+                    if (ci < C) {
+                        // visible in the FIFO; older than the destination (ev_graph.cu:64); dt <= delta (:69)
+                        valid = ((cxv[q] < 0) && it[q].x < e && !((float)(t - it[q].y) > delta_t)) ? 1 : 0;
+                        const int dx = (cxv[q] & 4095) - x;
+                        const int rr = rpv[q] >> 16;
+                        const int rank = sp_rank[(rr & 15) * 16 + (dx + r)];
+                        // spiral rank first, then newest first inside the pixel: the destination's own bucket before the
+                        // older one, larger slot = newer inside a range
+                        key = (rank << 20) | ((rr >> 4) << 19) | (0x7FFFF - (rpv[q] & 0xffff));
+                    }
+                    const unsigned bits = (unsigned)(__ballot(valid != 0) >> gshift) & 0xffffu;
+                    if (valid) v_keys[V + __popc(bits & lt_mask)] = key;
+                    V += __popc(bits);
                 }
-                const unsigned bits = (unsigned)(__ballot(valid) >> gshift) & 0xffffu;
-                if (valid) {
-                    const int pidx = V + __popc(bits & lt_mask);
-                    v_keys[pidx] = key;
-                }
-                V += __popc(bits);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -818,13 +780,19 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
             nbr_src[row] = n;  // self loop first (ev_graph.cu:44-46)
             nbr_code[row] = (int16_t)(r * side + r);
         }
+        auto emit = [&](int mk, int rk) {
+            const int dec = sp_dec[mk >> 20];
+            const int rr = (dec >> 12) + ((mk >> 19) & 1) * 16;
+            nbr_src[row + 1 + rk] = row_lo[grp][rr] + (0x7FFFF - (mk & 0x7FFFF));   // range start + position
+            nbr_code[row + 1 + rk] = (int16_t)(dec & 0xfff);
+        };
         // Dense neighbourhoods hold far more admissible candidates than the K-1 that survive, and the rank counting
         // below is quadratic in their number: first drop everything beyond the spiral-rank bin (16 positions per bin,
         // one bin per lane) in which the K-1'th candidate falls.
         if (V > 32) {
             int cntb = 0;
             for (int j = 0; j < V; j++) cntb += ((v_keys[j] >> 24) == l) ? 1 : 0;
-            const int incl_b = group16_inclusive_scan(cntb);
+            const int incl_b = row16_inclusive_scan(cntb);
             const unsigned reach = (unsigned)(__ballot(incl_b >= K - 1) >> gshift) & 0xffffu;
             const int bstar = reach ? (__ffs(reach) - 1) : 15;
             int Wk = 0;
@@ -840,15 +808,18 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
             }
             V = Wk;
         }
+        // rank = number of smaller keys, four keys per LDS read (the list is padded with three sentinels; measured against
+        // 15 DPP rotations of one key per lane: the rotations lose as soon as one group of the wave holds more than 16 keys)
+        if (l < 3) v_keys[V + l] = 0x7fffffff;
+        __builtin_amdgcn_wave_barrier();
         for (int vi = l; vi < V; vi += 16) {
             const int mk = v_keys[vi];
             int rk = 0;
-            for (int j = 0; j < V; j++) rk += (v_keys[j] < mk) ? 1 : 0;
-            if (rk < K - 1) {
-                const int dec = sp_dec[mk >> 20];
-                nbr_src[row + 1 + rk] = row_lo[grp][dec >> 12] + (0xFFFFF - (mk & 0xFFFFF));   // row range start + position
-                nbr_code[row + 1 + rk] = (int16_t)(dec & 0xfff);
+            for (int j = 0; j < V; j += 4) {
+                const int k0 = v_keys[j], k1 = v_keys[j + 1], k2 = v_keys[j + 2], k3 = v_keys[j + 3];
+                rk += (k0 < mk ? 1 : 0) + (k1 < mk ? 1 : 0) + (k2 < mk ? 1 : 0) + (k3 < mk ? 1 : 0);
             }
+            if (rk < K - 1) emit(mk, rk);
         }
         const int total = 1 + min(V, K - 1);
         if (l == 0) { deg[n] = total; edges_acc += total; }
@@ -872,6 +843,189 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
     __syncthreads();
     if (threadIdx.x == 0 && blk_edges)
         atomicAdd(reinterpret_cast<unsigned long long *>(status + 2), blk_edges);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6, the destinations the row kernel left: the position-centric walk of the reference (ev_graph.cu:48-78) on the
+// bucketed index, 16 lanes per destination, one spiral position per lane and round.  A position is one pixel = two
+// segments (the destination's bucket and the one before); timestamps being sorted, the admissible entries of a segment are
+// a slot range found by binary searches (admissible_range), the newer bucket's entries precede the older one's, a 16-lane
+// prefix sum reproduces the sequential "first K in spiral order" cut, and the walk ends with the round that fills K --
+// event-dense neighbourhoods (the ones deferred here: more than kRowCap candidates) end in the first rings.
+//
+// GENERIC form (every node of the window; chosen on the device when the timestamps are not sorted, status[6], and by the
+// host for radii beyond 7 pixels): candidate-centric over every row range that can hold a source -- all (2r+1) rows of
+// the buckets tb - 1 .. tb (sorted) or tb - 1 .. nb - 1 (unsorted: a source is OLDER BY ID, its timestamp may be later) --
+// every candidate tested on its own, keyed by (spiral rank, id descending) in 64 bits: exact whatever the order of the
+// timestamps, with the K - 1 smallest keys kept in a small LDS list that is compacted as it fills.  Slow and rare.
+__host__ __device__ inline int dense_gen_cap(int K) { return (K - 1 + 16 + 15) / 16 * 16; }
+__host__ __device__ inline size_t dense_lds_bytes(int K, int r) {
+    const int S = (2 * r + 1) * (2 * r + 1);
+    return (size_t)(kBlock / 16) * 2 * dense_gen_cap(K) * 12 + (size_t)((S + 3) / 4 * 4) * 4;
+}
+
+__global__ __launch_bounds__(kBlock) void k_search_dense(const int32_t *__restrict__ m_ptr, int W, int H, int K, int r,
+                                                        float delta_t, const TimeKey tk,
+                                                        const int32_t *__restrict__ slot_xyb,
+                                                        const int32_t *__restrict__ start,
+                                                        const int2 *__restrict__ slot_it,
+                                                        int32_t *__restrict__ nbr_src,
+                                                        int16_t *__restrict__ nbr_code, int32_t *__restrict__ deg,
+                                                        int32_t *__restrict__ status,
+                                                        const int32_t *__restrict__ node_list,
+                                                        const int32_t *__restrict__ node_list_count, int all_nodes,
+                                                        GatherArgs gather) {
+    constexpr int G = kBlock / 16;
+    extern __shared__ __align__(8) unsigned char dense_lds[];
+    if (gather.pos) {       // (independent of the search: the index is final since k_fix_pixels)
+        const int m = *m_ptr;
+        for (int n = blockIdx.x * kBlock + threadIdx.x; n < m; n += gridDim.x * kBlock) gather_node(gather, n, slot_it, slot_xyb);
+    }
+    const bool unsorted = status[6] != 0;
+    const bool generic = all_nodes != 0 || unsorted;
+    // list mode (the usual call): most windows defer nothing -- leave before the tables are built
+    const int M = generic ? *m_ptr : *node_list_count;
+    if (M <= 0) return;
+    const int side = 2 * r + 1;
+    const int S = side * side;
+    const int cap = dense_gen_cap(K);
+    unsigned long long *gk = reinterpret_cast<unsigned long long *>(dense_lds);                 // [G][2][cap]
+    int *gs = reinterpret_cast<int *>(dense_lds + (size_t)G * 2 * cap * 8);                      // [G][2][cap]
+    short *sp_tab = reinterpret_cast<short *>(dense_lds + (size_t)G * 2 * cap * 12);             // spiral index -> offset
+    unsigned short *sp_rank = reinterpret_cast<unsigned short *>(sp_tab + (S + 3) / 4 * 4);      // offset -> spiral index
+    for (int s = threadIdx.x; s < S; s += kBlock) {
+        int sx, sy;
+        spiral_offset(s, sx, sy);
+        sp_tab[s] = (short)((sx + 64) | ((sy + 64) << 8));
+        sp_rank[(sy + r) * side + (sx + r)] = (unsigned short)s;
+    }
+    __syncthreads();
+    const int l = threadIdx.x & 15;
+    const int grp = threadIdx.x >> 4;
+    const int gshift = threadIdx.x & 48;
+    const unsigned lt_mask = (1u << l) - 1u;
+    const bool hot = status[4] != 0;         // some pixel holds more than Q events: visibility has to be looked up
+    long long edges_acc = 0;
+    // every block sweeps a contiguous range of the list (= runs of neighbouring destinations: their probes share cache
+    // lines); XCD x = blockIdx % 8 owns the x-th eighth
+    const int Gd = gridDim.x, nx = (Gd % 8 == 0) ? 8 : 1;
+    const int xcd = blockIdx.x % nx, lb = blockIdx.x / nx, bpx = Gd / nx;
+    const int chunk = (M + nx - 1) / nx;
+    const int per_block = (chunk + bpx - 1) / bpx;
+    const int n_begin = xcd * chunk + lb * per_block;
+    const int n_end = min(min(M, (xcd + 1) * chunk), n_begin + per_block);
+    for (int ni = n_begin + grp; ni < n_end; ni += G) {
+        const int n = generic ? ni : node_list[ni];
+        const int2 me = slot_it[n];
+        const int e = me.x, t = me.y;
+        const int c = slot_xyb[n];
+        const int x = c & 4095, y = (c >> 12) & 4095, b = (c >> 24) & 127;
+        const int tb = bucket_of(tk, t);
+        const int64_t row = (int64_t)n * K;
+        if (l == 0) {
+            nbr_src[row] = n;  // self loop first (ev_graph.cu:44-46)
+            nbr_code[row] = (int16_t)(r * side + r);
+        }
+        int total = 1;
+        if (!generic) {
+            for (int s0 = 0; s0 < S && total < K; s0 += 16) {
+                const int s = s0 + l;
+                int code = 0, loN = 0, hiN = 0, loO = 0, hiO = 0;
+                if (s < S) {
+                    const int sc = sp_tab[s];
+                    const int sx = (sc & 255) - 64, sy = ((sc >> 8) & 255) - 64;
+                    code = (sx + r) * side + (sy + r);
+                    const int xn = x + sx, yn = y + sy;
+                    if (xn >= 0 && yn >= 0 && xn < W && yn < H) {          // out of FOV: skip this pixel only
+                        const int key = xn + W * (tb + tk.nb * (yn + H * b));
+                        const Pair sN = *reinterpret_cast<const Pair *>(start + key);      // one 8-byte load per segment
+                        const int aN = sN.a, bN = sN.b;
+                        int aO = 0, bO = 0;
+                        if (tb > 0) {
+                            const Pair sO = *reinterpret_cast<const Pair *>(start + key - W);
+                            aO = sO.a; bO = sO.b;
+                        }
+                        if (bN > aN) admissible_range(slot_it, slot_xyb, aN, bN, e, t, delta_t, true, hot, loN, hiN);
+                        if (bO > aO) admissible_range(slot_it, slot_xyb, aO, bO, e, t, delta_t, false, hot, loO, hiO);
+                    }
+                }
+                const int nN = hiN - loN;
+                const int v = min(nN + (hiO - loO), K);
+                int slot = total + row16_inclusive_scan(v) - v;
+                total += row16_sum(v);
+                for (int k = 0; k < v && slot < K; k++, slot++) {
+                    nbr_src[row + slot] = k < nN ? hiN - 1 - k : hiO - 1 - (k - nN);     // newest first
+                    nbr_code[row + slot] = (int16_t)code;
+                }
+            }
+            if (total > K) total = K;
+        } else {
+            unsigned long long *k0 = gk + (size_t)grp * 2 * cap, *k1 = k0 + cap;
+            int *s0p = gs + (size_t)grp * 2 * cap, *s1p = s0p + cap;
+            int V = 0;
+            // keep the K - 1 smallest keys of the list, in key order (keys are distinct: they carry the event id)
+            auto compact = [&]() {
+                __builtin_amdgcn_wave_barrier();
+                for (int vi = l; vi < V; vi += 16) {
+                    const unsigned long long mk = k0[vi];
+                    int rk = 0;
+                    for (int j = 0; j < V; j++) rk += (k0[j] < mk) ? 1 : 0;
+                    if (rk < K - 1) { k1[rk] = mk; s1p[rk] = s0p[vi]; }
+                }
+                __builtin_amdgcn_wave_barrier();
+                V = min(V, K - 1);
+                unsigned long long *tk_ = k0; k0 = k1; k1 = tk_;
+                int *ts_ = s0p; s0p = s1p; s1p = ts_;
+            };
+            const int j_hi = unsorted ? tk.nb - 1 : tb;
+            for (int j = j_hi; j >= max(tb - 1, 0); j--) {
+                for (int dy = -r; dy <= r; dy++) {
+                    const int yn = y + dy;
+                    if (yn < 0 || yn >= H) continue;
+                    const int base = W * (j + tk.nb * (yn + H * b));
+                    const int lo = start[base + max(x - r, 0)], hi = start[base + min(x + r, W - 1) + 1];
+                    for (int c0 = lo; c0 < hi; c0 += 16) {
+                        const int sv = c0 + l;
+                        bool valid = false;
+                        unsigned long long key = 0;
+                        if (sv < hi) {
+                            const int2 it = slot_it[sv];
+                            const int cx = slot_xyb[sv];
+                            // visible in the FIFO; older than the destination (ev_graph.cu:64); dt <= delta (:69)
+                            valid = (cx < 0) && it.x < e && !((float)(t - it.y) > delta_t);
+                            const int dx = (cx & 4095) - x;
+                            key = ((unsigned long long)sp_rank[(dy + r) * side + (dx + r)] << 32) |
+                                  (unsigned long long)(0xFFFFFFFFu - (unsigned)it.x);       // newest (largest id) first
+                        }
+                        const unsigned bits = (unsigned)(__ballot(valid) >> gshift) & 0xffffu;
+                        if (valid) {
+                            const int pidx = V + __popc(bits & lt_mask);
+                            k0[pidx] = key;
+                            s0p[pidx] = sv;
+                        }
+                        V += __popc(bits);
+                        if (V > cap - 16) compact();      // (group-uniform)
+                    }
+                }
+            }
+            compact();
+            for (int vi = l; vi < V; vi += 16) {
+                int sx, sy;
+                spiral_offset((int)(k0[vi] >> 32), sx, sy);
+                nbr_src[row + 1 + vi] = s0p[vi];
+                nbr_code[row + 1 + vi] = (int16_t)((sx + r) * side + (sy + r));
+            }
+            total = 1 + V;
+            __builtin_amdgcn_wave_barrier();  // the lists are reused by the next destination
+        }
+        if (l == 0) { deg[n] = total; edges_acc += total; }
+    }
+    {   // one atomic per wave instead of one per lane group (same single-counter drain as in k_search_rows)
+        unsigned long long v = (l == 0) ? (unsigned long long)edges_acc : 0ull;
+        v += __shfl_down(v, 32, 64);
+        v += __shfl_down(v, 16, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(reinterpret_cast<unsigned long long *>(status + 2), v);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -955,7 +1109,7 @@ __global__ __launch_bounds__(kBlock) void k_gather_inputs(const int32_t *__restr
 }
 
 // the caller's window -> the engine's static input buffers + the event count in device memory (captured-graph mode), and K1
-// of the graph build (denormalise + per-pixel count) on the way: the launch in front of the captured window does what the
+// of the graph build (denormalise + per-key count) on the way: the launch in front of the captured window does what the
 // window's first launch would (one launch less on the window's dependent chain).  The builder's status words are cleared
 // here, so what K1 has to report goes to two words of its own (status[8], status[9]; k_scatter moves them over).
 template <typename BatchT>
@@ -964,6 +1118,7 @@ __global__ __launch_bounds__(kBlock) void k_stage_window(const float *__restrict
                                                         float *__restrict__ pos_out, float *__restrict__ feat_out,
                                                         int32_t *__restrict__ batch_out, int32_t *__restrict__ n_dev,
                                                         int32_t *__restrict__ status8, int W, int H, int B, float fT,
+                                                        const TimeKey tk,
                                                         int32_t *__restrict__ cnt, int32_t *__restrict__ ev_xyb,
                                                         int32_t *__restrict__ ev_t, int32_t *__restrict__ ev_rank) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -972,8 +1127,8 @@ __global__ __launch_bounds__(kBlock) void k_stage_window(const float *__restrict
     if (i < N) {
         feat_out[i] = feat[i];
         batch_out[i] = (int32_t)batch[i];
-        count_event<BatchT, false>(i, pos, batch, W, H, B, (float)W, (float)H, fT, cnt, ev_xyb, ev_t, ev_rank, status8 + 8,
-                                   status8 + 9);
+        count_event<BatchT, false>(i, pos, batch, W, H, B, (float)W, (float)H, fT, tk, cnt, ev_xyb, ev_t, ev_rank,
+                                   status8 + 8, status8 + 9);
     }
     if (i < 3 * N) pos_out[i] = pos[i];
     if (i + gridDim.x * kBlock < 3 * N) pos_out[i + gridDim.x * kBlock] = pos[i + gridDim.x * kBlock];
@@ -997,22 +1152,24 @@ __global__ void k_format_events(const int16_t *__restrict__ xy, const int32_t *_
 using namespace dagr;
 
 namespace dagr {
-// views into the builder workspace for the level-0 pooling kernel (pooling.hip)
-void graph_ws_views(const dagr_graph_desc *desc, void *workspace, const int32_t **start, const int2 **slot_it) {
+// views into the builder workspace for the level-0 pooling kernel (pooling.hip) and the asynchronous update
+// (async_update.hip): the index is keyed (sample, y, time bucket, x) -- see PixelIndex in common.hpp
+void graph_ws_index(const dagr_graph_desc *desc, void *workspace, PixelIndex *out) {
     GraphWs ws;
     carve(*desc, (char *)workspace, &ws);
-    *start = ws.start;
-    *slot_it = ws.slot_it;
-}
-const int32_t *graph_ws_slot_xyb(const dagr_graph_desc *desc, void *workspace) {
-    GraphWs ws;
-    carve(*desc, (char *)workspace, &ws);
-    return ws.slot_xyb;
+    out->start = ws.start;
+    out->slot_it = ws.slot_it;
+    out->slot_xyb = ws.slot_xyb;
+    out->n_nodes = ws.start + ws.PK;
+    out->unsorted = ws.status + 6;
+    out->W = desc->width;
+    out->H = desc->height;
+    out->nb = ws.tk.nb;
 }
 const int32_t *graph_ws_node_count(const dagr_graph_desc *desc, void *workspace) {
     GraphWs ws;
     carve(*desc, (char *)workspace, &ws);
-    return ws.start + ws.P;
+    return ws.start + ws.PK;
 }
 }  // namespace dagr
 
@@ -1044,57 +1201,62 @@ int dagr_graph_workspace_init(const dagr_graph_desc *desc, void *workspace, size
         set_error("dagr_graph_workspace_init: workspace too small");
         return DAGR_ERR_WORKSPACE;
     }
-    DAGR_CHECK_HIP(hipMemsetAsync(ws.cnt, 0, (ws.P + 1 + 8) * 4, (hipStream_t)stream));
-    DAGR_CHECK_HIP(hipMemsetAsync(ws.start, 0, (ws.P + 1 + 8) * 4, (hipStream_t)stream));
+    DAGR_CHECK_HIP(hipMemsetAsync(ws.cnt, 0, (ws.PK + 1 + 8) * 4, (hipStream_t)stream));
+    DAGR_CHECK_HIP(hipMemsetAsync(ws.start, 0, (ws.PK + 1 + 8) * 4, (hipStream_t)stream));
     DAGR_CHECK_HIP(hipMemsetAsync(ws.status, 0, 16 * 4, (hipStream_t)stream));
-    DAGR_CHECK_HIP(hipMemsetAsync(ws.scan_tmp, 0, scan_chained_state_bytes(ws.P + 1), (hipStream_t)stream));
+    DAGR_CHECK_HIP(hipMemsetAsync(ws.scan_tmp, 0, scan_chained_state_bytes(ws.PK + 1), (hipStream_t)stream));
     return DAGR_OK;
 }
 
 static int launch_search(const dagr_graph_desc *desc, const GraphWs &ws, int64_t N, int32_t *nbr_src, int16_t *nbr_code,
                          int32_t *deg, hipStream_t stream, const GatherArgs *gather = nullptr) {
     const GatherArgs ga = gather ? *gather : GatherArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
-    const int W = desc->width, H = desc->height;
-    const unsigned gS = (unsigned)ceil_div(N * 16, kBlock);
-    if (2 * desc->radius + 2 <= 16) {
-        // fast path: candidate-centric row kernel; dense neighbourhoods are deferred (list in ev_rank, which
-        // is dead after k_scatter; counter in status[5]) to the position-centric tiled kernel
-        // (the deferral list lives in ev_rank, dead after k_scatter; its counter is status[5])
-        constexpr size_t rows_lds = (size_t)(kBlock / 16) * kRowCap * 4;
-        static const unsigned res_tiled = persistent_grid(k_search_tiled, kBlock, 0, 1 << 30);
-        // builder knob DAGR_ROWS_VARIANT = 10 * rounds + waves per SIMD (16 candidates per round); default 47
-        static const int variant = [] { const char *e = getenv("DAGR_ROWS_VARIANT"); return e ? atoi(e) : 47; }();
+    const int W = desc->width, H = desc->height, K = desc->max_neighbors, r = desc->radius;
+    const bool rows = 2 * r + 2 <= 16;
+    if (rows) {
+        // fast path: candidate-centric row kernel; dense neighbourhoods are deferred (list in ev_rank, which is dead
+        // after k_scatter; counter in status[5]) to the position-centric kernel
+        constexpr size_t rows_lds = (size_t)(kBlock / 16) * (kRowCap + 4) * 4;
+        // builder knob DAGR_ROWS_VARIANT = 10 * rounds + waves per SIMD (16 candidates per round)
+        static const int variant_env = [] { const char *e = getenv("DAGR_ROWS_VARIANT"); return e ? atoi(e) : 0; }();
+        const int variant = variant_env ? variant_env : (ws.tk.nb > 1 ? 45 : 47);    // (registers: 88 / 72)
+        // neighbourhoods beyond this many candidates go to the position-centric kernel (builder knob DAGR_DEFER_CAP).
+        // Measured (profiles/r5_search_buckets.md): with time buckets 128 is the best cut on event-dense streams (S-edges
+        // 8 x 200 k: 1.84 ms at 128, 2.07 at 192, 2.57 at 320), without them the list's capacity is.
+        static const int defer_env = [] { const char *e = getenv("DAGR_DEFER_CAP"); return e ? atoi(e) : 0; }();
+        const int defer_cap = std::min(kRowCap, std::max(16, defer_env ? defer_env : (ws.tk.nb > 1 ? 128 : kRowCap)));
         auto launch_rows = [&](auto kern) {
             static thread_local unsigned res_rows = 0;
             if (!res_rows) res_rows = persistent_grid(kern, kBlock, rows_lds, 1 << 30);
             const unsigned gR = round_grid8(std::min<int64_t>(ceil_div(N * 16, kBlock), res_rows));
-            kern<<<gR, kBlock, rows_lds, stream>>>(
-                ws.start + ws.P, W, H, desc->max_neighbors, desc->radius, (float)desc->delta_t_us, ws.slot_xyb, ws.start,
-                ws.slot_it, nbr_src, nbr_code, deg, ws.status, ws.ev_rank, ws.status + 5, nullptr, nullptr);
+            kern<<<gR, kBlock, rows_lds, stream>>>(ws.start + ws.PK, W, H, K, r, (float)desc->delta_t_us, ws.tk, defer_cap,
+                                                   ws.slot_xyb, ws.start, ws.slot_it, nbr_src, nbr_code, deg, ws.status,
+                                                   ws.ev_rank, ws.status + 5);
         };
+        const bool two = ws.tk.nb > 1;
+#define DAGR_ROWS(R, WV) do { if (two) launch_rows(k_search_rows<kRowCap, R, WV, true>); else launch_rows(k_search_rows<kRowCap, R, WV, false>); } while (0)
         switch (variant) {
-            case 57: launch_rows(k_search_rows<kRowCap, false, 5, 7>); break;
-            case 46: launch_rows(k_search_rows<kRowCap, false, 4, 6>); break;
-            case 66: launch_rows(k_search_rows<kRowCap, false, 6, 6>); break;
-            case 85: launch_rows(k_search_rows<kRowCap, false, 8, 5>); break;
-            default: launch_rows(k_search_rows<kRowCap, false, 4, 7>); break;
+            case 47: DAGR_ROWS(4, 7); break;
+            case 46: DAGR_ROWS(4, 6); break;
+            case 44: DAGR_ROWS(4, 4); break;
+            case 35: DAGR_ROWS(3, 5); break;
+            case 25: DAGR_ROWS(2, 5); break;
+            default: DAGR_ROWS(4, 5); break;
         }
+#undef DAGR_ROWS
         DAGR_CHECK_LAUNCH();
-        const unsigned gT = round_grid8(std::min<int64_t>(ceil_div(N * 16, kBlock), res_tiled));
-        k_search_tiled<<<gT, kBlock, 0, stream>>>(ws.start + ws.P, W, H, desc->max_neighbors, desc->queue_size,
-                                                  desc->radius, (float)desc->delta_t_us, ws.slot_xyb, ws.start,
-                                                  ws.slot_it, nbr_src, nbr_code, deg, ws.status, ws.ev_rank,
-                                                  ws.status + 5, ga);
-    } else {
-        k_search<<<gS, kBlock, 0, stream>>>(ws.start + ws.P, W, H, desc->max_neighbors, desc->queue_size, desc->radius,
-                                            (float)desc->delta_t_us, ws.slot_xyb, ws.start, ws.slot_it, nbr_src,
-                                            nbr_code, deg, ws.status);
-        if (gather) {
-            DAGR_CHECK_LAUNCH();
-            k_gather_inputs<<<(unsigned)ceil_div(N, kBlock), kBlock, 0, stream>>>(ws.start + ws.P, (int)N, ws.slot_it,
-                                                                                 ws.slot_xyb, ga);
-        }
     }
+    const size_t dense_lds = dense_lds_bytes(K, r);
+    static thread_local unsigned res_dense = 0;
+    static thread_local size_t res_dense_lds = 0;
+    if (!res_dense || res_dense_lds != dense_lds) {
+        res_dense = persistent_grid(k_search_dense, kBlock, dense_lds, 1 << 30);
+        res_dense_lds = dense_lds;
+    }
+    const unsigned gT = round_grid8(std::min<int64_t>(ceil_div(N * 16, kBlock), res_dense));
+    k_search_dense<<<gT, kBlock, dense_lds, stream>>>(ws.start + ws.PK, W, H, K, r, (float)desc->delta_t_us, ws.tk, ws.slot_xyb,
+                                                     ws.start, ws.slot_it, nbr_src, nbr_code, deg, ws.status, ws.ev_rank,
+                                                     ws.status + 5, rows ? 0 : 1, ga);
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;
 }
@@ -1123,7 +1285,7 @@ static int build_window(const dagr_graph_desc *desc, void *workspace, const void
         DAGR_CHECK_HIP(hipMemsetAsync(ws.status, 0, 8 * 4, stream));
 #define DAGR_LAUNCH_COUNT(BT, IP)                                                                          \
     k_count<BT, IP><<<gN, kBlock, 0, stream>>>(pos, (const BT *)batch, n, W, H, B, (float)W, (float)H,        \
-                                               (float)desc->time_window, ws.cnt, ws.ev_xyb, ws.ev_t,         \
+                                               (float)desc->time_window, ws.tk, ws.cnt, ws.ev_xyb, ws.ev_t,  \
                                                ws.ev_rank, ws.status)
         if (batch_is_int64) { if (pos_is_int32) DAGR_LAUNCH_COUNT(int64_t, true); else DAGR_LAUNCH_COUNT(int64_t, false); }
         else                { if (pos_is_int32) DAGR_LAUNCH_COUNT(int32_t, true); else DAGR_LAUNCH_COUNT(int32_t, false); }
@@ -1131,19 +1293,20 @@ static int build_window(const dagr_graph_desc *desc, void *workspace, const void
         DAGR_CHECK_LAUNCH();
     }
     // start = exclusive_scan(cnt); cnt is re-zeroed in the same pass (invariant for the next window)
-    DAGR_CHECK_HIP(exclusive_scan_i32_chained(ws.cnt, ws.start, ws.P + 1, ws.scan_tmp, true, stream));
-    k_scatter<<<gN, kBlock, 0, stream>>>(n, n_dev, W, H, ws.ev_xyb, ws.ev_rank, ws.start, ws.slot_tmp, ws.ev_slot, ws.status);
+    DAGR_CHECK_HIP(exclusive_scan_i32_chained(ws.cnt, ws.start, ws.PK + 1, ws.scan_tmp, true, stream));
+    k_scatter<<<gN, kBlock, 0, stream>>>(n, n_dev, W, H, ws.tk, ws.ev_xyb, ws.ev_t, ws.ev_rank, ws.start, ws.slot_tmp,
+                                         ws.ev_slot, ws.status);
     DAGR_CHECK_LAUNCH();
-    // number of occupied CSR slots M = start[P] <= N (dropped events excluded); slots are a
+    // number of occupied CSR slots M = start[PK] <= N (dropped events excluded); slots are a
     // prefix [0, M) so launching N threads with an in-kernel bound read would need M on the host.
-    // Out-of-FOV events are an error condition; we order all N slots but guard on start[P].
-    const int long_cap = (int)(desc->max_events / kShortSeg + 1);
-    k_order<<<gN, kBlock, 0, stream>>>(n, ws.P, W, H, desc->queue_size, ws.ev_xyb, ws.ev_t, ws.start, ws.slot_tmp, ws.slot_it,
-                                       ws.slot_xyb, ws.ev_slot, ws.long_list, long_cap, ws.status);
+    // Out-of-FOV events are an error condition; we order all N slots but guard on start[PK].
+    const int hot_cap = (int)(desc->max_events + 1);
+    const int hot_thr = std::min(kShortSeg, desc->queue_size / ws.tk.nb);
+    k_order<<<gN, kBlock, 0, stream>>>(n, ws.PK, W, H, ws.tk, hot_thr, ws.ev_xyb, ws.ev_t, ws.start, ws.slot_tmp, ws.slot_it,
+                                       ws.slot_xyb, ws.ev_slot, ws.hot_list, hot_cap, ws.status);
     DAGR_CHECK_LAUNCH();
-    k_order_long<<<64, kBlock, 0, stream>>>(desc->queue_size, ws.ev_xyb, ws.slot_xyb, ws.ev_slot, ws.ev_t, ws.start,
-                                            ws.slot_tmp, ws.slot_it,
-                                            ws.long_list, long_cap, ws.status);
+    k_fix_pixels<<<1024, kBlock, 0, stream>>>(desc->queue_size, W, ws.tk, ws.ev_xyb, ws.slot_xyb, ws.ev_slot, ws.ev_t, ws.start,
+                                            ws.slot_tmp, ws.slot_it, ws.hot_list, hot_cap, ws.status);
     DAGR_CHECK_LAUNCH();
     return launch_search(desc, ws, N, nbr_src, nbr_code, deg, stream, gather);
 }
@@ -1192,11 +1355,11 @@ int dagr_stage_window(const dagr_graph_desc *desc, void *workspace, const float 
     if (batch_is_int64)
         k_stage_window<int64_t><<<grid, kBlock, 0, (hipStream_t)stream>>>(
             pos, feat, (const int64_t *)batch, (int)N, pos_out, feat_out, batch_out, n_dev, ws.status, W, H, B,
-            (float)desc->time_window, ws.cnt, ws.ev_xyb, ws.ev_t, ws.ev_rank);
+            (float)desc->time_window, ws.tk, ws.cnt, ws.ev_xyb, ws.ev_t, ws.ev_rank);
     else
         k_stage_window<int32_t><<<grid, kBlock, 0, (hipStream_t)stream>>>(
             pos, feat, (const int32_t *)batch, (int)N, pos_out, feat_out, batch_out, n_dev, ws.status, W, H, B,
-            (float)desc->time_window, ws.cnt, ws.ev_xyb, ws.ev_t, ws.ev_rank);
+            (float)desc->time_window, ws.tk, ws.cnt, ws.ev_xyb, ws.ev_t, ws.ev_rank);
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;
 }
@@ -1319,7 +1482,7 @@ int dagr_graph_node_order(const dagr_graph_desc *desc, void *workspace, int64_t 
     GraphWs ws;
     carve(*desc, (char *)workspace, &ws);
     k_node_order<<<(unsigned)ceil_div(N, kBlock), kBlock, 0, (hipStream_t)stream>>>((int)N, ws.slot_it, ws.ev_slot,
-                                                                                 ws.start + ws.P, slot_event,
+                                                                                 ws.start + ws.PK, slot_event,
                                                                                  event_slot);
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;
@@ -1337,7 +1500,7 @@ int dagr_graph_gather_inputs(const dagr_graph_desc *desc, void *workspace, const
     GraphWs ws;
     carve(*desc, (char *)workspace, &ws);
     const GatherArgs ga{pos, feat, pos_nodes, batch_nodes, x0, ldx0, col_feat, col_pos};
-    k_gather_inputs<<<(unsigned)ceil_div(N, kBlock), kBlock, 0, (hipStream_t)stream>>>(ws.start + ws.P, (int)N, ws.slot_it,
+    k_gather_inputs<<<(unsigned)ceil_div(N, kBlock), kBlock, 0, (hipStream_t)stream>>>(ws.start + ws.PK, (int)N, ws.slot_it,
                                                                                      ws.slot_xyb, ga);
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_accumulate(dagr_pool_desc d, co
 }
 
 // ---------------------------------------------------------------------------------------------
-// level 0, streaming form.  Nodes are CSR slots in (sample, y, x, time) order, so all voxels of one sample / voxel row
+// level 0, streaming form.  Nodes are CSR slots in (sample, y, time bucket, x, time) order, so all voxels of one sample / voxel row
 // (a "band") own ONE contiguous run of slots, and their table ids are contiguous too (raw = cx + gx * (cy + gy * b)).
 // The kernel therefore never looks a member up: the slots are cut into EQUAL contiguous runs, one per workgroup (balanced
 // whatever the event density: S-edges puts thousands of members into a few voxels), and every workgroup streams its run
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(kPoolL0Block) void k_pool_l0_slots(dagr_pool_desc d
                                                                const int32_t *__restrict__ n_ptr,
                                                                const int32_t *__restrict__ xlo,  // [gx+1] pixel bounds
                                                                const int32_t *__restrict__ ylo,  // [gy+1]
-                                                               const int32_t *__restrict__ start,
+                                                               const int32_t *__restrict__ start, int row_keys,
                                                                const int2 *__restrict__ slot_it,
                                                                const int32_t *__restrict__ slot_xyb,
                                                                const float *__restrict__ x, int ldx,
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(kPoolL0Block) void k_pool_l0_slots(dagr_pool_desc d
         const int qe = q0 + WB;
         if (qe < d.gy * d.batch_size) {
             const int be = qe / d.gy, cye = qe - be * d.gy;
-            seg_end = min(s_end, max(seg_begin + 1, start[W * (min(ylo[cye], H) + H * be)]));
+            seg_end = min(s_end, max(seg_begin + 1, start[row_keys * (min(ylo[cye], H) + H * be)]));
         }
     }
     for (int cs = seg_begin + 64 * wv; cs < seg_end; cs += 64 * NW) {
@@ -959,10 +959,12 @@ int launch_pool_l0_slots(const dagr_pool_desc *desc, const dagr_graph_desc *gdes
                          const int32_t *ylo, const float *x, int ldx, const float *pos, const PoolWs &ws,
                          const int16_t *nbr_code, const int32_t *nbr_src, const int32_t *deg, int64_t n_cap,
                          hipStream_t stream) {
-    const int32_t *start; const int2 *slot_it;
-    graph_ws_views(gdesc, graph_ws, &start, &slot_it);
-    const int32_t *slot_xyb = graph_ws_slot_xyb(gdesc, graph_ws);
-    const int32_t *n_ptr = graph_ws_node_count(gdesc, graph_ws);
+    PixelIndex ix;
+    graph_ws_index(gdesc, graph_ws, &ix);
+    const int32_t *start = ix.start; const int2 *slot_it = ix.slot_it;
+    const int32_t *slot_xyb = ix.slot_xyb;
+    const int32_t *n_ptr = ix.n_nodes;
+    const int row_keys = ix.W * ix.nb;        // keys per pixel row: the band of a voxel row starts at a row's first key
     const int C = desc->channels, W = gdesc->width, H = gdesc->height, K = gdesc->max_neighbors;
     const bool vec4 = C % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0;
     // LDS window: up to 60 KB of accumulators per (16-wave) workgroup, at least one voxel row, at most 1024 table slots
@@ -980,7 +982,7 @@ int launch_pool_l0_slots(const dagr_pool_desc *desc, const dagr_graph_desc *gdes
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)gmult * device_cu_count(),
                                                                           ceil_div(n_cap, kPoolL0Block)));
 #define DAGR_POOL_L0_LAUNCH(AG, VEC)                                                                                  \
-    k_pool_l0_slots<AG, VEC><<<grid, kPoolL0Block, lds, stream>>>(*desc, W, H, (int)n_cap, VW, n_ptr, xlo, ylo, start, slot_it, \
+    k_pool_l0_slots<AG, VEC><<<grid, kPoolL0Block, lds, stream>>>(*desc, W, H, (int)n_cap, VW, n_ptr, xlo, ylo, start, row_keys, slot_it, \
                                                                    slot_xyb, x, ldx, pos, ws, nbr_code, nbr_src, deg, K, \
                                                                    gdesc->radius)
     if (desc->aggr == 0) { if (vec4) DAGR_POOL_L0_LAUNCH(0, 4); else DAGR_POOL_L0_LAUNCH(0, 1); }

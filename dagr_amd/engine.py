@@ -477,6 +477,8 @@ class WindowEngine:
                 dense=torch.zeros((self.B, 5 + self.num_classes, Hc, Wc), dtype=torch.float32, device=dev)))
         self.status = torch.zeros((4,), dtype=torch.int32, device=dev)
         self.fused_passes_max_nodes = int(os.environ.get("DAGR_FUSED_PASSES_MAX_NODES", "1600"))
+        # builder knob: levels with more node slots than this take tap aggregation + GEMM as two launches
+        self.fuse_max_nodes = int(os.environ.get("DAGR_FUSE_MAX_NODES", str(10 ** 9)))
         # a head whose table domain is not its input level's (num_scales = 1: head "1" on out4 with the pool3
         # table) gets its own LUT coordinates (dagr_pool_recode)
         self.head_code = []
@@ -704,7 +706,8 @@ class WindowEngine:
         code = lvl.code if code is None else code
         scratch = self.A if scratch is None else scratch
         passes = L.dagr_spline_conv_fused_passes(pack.cin, pack.cskip)
-        if self.fuse_convs and (passes == 1 or (passes > 1 and lvl.T <= self.fused_passes_max_nodes)):
+        if self.fuse_convs and lvl.T <= self.fuse_max_nodes and \
+                (passes == 1 or (passes > 1 and lvl.T <= self.fused_passes_max_nodes)):
             # tap aggregation + contraction in one launch (A tile lives in LDS; rows wider than the tile in passes over
             # the edges, which pays on small levels only: tools/microbench/head_ab.hip)
             _lib.check(L.dagr_spline_conv_fused(P(lvl.counts), lvl.T, P(lvl.rowptr), P(lvl.col), P(code), x, ldx,

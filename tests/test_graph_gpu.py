@@ -212,3 +212,23 @@ def test_staged_device_count_build_equals_host_count_build(mutate):
         if mutate == "out_of_range":
             assert want_status[1] & 1
         assert torch.equal(_edges(g1, want, n), _edges(g2, out, n)), (mutate, n)
+
+
+def test_time_bucketed_index_builds_the_same_graphs():
+    """The builder's index can carry a time dimension (DAGR_TIME_BUCKETS = n: keys (sample, y, time bucket, x), buckets one
+    delta_t wide; csrc/graph_build.hip, profiles/r5_search_buckets.md) -- off by default, because it only pays on dense
+    uniform streams.  The knob is read once per process, so the graph, property and asynchronous-update suites are run
+    again in a child process with five buckets: same oracle, same bit-exact assertions (two-bucket row ranges, segments
+    per (pixel, bucket), the FIFO depth counted over a pixel's buckets, the generic walk for unsorted timestamps)."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("DAGR_TIME_BUCKETS"):
+        pytest.skip("already inside the bucketed run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DAGR_TIME_BUCKETS="5")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", "tests/test_graph_gpu.py",
+                        "tests/test_properties_gpu.py", "tests/test_async_update_gpu.py"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
