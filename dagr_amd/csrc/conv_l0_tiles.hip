@@ -23,6 +23,8 @@
 // Exact fp32 throughout (the f32 MFMA is a k-ordered fmaf chain); only the summation order differs from the oracle.
 #include "common.hpp"
 
+#include <stdlib.h>
+
 namespace dagr {
 namespace {
 
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(kTileWaves * 64, LEAN ? 3 : 2) void k_conv_l0_tiles
     int n_first, int N, const int32_t *__restrict__ n_ptr, int rx, int ry, float den_x, float den_y, int win_x, int win_y, const int32_t *__restrict__ nbr_src,
     const int16_t *__restrict__ nbr_code, const int32_t *__restrict__ deg, const float *__restrict__ x, int ldx,
     const float *__restrict__ xskip, int ldskip, const float *__restrict__ wpack, const float *__restrict__ shift,
-    int relu, float *__restrict__ out, int ldo) {
+    int relu, float *__restrict__ out, int ldo, int ablate) {
     using S = L0Steps<CM, CE, CS, TX, TY>;
     constexpr int NT = S::NT;
     extern __shared__ __align__(16) float lds[];
@@ -260,6 +262,7 @@ __global__ __launch_bounds__(kTileWaves * 64, LEAN ? 3 : 2) void k_conv_l0_tiles
             }
             __builtin_amdgcn_sched_barrier(0);   // one edge's weights live at a time (register pressure)
         };
+        if (ablate & 1) dmax = min(dmax, 1);     // (measurement only, DAGR_L0_ABLATE: phase 1 cut to one edge)
 #pragma unroll
         for (int u = 0; u < 8; u++)
             if (u < dmax) edge(u);               // group-uniform
@@ -287,6 +290,17 @@ __global__ __launch_bounds__(kTileWaves * 64, LEAN ? 3 : 2) void k_conv_l0_tiles
         else o0 = __builtin_amdgcn_mfma_f32_16x16x4f32((aval), wb[(s) * 64], o0, 0, 0, 0);       \
         s++;                                                                                   \
     } while (0)
+        if (ablate & 2) {                        // (measurement only: phase 2 cut to the root / skip steps)
+            if (CM) {
+#pragma unroll
+                for (int t = 0; t < NT; t++) { o0[0] += acc[t][0][0] + acc[t][0][1]; o1[0] += acc[t][1][0] + acc[t][1][1]; }
+            }
+            if (CE) {
+#pragma unroll
+                for (int t = 0; t < NT; t++) o0[1] += acce[t];
+            }
+            s = S::kMain + S::kExtra;
+        } else {
         if (CM) {
 #pragma unroll
             for (int t = 0; t < NT; t++) {
@@ -296,6 +310,7 @@ __global__ __launch_bounds__(kTileWaves * 64, LEAN ? 3 : 2) void k_conv_l0_tiles
         if (CE) {
 #pragma unroll
             for (int t = 0; t < NT; t++) DAGR_STEP(acce[t]);
+        }
         }
         if (CM) { DAGR_STEP(xr.x); DAGR_STEP(xr.y); DAGR_STEP(xr.z); DAGR_STEP(xr.w); }
         if (CE) DAGR_STEP(xre);
@@ -336,8 +351,9 @@ int launch_tiles_v(int64_t n_first, int64_t N, const int32_t *n_ptr, int rx, int
     }
     const int64_t tiles = ceil_div(N, 16);
     const unsigned grid = round_grid8(persistent_grid(kern, kTileWaves * 64, lds_bytes, ceil_div(tiles, kTileWaves)));
+    static const int ablate = [] { const char *e = getenv("DAGR_L0_ABLATE"); return e ? atoi(e) : 0; }();   // measurement only
     kern<<<grid, kTileWaves * 64, lds_bytes, stream>>>((int)n_first, (int)N, n_ptr, rx, ry, den_x, den_y, win_x, win_y, nbr_src, nbr_code, deg,
-                                                       x, ldx, xskip, ldskip, wpack, shift, relu, out, ldo);
+                                                       x, ldx, xskip, ldskip, wpack, shift, relu, out, ldo, ablate);
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;
 }

@@ -206,7 +206,9 @@ def _baseconv_forward(m, x):
 
 def _conv_bias_relu(blk, name, x):
     """relu(conv(x) + bias): spatial convs of the inference copy run bias-free (MIOpen would add the bias in a pass of
-    its own) and get bias + ReLU in one pass; the 1x1 GEMMs keep their epilogue."""
+    its own) and get bias + ReLU in one pass; the 1x1 GEMMs keep their epilogue.  (MIOpen's own conv + bias + ReLU fusion
+    plan, aten::miopen_convolution_relu, was measured in round 5: it falls to a naive kernel on these fp32 NHWC shapes --
+    260 ms per B = 8 forward instead of 4.7; profiles/r5_conv_phases.md.)"""
     conv = getattr(blk, name)
     b = getattr(blk, "_" + name + "_bias", None)
     out = conv(x)
