@@ -230,10 +230,13 @@ def _bottleneck_forward(blk, x):
     return _add_relu_(blk.conv3(out), identity)
 
 
-def _resnet_features_forward(net, x):
+def _resnet_features_forward(net, x, emit=None):
     """ResNet.forward_features (net_img.py:80-88) of the inference copy: bn1 -> relu -> maxpool after the raw conv1
-    output (which the reference taps) in one pass over the largest activation map of the network."""
+    output (which the reference taps) in one pass over the largest activation map of the network.  ``emit(name, map)`` is
+    called as soon as a stage's output exists (the engine's pipelined window starts a graph level when ITS map is ready)."""
+    emit = emit or (lambda name, t: None)
     c1 = net.conv1(x)
+    emit("conv1", c1)
     mp = net.maxpool
     ok = (c1.is_cuda and c1.dtype == torch.float32 and c1.is_contiguous(memory_format=torch.channels_last)
           and c1.shape[1] % 4 == 0 and mp.kernel_size == 3 and mp.stride == 2 and mp.padding == 1
@@ -248,9 +251,13 @@ def _resnet_features_forward(net, x):
     else:
         y = net.maxpool(net.relu(net.bn1(c1)))
     l1 = net.layer1(y)
+    emit("layer1", l1)
     l2 = net.layer2(l1)
+    emit("layer2", l2)
     l3 = net.layer3(l2)
+    emit("layer3", l3)
     l4 = net.layer4(l3)
+    emit("layer4", l4)
     return dict(conv1=c1, layer1=l1, layer2=l2, layer3=l3, layer4=l4)
 
 
@@ -312,6 +319,10 @@ class WindowEngine:
         self._keep = []
         self._cnn_out = None
         self._img_stream = None
+        self._feat_ready = None                 # pipelined window: event per feature map (keyed by the map's id)
+        self._cnn_ready = None
+        # captured --use_image windows: graph levels start when THEIR feature map exists (builder knob to A/B)
+        self.pipeline_image = os.environ.get("DAGR_PIPELINE_IMAGE", "1") != "0"
         self._net_f = self._cnn_f = None
         self.fuse_convs = os.environ.get("DAGR_FUSE_CONVS", "1") != "0"
         # head scale 1's convs ride in the launches of layer5 / head scale 2 (dagr_spline_conv_fused_multi)
@@ -752,6 +763,9 @@ class WindowEngine:
 
     def _sample(self, n_ptr, n_max, pos, batch, b64, fmap, out, coff):
         """sample_features (net.py:193-221) of one channels-last feature map into out[:, coff:coff+C]."""
+        ready = self._feat_ready.get(id(fmap)) if self._feat_ready else None
+        if ready is not None:                       # pipelined window: the map comes from the image branch's stream
+            torch.cuda.current_stream(self.device).wait_event(ready)
         Bf, C, h, w = fmap.shape
         nhwc = fmap.permute(0, 2, 3, 1)
         if not nhwc.is_contiguous():
@@ -817,11 +831,28 @@ class WindowEngine:
         _gemmify_1x1(net.output_dconv)
         self._net_f, self._cnn_f = net, cnn
 
-    def _image_branch(self, image):
+    def _image_branch(self, image, on_feature=None):
+        """``on_feature(j, map)``: called when feature map j (feature_layers[j] through its 1x1 dconv) has been issued --
+        HookModule.forward (net_img.py:137-145) applies the dconvs after the whole trunk; here each one follows its layer."""
         if self._net_f is None:
             self._fold_image_branch()
         bb, head = types.SimpleNamespace(net=self._net_f), types.SimpleNamespace(cnn_head=self._cnn_f)
-        feats, outs = bb.net(image.contiguous(memory_format=torch.channels_last))
+        x = image.contiguous(memory_format=torch.channels_last)
+        net = self._net_f
+        if on_feature is not None and hasattr(net.module, "_stem_affine"):
+            feats = [None] * len(net.feature_layers)
+
+            def emit(name, t):
+                if name in net.feature_layers:
+                    j = net.feature_layers.index(name)
+                    feats[j] = net.feature_dconv[j](t) if len(net.feature_dconv) > 0 else t
+                    on_feature(j, feats[j])
+            d = _resnet_features_forward(net.module, x, emit)
+            outs = [d[l] for l in net.output_layers]
+            if len(net.output_dconv) > 0:
+                outs = [dconv(o) for o, dconv in zip(outs, net.output_dconv)]
+        else:
+            feats, outs = bb.net(x)
         outs = outs[-self.num_scales:]
         resized = [torch.nn.functional.interpolate(f, o) for f, o in zip(outs, self.out_sizes)]
         return feats, head.cnn_head(resized)
@@ -1098,6 +1129,10 @@ class WindowEngine:
         collect_outputs / decode_outputs (dagr.py:283-312): one launch (dagr_heads_finish).  The fused logit maps land in
         ``head_buf[i]["dense"]`` as a by-product (traces, tests)."""
         P = _lib.ptr
+        if self._cnn_ready is not None:             # pipelined window: the CNN head ran beside the graph levels
+            torch.cuda.current_stream(self.device).wait_event(self._cnn_ready)
+            self._cnn_ready = None
+            self._feat_ready = None
         scales = []
         for i, lvln in enumerate(self.head_levels):
             lvl, hb = self.levels[lvln - 1], self.head_buf[i]
@@ -1229,7 +1264,32 @@ class WindowEngine:
                     self.stage_graph(self.in_pos, self.in_batch, self.in_feat)
                     join = torch.cuda.Event()
                     join.record(self._head_stream)
-                self.stage_image(self.in_image)
+                if self.pipeline_image:
+                    # The graph levels do not wait for the whole image branch: level k samples feature map k (+ 1), which
+                    # exists as soon as ResNet stage k has run (net.py:110-184: the reference calls the CNN first, but its
+                    # outputs are consumed level by level).  The branch gets a stream of its own and records an event per
+                    # map; a B = 1 window is two chains of small dependent kernels, and the shorter one (the graph levels,
+                    # ~0.4 ms) now runs UNDER the longer one (the CNN, ~1.3 ms) instead of after it.
+                    if self._img_stream is None:
+                        self._img_stream = torch.cuda.Stream(self.device)
+                    s_img = self._img_stream
+                    s_img.wait_event(fork)
+                    self._feat_ready = {}
+                    self._keep = []
+                    with torch.cuda.stream(s_img):
+                        def on_feature(j, fmap):
+                            ev = torch.cuda.Event()
+                            ev.record(s_img)
+                            self._feat_ready[id(fmap)] = ev
+                            fmap.record_stream(cur)
+                        self._img_feats, self._cnn_out = self._image_branch(self.in_image, on_feature)
+                        for v in self._cnn_out.values():
+                            for o in v:
+                                o.record_stream(cur)
+                        self._cnn_ready = torch.cuda.Event()
+                        self._cnn_ready.record(s_img)
+                else:
+                    self.stage_image(self.in_image)
                 cur.wait_event(join)
             else:
                 self.stage_graph(self.in_pos, self.in_batch, self.in_feat)

@@ -20,7 +20,7 @@ WIN = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 dev = torch.device("cuda:0")
 torch.cuda.set_device(0)
 with torch.no_grad():
-    rig = bench.Rig(640, 480, B, False, "resnet50", 1, dev, low_latency=True)
+    rig = bench.Rig(640, 480, B, os.environ.get("PROBE_IMAGE", "0") == "1", "resnet50", 1, dev, low_latency=True)
     eng = rig.engines[0]
     slots = rig.make_slots(syn.uniform_window, N, 2, seed=4234)
 
