@@ -211,6 +211,7 @@ def cpu_baseline(model_cpu, model_sd, W, H, B, n_events, n_steps, stream, use_im
     med = float(np.median(times))
     what = f"dagr-s + {img_net} image branch" if use_image else "events-only dagr-s"
     return dict(value=B * n_events / med, unit="events/s", cores=torch.get_num_threads(), kind="port",
+                windows_per_step=B, ms_per_window=round(1e3 * med / B, 1),   # (the GPU line's step holds gpu_windows_per_step)
                 step_ms_median=round(1e3 * med, 1), step_ms_all=[round(1e3 * t, 1) for t in times],
                 graph_ms_median=round(1e3 * float(np.median(t_graph)), 1), graph_threads=min(B, os.cpu_count() or 1),
                 sample=f"median of {n_steps} steps of B={B} windows x {n_events} events, {W}x{H}, {what} (the GPU line's "
@@ -420,7 +421,10 @@ def stage_timings(rig, slots, n_events_step):
     comp["pool1_accumulate"] = comp.pop("pool1")
     cands = ("graph_search", "l0_conv1", "l0_conv2", "pool1_accumulate")
     dom = max(cands, key=lambda k: stages[k])
-    names = dict(eng.l0_kernel_names(), graph_search="k_search_rows<320, false, 4, 7>",
+    # (the row kernel's instantiation: one bucket unless the builder's time dimension is switched on, graph_build.hip)
+    rows_name = "k_search_rows<320, 4, 5, true>" if int(os.environ.get("DAGR_TIME_BUCKETS", "1") or 1) > 1 \
+        else "k_search_rows<320, 4, 7, false>"
+    names = dict(eng.l0_kernel_names(), graph_search=rows_name,
                  pool1_accumulate=f"k_pool_l0_slots<0, {4 if cp % 4 == 0 else 1}>")
     kname = names[dom]
     # fp32 work of a level-0 conv launch (conv_l0_tiles.hip): phase 1 updates ALL taps of the TX x TY window per edge
@@ -735,6 +739,10 @@ def main():
         Bc = max(1, min(B, a.cpu_batch))
         result["cpu_baseline"] = cpu_baseline(model_cpu, sd_cpu, W, H, Bc, NPW, a.cpu_steps, a.stream, use_image,
                                               a.img_net)
+        # a BOUNDED SAMPLE of the step: fewer windows per step than the GPU line, hence fewer graph-builder
+        # threads and smaller torch batches; per-window times of both legs side by side
+        result["cpu_baseline"]["gpu_windows_per_step"] = B
+        result["cpu_baseline"]["gpu_ms_per_window"] = round(result["ms_per_step"] / B, 4)
         if ev_sd_cpu is not None and "events_only" in result:
             # BASELINE config 1's shape (events-only dagr-s on the CPU) beside the events_only leg of the GPU line
             result["events_only"]["cpu_baseline"] = cpu_baseline(None, ev_sd_cpu, W, H, Bc, NPW, a.cpu_steps, a.stream,

@@ -67,3 +67,18 @@ def medium_cases():
     x, y, t, p, b = syn.batch_windows(syn.edges_window, 50000, 1, 640, 480, seed=301)
     cases.append(_case("vga_edges_b1", x, y, t, b, 640, 480, 1, 7, 10000))
     return cases
+
+
+def wide_radius_cases():
+    """Search radii beyond 7 pixels (a sensor wider than 700 px at radius 0.01): the builder's generic search form
+    (csrc/graph_build.hip:k_search_dense, every node; the row kernel's 16-lane layout stops at 2r + 1 = 15 rows)."""
+    cases = []
+    rng = np.random.default_rng(17)
+    x, y, t, p, b = syn.batch_windows(syn.uniform_window, 2500, 2, 96, 72, seed=31)
+    cases.append(_case("r9_uniform_b2", x, y, t, b, 96, 72, 2, 9, 10000))
+    x, y, t, p, b = syn.batch_windows(syn.edges_window, 4000, 1, 96, 72, seed=41)
+    cases.append(_case("r12_edges_b1", x, y, t, b, 96, 72, 1, 12, 10000, K=16, Q=16))
+    n = 900
+    cases.append(_case("r8_unsorted_k24", rng.integers(0, 64, n), rng.integers(0, 48, n), rng.integers(960000, 1000001, n),
+                       np.zeros(n), 64, 48, 1, 8, 10000, K=24, Q=8))
+    return cases

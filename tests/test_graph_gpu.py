@@ -5,7 +5,7 @@ import torch
 
 from oracle import graph as og
 from dagr_amd.utils import synthetic as syn
-from tests.graph_cases import small_cases, medium_cases
+from tests.graph_cases import small_cases, medium_cases, wide_radius_cases
 
 pytestmark = pytest.mark.gpu
 
@@ -67,6 +67,19 @@ def test_small_cases_bit_exact(case):
     assert ei.shape == ref.shape, (ei.shape, ref.shape)
     assert (ei == ref).all()
     assert ne == ref.shape[1]
+    _check_codes(case, nbr_src, nbr_code, deg)
+
+
+@pytest.mark.parametrize("case", wide_radius_cases(), ids=lambda c: c["name"])
+def test_wide_radius_cases_bit_exact(case):
+    """r > 7: every node goes through the generic form of k_search_dense (sorted and unsorted timestamps, K = 24,
+    FIFO depths 8 / 16 so that pixels exceed them)."""
+    ei, nbr_src, nbr_code, deg, ne, flags = _run_hip(case)
+    ref = _oracle(case)
+    assert flags == 0
+    assert ei.shape == ref.shape, (ei.shape, ref.shape)
+    assert (ei == ref).all()
+    assert ne == ref.shape[1] and deg.max() <= case["K"]
     _check_codes(case, nbr_src, nbr_code, deg)
 
 
