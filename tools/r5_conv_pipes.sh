@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, GPU call 1: (1) counter list of the box, (2) MFMA-pipe vs VALU-pipe busy counters of the level-0 convs (is phase 2
+# round 5: counter list of the box, MFMA-pipe / VALU-pipe busy counters of the level-0 convs, the new GPU tests, a short bench line
 # of a tile hidden under phase 1 of other waves' tiles?), (3) the new tests, (4) a short default bench line (one-rank RCCL group).
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
