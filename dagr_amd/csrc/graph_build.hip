@@ -7,15 +7,15 @@
 // -1-padded int64 edge buffer.
 //
 // What this file does instead (same edge set, same order, bit-exact):
-//   * events are bucketed by the key (sample, y, TIME BUCKET, x) into a CSR array (per-key counters -> exclusive scan ->
-//     scatter -> in-segment order fix-up).  A time bucket is delta_t wide (a hair more), so every admissible source of
-//     a destination (older, dt <= delta_t: ev_graph.cu:64,69) lies in the destination's own bucket or the one before,
-//     and in slot order the events of one pixel row of one bucket are ONE contiguous range: a destination fetches
-//     2 x (2r+1) row ranges that hold ~0.4 of the window's events in its (2r+1)^2 pixels (a 50 ms window, delta_t = 10 ms),
-//     where an index without the time dimension (rounds 1-4: CSR by pixel) handed it every event of those pixels and
-//     four in five failed the dt test.  After all N events of a reset window are inserted, the FIFO column of a pixel
-//     holds exactly the newest min(count, Q) events of that pixel, newest first -- its segments read backwards, newest
-//     bucket first; the 157 MB volume and its refill disappear.
+//   * events are bucketed by the key (sample, y, [time bucket,] x) into a CSR array (per-key counters -> exclusive scan ->
+//     scatter -> in-segment order fix-up).  In slot order the events of one pixel row of the neighbourhood are ONE
+//     contiguous range.  After all N events of a reset window are inserted, the FIFO column of a pixel holds exactly the
+//     newest min(count, Q) events of that pixel, newest first -- its segment(s) read backwards; the 157 MB volume and its
+//     refill disappear.  The TIME BUCKET is optional (TimeKey below, off as shipped): buckets delta_t wide put every
+//     admissible source of a destination (older, dt <= delta_t: ev_graph.cu:64,69) into the destination's own bucket or
+//     the one before, so that a destination fetches 2 x (2r+1) row ranges holding ~0.4 of the window's events in its
+//     (2r+1)^2 pixels (50 ms window, delta_t = 10 ms) instead of all of them -- measured in round 5, the search is bound
+//     by its scattered offset loads, which the second bucket doubles, and only dense uniform streams gain.
 //   * the search is candidate-centric (k_search_rows): the row ranges' events are tested 16 at a time and keyed by
 //     (spiral rank of their pixel, recency); the reference's sequential "first K in spiral order, newest first inside a
 //     pixel" cut is "the K-1 smallest keys in key order".  Event-dense neighbourhoods go to a position-centric walk

@@ -68,7 +68,7 @@ def _hot_pixel_320():
 
 
 @pytest.mark.parametrize("case", [c for c in small_cases() if len(c["x"]) >= 40 and c["K"] == 16 and c["W"] >= 64
-                                  and c["B"] == 1 and c["name"] != "unsorted_t"] + [_hot_pixel_320()],
+                                  and c["B"] == 1] + [_hot_pixel_320()],
                          ids=lambda c: c["name"])
 def test_appended_rows_have_the_reference_edges(case):
     """Window of the first part of the events, the rest appended in three micro-batches (one of them a single event):
