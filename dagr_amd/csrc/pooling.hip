@@ -13,8 +13,8 @@
 //   * reductions are order-independent and therefore deterministic: max through an order-preserving
 //     int mapping, means through exact 64-bit fixed-point sums (2^-40 for positions, 2^-32 for
 //     features) divided once at the end.
-//   * level 0 (N events): one wave per voxel walks the CSR-by-pixel index of the graph builder
-//     (pixel rows of a voxel are contiguous slot ranges) -- no atomics except for the rare leak events.
+//   * level 0 (N events): nodes are the graph builder's CSR slots, so the voxels of one sample / voxel row own one
+//     contiguous run of them: equal runs of slots are streamed into LDS windows of table slots (k_pool_l0_slots below).
 //     Coarser levels (<= 2240*(B+1) nodes): atomics into the same accumulators.
 //   * coarse edges: per destination cluster a 64-slot open-addressing set of source clusters
 //     (atomicCAS) -- or, from level 0, two 5x5 bitmaps of source cells -- then one wave per cluster sorts

@@ -102,7 +102,7 @@ typedef struct {
 } dagr_graph_desc;
 
 size_t dagr_graph_workspace_bytes(const dagr_graph_desc *desc);
-/* must be called once on a fresh workspace (zeroes the per-pixel counters) */
+/* must be called once on a fresh workspace (zeroes the per-key counters) */
 int dagr_graph_workspace_init(const dagr_graph_desc *desc, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Node numbering: the graph comes out in *slot space* -- node n is the n-th event in (sample, y, x,
@@ -128,7 +128,7 @@ int dagr_graph_build_window(const dagr_graph_desc *desc, void *workspace,
 /* dagr_graph_build_window with the event count in DEVICE memory: every launch is sized for `n_cap` events and bounded by
  * *n_dev (<= n_cap) on the device, so the call can be captured in a HIP graph once and replayed for windows of any size.
  * pos / batch: the static buffers dagr_stage_window filled -- that launch has already run the build's first step
- * (denormalise + per-pixel count) on them and cleared the status words; this call continues from there. */
+ * (denormalise + per-key count) on them and cleared the status words; this call continues from there. */
 int dagr_graph_build_window_dev(const dagr_graph_desc *desc, void *workspace, const void *pos, int32_t pos_is_int32,
                                 const void *batch, int32_t batch_is_int64, int64_t n_cap, const int32_t *n_dev,
                                 int32_t *nbr_src, int16_t *nbr_code, int32_t *deg, void *stream);
@@ -137,7 +137,7 @@ int dagr_graph_build_window_dev(const dagr_graph_desc *desc, void *workspace, co
 const int32_t *dagr_graph_node_count_ptr(const dagr_graph_desc *desc, void *workspace);
 /* One launch that copies a caller's window (format_data output: pos fp32[N,3], feat fp32[N], batch int32/int64[N]) into
  * static buffers (batch as int32), writes N to *n_dev, clears the builder's status words and runs the build's first step
- * (denormalise_pos + the per-pixel count, ev_tgn.py:11-16): the only per-window launch in front of a captured window graph
+ * (denormalise_pos + the per-key count, ev_tgn.py:11-16): the only per-window launch in front of a captured window graph
  * (dagr_graph_build_window_dev continues from its results). */
 int dagr_stage_window(const dagr_graph_desc *desc, void *workspace, const float *pos, const float *feat, const void *batch,
                       int32_t batch_is_int64, int64_t N, float *pos_out, float *feat_out, int32_t *batch_out,

@@ -436,7 +436,7 @@ def _last_log(name):
 def test_vga_edges_b8_100k_whole_engine():
     """S-edges at the BASELINE size (640x480, B = 8 x 100 k) through the whole engine: the stream the latency table
     reports next to S-uniform.  Its event-dense neighbourhoods leave the row kernel (> 320 candidates: deferred to
-    k_search_tiled, ev_graph.cu:48-78 semantics) and its voxels hold thousands of members."""
+    k_search_dense, ev_graph.cu:48-78 semantics) and its voxels hold thousands of members."""
     W, H, B = 640, 480, 8
     args, model, sd = _setup(W, H, B, seed=0, calibrate=syn.edges_window)
     name = "vga_edges_events_only_b8_100k"
