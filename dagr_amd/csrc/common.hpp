@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string>
 
 #include "dagr_hip.h"
@@ -138,6 +139,22 @@ __device__ __forceinline__ XcdSplit xcd_split(int n_items, int items_per_block, 
     s.stride = bpx * items_per_block;
     return s;
 }
+// One-item-per-thread launches over E items in natural order (events: sample after sample; CSR slots: sample, row, pixel):
+// workgroup b of the grid sits on XCD b % 8 (see xcd_split), so the natural block index deals every sample's items to all
+// eight L2s.  Remapped, XCD x takes the x-th contiguous eighth of the blocks -- with B = 8 samples one sample's per-pixel
+// counters, offsets and slots (1.2 + 1.2 + 1.2 MB at 640x480) stay in ONE 4-MiB L2.  Returns the logical block, or -1 for
+// the padding blocks of a grid rounded up to a multiple of 8.  xcd_remap = 0: identity (measurement knob).
+__device__ __forceinline__ int xcd_block(int n_blocks, int xcd_remap) {
+    if (!xcd_remap) return (int)blockIdx.x < n_blocks ? (int)blockIdx.x : -1;
+    const int bpx = (n_blocks + 7) >> 3;
+    const int lb = (int)(blockIdx.x >> 3) + (int)(blockIdx.x & 7) * bpx;
+    return ((int)(blockIdx.x >> 3) < bpx && lb < n_blocks) ? lb : -1;
+}
+inline int xcd_remap_on() {      // DAGR_XCD_REMAP=0: natural block order (A/B measurements)
+    static const int v = [] { const char *e = getenv("DAGR_XCD_REMAP"); return e ? atoi(e) : 1; }();
+    return v;
+}
+inline unsigned xcd_grid(int64_t n_blocks) { return (unsigned)((n_blocks + 7) / 8 * 8); }   // whole rounds of the eight XCDs
 inline unsigned round_grid8(int64_t g) { return (unsigned)(g <= 8 ? (g < 1 ? 1 : g) : (g + 7) / 8 * 8); }
 
 // ---- generic int32 exclusive scan over n elements (3 launches) --------------------------

@@ -223,9 +223,10 @@ __global__ __launch_bounds__(kBlock) void k_count(const void *__restrict__ pos_,
                                                  int N, int W, int H, int B, float fW,
                                                  float fH, float fT, const TimeKey tk, int32_t *__restrict__ cnt,
                                                  int32_t *__restrict__ ev_xyb, int32_t *__restrict__ ev_t,
-                                                 int32_t *__restrict__ ev_rank, int32_t *__restrict__ status) {
-    const int e = blockIdx.x * kBlock + threadIdx.x;
-    if (e >= N) return;
+                                                 int32_t *__restrict__ ev_rank, int32_t *__restrict__ status, int xcd_remap) {
+    const int lb = xcd_block((N + kBlock - 1) / kBlock, xcd_remap);
+    const int e = lb * kBlock + threadIdx.x;
+    if (lb < 0 || e >= N) return;
     count_event<BatchT, kIntPos>(e, pos_, batch, W, H, B, fW, fH, fT, tk, cnt, ev_xyb, ev_t, ev_rank, status + 1, status + 6);
 }
 
@@ -241,13 +242,15 @@ __global__ __launch_bounds__(kBlock) void k_scatter(int N, const int32_t *__rest
                                                    const int32_t *__restrict__ ev_rank,
                                                    const int32_t *__restrict__ start,
                                                    int32_t *__restrict__ slot_tmp, int32_t *__restrict__ ev_slot,
-                                                   int32_t *__restrict__ status) {
-    const int e = blockIdx.x * kBlock + threadIdx.x;
-    if (n_dev && e == 0) {
+                                                   int32_t *__restrict__ status, int xcd_remap) {
+    if (n_dev && blockIdx.x == 0 && threadIdx.x == 0) {
         if (status[8]) { atomicOr(&status[1], 1); status[8] = 0; }
         if (status[9]) { status[6] = 1; status[9] = 0; }
     }
-    if (e >= N || (n_dev && e >= *n_dev)) return;
+    const int Nw = n_dev ? min(N, *n_dev) : N;       // (a captured launch is sized for the capacity)
+    const int lb = xcd_block((Nw + kBlock - 1) / kBlock, xcd_remap);
+    const int e = lb * kBlock + threadIdx.x;
+    if (lb < 0 || e >= Nw) return;
     const int c = ev_xyb[e];
     if (c < 0) { ev_slot[e] = -1; return; }
     slot_tmp[start[key_of_event(c, ev_t[e], W, H, tk)] + ev_rank[e]] = e;
@@ -264,9 +267,11 @@ __global__ __launch_bounds__(kBlock) void k_order(int N, int64_t PK, int W, int 
                                                  const int32_t *__restrict__ slot_tmp, int2 *__restrict__ slot_it,
                                                  int32_t *__restrict__ slot_xyb, int32_t *__restrict__ ev_slot,
                                                  int32_t *__restrict__ hot_list, int hot_cap,
-                                                 int32_t *__restrict__ status) {
-    const int s = blockIdx.x * kBlock + threadIdx.x;
-    if (s >= N || s >= start[PK]) return;  // start[PK] = number of indexed events (<= N)
+                                                 int32_t *__restrict__ status, int xcd_remap) {
+    const int M = min(N, start[PK]);       // start[PK] = number of indexed events (<= N)
+    const int lb = xcd_block((M + kBlock - 1) / kBlock, xcd_remap);
+    const int s = lb * kBlock + threadIdx.x;
+    if (lb < 0 || s >= M) return;  // start[PK] = number of indexed events (<= N)
     const int e = slot_tmp[s];
     const int c = ev_xyb[e];
     const int t = ev_t[e];
@@ -1277,7 +1282,8 @@ static int build_window(const dagr_graph_desc *desc, void *workspace, const void
     }
     DAGR_CHECK_ARG(pos && batch && nbr_src && nbr_code && deg, "NULL pointer");
     const int n = (int)N;
-    const unsigned gN = (unsigned)ceil_div(N, kBlock);
+    const unsigned gN = xcd_grid(ceil_div(N, kBlock));
+    const int xr = xcd_remap_on();
     const int W = desc->width, H = desc->height, B = desc->batch_size;
     // (device-count form: dagr_stage_window, the launch in front of the captured window, has cleared the status words and
     // run K1 on the window it staged)
@@ -1286,7 +1292,7 @@ static int build_window(const dagr_graph_desc *desc, void *workspace, const void
 #define DAGR_LAUNCH_COUNT(BT, IP)                                                                          \
     k_count<BT, IP><<<gN, kBlock, 0, stream>>>(pos, (const BT *)batch, n, W, H, B, (float)W, (float)H,        \
                                                (float)desc->time_window, ws.tk, ws.cnt, ws.ev_xyb, ws.ev_t,  \
-                                               ws.ev_rank, ws.status)
+                                               ws.ev_rank, ws.status, xr)
         if (batch_is_int64) { if (pos_is_int32) DAGR_LAUNCH_COUNT(int64_t, true); else DAGR_LAUNCH_COUNT(int64_t, false); }
         else                { if (pos_is_int32) DAGR_LAUNCH_COUNT(int32_t, true); else DAGR_LAUNCH_COUNT(int32_t, false); }
 #undef DAGR_LAUNCH_COUNT
@@ -1295,7 +1301,7 @@ static int build_window(const dagr_graph_desc *desc, void *workspace, const void
     // start = exclusive_scan(cnt); cnt is re-zeroed in the same pass (invariant for the next window)
     DAGR_CHECK_HIP(exclusive_scan_i32_chained(ws.cnt, ws.start, ws.PK + 1, ws.scan_tmp, true, stream));
     k_scatter<<<gN, kBlock, 0, stream>>>(n, n_dev, W, H, ws.tk, ws.ev_xyb, ws.ev_t, ws.ev_rank, ws.start, ws.slot_tmp,
-                                         ws.ev_slot, ws.status);
+                                         ws.ev_slot, ws.status, xr);
     DAGR_CHECK_LAUNCH();
     // number of occupied CSR slots M = start[PK] <= N (dropped events excluded); slots are a
     // prefix [0, M) so launching N threads with an in-kernel bound read would need M on the host.
@@ -1303,7 +1309,7 @@ static int build_window(const dagr_graph_desc *desc, void *workspace, const void
     const int hot_cap = (int)(desc->max_events + 1);
     const int hot_thr = std::min(kShortSeg, desc->queue_size / ws.tk.nb);
     k_order<<<gN, kBlock, 0, stream>>>(n, ws.PK, W, H, ws.tk, hot_thr, ws.ev_xyb, ws.ev_t, ws.start, ws.slot_tmp, ws.slot_it,
-                                       ws.slot_xyb, ws.ev_slot, ws.hot_list, hot_cap, ws.status);
+                                       ws.slot_xyb, ws.ev_slot, ws.hot_list, hot_cap, ws.status, xr);
     DAGR_CHECK_LAUNCH();
     k_fix_pixels<<<1024, kBlock, 0, stream>>>(desc->queue_size, W, ws.tk, ws.ev_xyb, ws.slot_xyb, ws.ev_slot, ws.ev_t, ws.start,
                                             ws.slot_tmp, ws.slot_it, ws.hot_list, hot_cap, ws.status);

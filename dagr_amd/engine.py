@@ -6,7 +6,9 @@ level lives in pre-sized device buffers with device-side node/edge counts, so a 
 host synchronisation: graph build -> fused level-0 convs -> voxel pooling -> (tap aggregation +
 GEMM) per pooled conv -> dense head maps.  PyTorch supplies memory and the stream only.
 """
+import contextlib
 import ctypes
+import gc
 import os
 import types
 
@@ -33,6 +35,22 @@ def _bn_affine(bn):
     shift = (m.bias - m.running_mean * scale).detach().float()
     return scale, shift
 
+
+
+@contextlib.contextmanager
+def _capture(graph):
+    """``torch.cuda.graph`` with Python's cyclic collector paused for the length of the capture.  Entering the context
+    collects everything that is garbage already; a collection that starts in the middle of the capture would run
+    finalizers (of objects a previous engine left in a cycle, of temporaries of the body) that may call into the HIP runtime
+    while the stream is capturing -- one ad-hoc ordering of the GPU test files aborted inside a captured tail that way."""
+    was_enabled = gc.isenabled()
+    with torch.cuda.graph(graph):
+        gc.disable()
+        try:
+            yield
+        finally:
+            if was_enabled:
+                gc.enable()
 
 class _ConvPack:
     """Packed weights of one fused contraction: Wm[K, N], bias[N] (BN folded), plus shape info."""
@@ -1329,7 +1347,7 @@ class WindowEngine:
                 out = self._forward_static()
             else:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with _capture(g):
                     out = self._forward_static()
                 self._wg, self._wg_out = g, out
                 g.replay()
@@ -1355,7 +1373,7 @@ class WindowEngine:
                 self._graph_warm += 1
                 return self._tail_and_head()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with _capture(g):
                 out = self._tail_and_head()
             self._graph, self._graph_out = g, out
         self._graph.replay()

@@ -91,7 +91,14 @@ class GNNHead(YOLOXHeadParams):
             try:
                 sample = (torch.zeros_like(lab),) + tuple(torch.randn_like(t).requires_grad_(True) for t in flat)
                 sample[0][:, 0, 1:] = torch.tensor([40.0, 40.0, 30.0, 30.0], device=lab.device)      # one box per image
-                cache[key] = torch.cuda.make_graphed_callables(fn, sample)
+                import gc
+                gc_was_on = gc.isenabled()
+                gc.disable()                            # (no finalizers into the HIP runtime while the stream captures)
+                try:
+                    cache[key] = torch.cuda.make_graphed_callables(fn, sample)
+                finally:
+                    if gc_was_on:
+                        gc.enable()
             except Exception as exc:                    # capture not possible here: keep the eager form
                 import warnings
                 warnings.warn(f"loss graph capture failed ({exc}); using the launch-by-launch form")
