@@ -286,7 +286,8 @@ class Rig:
         k = i % len(self.engines)
         e, st = self.engines[k], self.streams[k]
         with torch.cuda.stream(st):
-            out = e.forward_raw(pos, feat, batch, image=image)
+            # (post-processed at once, on the engine's stream, before its next window: no copy of the output buffer)
+            out = e.forward_raw(pos, feat, batch, image=image, static_out=True)
             return postprocess_device(out, self.num_classes, self.model.conf_threshold, self.model.nms_threshold,
                                       self.H, self.W)
 
