@@ -1257,7 +1257,7 @@ class WindowEngine:
                 trace["x0"] = self._x0[ev_slot][:, back].clone()
         self.stage_pool1()
         if trace is None and self.tail_graph and not self.use_image:
-            return self._replay_tail()
+            return self._replay_tail(static_out)
         out = self._tail_and_head(trace)
         if trace is not None:
             trace["head_dense"] = [o.clone() for o in self._fused_dense]
