@@ -125,7 +125,8 @@ struct GraphWs {
     int32_t *ev_slot;   // [Nmax] CSR slot of every event (-1: dropped)
     int32_t *hot_list;  // [Nmax + 1] pixels with a segment beyond kShortSeg / Q / nb events (k_fix_pixels)
     int32_t *status;    // [16]: 0 listed pixels, 1 flags, 2..3 num_edges (uint64), 4 pixels beyond the FIFO depth,
-                        //       5 deferral list length, 6 unsorted timestamps, 8 / 9 the staging launch's flag words
+                        //       5 deferral list length, 6 unsorted timestamps, 7 destinations answered from their inner
+                        //       rings, 8 / 9 the staging launch's flag words
     int64_t P;          // pixels: B * H * W
     int64_t PK;         // keys: P * nb
     TimeKey tk;
@@ -598,7 +599,7 @@ struct alignas(4) Pair { int a, b; };
 // ranges' bases -- cheaper than the expansion when a range holds ~5 events instead of ~1.
 template <int CAP, int ROUNDS, int WAVES, bool TWO>
 __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__restrict__ m_ptr, int W, int H, int K, int r,
-                                                       float delta_t, const TimeKey tk, int defer_cap,
+                                                       float delta_t, const TimeKey tk, int defer_cap, int ring_thr,
                                                        const int32_t *__restrict__ slot_xyb,
                                                        const int32_t *__restrict__ start,
                                                        const int2 *__restrict__ slot_it,
@@ -618,6 +619,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
     extern __shared__ int v_key_dyn[];
     __shared__ int def_buf[kBlock / 64][64];
     __shared__ unsigned long long blk_edges;   // the block's edge count: ONE global atomic per workgroup at the end
+    __shared__ int blk_ring;                   // destinations answered from their inner rings (status[7])
     int wcnt = 0;    // entries of this wave's deferral buffer (uniform over the wave's active lanes)
     const int side = 2 * r + 1;
     const int S = side * side;
@@ -627,7 +629,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
         sp_rank[(sy + r) * 16 + (sx + r)] = (unsigned char)s;
         sp_dec[s] = (unsigned short)(((sx + r) * side + (sy + r)) | ((sy + r) << 12));
     }
-    if (threadIdx.x == 0) blk_edges = 0ull;
+    if (threadIdx.x == 0) { blk_edges = 0ull; blk_ring = 0; }
     __syncthreads();
     const int l = threadIdx.x & 15;
     const int grp = threadIdx.x >> 4;
@@ -635,6 +637,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
     const int gshift = threadIdx.x & 48;
     const unsigned lt_mask = (1u << l) - 1u;
     long long edges_acc = 0;
+    int ring_acc = 0;
     const int M = *m_ptr;
     // timestamps out of order: sources may sit in any later bucket -- k_search_dense takes every node in its generic form
     if (M <= 0 || status[6] != 0) return;
@@ -689,6 +692,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
         const int C = TWO ? C0 + row16_sum(len1) : C0;
         const int cb0 = row16_inclusive_scan(len0) - len0, cb1 = TWO ? C0 + row16_inclusive_scan(len1) - len1 : 0;
         const int clo0 = lo0, clo1 = lo1, cl0 = len0, cl1 = len1;
+        const int c_dst = c;
         me = me1; c = c1; me1 = me2; c1 = c2; lo0 = nlo0; len0 = nlen0; lo1 = nlo1; len1 = nlen1;   // rotate the pipeline
         // Dense neighbourhoods are deferred to the position-centric kernel.  The list append is aggregated per wave
         // (LDS buffer, one global atomic per ~48 entries): one atomicAdd per destination on a single counter
@@ -715,7 +719,45 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
             }
         }
         if (defer) continue;
-        row_lo[grp][l] = clo0;
+        // Ring limit (one bucket).  The walk keeps the first K - 1 admissible sources in spiral order and the spiral runs
+        // ring by ring (Chebyshev distance), so once the rings <= rho hold K - 1 admissible sources nothing outside them is
+        // kept: a neighbourhood with many candidates is searched in its inner (2 rho + 1)^2 window first -- exact when that
+        // yields K - 1 sources, otherwise the full window is searched as before (the inner pass is then lost work).
+        // Numbers (S-edges 100 k events per sample, 15 x 15 window): 34 % of the destinations have 96 < C <= 320
+        // candidates, mean 195; the ring that fills their K - 1 holds 60 (tools/ring_stats.py).  ring_thr: low 16 bits = the
+        // candidate count from which this is tried, high bits = candidates wanted per source.
+        int u_lo = clo0, u_len = cl0, Cu = C;
+        bool inner = false;
+        if constexpr (!TWO) {
+            if ((ring_thr & 0xffff) > 0 && C > (ring_thr & 0xffff)) {
+                const int xd = c_dst & 4095, yd = (c_dst >> 12) & 4095, bd = (c_dst >> 24) & 127;
+                const int yn = yd + l - r;
+                const bool row_ok = l < side && yn >= 0 && yn < H;
+                const int rbase = W * (yn + H * bd);
+                auto window = [&](int rho, int &wlo, int &wlen) {
+                    wlo = 0; wlen = 0;
+                    if (row_ok && l >= r - rho && l <= r + rho) {
+                        wlo = start[rbase + max(xd - rho, 0)];
+                        wlen = start[rbase + min(xd + rho, W - 1) + 1] - wlo;
+                    }
+                };
+                int wlo, wlen;
+                window(3, wlo, wlen);
+                int Cw = row16_sum(wlen);
+                // enough candidates for K - 1 admissible ones?  (about one in four is: dt <= delta_t, older, visible)
+                const int want = (ring_thr >> 16) * (K - 1);
+                if (Cw < want && r > 5) {
+                    // density of the inner window (or of the whole one, if larger) -> the ring that should hold `want`
+                    const int d225 = max(Cw * 225 / 49, C);          // candidates per 225 pixels
+                    const int rho = (d225 * 81 >= want * 225) ? 4 : ((d225 * 121 >= want * 225) ? 5 : 0);
+                    if (rho > 0) { window(rho, wlo, wlen); Cw = row16_sum(wlen); } else Cw = 0;
+                }
+                if (Cw >= want && 2 * Cw <= C) { u_lo = wlo; u_len = wlen; Cu = Cw; inner = true; }
+            }
+        }
+        int V = 0;
+        for (;;) {       // at most twice: the inner window, then (if that fell short of K - 1 sources) the whole one
+        row_lo[grp][l] = TWO ? clo0 : u_lo;
         if constexpr (TWO) {
             row_lo[grp][16 + l] = clo1;
             // every range writes its events into the candidate list: (range << 16) | position in the range
@@ -725,15 +767,15 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
                 if (k < cl1) v_keys[cb1 + k] = ((16 + l) << 16) | k;
             }
         } else {
-            row_base[grp][l] = cb0;
-            if (l == 15) row_base[grp][16] = C;
+            row_base[grp][l] = inner ? row16_inclusive_scan(u_len) - u_len : cb0;
+            if (l == 15) row_base[grp][16] = Cu;
         }
         __builtin_amdgcn_wave_barrier();
         // 2. candidates, 16 per round, ROUNDS rounds of loads in flight.  The admissible ones are compacted into the SAME
         //    list: their number never exceeds the number of candidates read so far, and a batch reads all of its list
         //    entries before it writes any key.
-        int V = 0;
-        for (int c0 = 0; c0 < C; c0 += 16 * ROUNDS) {
+        V = 0;
+        for (int c0 = 0; c0 < Cu; c0 += 16 * ROUNDS) {
             int2 it[ROUNDS];
             int cxv[ROUNDS], rpv[ROUNDS];     // rpv: (range << 16) | position in the range
 #pragma unroll
@@ -741,7 +783,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
                 const int ci = c0 + 16 * q + l;
                 it[q] = make_int2(0, 0);
                 cxv[q] = 0; rpv[q] = 0;
-                if (ci < C) {
+                if (ci < Cu) {
                     if constexpr (TWO) {
                         rpv[q] = v_keys[ci];
                     } else {
@@ -760,10 +802,10 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int q = 0; q < ROUNDS; q++) {
-                if (c0 + 16 * q < C) {        // (group-uniform: a round no group of the wave needs is skipped as a whole)
+                if (c0 + 16 * q < Cu) {        // (group-uniform: a round no group of the wave needs is skipped as a whole)
                     const int ci = c0 + 16 * q + l;
                     int valid = 0, key = 0;
-                    if (ci < C) {
+                    if (ci < Cu) {
                         // visible in the FIFO; older than the destination (ev_graph.cu:64); dt <= delta (:69)
                         valid = ((cxv[q] < 0) && it[q].x < e && !((float)(t - it[q].y) > delta_t)) ? 1 : 0;
                         const int dx = (cxv[q] & 4095) - x;
@@ -780,6 +822,9 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
             }
         }
         __builtin_amdgcn_wave_barrier();
+        if (!inner || V >= K - 1) { ring_acc += (inner && l == 0) ? 1 : 0; break; }
+        inner = false; u_lo = clo0; u_len = cl0; Cu = C;      // the inner window fell short: the whole neighbourhood
+        }
         // 3. the K-1 smallest keys, in key order
         if (l == 0) {
             nbr_src[row] = n;  // self loop first (ev_graph.cu:44-46)
@@ -845,9 +890,11 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
     // single counter drained at ~350 M/s, i.e. ~70 us after the last neighbourhood was written (most of the kernel at
     // 25 k events, a quarter of it at 800 k).  Reduced in LDS first.
     if (l == 0 && edges_acc) atomicAdd(&blk_edges, (unsigned long long)edges_acc);
+    if (ring_acc) atomicAdd(&blk_ring, ring_acc);
     __syncthreads();
     if (threadIdx.x == 0 && blk_edges)
         atomicAdd(reinterpret_cast<unsigned long long *>(status + 2), blk_edges);
+    if (threadIdx.x == 0 && blk_ring) atomicAdd(&status[7], blk_ring);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1230,12 +1277,19 @@ static int launch_search(const dagr_graph_desc *desc, const GraphWs &ws, int64_t
         // 8 x 200 k: 1.84 ms at 128, 2.07 at 192, 2.57 at 320), without them the list's capacity is.
         static const int defer_env = [] { const char *e = getenv("DAGR_DEFER_CAP"); return e ? atoi(e) : 0; }();
         const int defer_cap = std::min(kRowCap, std::max(16, defer_env ? defer_env : (ws.tk.nb > 1 ? 128 : kRowCap)));
+        // candidates from which a neighbourhood is searched in its inner rings first (k_search_rows; 0 = never)
+        static const int ring_env = [] { const char *e = getenv("DAGR_RING_THR"); return e ? atoi(e) : -1; }();
+        static const int want_env = [] { const char *e = getenv("DAGR_RING_WANT"); return e ? atoi(e) : 0; }();
+        // measured (gpurun_out/r5ring, whole build in us, threshold x candidates wanted per source): S-edges 8 x 100 k 829 ->
+        // 763, 8 x 200 k 1637 -> 1540, S-uniform 8 x 400 k 2804 -> 2715 at (200, 5); wanting fewer than 5 per source makes
+        // the inner pass fall short on uniform streams (3160), thresholds below 200 cost sparse windows two loads for nothing
+        const int ring_thr = (ring_env >= 0 ? ring_env : 200) | ((want_env > 0 ? want_env : 5) << 16);
         auto launch_rows = [&](auto kern) {
             static thread_local unsigned res_rows = 0;
             if (!res_rows) res_rows = persistent_grid(kern, kBlock, rows_lds, 1 << 30);
             const unsigned gR = round_grid8(std::min<int64_t>(ceil_div(N * 16, kBlock), res_rows));
             kern<<<gR, kBlock, rows_lds, stream>>>(ws.start + ws.PK, W, H, K, r, (float)desc->delta_t_us, ws.tk, defer_cap,
-                                                   ws.slot_xyb, ws.start, ws.slot_it, nbr_src, nbr_code, deg, ws.status,
+                                                   ring_thr, ws.slot_xyb, ws.start, ws.slot_it, nbr_src, nbr_code, deg, ws.status,
                                                    ws.ev_rank, ws.status + 5);
         };
         const bool two = ws.tk.nb > 1;
@@ -1384,6 +1438,7 @@ int dagr_graph_search_window(const dagr_graph_desc *desc, void *workspace, int64
     // edge counter (status[2..3]) and deferral list length (status[5]) start over; the pixel index stays
     DAGR_CHECK_HIP(hipMemsetAsync(ws.status + 2, 0, 2 * 4, stream));
     DAGR_CHECK_HIP(hipMemsetAsync(ws.status + 5, 0, 4, stream));
+    DAGR_CHECK_HIP(hipMemsetAsync(ws.status + 7, 0, 4, stream));
     return launch_search(desc, ws, N, nbr_src, nbr_code, deg, stream);
 }
 

@@ -83,8 +83,9 @@ def _log(name, rec):
 def _path_counters(eng):
     """Which paths the last window took (device-side counters): pixels handed to k_fix_pixels (a segment beyond 64 events or
     beyond Q / buckets) and those among them that hold more than Q events, destinations deferred by the row kernel to the
-    position-centric walk (> 320 candidates), unsorted-timestamp fallback, and -- cumulative -- level-0 nodes the pooling
-    merged through its global path."""
+    position-centric walk (> 320 candidates), destinations the row kernel answered from the inner rings of their
+    neighbourhood (> 200 candidates), unsorted-timestamp fallback, and -- cumulative -- level-0 nodes the pooling merged
+    through its global path."""
     import ctypes
     from dagr_amd import _lib
     g = eng.graph
@@ -95,7 +96,7 @@ def _path_counters(eng):
     _lib.check(eng.L.dagr_pool_counters(ctypes.byref(eng.pool_desc[0]), _lib.ptr(eng.pool_ws[0]),
                                         ctypes.cast(pc, ctypes.c_void_p), _lib.cur_stream(eng.device)), "pool_counters")
     return dict(long_pixels=int(gc[0]), beyond_fifo=int(gc[4]), deferred=int(gc[5]), unsorted=int(gc[6]),
-                pool1_global_path=int(pc[5]))
+                ring_limited=int(gc[7]), pool1_global_path=int(pc[5]))
 
 
 def _events(gen, n, B, W, H, seed):
@@ -442,6 +443,7 @@ def test_vga_edges_b8_100k_whole_engine():
     name = "vga_edges_events_only_b8_100k"
     _compare(args, model, sd, W, H, B, *_events(syn.edges_window, 100000, B, W, H, seed=1234), plain=True, log=name)
     assert _last_log(name)["paths"]["deferred"] > 0, "the dense-neighbourhood path did not run"
+    assert _last_log(name)["paths"]["ring_limited"] > 0, "no neighbourhood was answered from its inner rings"
 
 
 @pytest.mark.parametrize("stream,n", [("uniform", 200000), ("uniform", 400000), ("edges", 200000), ("edges", 400000)])

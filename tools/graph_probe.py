@@ -57,6 +57,15 @@ def main():
         torch.cuda.synchronize()
         rec = {"spec": spec, "edges": ne, "flags": flags,
                "build_us": round(a.elapsed_time(c) / REPS * 1e3, 1)}
+        try:        # device-side path counters of the last build (a library without the call: skipped)
+            import ctypes
+            from dagr_amd import _lib
+            gc = (ctypes.c_int32 * 8)()
+            _lib.check(_lib.lib().dagr_graph_counters(ctypes.byref(g.desc), _lib.ptr(g.workspace),
+                                                      ctypes.cast(gc, ctypes.c_void_p), _lib.cur_stream(dev)), "counters")
+            rec["deferred"], rec["ring_limited"] = int(gc[5]), int(gc[7])
+        except Exception:
+            pass
         if os.environ.get("PROBE_CHECK") == "1":
             rec["digest"] = digest(g, *outb)
         print(json.dumps(rec), flush=True)
