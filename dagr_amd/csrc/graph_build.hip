@@ -612,6 +612,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
     __shared__ unsigned short sp_dec[256];      // spiral index -> offset code (dx + r) * side + (dy + r) | (dy + r) << 12
     __shared__ int row_lo[G][TWO ? 32 : 16];    // first slot of the ranges 0..15 (bucket tb) and 16..31 (bucket tb - 1)
     __shared__ int row_base[TWO ? 1 : G][TWO ? 1 : 17];   // one bucket: the ranges' positions in the concatenation
+    __shared__ int row_sub[TWO ? 1 : G][TWO ? 1 : 16];    // ... minus the range's offset inside its row: candidate index -> position in the ROW
     // the group's list: first the candidates as (range << 16 | position in the range), then -- compacted in place behind
     // the reads -- the keys of the admissible ones, (spiral rank << 20) | (older bucket << 19) | (0x7FFFF - position): the
     // source slot follows from the key.  Dynamic LDS on purpose: with the size visible the compiler's occupancy estimate
@@ -726,7 +727,12 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
         // Numbers (S-edges 100 k events per sample, 15 x 15 window): 34 % of the destinations have 96 < C <= 320
         // candidates, mean 195; the ring that fills their K - 1 holds 60 (tools/ring_stats.py).  ring_thr: low 16 bits = the
         // candidate count from which this is tried, high bits = candidates wanted per source.
-        int u_lo = clo0, u_len = cl0, Cu = C;
+        // The row's range is cut into [left | inner window | right] (slots relative to the row's first one); the passes
+        // are: the inner windows of all rows; then, only if those fell short of K - 1 sources, the left parts (whole rows
+        // outside the window) and the right parts.  Keys carry positions relative to the row's first slot in every pass, so
+        // the passes append to one list and nothing is examined twice.
+        int in_off = cl0, in_len = 0;          // (a row outside the window: everything is "left")
+        int Cu = C, pb = cb0, p_off = 0;
         bool inner = false;
         if constexpr (!TWO) {
             if ((ring_thr & 0xffff) > 0 && C > (ring_thr & 0xffff)) {
@@ -741,7 +747,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
                         wlen = start[rbase + min(xd + rho, W - 1) + 1] - wlo;
                     }
                 };
-                int wlo, wlen;
+                int wlo, wlen, rho = 3;
                 window(3, wlo, wlen);
                 int Cw = row16_sum(wlen);
                 // enough candidates for K - 1 admissible ones?  (about one in four is: dt <= delta_t, older, visible)
@@ -749,15 +755,19 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
                 if (Cw < want && r > 5) {
                     // density of the inner window (or of the whole one, if larger) -> the ring that should hold `want`
                     const int d225 = max(Cw * 225 / 49, C);          // candidates per 225 pixels
-                    const int rho = (d225 * 81 >= want * 225) ? 4 : ((d225 * 121 >= want * 225) ? 5 : 0);
+                    rho = (d225 * 81 >= want * 225) ? 4 : ((d225 * 121 >= want * 225) ? 5 : 0);
                     if (rho > 0) { window(rho, wlo, wlen); Cw = row16_sum(wlen); } else Cw = 0;
                 }
-                if (Cw >= want && 2 * Cw <= C) { u_lo = wlo; u_len = wlen; Cu = Cw; inner = true; }
+                if (Cw >= want && Cw + 48 <= C) {
+                    inner = true;
+                    if (row_ok && l >= r - rho && l <= r + rho) { in_off = wlo - clo0; in_len = wlen; }
+                    Cu = Cw; p_off = in_off;
+                    pb = row16_inclusive_scan(in_len) - in_len;
+                }
             }
         }
         int V = 0;
-        for (;;) {       // at most twice: the inner window, then (if that fell short of K - 1 sources) the whole one
-        row_lo[grp][l] = TWO ? clo0 : u_lo;
+        row_lo[grp][l] = clo0;
         if constexpr (TWO) {
             row_lo[grp][16 + l] = clo1;
             // every range writes its events into the candidate list: (range << 16) | position in the range
@@ -766,15 +776,17 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
                 if (k < cl0) v_keys[cb0 + k] = (l << 16) | k;
                 if (k < cl1) v_keys[cb1 + k] = ((16 + l) << 16) | k;
             }
-        } else {
-            row_base[grp][l] = inner ? row16_inclusive_scan(u_len) - u_len : cb0;
+        }
+        for (int pass = 0;; pass++) {       // one pass, or up to three for a ring-limited destination
+        if constexpr (!TWO) {
+            row_base[grp][l] = pb;
+            row_sub[grp][l] = pb - p_off;
             if (l == 15) row_base[grp][16] = Cu;
         }
         __builtin_amdgcn_wave_barrier();
         // 2. candidates, 16 per round, ROUNDS rounds of loads in flight.  The admissible ones are compacted into the SAME
         //    list: their number never exceeds the number of candidates read so far, and a batch reads all of its list
         //    entries before it writes any key.
-        V = 0;
         for (int c0 = 0; c0 < Cu; c0 += 16 * ROUNDS) {
             int2 it[ROUNDS];
             int cxv[ROUNDS], rpv[ROUNDS];     // rpv: (range << 16) | position in the range
@@ -792,7 +804,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
                         if (row_base[grp][rr + 4] <= ci) rr += 4;
                         if (row_base[grp][rr + 2] <= ci) rr += 2;
                         if (row_base[grp][rr + 1] <= ci) rr += 1;
-                        rpv[q] = (rr << 16) | (ci - row_base[grp][rr]);
+                        rpv[q] = (rr << 16) | (ci - row_sub[grp][rr]);
                     }
                     const int sv = row_lo[grp][rpv[q] >> 16] + (rpv[q] & 0xffff);
                     it[q] = slot_it[sv];
@@ -822,8 +834,13 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
             }
         }
         __builtin_amdgcn_wave_barrier();
-        if (!inner || V >= K - 1) { ring_acc += (inner && l == 0) ? 1 : 0; break; }
-        inner = false; u_lo = clo0; u_len = cl0; Cu = C;      // the inner window fell short: the whole neighbourhood
+        if (TWO || !inner || pass == 2) break;
+        if (pass == 0 && V >= K - 1) { ring_acc += (l == 0) ? 1 : 0; break; }
+        // the inner window fell short: the left parts (whole rows outside the window), then the right parts
+        const int p_len = pass == 0 ? in_off : cl0 - (in_off + in_len);
+        p_off = pass == 0 ? 0 : in_off + in_len;
+        Cu = row16_sum(p_len);
+        pb = row16_inclusive_scan(p_len) - p_len;
         }
         // 3. the K-1 smallest keys, in key order
         if (l == 0) {
@@ -1271,7 +1288,9 @@ static int launch_search(const dagr_graph_desc *desc, const GraphWs &ws, int64_t
         constexpr size_t rows_lds = (size_t)(kBlock / 16) * (kRowCap + 4) * 4;
         // builder knob DAGR_ROWS_VARIANT = 10 * rounds + waves per SIMD (16 candidates per round)
         static const int variant_env = [] { const char *e = getenv("DAGR_ROWS_VARIANT"); return e ? atoi(e) : 0; }();
-        const int variant = variant_env ? variant_env : (ws.tk.nb > 1 ? 45 : 47);    // (registers: 88 / 72)
+        // (registers: 88 / 78.  The block's 25 KB of LDS hold six workgroups per CU either way; the 72-register form of the
+        // one-bucket kernel, variant 47, spills three registers since the ring-limited passes and measures the same)
+        const int variant = variant_env ? variant_env : (ws.tk.nb > 1 ? 45 : 46);
         // neighbourhoods beyond this many candidates go to the position-centric kernel (builder knob DAGR_DEFER_CAP).
         // Measured (profiles/r5_search_buckets.md): with time buckets 128 is the best cut on event-dense streams (S-edges
         // 8 x 200 k: 1.84 ms at 128, 2.07 at 192, 2.57 at 320), without them the list's capacity is.
@@ -1280,10 +1299,11 @@ static int launch_search(const dagr_graph_desc *desc, const GraphWs &ws, int64_t
         // candidates from which a neighbourhood is searched in its inner rings first (k_search_rows; 0 = never)
         static const int ring_env = [] { const char *e = getenv("DAGR_RING_THR"); return e ? atoi(e) : -1; }();
         static const int want_env = [] { const char *e = getenv("DAGR_RING_WANT"); return e ? atoi(e) : 0; }();
-        // measured (gpurun_out/r5ring, whole build in us, threshold x candidates wanted per source): S-edges 8 x 100 k 829 ->
-        // 763, 8 x 200 k 1637 -> 1540, S-uniform 8 x 400 k 2804 -> 2715 at (200, 5); wanting fewer than 5 per source makes
-        // the inner pass fall short on uniform streams (3160), thresholds below 200 cost sparse windows two loads for nothing
-        const int ring_thr = (ring_env >= 0 ? ring_env : 200) | ((want_env > 0 ? want_env : 5) << 16);
+        // measured (whole build in us; threshold x candidates wanted per source): S-edges 8 x 100 k 833 -> 748, 8 x 200 k
+        // 1631 -> 1511, S-uniform 8 x 400 k 2761 -> 2449 at (200, 6); wanting 4 per source makes the inner pass fall short
+        // three times in four on uniform streams (2986: the extra passes are not free), thresholds below 200 cost sparse
+        // windows two loads for nothing (S-uniform 1 x 200 k: 150 -> 162 at 128)
+        const int ring_thr = (ring_env >= 0 ? ring_env : 200) | ((want_env > 0 ? want_env : 6) << 16);
         auto launch_rows = [&](auto kern) {
             static thread_local unsigned res_rows = 0;
             if (!res_rows) res_rows = persistent_grid(kern, kBlock, rows_lds, 1 << 30);
