@@ -82,3 +82,32 @@ def test_denormalize_roundtrip_matches_raw_pixels():
         x = np.arange(W); y = np.arange(W) % H
         pos = og.denormalize_pos(format_data_np(x, y, np.zeros(W), W, H), W, H, 1000000)
         assert (pos[:, 0] == x).all() and (pos[:, 1] == y).all()
+
+
+@pytest.mark.parametrize("rho", [1, 2, 3])
+def test_a_destination_filled_by_its_inner_rings_needs_nothing_outside_them(rho):
+    """What the row search's ring limit relies on (csrc/graph_build.hip, k_search_rows): the walk takes sources in spiral
+    order, the spiral runs ring by ring (spiral.h:1-15), and it stops at K entries (ev_graph.cu:48-78) -- so a destination
+    whose in-edges at search radius rho already number K has exactly the same in-edges at any larger radius.  Checked on the
+    oracle: dense windows, radius rho against radius 7."""
+    from dagr_amd.utils import synthetic as syn
+    W, H, K, Q, dt = 96, 72, 16, 128, 10000
+    x, y, t, p, b = syn.batch_windows(syn.edges_window, 6000, 1, W, H, seed=91 + rho)
+    t = (t - t.max() + 1000000).astype(np.int64)     # windows end at the normaliser (dsec_data.py:145)
+    full = og.build_window_graph(x, y, t, b, W, H, 1, 7, dt, K=K, Q=Q)
+    inner = og.build_window_graph(x, y, t, b, W, H, 1, rho, dt, K=K, Q=Q)
+
+    def rows(e):
+        order = np.argsort(e[1], kind="stable")
+        src, dst = e[0][order], e[1][order]
+        cut = np.flatnonzero(np.diff(dst)) + 1
+        return dict(zip(dst[np.r_[0, cut]].tolist(), np.split(src, cut)))
+    rf, ri = rows(full), rows(inner)
+    filled = [d for d, s in ri.items() if len(s) == K]
+    assert len(filled) > 500, "the window is not dense enough to exercise the claim"
+    for d in filled:
+        assert (rf[d] == ri[d]).all(), f"destination {d}: radius {rho} fills K, radius 7 gives another list"
+    # and the converse bound: a destination NOT filled at rho keeps those sources as a prefix at radius 7
+    for d, s in ri.items():
+        if len(s) < K:
+            assert (rf[d][:len(s)] == s).all(), f"destination {d}: the inner sources are not a prefix of the full list"
