@@ -1,29 +1,63 @@
 """Mirror of ``src/dagr/utils/args.py``: same flags (every option ``default=SUPPRESS`` so that the YAML
-only fills keys absent from the command line, args.py:104-110) and the shipped model configs as data."""
+only fills keys absent from the command line, args.py:104-110).  The model configurations are the YAML files under
+``config/`` at the repository root (data: ``dagr-{n,s,m,l}-dsec.yaml``, ``dagr-l-ncaltech.yaml``); ``--config`` takes a
+path to one of them exactly as the reference's command lines do (readme.md:68-75,107-113,131-138,168-171,180-184), or a
+short name (``dagr-s``) as an alias."""
 import argparse
+import sys
 import types
 from pathlib import Path
 
 import yaml
 
-# config/dagr-{n,s,m,l}-dsec.yaml differ only in net_stem_width / yolo_stem_width (lines 23-24)
-MODEL_CONFIGS = {
-    "dagr-n": dict(net_stem_width=0.25, yolo_stem_width=0.25),
-    "dagr-s": dict(net_stem_width=0.5, yolo_stem_width=0.5),
-    "dagr-m": dict(net_stem_width=0.75, yolo_stem_width=0.75),
-    "dagr-l": dict(net_stem_width=1.0, yolo_stem_width=1.0),
-}
-BASE_CONFIG = dict(task="detection", dataset="dsec", radius=0.01, time_window_us=1000000, max_neighbors=16,
-                   n_nodes=50000, batch_size=64, activation="relu", edge_attr_dim=2, aggr="sum", kernel_size=5,
-                   pooling_aggr="max", base_width=0.5, after_pool_width=1, num_scales=2, weight_decay=0.00001,
-                   clip=0.1, pooling_dim_at_output="5x7", aug_trans=0.1, aug_zoom=1.5, aug_p_flip=0.5,
-                   img_net="resnet18", l_r=0.0002, tot_num_epochs=801)
+CONFIG_DIR = Path(__file__).resolve().parents[2] / "config"
+
+
+def _load_yaml(path):
+    with Path(path).open() as f:
+        return yaml.load(f, Loader=yaml.SafeLoader)
+
+
+def _model_configs():
+    out = {}
+    for path in sorted(CONFIG_DIR.glob("dagr-*-dsec.yaml")):
+        cfg = _load_yaml(path)
+        out[path.name[:-len("-dsec.yaml")]] = dict(net_stem_width=float(cfg["net_stem_width"]),
+                                                    yolo_stem_width=float(cfg["yolo_stem_width"]))
+    return out
+
+
+# short name -> the two keys in which config/dagr-{n,s,m,l}-dsec.yaml differ (read from the files)
+MODEL_CONFIGS = _model_configs()
+
+
+def resolve_config(config):
+    """``--config`` as the reference's command lines give it (a YAML path, relative to the working directory or to the
+    repository root), or a short name (``dagr-s`` -> ``config/dagr-s-dsec.yaml``).  The reference's readme also names
+    ``config/eagr-s-dsec.yaml`` (readme.md:122,134), a file its tree does not hold: it resolves to ``dagr-s-dsec.yaml``
+    with a printed notice."""
+    config = Path(config)
+    tried = [config, CONFIG_DIR.parent / config, CONFIG_DIR / config.name]
+    name = config.name
+    if not name.endswith((".yaml", ".yml")):
+        tried += [CONFIG_DIR / f"{name}-dsec.yaml", CONFIG_DIR / f"{name}.yaml"]
+    if name.startswith("eagr-"):
+        tried.append(CONFIG_DIR / ("dagr-" + name[len("eagr-"):]))
+    for path in tried:
+        if path.is_file():
+            if path.name != name:
+                print(f"[dagr] --config {config}: using {path}", file=sys.stderr)
+            return path
+    raise FileNotFoundError(f"--config {config}: no such file (looked in {', '.join(str(t) for t in tried)})")
 
 
 def model_args(name="dagr-s", **over):
-    """Namespace equivalent to ``FLAGS()`` with ``--config config/<name>-dsec.yaml``."""
-    cfg = dict(BASE_CONFIG, use_image=False, no_events=False, pretrain_cnn=False, keep_temporal_ordering=False)
-    cfg.update(MODEL_CONFIGS[name])
+    """Namespace equivalent to ``FLAGS()`` with ``--config config/<name>-dsec.yaml``: every key of that file."""
+    path = name if str(name).endswith((".yaml", ".yml")) else CONFIG_DIR / f"{name}-dsec.yaml"
+    cfg = dict(_load_yaml(resolve_config(path)), use_image=False, no_events=False, pretrain_cnn=False,
+               keep_temporal_ordering=False)
+    cfg.pop("dataset_directory", None)
+    cfg.pop("output_directory", None)
     cfg.update(over)
     return types.SimpleNamespace(**cfg)
 
@@ -59,7 +93,8 @@ def parse_config(args, config):
     return args
 
 
-def FLAGS(argv=None):
+def FLAGS_PARSER():
+    """The parser of ``FLAGS`` (args.py:54-70); the scripts add their synthetic-data options to it."""
     p = BASE_FLAGS()
     S = argparse.SUPPRESS
     for name, typ in (("aug_trans", float), ("aug_zoom", float), ("exp_name", str), ("l_r", float),
@@ -68,11 +103,38 @@ def FLAGS(argv=None):
     p.add_argument("--no_eval", action="store_true")
     p.add_argument("--run_test", action="store_true")
     p.add_argument("--num_interframe_steps", type=int, default=10)
-    args = p.parse_args(argv)
+    return p
+
+
+def FLAGS(argv=None):
+    args = FLAGS_PARSER().parse_args(argv)
     if args.config != "":
         args = parse_config(args, args.config)
     args.dataset_directory = Path(args.dataset_directory)
     args.output_directory = Path(args.output_directory)
     if "checkpoint" in args:
+        args.checkpoint = Path(args.checkpoint)
+    return args
+
+
+def SCRIPT_FLAGS(argv=None, description=None, default_config="dagr-s-dsec.yaml", extra=None):
+    """``FLAGS`` for the shipped scripts: the reference's command lines parse to the reference's namespace (same parser, same
+    YAML merge), plus (i) ``--config`` also takes a short name / is looked up under the repository's ``config/``, with
+    `default_config` when absent (the reference's default ``../config/detection.yaml`` exists nowhere), (ii) the options of
+    the synthetic stand-in data (`extra(parser)`), used when the dataset's readers cannot run, (iii) ``--dataset_directory``
+    may be left out (-> None; the YAML's ``dataset_directory`` is a placeholder and is not used)."""
+    p = FLAGS_PARSER()
+    p.description = description
+    p.formatter_class = argparse.RawDescriptionHelpFormatter
+    p.set_defaults(config=None)
+    if extra is not None:
+        extra(p)
+    args = p.parse_args(argv)
+    given = set(vars(args))                          # SUPPRESS defaults: present <=> given on the command line
+    args.config = resolve_config(args.config if args.config is not None else default_config)
+    args = parse_config(args, args.config)
+    args.dataset_directory = Path(args.dataset_directory) if "dataset_directory" in given else None
+    args.output_directory = Path(args.output_directory)
+    if "checkpoint" in given:                        # absent stays absent ("checkpoint" in args, run_test.py:56)
         args.checkpoint = Path(args.checkpoint)
     return args

@@ -15,35 +15,61 @@ from dagr.data.augment import Augmentations                      # noqa: E402
 from dagr.data.synthetic_data import SyntheticObjects, SyntheticWindows   # noqa: E402
 from dagr.model.networks.dagr import DAGR                        # noqa: E402
 from dagr.model.networks.ema import ModelEMA                     # noqa: E402
-from dagr.utils.args import MODEL_CONFIGS, model_args            # noqa: E402
+from dagr.utils.args import SCRIPT_FLAGS                         # noqa: E402
 from dagr.utils.buffers import detections_to_records             # noqa: E402
 from dagr.utils.testing_weights import randomize_                # noqa: E402
 
 
-def flags(description, extra=None):
-    p = argparse.ArgumentParser(description=description, formatter_class=argparse.RawDescriptionHelpFormatter)
-    p.add_argument("--config", default="dagr-s", choices=sorted(MODEL_CONFIGS))
-    p.add_argument("--checkpoint", type=Path, default=None, help="torch.load(path)['ema'] -> ema.ema (strict)")
-    p.add_argument("--output_directory", type=Path, default=Path("run_test_out"))
-    p.add_argument("--batch_size", type=int, default=8)
-    p.add_argument("--windows", type=int, default=32)
-    p.add_argument("--events_per_window", type=int, default=50000)
-    p.add_argument("--width", type=int, default=640)
-    p.add_argument("--height", type=int, default=480)
-    p.add_argument("--stream", default="uniform", choices=["uniform", "edges"])
-    p.add_argument("--dataset_directory", type=Path, default=None,
-                   help="DSEC root (run_test.py:45: DSEC(root, 'test', transform_testing, ...)); needs dsec-det + h5py + "
-                        "hdf5plugin.  Default: the synthetic event stream with the DSEC sample contract")
-    p.add_argument("--split", default="test")
-    p.add_argument("--no_eval", action="store_true", help="utils/args.py:62: no ground truth is loaded / scored")
-    p.add_argument("--labelled", action="store_true",
+def _synthetic_options(p):
+    """Options of the synthetic stand-in data (no counterpart in the reference): used when the run has no
+    ``--dataset_directory`` or the dataset's readers (dsec-det, h5py, hdf5plugin) are not installed."""
+    g = p.add_argument_group("synthetic stand-in data")
+    g.add_argument("--windows", type=int, default=None, help="number of 50 ms windows (default: max(32, 4 x batch_size))")
+    g.add_argument("--events_per_window", type=int, default=50000)
+    g.add_argument("--width", type=int, default=640)
+    g.add_argument("--height", type=int, default=480)
+    g.add_argument("--stream", default="uniform", choices=["uniform", "edges"])
+    g.add_argument("--split", default="test")
+    g.add_argument("--labelled", action="store_true",
                    help="synthetic windows WITH boxes (dagr/data/synthetic_data.py:SyntheticObjects): the run is scored "
                         "(COCO-protocol mAP of the whole run, also when it is sharded over several GPUs)")
-    p.add_argument("--use_image", action="store_true")
-    p.add_argument("--img_net", default="resnet50")
-    if extra:
-        extra(p)
-    return p
+
+
+def flags(description, argv=None, extra=None, default_config="dagr-s-dsec.yaml"):
+    """The reference's ``FLAGS()`` (``dagr.utils.args``: same parser, ``--config <yaml>`` merged under the command line --
+    run_test.py:31, readme.md:107-113) plus the synthetic-data options.  Returns the namespace the model is built from."""
+    def more(p):
+        _synthetic_options(p)
+        if extra:
+            extra(p)
+    a = SCRIPT_FLAGS(argv, description=description, default_config=default_config, extra=more)
+    if a.windows is None:
+        a.windows = max(32, 4 * a.batch_size)
+    return a
+
+
+def real_data_available(a, what="DSEC"):
+    """Whether ``--dataset_directory`` can be read here; a printed notice when it cannot (the run then goes over the synthetic
+    stand-in stream: same sample contract, same engine path)."""
+    if a.dataset_directory is None:
+        return False
+    missing = []
+    for name in (("dsec_det", "h5py", "hdf5plugin") if what == "DSEC" else ("h5py",)):
+        try:
+            __import__(name)
+        except ImportError:
+            missing.append(name)
+    reason = None
+    if missing:
+        reason = f"the {what} reader needs {', '.join(missing)} (not installed)"
+    elif not Path(a.dataset_directory).exists():
+        reason = f"{a.dataset_directory} does not exist"
+    if reason is None:
+        return True
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"NOTICE: --dataset_directory {a.dataset_directory}: {reason}; running on the SYNTHETIC stand-in data "
+              f"instead (no ground truth, no mAP).", flush=True)
+    return False
 
 
 def distributed():
@@ -81,12 +107,13 @@ def finish(world):
 def dataset_and_loader(a, world, rank):
     """The dataset and THIS rank's loader: batch k holds windows [k*B, (k+1)*B) (drop_last=True, run_test.py:48) and
     goes to rank k mod G -- independent windows, no collective on the data path."""
-    if getattr(a, "dataset_directory", None) is not None:
+    a.real_data = real_data_available(a)
+    if a.real_data:
         # run_test.py:43 / run_test_interframe.py:66-68: the DSEC test split, boxes of at least 15 px diagonal and 10 px
         # height; run_test.py scores every frame pair (no_eval left at its default False), the interframe script restricts
         # itself to perfect tracks and passes --no_eval through
         from dagr.data.dsec_data import DSEC
-        interframe = hasattr(a, "num_interframe_steps")
+        interframe = bool(getattr(a, "interframe", False))
         ds = DSEC(a.dataset_directory, a.split, Augmentations.transform_testing, debug=False, min_bbox_diag=15,
                   min_bbox_height=10, only_perfect_tracks=interframe, no_eval=bool(a.no_eval) if interframe else False)
     elif getattr(a, "labelled", False):
@@ -102,24 +129,34 @@ def dataset_and_loader(a, world, rank):
 
 
 def build_model(a, ds, dev):
-    """run_test.py:52-59: DAGR(args, height, width).cuda() -> ModelEMA -> checkpoint['ema'] (strict) -> cache_luts."""
-    args = model_args(a.config, batch_size=a.batch_size, use_image=a.use_image, img_net=a.img_net)
-    model = DAGR(args, height=ds.height, width=ds.width)
-    if a.checkpoint is None:
+    """run_test.py:52-59: DAGR(args, height, width).cuda() -> ModelEMA -> checkpoint['ema'] (strict) -> cache_luts, with
+    ``args`` = the parsed namespace (every key of the YAML under the command line).  The reference asserts a checkpoint;
+    here a run without one keeps seeded random weights, with a printed notice."""
+    model = DAGR(a, height=ds.height, width=ds.width)
+    checkpoint = a.checkpoint if "checkpoint" in a else None
+    if checkpoint is None:
+        if int(os.environ.get("RANK", "0")) == 0:
+            print("NOTICE: no --checkpoint: the model keeps seeded random weights.", flush=True)
         model = randomize_(model, seed=0)
     model = model.to(dev)
     ema = ModelEMA(model)
-    if a.checkpoint is not None:
-        ema.ema.load_state_dict(torch.load(a.checkpoint, map_location=dev)["ema"])
+    if checkpoint is not None:
+        ema.ema.load_state_dict(torch.load(checkpoint, map_location=dev)["ema"])
     else:
         ema.ema.load_state_dict(model.state_dict())
-    ema.ema.cache_luts(radius=args.radius, height=ds.height, width=ds.width)
-    return args, ema.ema
+    ema.ema.cache_luts(radius=a.radius, height=ds.height, width=ds.width)
+    return a, ema.ema
+
+
+def logging_dataset(a):
+    """First component of the run directory (logging.py:101-110: <output>/<dataset>/<task>/<exp_name>): the YAML's dataset
+    when its data is read, "synthetic" when the stand-in stream is."""
+    return a.dataset if getattr(a, "real_data", False) else "synthetic"
 
 
 def is_labelled(a):
     """Whether the run is scored: DSEC with ground truth (run_test.py:43: no_eval stays False), or labelled synthetic data."""
-    return (a.dataset_directory is not None or bool(getattr(a, "labelled", False))) and not a.no_eval
+    return (bool(getattr(a, "real_data", False)) or bool(getattr(a, "labelled", False))) and not a.no_eval
 
 
 def save_metrics(metrics, output_directory, rank, name="metrics.json"):

@@ -10,6 +10,10 @@ with ``--dataset_directory`` (DSEC) or ``--labelled`` (synthetic objects with bo
 (COCO-protocol mAP, ``dagr/utils/coco_eval.py``): ONE mAP for the run -- a sharded run gathers detections and ground truth
 of all ranks before the evaluation, as the reference's single process sees them (run_test.py:61-65).
 
+The reference's command line is taken as it is (readme.md:107-113); ``--config`` also accepts a short name:
+
+  python scripts/run_test.py --config config/dagr-s-dsec.yaml --use_image --img_net resnet50 \
+         --checkpoint data/dagr_s_50.pth --batch_size 8 --dataset_directory $DSEC_ROOT --output_directory $LOG_DIR
   python scripts/run_test.py --config dagr-s --windows 64 --batch_size 8 --output_directory /tmp/out
   python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 scripts/run_test.py ...
 """
@@ -24,13 +28,14 @@ from dagr.utils.testing import run_test_with_visualization
 
 
 def main(argv=None, model_factory=None):
-    a = C.flags(__doc__).parse_args(argv)
+    a = C.flags(__doc__, argv)
     world, rank, dev = C.distributed()
     torch.manual_seed(42)
     np.random.seed(42)
     ds, loader = C.dataset_and_loader(a, world, rank)
     args, net = (model_factory or C.build_model)(a, ds, dev)
-    out_dir = set_up_logging_directory("synthetic", "detection", a.output_directory, exp_name="run_test")
+    out_dir = set_up_logging_directory(C.logging_dataset(a), a.task, a.output_directory,
+                                       exp_name=getattr(a, "exp_name", "run_test"))
     if rank == 0:
         log_hparams(args)
     t0 = time.perf_counter()

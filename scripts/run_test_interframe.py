@@ -16,13 +16,15 @@ from dagr.utils.testing import run_test_with_visualization
 
 
 def main(argv=None, model_factory=None):
-    a = C.flags(__doc__, lambda p: p.add_argument("--num_interframe_steps", type=int, default=10)).parse_args(argv)
+    a = C.flags(__doc__, argv)            # --num_interframe_steps / --no_eval are FLAGS' own (args.py:64,68)
+    a.interframe = True
     world, rank, dev = C.distributed()
     torch.manual_seed(42)
     np.random.seed(42)
     ds, loader = C.dataset_and_loader(a, world, rank)
     args, net = (model_factory or C.build_model)(a, ds, dev)
-    out_dir = set_up_logging_directory("synthetic", "detection", a.output_directory, exp_name="run_test_interframe")
+    out_dir = set_up_logging_directory(C.logging_dataset(a), a.task, a.output_directory,
+                                       exp_name=getattr(a, "exp_name", "run_test_interframe"))
     if rank == 0:
         log_hparams(args)
     detections = []

@@ -15,12 +15,17 @@ The N-Caltech101 reader needs h5py (absent here): with ``--dataset_directory`` i
 ``SyntheticObjects`` (labelled synthetic rectangles, 240 x 180).  The validation pass computes the COCO-protocol mAP
 (``dagr/utils/coco_eval.py``) of ``ema.ema``'s detections and keeps the best checkpoint, as the reference does.
 
+The reference's command line is taken as it is (readme.md:168-171); ``--config`` also accepts a short name:
+
+  python scripts/train_ncaltech101.py --config config/dagr-l-ncaltech.yaml --exp_name ncaltech_l \
+         --dataset_directory $DAGR_DIR/data/ --output_directory $DAGR_DIR/logs/
   python scripts/train_ncaltech101.py --epochs 3 --samples 256 --batch_size 16
   python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 scripts/train_ncaltech101.py --batch_size 64
 """
 import argparse
 import os
 import random
+import sys
 import time
 from pathlib import Path
 
@@ -34,31 +39,40 @@ from dagr.data.augment import Augmentations
 from dagr.data.synthetic_data import SyntheticObjects
 from dagr.model.networks.dagr import DAGR
 from dagr.model.networks.ema import ModelEMA
-from dagr.utils.args import model_args
+from dagr.utils.args import MODEL_CONFIGS
 from dagr.utils.buffers import format_data
 from dagr.utils.learning_rate_scheduler import LRSchedule
 from dagr.utils.logging import Checkpointer, log_hparams, set_up_logging_directory
 
 
-def flags():
-    p = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
-    p.add_argument("--dataset_directory", type=Path, default=None, help="root holding ncaltech101/{training,validation,annotations}")
-    p.add_argument("--output_directory", type=Path, default=Path("train_out"))
-    p.add_argument("--exp_name", default="train")
-    p.add_argument("--config", default="dagr-l", help="width preset; the N-Caltech101 settings of config/dagr-l-ncaltech.yaml apply")
-    p.add_argument("--batch_size", type=int, default=64, help="GLOBAL batch (config/dagr-l-ncaltech.yaml:14)")
-    p.add_argument("--epochs", type=int, default=801)
-    p.add_argument("--samples", type=int, default=512, help="synthetic training samples (no --dataset_directory)")
-    p.add_argument("--val_samples", type=int, default=64)
-    p.add_argument("--n_nodes", type=int, default=50000)
-    p.add_argument("--l_r", type=float, default=0.001)
-    p.add_argument("--weight_decay", type=float, default=0.00001)
-    p.add_argument("--clip", type=float, default=0.1)
-    p.add_argument("--max_iters", type=int, default=-1, help="stop after this many iterations (smoke runs)")
-    p.add_argument("--resume_checkpoint", type=Path, default=None)
-    p.add_argument("--use_image", action="store_true", help="(train_dsec.py) fuse the image branch")
-    p.add_argument("--img_net", default="resnet50")
-    return p
+def flags(argv=None, preset="ncaltech101"):
+    """The reference's ``FLAGS()`` (readme.md:168-171 / :180-184 parse as they are) plus the options of the synthetic
+    stand-in data and of short runs.  A short ``--config`` name (``dagr-s``) under the N-Caltech101 preset means
+    ``config/dagr-l-ncaltech.yaml`` at that model's widths."""
+    def more(p):
+        g = p.add_argument_group("short runs / synthetic stand-in data")
+        g.add_argument("--epochs", type=int, default=None, help="alias of --tot_num_epochs")
+        g.add_argument("--samples", type=int, default=512, help="synthetic training samples (no dataset to read)")
+        g.add_argument("--val_samples", type=int, default=64)
+        g.add_argument("--max_iters", type=int, default=-1, help="stop after this many iterations (smoke runs)")
+        g.add_argument("--resume_checkpoint", type=Path, default=None)
+    argv = list(sys.argv[1:] if argv is None else argv)
+    widths = {}
+    if preset == "ncaltech101" and "--config" in argv:
+        name = argv[argv.index("--config") + 1]
+        if name in MODEL_CONFIGS:
+            widths = MODEL_CONFIGS[name]
+            argv[argv.index("--config") + 1] = "dagr-l-ncaltech.yaml"
+    a = C.flags(__doc__, argv, extra=more,
+                default_config="dagr-l-ncaltech.yaml" if preset == "ncaltech101" else "dagr-s-dsec.yaml")
+    for k, v in widths.items():
+        if f"--{k}" not in argv:
+            setattr(a, k, v)
+    if a.epochs is not None:
+        a.tot_num_epochs = a.epochs
+    if "exp_name" not in a:
+        a.exp_name = "train"
+    return a
 
 
 def gradients_broken(model):
@@ -132,23 +146,19 @@ def build(a, world, rank, dev, model_factory=None, preset="ncaltech101"):
     per_rank = a.batch_size // world
     if per_rank * world != a.batch_size or per_rank < 1:
         raise ValueError(f"--batch_size {a.batch_size} must be a positive multiple of the {world} ranks")
-    common = dict(batch_size=per_rank, n_nodes=a.n_nodes, l_r=a.l_r, weight_decay=a.weight_decay, clip=a.clip,
-                  tot_num_epochs=a.epochs)
-    if preset == "dsec":
-        # config/dagr-*-dsec.yaml: two output scales, flip 0.5, zoom up to 1.5, 10 % translation; optional image branch
-        args = model_args(a.config, dataset="dsec", use_image=a.use_image, img_net=a.img_net, **common)
-    else:
-        # config/dagr-l-ncaltech.yaml: one output scale, no flip, no zoom, 10 % translation
-        args = model_args(a.config, dataset="ncaltech101", num_scales=1, aug_trans=0.1, aug_p_flip=0, aug_zoom=1, **common)
+    # the namespace the model and the augmentations read (every key of the YAML under the command line); its
+    # batch_size is this replica's share of the global batch
+    args = argparse.Namespace(**dict(vars(a), batch_size=per_rank))
     aug = Augmentations(args)
-    if a.dataset_directory is not None and preset == "dsec":
-        from dagr.data.dsec_data import DSEC                    # train_dsec.py:125-128
-        root = a.dataset_directory / "dsec"
+    real = C.real_data_available(a, "DSEC" if preset == "dsec" else "N-Caltech101")
+    if real and preset == "dsec":
+        from dagr.data.dsec_data import DSEC                    # train_dsec.py:122,125-128
+        root = a.dataset_directory / args.dataset
         train_ds = DSEC(root=root, split="train", transform=aug.transform_training, min_bbox_diag=15, min_bbox_height=10)
         val_ds = DSEC(root=root, split="val", transform=aug.transform_testing, min_bbox_diag=15, min_bbox_height=10)
-    elif a.dataset_directory is not None:
-        from dagr.data.ncaltech101_data import NCaltech101
-        root = a.dataset_directory / "ncaltech101"
+    elif real:
+        from dagr.data.ncaltech101_data import NCaltech101      # train_ncaltech101.py:122-125
+        root = a.dataset_directory / args.dataset
         train_ds = NCaltech101(root, "training", aug.transform_training, num_events=args.n_nodes)
         val_ds = NCaltech101(root, "validation", aug.transform_testing, num_events=args.n_nodes)
     else:
@@ -171,7 +181,7 @@ def build(a, world, rank, dev, model_factory=None, preset="ncaltech101"):
 
 
 def main(argv=None, model_factory=None, preset="ncaltech101"):
-    a = flags().parse_args(argv)
+    a = flags(argv, preset)
     world, rank, dev = C.distributed()
     seed = 42
     torch.manual_seed(seed)
@@ -191,7 +201,7 @@ def main(argv=None, model_factory=None, preset="ncaltech101"):
                                   weight_decay=args.weight_decay, fused=(dev.type == "cuda"))
     schedule = LRSchedule(warmup_epochs=.3, num_iters_per_epoch=len(train_loader), tot_num_epochs=args.tot_num_epochs)
     scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer=optimizer, lr_lambda=schedule)
-    out_dir = set_up_logging_directory(preset, "detection", a.output_directory, exp_name=a.exp_name)
+    out_dir = set_up_logging_directory(args.dataset, args.task, a.output_directory, exp_name=a.exp_name)   # :115
     ckpt = Checkpointer(output_directory=out_dir, model=model, optimizer=optimizer, scheduler=scheduler, ema=ema, args=args)
     if model_factory is not None:
         ckpt.mAP_max = float("-inf")        # stand-in models report a negative validation loss in place of mAP
@@ -217,9 +227,7 @@ def main(argv=None, model_factory=None, preset="ncaltech101"):
         if rank == 0:
             print(f"epoch {epoch}: validation {metrics}")
             ckpt.process(metrics, epoch)
-    if world > 1:
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
+    C.finish(world)
     return out_dir, log
 
 

@@ -56,3 +56,35 @@ def test_run_test_script_scores_a_labelled_run(tmp_path):
     assert "metrics of the run (1 rank(s))" in r.stdout
     m = json.load(open(out / "synthetic" / "detection" / "run_test" / "metrics.json"))
     assert set(m) >= {"mAP", "mAP_50", "mAP_75"} and all(np.isfinite(v) for v in m.values())
+
+
+def test_run_test_takes_the_reference_command_line(tmp_path):
+    """readme.md:107-113 as it stands (minus the checkpoint file, which is not in this image): ``--config <yaml path>
+    --use_image --img_net resnet50 --batch_size 8 --dataset_directory $DSEC_ROOT --output_directory $LOG_DIR``.  The DSEC
+    readers are absent, so the run announces the synthetic stand-in stream and goes through the whole engine path
+    (ResNet-50 branch + event graph, B = 8) built from the YAML's keys."""
+    out = tmp_path / "log"
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "run_test.py"), "--config", "config/dagr-s-dsec.yaml", "--use_image",
+           "--img_net", "resnet50", "--batch_size", "8", "--dataset_directory", str(tmp_path / "DSEC_ROOT"),
+           "--output_directory", str(out), "--windows", "16", "--events_per_window", "20000"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))   # config/ is found from any cwd
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "NOTICE: --dataset_directory" in r.stdout and "SYNTHETIC" in r.stdout
+    assert "NOTICE: no --checkpoint" in r.stdout
+    assert "'img_net': 'resnet50'" in r.stdout and "'use_image': True" in r.stdout and "'max_neighbors': 16" in r.stdout
+    assert "16 windows on 1 GPU(s)" in r.stdout
+    rec = np.load(out / "synthetic" / "detection" / "run_test" / "detections_synthetic000.npy")
+    assert rec.dtype.names == NAMES and len(rec) > 0
+
+
+def test_run_test_interframe_takes_the_reference_command_line(tmp_path):
+    """readme.md:131-138 (``config/eagr-s-dsec.yaml`` -- a name the reference's own tree lacks -- resolves to
+    ``dagr-s-dsec.yaml`` with a notice; ``--num_interframe_steps``, ``--no_eval``)."""
+    out = tmp_path / "log"
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "run_test_interframe.py"), "--config", "config/eagr-s-dsec.yaml",
+           "--use_image", "--img_net", "resnet18", "--batch_size", "2", "--dataset_directory", str(tmp_path / "DSEC_ROOT"),
+           "--no_eval", "--output_directory", str(out), "--num_interframe_steps", "2", "--windows", "4",
+           "--events_per_window", "3000", "--width", "320", "--height", "215"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "dagr-s-dsec.yaml" in r.stderr and "2 offsets x 4 windows" in r.stdout
