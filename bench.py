@@ -422,9 +422,8 @@ def stage_timings(rig, slots, n_events_step):
     comp["pool1_accumulate"] = comp.pop("pool1")
     cands = ("graph_search", "l0_conv1", "l0_conv2", "pool1_accumulate")
     dom = max(cands, key=lambda k: stages[k])
-    # (the row kernel's instantiation: one bucket unless the builder's time dimension is switched on, graph_build.hip)
-    rows_name = "k_search_rows<320, 4, 5, true>" if int(os.environ.get("DAGR_TIME_BUCKETS", "1") or 1) > 1 \
-        else "k_search_rows<320, 4, 6, false>"
+    # (the row search kernel as the product library launches it: graph_build.hip:launch_search)
+    rows_name = "k_search_rows<320, 4, 6>"
     names = dict(eng.l0_kernel_names(), graph_search=rows_name,
                  pool1_accumulate=f"k_pool_l0_slots<0, {4 if cp % 4 == 0 else 1}>")
     kname = names[dom]

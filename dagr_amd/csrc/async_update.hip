@@ -114,41 +114,15 @@ __global__ __launch_bounds__(kChunk) void k_async_insert(const void *__restrict_
     if (p >= 0 && last) app_head[p] = first_id + i;
 }
 
-// The window events of pixel (xn, yb), newest (largest id) first: fn(slot) until it returns false.  The pixel's events are
-// its nb segments (one per time bucket, ids ascending inside a segment); sorted timestamps make "newest bucket first, each
-// segment backwards" the order by id.  Unsorted timestamps (ids no longer follow the buckets): the next entry is the
-// largest id below the last one over all segments, found by one binary search per segment and step -- slow, rare, exact.
+// The window events of pixel (xn, yb), newest (largest id) first: fn(slot) until it returns false.  A pixel's events are
+// one segment of the index with ids ascending along its slots -- sorted timestamps or not -- so the order by id is the
+// segment read backwards.
 template <typename Fn>
-__device__ __forceinline__ void walk_window_pixel(const PixelIndex &ix, bool unsorted, int xn, int yb, Fn fn) {
-    if (!unsorted) {
-        for (int j = ix.nb - 1; j >= 0; j--) {
-            const int key = ix.segment(xn, j, yb);
-            const int a0 = ix.start[key], a1 = ix.start[key + 1];
-            for (int k = a1 - 1; k >= a0; k--)
-                if (!fn(k)) return;
-        }
-        return;
-    }
-    int last = 0x7fffffff;
-    for (;;) {
-        int best = -1, bk = -1;
-        for (int j = 0; j < ix.nb; j++) {
-            const int key = ix.segment(xn, j, yb);
-            int a = ix.start[key], b = ix.start[key + 1];
-            const int a0 = a;
-            while (a < b) {                      // first slot of the segment with id >= last
-                const int m = (a + b) >> 1;
-                if (ix.slot_it[m].x < last) a = m + 1; else b = m;
-            }
-            if (a - 1 >= a0) {
-                const int id = ix.slot_it[a - 1].x;
-                if (id > best) { best = id; bk = a - 1; }
-            }
-        }
-        if (bk < 0) return;
-        last = best;
-        if (!fn(bk)) return;
-    }
+__device__ __forceinline__ void walk_window_pixel(const PixelIndex &ix, int xn, int yb, Fn fn) {
+    const int key = ix.segment(xn, yb);
+    const int a0 = ix.start[key], a1 = ix.start[key + 1];
+    for (int k = a1 - 1; k >= a0; k--)
+        if (!fn(k)) return;
 }
 
 __global__ __launch_bounds__(kBlock) void k_async_fill(int n, int first_id, int n_static, int W, int H, int B, int K, int Q, int r,
@@ -161,7 +135,6 @@ __global__ __launch_bounds__(kBlock) void k_async_fill(int n, int first_id, int 
     const int i = (blockIdx.x * kBlock + threadIdx.x) >> 4;
     if (i >= n) return;
     const int2 *__restrict__ slot_it = ix.slot_it;
-    const bool unsorted = *ix.unsorted != 0;
     const int own = first_id + i;
     const int4 me = app_xytb[own - n_static];
     const int x = me.x, y = me.y, ts = me.z, b = me.w;
@@ -200,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void k_async_fill(int n, int first_id, int 
                 }
             }
             if (depth < Q && v < K)
-                walk_window_pixel(ix, unsorted, xn, yb, [&](int k) {
+                walk_window_pixel(ix, xn, yb, [&](int k) {
                     if (!((float)(ts - slot_it[k].y) > delta_t)) v++;             // window events: always older than own
                     depth++;
                     return depth < Q && v < K;
@@ -220,7 +193,7 @@ __global__ __launch_bounds__(kBlock) void k_async_fill(int n, int first_id, int 
                 }
             }
             if (depth < Q && slot < K)
-                walk_window_pixel(ix, unsorted, xn, yb, [&](int k) {
+                walk_window_pixel(ix, xn, yb, [&](int k) {
                     if (!((float)(ts - slot_it[k].y) > delta_t)) {
                         nbr_src[row + slot] = k;               // a window event's node is its CSR slot
                         nbr_code[row + slot] = (int16_t)code;

@@ -150,8 +150,20 @@ __device__ __forceinline__ int xcd_block(int n_blocks, int xcd_remap) {
     const int lb = (int)(blockIdx.x >> 3) + (int)(blockIdx.x & 7) * bpx;
     return ((int)(blockIdx.x >> 3) < bpx && lb < n_blocks) ? lb : -1;
 }
+// Measurement knobs (A/B switches read from the environment) exist only in the measurement build of the library
+// (`make measure`: -DDAGR_MEASURE -> dagr_amd/lib/libdagr_hip_measure.so, loaded with DAGR_LIB=measure by the probes
+// under tools/).  The product library reads no environment variable: every knob is its default.
+inline long long knob(const char *name, long long dflt) {
+#ifdef DAGR_MEASURE
+    const char *e = getenv(name);
+    return e ? atoll(e) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
 inline int xcd_remap_on() {      // DAGR_XCD_REMAP=0: natural block order (A/B measurements)
-    static const int v = [] { const char *e = getenv("DAGR_XCD_REMAP"); return e ? atoi(e) : 1; }();
+    static const int v = (int)knob("DAGR_XCD_REMAP", 1);
     return v;
 }
 inline unsigned xcd_grid(int64_t n_blocks) { return (unsigned)((n_blocks + 7) / 8 * 8); }   // whole rounds of the eight XCDs
@@ -174,19 +186,18 @@ hipError_t launch_gemm_mfma(const int32_t *m_ptr, int m_max, const float *A, int
                             const float *bias, float *C, int ldc, int K, int N, int relu, hipStream_t stream);
 const int32_t *graph_ws_node_count(const dagr_graph_desc *desc, void *workspace);
 // The window builder's event index as the other kernels see it (graph_build.hip).  Events are CSR slots in
-// (sample, y, time bucket, x) order, ids ascending inside a segment (one pixel, one bucket); key of a segment:
-// x + W * (bucket + nb * (y + H * sample)); start[key] .. start[key + 1] are its slots.  All events of a range of pixel
-// rows of one sample are ONE contiguous run of slots (rows(y0) .. rows(y1)); a pixel's events, oldest bucket first, are its
-// nb segments (when the window's timestamps are sorted -- *unsorted == 0 -- that is also oldest event first).
+// (sample, y, x) order, ids ascending inside a segment (one pixel); key of a segment: x + W * (y + H * sample);
+// start[key] .. start[key + 1] are its slots.  All events of a range of pixel rows of one sample are ONE contiguous run of
+// slots (rows(y0) .. rows(y1)); a pixel's events, oldest (smallest id) first, are its segment.
 struct PixelIndex {
     const int32_t *start;
     const int2 *slot_it;        // {event id, t} per slot
     const int32_t *slot_xyb;    // x | y << 12 | sample << 24 | visible << 31 per slot
     const int32_t *n_nodes;     // number of indexed events (device)
     const int32_t *unsorted;    // != 0: timestamps were not non-decreasing in event order inside a sample (device)
-    int W, H, nb;
-    __host__ __device__ int segment(int x, int bucket, int yb) const { return x + W * (bucket + nb * yb); }   // yb = y + H * sample
-    __host__ __device__ int row_begin(int yb) const { return W * nb * yb; }    // key of the first segment of pixel row yb
+    int W, H;
+    __host__ __device__ int segment(int x, int yb) const { return x + W * yb; }   // yb = y + H * sample
+    __host__ __device__ int row_begin(int yb) const { return W * yb; }            // key of the first segment of pixel row yb
 };
 void graph_ws_index(const dagr_graph_desc *desc, void *workspace, PixelIndex *out);
 

@@ -351,7 +351,7 @@ int launch_tiles_v(int64_t n_first, int64_t N, const int32_t *n_ptr, int rx, int
     }
     const int64_t tiles = ceil_div(N, 16);
     const unsigned grid = round_grid8(persistent_grid(kern, kTileWaves * 64, lds_bytes, ceil_div(tiles, kTileWaves)));
-    static const int ablate = [] { const char *e = getenv("DAGR_L0_ABLATE"); return e ? atoi(e) : 0; }();   // measurement only
+    static const int ablate = (int)knob("DAGR_L0_ABLATE", 0);   // measurement build only (results are wrong when set)
     kern<<<grid, kTileWaves * 64, lds_bytes, stream>>>((int)n_first, (int)N, n_ptr, rx, ry, den_x, den_y, win_x, win_y, nbr_src, nbr_code, deg,
                                                        x, ldx, xskip, ldskip, wpack, shift, relu, out, ldo, ablate);
     DAGR_CHECK_LAUNCH();

@@ -829,7 +829,7 @@ static int launch_conv_jobs(const HostConvJob *hj, int count, const dagr::PoolFu
     DAGR_CHECK_ARG(!(pool && (mp || dev[0].gy == 0)), "the fused pooling merge needs the single-pass form of the conv");
     // two workgroups per CU (the 62-register form) when the launch takes more than one round of workgroups and two tiles
     // fit the LDS; builder knob DAGR_CONV_DENSE=0: never
-    static const bool dense_ok = [] { const char *e = getenv("DAGR_CONV_DENSE"); return !(e && atoi(e) == 0); }();
+    static const bool dense_ok = knob("DAGR_CONV_DENSE", 1) != 0;
     const bool dense = dense_ok && !mp && lds_max <= 80 * 1024 && (int64_t)gx * gy * count > device_cu_count();
     const int which = mp ? 1 : (dense ? 2 : 0);
     static thread_local size_t set_max[3] = {0, 0, 0};

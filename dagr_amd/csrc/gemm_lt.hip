@@ -91,7 +91,7 @@ extern "C" int dagr_gemm_epilogue(const float *A, int64_t M, int32_t K, int64_t 
         int best = 0;
         // The library ranks its kernels by a model; the first time a shape is seen (a warm-up call, never inside a stream
         // capture) the candidates are timed on the caller's own operands and the fastest is kept for the shape.
-        static const bool tune = [] { const char *e = getenv("DAGR_LT_TUNE"); return !(e && e[0] == '0'); }();
+        static const bool tune = knob("DAGR_LT_TUNE", 1) != 0;
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing((hipStream_t)stream, &cap);
         if (tune && found > 1 && cap == hipStreamCaptureStatusNone) {

@@ -7,19 +7,19 @@
 // -1-padded int64 edge buffer.
 //
 // What this file does instead (same edge set, same order, bit-exact):
-//   * events are bucketed by the key (sample, y, [time bucket,] x) into a CSR array (per-key counters -> exclusive scan ->
-//     scatter -> in-segment order fix-up).  In slot order the events of one pixel row of the neighbourhood are ONE
-//     contiguous range.  After all N events of a reset window are inserted, the FIFO column of a pixel holds exactly the
-//     newest min(count, Q) events of that pixel, newest first -- its segment(s) read backwards; the 157 MB volume and its
-//     refill disappear.  The TIME BUCKET is optional (TimeKey below, off as shipped): buckets delta_t wide put every
-//     admissible source of a destination (older, dt <= delta_t: ev_graph.cu:64,69) into the destination's own bucket or
-//     the one before, so that a destination fetches 2 x (2r+1) row ranges holding ~0.4 of the window's events in its
-//     (2r+1)^2 pixels (50 ms window, delta_t = 10 ms) instead of all of them -- measured in round 5, the search is bound
-//     by its scattered offset loads, which the second bucket doubles, and only dense uniform streams gain.
-//   * the search is candidate-centric (k_search_rows): the row ranges' events are tested 16 at a time and keyed by
-//     (spiral rank of their pixel, recency); the reference's sequential "first K in spiral order, newest first inside a
-//     pixel" cut is "the K-1 smallest keys in key order".  Event-dense neighbourhoods go to a position-centric walk
-//     (k_search_dense), unsorted timestamps and radii beyond 7 pixels to its generic form.
+//   * events are bucketed by the key (sample, y, x) into a CSR array (per-key counters -> exclusive scan -> scatter ->
+//     in-segment order fix-up).  In slot order the events of one pixel row of the neighbourhood are ONE contiguous range.
+//     After all N events of a reset window are inserted, the FIFO column of a pixel holds exactly the newest min(count, Q)
+//     events of that pixel, newest first -- its segment read backwards; the 157 MB volume and its refill disappear.
+//     (Rounds 5 carried an optional time dimension in the key -- buckets delta_t wide, so that a destination fetched
+//     2 x (2r+1) row ranges holding ~0.4 of its candidates.  Measured there, profiles/r5_search_buckets.md: the search is
+//     bound by its scattered offset loads, which the second bucket doubles; only dense UNIFORM streams gained, clustered
+//     ones -- what recordings look like -- lost.  Removed in round 6.)
+//   * the search is candidate-centric: the row ranges' events are tested and keyed by (spiral rank of their pixel,
+//     recency); the reference's sequential "first K in spiral order, newest first inside a pixel" cut is "the K-1
+//     smallest keys in key order".  Light neighbourhoods: k_search_rows, 16 lanes per destination.  Event-dense ones:
+//     one destination per wave over nested ring windows (search_heavy in k_search_dense), with the reference's
+//     position-centric walk as the last resort; unsorted timestamps and radii beyond 7 pixels: k_search_dense's generic form.
 //   * output is a fixed-stride neighbour list [N, K] (int32 source + int16 offset code) + deg[N]:
 //     no -1 fill, no compaction pass, no host sync; the offset code is the SplineConv LUT index.
 #include "common.hpp"
@@ -35,62 +35,6 @@ constexpr int kVisBit = (int)0x80000000;  // slot_xyb bit 31: among the newest Q
 constexpr int kShortSeg = 64;    // segments up to this length are ordered by per-slot rank counting
 constexpr int kMaxQueue = 1024;  // LDS staging bound for the long-segment path
 constexpr int kMaxSpiral = 4096; // (2r+1)^2 bound for the LDS spiral tables (r <= 31)
-constexpr int kMaxBuckets = 16;
-
-// Time buckets.  bucket(t) = clamp(floor((t - t_base) / wb), 0, nb - 1): monotone in t, so for ANY timestamps the sources
-// with t - delta <= ts <= t lie in the buckets bucket(t - delta) .. bucket(t), and wb >= delta makes that {tb - 1, tb}.
-// The nb buckets end at the window's normaliser T (the datasets shift a window so that its last event sits at T,
-// dsec_data.py:145); everything older shares bucket 0, everything later the last one -- slower, never wrong.
-struct TimeKey {
-    int t_base;         // start of bucket 0
-    int t_end;          // t_base + nb * wb
-    int wb;             // bucket width, us (>= delta_t_us + float-rounding slack)
-    float inv_wb;
-    int nb;             // number of buckets (1: the index of rounds 1-4)
-};
-
-TimeKey time_key(const dagr_graph_desc &d) {
-    // builder knobs: DAGR_TIME_BUCKETS (5 covers a 50 ms window at delta_t = 10 ms), DAGR_BUCKET_US (>= delta_t)
-    static const int env_nb = [] { const char *e = getenv("DAGR_TIME_BUCKETS"); return e ? atoi(e) : 0; }();
-    static const long long env_wb = [] { const char *e = getenv("DAGR_BUCKET_US"); return e ? atoll(e) : 0ll; }();
-    const long long delta = std::max<long long>(1, d.delta_t_us);
-    // the admissibility test is made in fp32 ((float)(t - ts) > delta_t, ev_graph.cu:69): beyond 2^24 us a difference of
-    // delta + 1 can round onto delta, hence the slack
-    long long wb = delta + (delta >> 22) + 1;
-    if (env_wb > wb) wb = env_wb;
-    // Default: ONE bucket (the index keyed by pixel of rounds 1-4).  Measured in round 5 (profiles/r5_search_buckets.md,
-    // 640x480, delta_t = 10 ms, 50 ms windows): with five buckets a destination examines 0.4 of the candidates but fetches
-    // 2 x (2r+1) row ranges instead of (2r+1), and the search kernel's time goes into exactly those scattered offset
-    // loads (one L1 line per lane: ~1 line per cycle and CU; 104 us of a 220-us launch with the candidate work removed) --
-    // a wash on sparse windows, a gain only on dense UNIFORM streams (-23 % of the build at 8 x 400 k events), a loss on
-    // clustered ones (S-edges 8 x 200 k: 1.79 ms against 1.65), which is what real recordings look like.  DAGR_DENSE_EVENTS
-    // = n switches buckets on for workspaces sized for >= n events per sample.
-    static const long long dense_thr = [] { const char *e = getenv("DAGR_DENSE_EVENTS"); return e ? atoll(e) : 0ll; }();
-    int nb = env_nb > 0 ? env_nb : (dense_thr > 0 && d.max_events / std::max(1, d.batch_size) >= dense_thr ? 5 : 1);
-    nb = std::min(std::max(nb, 1), kMaxBuckets);
-    const long long P = (long long)d.width * d.height * d.batch_size;
-    while (nb > 1 && (P * nb >= (1ll << 31) - 16 || P * nb > (1ll << 28))) nb--;   // table: 8 bytes per key
-    if (wb >= (1ll << 30)) { wb = 1ll << 30; nb = 1; }
-    while (nb > 1 && (long long)nb * wb >= (1ll << 31) - 1) nb--;                   // every quantity below fits int32
-    TimeKey k;
-    k.wb = (int)wb;
-    k.inv_wb = 1.0f / (float)wb;
-    k.nb = nb;
-    k.t_end = d.time_window;
-    k.t_base = (int)((long long)d.time_window - (long long)nb * wb);
-    return k;
-}
-
-__device__ __forceinline__ int bucket_of(const TimeKey &k, int t) {
-    if (k.nb == 1) return 0;
-    // t - t_base cannot overflow where it is taken: t_base <= t < t_end = t_base + nb * wb < t_base + 2^31
-    const int d = t < k.t_base ? 0 : (t >= k.t_end ? k.t_end - 1 - k.t_base : t - k.t_base);
-    int q = (int)((float)d * k.inv_wb);          // within one of the quotient (q < 16, fp32 relative error 2^-22)
-    q = min(q, k.nb - 1);
-    if (q * k.wb > d) q--;
-    else if ((q + 1) * k.wb <= d) q++;
-    return q;
-}
 
 // 16-lane rows by DPP (a lane group of the search kernels is one DPP row): no LDS round trip, one VALU per step
 template <int CTRL>
@@ -123,19 +67,17 @@ struct GraphWs {
     int2 *slot_it;      // [Nmax] {event id, t} per CSR slot, ascending id inside a segment
     int32_t *slot_xyb;  // [Nmax] x | y<<12 | b<<24 per CSR slot
     int32_t *ev_slot;   // [Nmax] CSR slot of every event (-1: dropped)
-    int32_t *hot_list;  // [Nmax + 1] pixels with a segment beyond kShortSeg / Q / nb events (k_fix_pixels)
+    int32_t *hot_list;  // [Nmax + 1] pixels with more than min(kShortSeg, Q) events (k_fix_pixels)
     int32_t *status;    // [16]: 0 listed pixels, 1 flags, 2..3 num_edges (uint64), 4 pixels beyond the FIFO depth,
                         //       5 deferral list length, 6 unsorted timestamps, 7 destinations answered from their inner
                         //       rings, 8 / 9 the staging launch's flag words
     int64_t P;          // pixels: B * H * W
-    int64_t PK;         // keys: P * nb
-    TimeKey tk;
+    int64_t PK;         // keys of the index (= P: one segment per pixel)
 };
 
 size_t carve(const dagr_graph_desc &d, char *base, GraphWs *ws) {
     const int64_t P = (int64_t)d.width * d.height * d.batch_size;
-    const TimeKey tk = time_key(d);
-    const int64_t PK = P * tk.nb;
+    const int64_t PK = P;
     size_t off = 0;
     auto take = [&](size_t bytes) {
         size_t o = off;
@@ -154,7 +96,7 @@ size_t carve(const dagr_graph_desc &d, char *base, GraphWs *ws) {
     int32_t *ev_slot = (int32_t *)take(d.max_events * 4);
     int32_t *hot_list = (int32_t *)take((d.max_events + 2) * 4);
     int32_t *status = (int32_t *)take(16 * 4);
-    if (ws) *ws = GraphWs{cnt, start, scan_tmp, ev_xyb, ev_t, ev_rank, slot_tmp, slot_it, slot_xyb, ev_slot, hot_list, status, P, PK, tk};
+    if (ws) *ws = GraphWs{cnt, start, scan_tmp, ev_xyb, ev_t, ev_rank, slot_tmp, slot_it, slot_xyb, ev_slot, hot_list, status, P, PK};
     return off;
 }
 
@@ -180,7 +122,7 @@ int validate(const dagr_graph_desc *d) {
 // the sensor / batch; flags[6] = 1: timestamps not sorted), or the staging launch's own two words (see k_stage_window).
 template <typename BatchT, bool kIntPos>
 __device__ __forceinline__ void count_event(int e, const void *__restrict__ pos_, const BatchT *__restrict__ batch, int W,
-                                            int H, int B, float fW, float fH, float fT, const TimeKey tk,
+                                            int H, int B, float fW, float fH, float fT,
                                             int32_t *__restrict__ cnt,
                                             int32_t *__restrict__ ev_xyb, int32_t *__restrict__ ev_t,
                                             int32_t *__restrict__ ev_rank, int32_t *__restrict__ flag_fov,
@@ -199,7 +141,7 @@ __device__ __forceinline__ void count_event(int e, const void *__restrict__ pos_
     const int b = (int)batch[e];
     ev_t[e] = t;
     // time flag: set when timestamps are not non-decreasing in event order inside a sample.  Ids then do not order time:
-    // the search takes its generic form (every later bucket examined, ids instead of positions as recency).
+    // the search takes its generic form (every candidate tested on its own, ids instead of positions as recency).
     if (e > 0 && (int)batch[e - 1] == b) {
         int tp;
         if (kIntPos) tp = static_cast<const int32_t *>(pos_)[3 * (int64_t)(e - 1) + 2];
@@ -215,31 +157,31 @@ __device__ __forceinline__ void count_event(int e, const void *__restrict__ pos_
         return;
     }
     ev_xyb[e] = x | (y << 12) | (b << 24);
-    const int key = x + W * (bucket_of(tk, t) + tk.nb * (y + H * b));
+    const int key = x + W * (y + H * b);
     ev_rank[e] = atomicAdd(&cnt[key], 1);
 }
 
 template <typename BatchT, bool kIntPos>
 __global__ __launch_bounds__(kBlock) void k_count(const void *__restrict__ pos_, const BatchT *__restrict__ batch,
                                                  int N, int W, int H, int B, float fW,
-                                                 float fH, float fT, const TimeKey tk, int32_t *__restrict__ cnt,
+                                                 float fH, float fT, int32_t *__restrict__ cnt,
                                                  int32_t *__restrict__ ev_xyb, int32_t *__restrict__ ev_t,
                                                  int32_t *__restrict__ ev_rank, int32_t *__restrict__ status, int xcd_remap) {
     const int lb = xcd_block((N + kBlock - 1) / kBlock, xcd_remap);
     const int e = lb * kBlock + threadIdx.x;
     if (lb < 0 || e >= N) return;
-    count_event<BatchT, kIntPos>(e, pos_, batch, W, H, B, fW, fH, fT, tk, cnt, ev_xyb, ev_t, ev_rank, status + 1, status + 6);
+    count_event<BatchT, kIntPos>(e, pos_, batch, W, H, B, fW, fH, fT, cnt, ev_xyb, ev_t, ev_rank, status + 1, status + 6);
 }
 
-__device__ __forceinline__ int key_of_event(int c, int t, int W, int H, const TimeKey &tk) {
-    return (c & 4095) + W * (bucket_of(tk, t) + tk.nb * (((c >> 12) & 4095) + H * (c >> 24)));
+__device__ __forceinline__ int key_of_event(int c, int W, int H) {
+    return (c & 4095) + W * (((c >> 12) & 4095) + H * (c >> 24));
 }
 
 // K3: scatter event ids into their key's segment (arrival order).
 // n_dev: the window's event count in device memory (launches sized for a capacity N: captured HIP graphs); K1 then ran
 // inside the staging launch, whose two flag words (status[8], status[9]) this launch moves into the builder's and re-arms.
-__global__ __launch_bounds__(kBlock) void k_scatter(int N, const int32_t *__restrict__ n_dev, int W, int H, const TimeKey tk,
-                                                   const int32_t *__restrict__ ev_xyb, const int32_t *__restrict__ ev_t,
+__global__ __launch_bounds__(kBlock) void k_scatter(int N, const int32_t *__restrict__ n_dev, int W, int H,
+                                                   const int32_t *__restrict__ ev_xyb,
                                                    const int32_t *__restrict__ ev_rank,
                                                    const int32_t *__restrict__ start,
                                                    int32_t *__restrict__ slot_tmp, int32_t *__restrict__ ev_slot,
@@ -254,14 +196,13 @@ __global__ __launch_bounds__(kBlock) void k_scatter(int N, const int32_t *__rest
     if (lb < 0 || e >= Nw) return;
     const int c = ev_xyb[e];
     if (c < 0) { ev_slot[e] = -1; return; }
-    slot_tmp[start[key_of_event(c, ev_t[e], W, H, tk)] + ev_rank[e]] = e;
+    slot_tmp[start[key_of_event(c, W, H)] + ev_rank[e]] = e;
 }
 
-// K4: order each segment by ascending event id (== the reference's stable sort by pixel, graph/utils.py:10, restricted
-// to one time bucket).  One thread per CSR slot; every event starts out visible (kVisBit), and the first slot of a segment
-// that MAY belong to a pixel with more than Q events in the window (segment longer than Q / nb: all segments at or below
-// that bound sum to <= Q), or that is too long for the rank counting, lists its pixel for k_fix_pixels.
-__global__ __launch_bounds__(kBlock) void k_order(int N, int64_t PK, int W, int H, const TimeKey tk, int hot_thr,
+// K4: order each segment by ascending event id (== the reference's stable sort by pixel, graph/utils.py:10).  One thread
+// per CSR slot; every event starts out visible (kVisBit), and the first slot of a segment that holds more than Q events
+// (FIFO depth), or that is too long for the rank counting, lists its pixel for k_fix_pixels.
+__global__ __launch_bounds__(kBlock) void k_order(int N, int64_t PK, int W, int H, int hot_thr,
                                                  const int32_t *__restrict__ ev_xyb,
                                                  const int32_t *__restrict__ ev_t,
                                                  const int32_t *__restrict__ start,
@@ -276,7 +217,7 @@ __global__ __launch_bounds__(kBlock) void k_order(int N, int64_t PK, int W, int 
     const int e = slot_tmp[s];
     const int c = ev_xyb[e];
     const int t = ev_t[e];
-    const int key = key_of_event(c, t, W, H, tk);
+    const int key = key_of_event(c, W, H);
     const int a = start[key];
     const int n = start[key + 1] - a;
     if (n <= kShortSeg) {
@@ -287,18 +228,9 @@ __global__ __launch_bounds__(kBlock) void k_order(int N, int64_t PK, int W, int 
         ev_slot[e] = a + rank;
     }
     if (s == a && n > hot_thr) {
-        // (listed once: by the oldest of the pixel's segments that are over the bound -- a few loads, on few threads)
-        const int j = bucket_of(tk, t);
-        bool first = true;
-        for (int q = 0; q < j && first; q++) {
-            const int kq = key - W * (j - q);
-            first = start[kq + 1] - start[kq] <= hot_thr;
-        }
-        if (first) {
-            const int i = atomicAdd(&status[0], 1);
-            if (i < hot_cap) hot_list[i] = (c & 4095) + W * (((c >> 12) & 4095) + H * (c >> 24));
-            else atomicOr(&status[1], 2);
-        }
+        const int i = atomicAdd(&status[0], 1);
+        if (i < hot_cap) hot_list[i] = key;
+        else atomicOr(&status[1], 2);
     }
 }
 
@@ -347,15 +279,11 @@ __device__ __forceinline__ unsigned select_kth_largest(int k, int *hist, int *sh
     return (unsigned)sh[0] + vmin;
 }
 
-// K5: the listed pixels.  Only the newest Q events of a PIXEL -- over all of its time buckets -- are visible to the
-// search (FIFO depth Q, ev_graph.cu:201-211; "newest" = largest ids: the FIFO is filled in event order), and segments
-// longer than kShortSeg are ordered here.  Sorted timestamps (the usual case): buckets follow the ids, so the pixel's
-// segments are walked newest first with the FIFO's remaining depth -- a segment is entirely visible (long: rank-sorted),
-// entirely invisible (long: copied as it lies, any order: it can never be a source) or, for ONE segment of the pixel, cut
-// at its (remaining depth)-th largest id (radix selection; the visible ids rank-sorted into its tail).  Unsorted
-// timestamps: the Q-th largest id of the whole pixel is the threshold of all segments, and every long segment gets its
-// min(n, Q) largest ids sorted into its tail (the rest is invisible whatever the threshold).
-__global__ __launch_bounds__(kBlock) void k_fix_pixels(int Q, int W, const TimeKey tk, const int32_t *__restrict__ ev_xyb,
+// K5: the listed pixels.  Only the newest Q events of a pixel are visible to the search (FIFO depth Q, ev_graph.cu:201-211;
+// "newest" = largest ids: the FIFO is filled in event order), and segments longer than kShortSeg are ordered here: the
+// min(n, Q) largest ids (radix selection of the Q-th largest when n > Q) rank-sorted into the segment's tail and marked
+// visible, the rest -- invisible whatever their order: they can never be a source -- copied into its head as they lie.
+__global__ __launch_bounds__(kBlock) void k_fix_pixels(int Q, const int32_t *__restrict__ ev_xyb,
                                                       int32_t *__restrict__ slot_xyb, int32_t *__restrict__ ev_slot,
                                                       const int32_t *__restrict__ ev_t,
                                                       const int32_t *__restrict__ start,
@@ -368,15 +296,28 @@ __global__ __launch_bounds__(kBlock) void k_fix_pixels(int Q, int W, const TimeK
     __shared__ int sh_sel[4], sh_nsel, sh_nrest;
     int n_hot = status[0];
     if (n_hot > hot_cap) n_hot = hot_cap;
-    const int nb = tk.nb;
-    const bool sorted_t = status[6] == 0;
-    // a long segment: its m ids >= thr_sel rank-sorted into the tail, visible from thr_vis on; the rest into the head
-    auto order_long = [&](int a, int n, int m, unsigned thr_sel, unsigned thr_vis) {
+    for (int li = blockIdx.x; li < n_hot; li += gridDim.x) {
+        const int key = hot_list[li];
+        const int a = start[key];
+        const int n = start[key + 1] - a;
+        const int m = n < Q ? n : Q;               // visible entries
+        unsigned thr = 0;                          // the m-th largest id of a long segment
+        if (n > Q) {
+            if (n > kShortSeg)
+                thr = select_kth_largest(Q, hist, sh_sel, [&](auto f) {
+                    for (int k = threadIdx.x; k < n; k += kBlock) f((unsigned)slot_tmp[a + k]);
+                });
+            if (threadIdx.x == 0) atomicAdd(&status[4], 1);
+        }
+        if (n <= kShortSeg) {                      // ordered by k_order: only the visibility may change
+            for (int i = threadIdx.x; i < n - m; i += kBlock) slot_xyb[a + i] &= ~kVisBit;
+            continue;
+        }
         if (threadIdx.x == 0) { sh_nsel = 0; sh_nrest = 0; }
         __syncthreads();
         for (int k = threadIdx.x; k < n; k += kBlock) {
             const int v = slot_tmp[a + k];
-            if ((unsigned)v >= thr_sel) sel[atomicAdd(&sh_nsel, 1)] = v;
+            if ((unsigned)v >= thr) sel[atomicAdd(&sh_nsel, 1)] = v;
             // older events are invisible to the search (beyond the FIFO depth) but remain graph nodes:
             // keep them, in any order, in the head of the segment (voxel pooling walks the segment)
             else {
@@ -393,83 +334,10 @@ __global__ __launch_bounds__(kBlock) void k_fix_pixels(int Q, int W, const TimeK
             int rank = 0;
             for (int q = 0; q < m; q++) rank += (sel[q] < v) ? 1 : 0;
             slot_it[a + (n - m) + rank] = make_int2(v, ev_t[v]);
-            slot_xyb[a + (n - m) + rank] = ev_xyb[v] | ((unsigned)v >= thr_vis ? kVisBit : 0);
+            slot_xyb[a + (n - m) + rank] = ev_xyb[v] | kVisBit;
             ev_slot[v] = a + (n - m) + rank;
         }
         __syncthreads();
-    };
-    for (int li = blockIdx.x; li < n_hot; li += gridDim.x) {
-        const int p = hot_list[li];
-        const int x = p % W, yb = p / W;
-        const int key0 = x + W * nb * yb;              // bucket j of the pixel: key0 + W * j
-        if (sorted_t) {
-            int newer = 0;
-            bool cut = false;
-            for (int j = nb - 1; j >= 0; j--) {
-                const int a = start[key0 + W * j];
-                const int n = start[key0 + W * j + 1] - a;
-                if (n == 0) continue;
-                const int budget = Q - newer;          // what is left of the FIFO's depth for this segment
-                newer = min(newer + n, Q);
-                if (budget >= n) {                     // all visible
-                    if (n > kShortSeg) order_long(a, n, n, 0u, 0u);
-                } else if (budget <= 0) {              // all invisible
-                    cut = true;
-                    if (n <= kShortSeg) {
-                        for (int i = threadIdx.x; i < n; i += kBlock) slot_xyb[a + i] &= ~kVisBit;
-                    } else {
-                        for (int k = threadIdx.x; k < n; k += kBlock) {
-                            const int v = slot_tmp[a + k];
-                            slot_it[a + k] = make_int2(v, ev_t[v]);
-                            slot_xyb[a + k] = ev_xyb[v];
-                            ev_slot[v] = a + k;
-                        }
-                    }
-                } else {                               // the newest `budget` of the segment
-                    cut = true;
-                    if (n <= kShortSeg) {              // ordered by k_order: ids ascend along the slots
-                        for (int i = threadIdx.x; i < n - budget; i += kBlock) slot_xyb[a + i] &= ~kVisBit;
-                    } else {
-                        const unsigned thr = select_kth_largest(budget, hist, sh_sel, [&](auto f) {
-                            for (int k = threadIdx.x; k < n; k += kBlock) f((unsigned)slot_tmp[a + k]);
-                        });
-                        order_long(a, n, budget, thr, thr);
-                    }
-                }
-            }
-            if (cut && threadIdx.x == 0) atomicAdd(&status[4], 1);
-            continue;
-        }
-        int total = 0;
-        for (int j = 0; j < nb; j++) total += start[key0 + W * j + 1] - start[key0 + W * j];
-        unsigned thr_pix = 0;
-        if (total > Q) {
-            thr_pix = select_kth_largest(Q, hist, sh_sel, [&](auto f) {
-                for (int j = 0; j < nb; j++) {
-                    const int a = start[key0 + W * j], n = start[key0 + W * j + 1] - a;
-                    for (int k = threadIdx.x; k < n; k += kBlock) f((unsigned)slot_tmp[a + k]);
-                }
-            });
-            if (threadIdx.x == 0) atomicAdd(&status[4], 1);
-        }
-        for (int j = 0; j < nb; j++) {
-            const int a = start[key0 + W * j];
-            const int n = start[key0 + W * j + 1] - a;
-            if (n == 0) continue;
-            if (n <= kShortSeg) {       // ordered by k_order: only the visibility may change
-                if (thr_pix)
-                    for (int i = threadIdx.x; i < n; i += kBlock)
-                        if ((unsigned)slot_it[a + i].x < thr_pix) slot_xyb[a + i] &= ~kVisBit;
-                continue;
-            }
-            const int m = n < Q ? n : Q;
-            unsigned thr = 0;
-            if (n > m)
-                thr = select_kth_largest(m, hist, sh_sel, [&](auto f) {
-                    for (int k = threadIdx.x; k < n; k += kBlock) f((unsigned)slot_tmp[a + k]);
-                });
-            order_long(a, n, m, thr, thr_pix);
-        }
     }
 }
 
@@ -526,32 +394,27 @@ __device__ __forceinline__ void gather_node(const GatherArgs &g, int n, const in
     row[g.col_pos + 1] = py;
 }
 
-// Admissible sources of one segment (one pixel, one time bucket; ids and -- timestamps being sorted -- times ascend along
-// its slots) for destination (e, t): "older than the destination" (ev_graph.cu:64) is a prefix [a, hi), "dt <= delta"
-// (ev_graph.cu:69) a suffix of it, "inside the FIFO depth" a suffix too: binary searches instead of the reference's
-// newest-first walk over up to Q entries.  Returns [lo, hi); the walk order newest-first is hi-1 .. lo.
-// own: the destination's own bucket (the bucket before it holds older events only).  hot: some pixel of the window
-// holds more than Q events (status[4]) -- otherwise every slot is visible and the third search is skipped.
+// Admissible sources of one segment (one pixel; ids and -- timestamps being sorted -- times ascend along its slots) for
+// destination (e, t): "older than the destination" (ev_graph.cu:64) is a prefix [a, hi), "dt <= delta" (ev_graph.cu:69) a
+// suffix of it, "inside the FIFO depth" a suffix too: binary searches instead of the reference's newest-first walk over up
+// to Q entries.  Returns [lo, hi); the walk order newest-first is hi-1 .. lo.  hot: some pixel of the window holds more
+// than Q events (status[4]) -- otherwise every slot is visible and the third search is skipped.
 __device__ __forceinline__ void admissible_range(const int2 *__restrict__ slot_it, const int32_t *__restrict__ slot_xyb,
-                                                 int a, int b, int e, int t, float delta_t, bool own, bool hot, int &lo,
-                                                 int &hi) {
+                                                 int a, int b, int e, int t, float delta_t, bool hot, int &lo, int &hi) {
     const int a0 = a, b0 = b;
     if (b0 - a0 == 1) {                       // one entry (most segments): tested directly
         const int2 it = slot_it[a0];
-        bool ok = (!own || it.x < e) && !((float)(t - it.y) > delta_t);
+        bool ok = it.x < e && !((float)(t - it.y) > delta_t);
         if (ok && hot) ok = slot_xyb[a0] < 0;
         lo = a0;
         hi = ok ? b0 : a0;
         return;
     }
-    hi = b0;
-    if (own) {                                // first slot in [a, b) with id >= e
-        while (a < b) {
-            const int m = (a + b) >> 1;
-            if (slot_it[m].x < e) a = m + 1; else b = m;
-        }
-        hi = a;
+    while (a < b) {                           // first slot in [a, b) with id >= e
+        const int m = (a + b) >> 1;
+        if (slot_it[m].x < e) a = m + 1; else b = m;
     }
+    hi = a;
     a = a0; b = hi;                           // first slot in [a, hi) with dt <= delta
     while (a < b) {
         const int m = (a + b) >> 1;
@@ -570,36 +433,33 @@ __device__ __forceinline__ void admissible_range(const int2 *__restrict__ slot_i
 }
 
 // ---------------------------------------------------------------------------------------------
-// K6 fast path (r <= 7, timestamps sorted): candidate-centric search.  In slot order the events of one pixel row of the
-// neighbourhood inside one time bucket are ONE contiguous slot range [start(row, bucket, x-r), start(row, bucket, x+r+1)),
-// and every admissible source lies in the destination's bucket tb or in tb - 1 (TimeKey), so
-//   1. 2 x 15 lanes fetch the row ranges of the two buckets (2 offsets each), two 16-lane scans concatenate them and
-//      every range lane writes (range, position) of its events into the group's candidate list in LDS;
-//   2. the C candidates are read 16 at a time, coalesced ({id,t} + packed x|y|visible): each lane
-//      tests its candidate (older than the destination, dt <= delta, inside the FIFO depth) and
-//      keys it with (spiral rank of its pixel, recency inside the pixel: bucket tb before tb - 1, then position);
-//   3. the reference's sequential walk "spiral order, newest first, stop at K" is exactly "the K-1
-//      smallest keys in key order": valid candidates are compacted into LDS (ballot/popcount) and
-//      each takes the slot given by the number of smaller keys.
-// Work is proportional to the events present in the neighbourhood during the last ~2 delta_t (0.4 of a 50 ms window at
-// delta_t = 10 ms) instead of to its (2r+1)^2 pixels or to the whole window.  Neighbourhoods with more than `defer_cap`
-// (<= kRowCap) candidates (event-dense scenes, where the position-centric walk exits after the first rings anyway) are
-// appended to a list that k_search_dense processes afterwards; the list is the kernel's LDS footprint (20 KiB per
-// workgroup).  The kernel is bound by VALU issue (rocprofv3: ~80 % of the SIMDs' cycles); what the round-5 form removed
-// from a destination's ~130 instructions: the 64-bit bucket arithmetic, the LDS round trips of the 16-lane scans
-// (ds_bpermute -> DPP row operations), the binary search that mapped a flat candidate index to its range (five LDS reads
-// per candidate -> one, the ranges expand themselves into the list), the LDS loop of the rank counting (-> 15 DPP
-// rotations when a neighbourhood keeps <= 16 admissible candidates, the usual case).
+// K6 (r <= 7, timestamps sorted): candidate-centric search.  In slot order the events of one pixel row of the neighbourhood
+// are ONE contiguous slot range [start(row, x-r), start(row, x+r+1)), so
+//   1. 15 lanes fetch the row ranges (2 offsets each) and a 16-lane scan concatenates them;
+//   2. the C candidates are read 16 at a time, coalesced ({id,t} + packed x|y|visible): each lane finds its candidate's row
+//      by a binary search over the ranges' bases, tests it (older than the destination, dt <= delta, inside the FIFO depth)
+//      and keys it with (spiral rank of its pixel, recency inside the pixel = position in the row);
+//   3. the reference's sequential walk "spiral order, newest first, stop at K" is exactly "the K-1 smallest keys in key
+//      order": valid candidates are compacted into LDS (ballot/popcount) and each takes the slot given by the number of
+//      smaller keys.
+// Work is proportional to the events present in the neighbourhood instead of to its (2r+1)^2 pixels.  Neighbourhoods with
+// more than `defer_cap` (<= kRowCap) candidates (event-dense scenes, where the position-centric walk exits after the first
+// rings anyway) are appended to a list (ev_rank, dead after k_scatter; counter in status[5]) that k_search_dense walks
+// afterwards; the list is the kernel's LDS footprint (20 KiB per workgroup).  The kernel is bound by VALU issue (a wave64
+// instruction holds the SIMD for four cycles: the measured 0.22 wave-instructions per cycle and SIMD are 87 % of that).
+// Round 6 tried the two other shapes of the dense class (profiles/r6_search_sweep.md; both bit-exact, both slower): ONE
+// destination per wave over an LDS matrix of all row offsets -- ~800 dependent LDS / bpermute round trips per destination
+// -- and a separate list of heavy destinations searched in nested ring windows, 16 lanes each, with prefetched inputs:
+// 1.16 ns per heavy destination against 0.83 ns for the walk and 0.74 ns for the ring-limited passes below.  What decides
+// is instructions per destination: ~40 per 16 candidates here, ~100 per 16 spiral positions in the walk, which is why the
+// walk wins from ~1.4 events per pixel (C > 320) and the candidate form below that.
 constexpr int kRowCap = 320;
 struct alignas(4) Pair { int a, b; };
 
 // ROUNDS x 16 candidates are requested before the first is examined; WAVES per SIMD = the register budget (512 / WAVES)
-// TWO: the index has time buckets (ranges of two buckets per destination; the ranges expand themselves into the candidate
-// list).  One bucket (the index of a sparse workspace): 15 ranges, a candidate finds its range by binary search over the
-// ranges' bases -- cheaper than the expansion when a range holds ~5 events instead of ~1.
-template <int CAP, int ROUNDS, int WAVES, bool TWO>
+template <int CAP, int ROUNDS, int WAVES>
 __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__restrict__ m_ptr, int W, int H, int K, int r,
-                                                       float delta_t, const TimeKey tk, int defer_cap, int ring_thr,
+                                                       float delta_t, int defer_cap, int ring_thr,
                                                        const int32_t *__restrict__ slot_xyb,
                                                        const int32_t *__restrict__ start,
                                                        const int2 *__restrict__ slot_it,
@@ -610,11 +470,10 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
     constexpr int G = kBlock / 16;
     __shared__ unsigned char sp_rank[256];      // spiral index of offset (dy + r) * 16 + (dx + r)
     __shared__ unsigned short sp_dec[256];      // spiral index -> offset code (dx + r) * side + (dy + r) | (dy + r) << 12
-    __shared__ int row_lo[G][TWO ? 32 : 16];    // first slot of the ranges 0..15 (bucket tb) and 16..31 (bucket tb - 1)
-    __shared__ int row_base[TWO ? 1 : G][TWO ? 1 : 17];   // one bucket: the ranges' positions in the concatenation
-    __shared__ int row_sub[TWO ? 1 : G][TWO ? 1 : 16];    // ... minus the range's offset inside its row: candidate index -> position in the ROW
-    // the group's list: first the candidates as (range << 16 | position in the range), then -- compacted in place behind
-    // the reads -- the keys of the admissible ones, (spiral rank << 20) | (older bucket << 19) | (0x7FFFF - position): the
+    __shared__ int row_lo[G][16];               // first slot of the 15 row ranges
+    __shared__ int row_base[G][17];             // the ranges' positions in the concatenation
+    __shared__ int row_sub[G][16];              // ... minus the range's offset inside its row: candidate index -> position in the ROW
+    // the group's list: the keys of the admissible candidates, (spiral rank << 20) | (0x7FFFF - position in the row): the
     // source slot follows from the key.  Dynamic LDS on purpose: with the size visible the compiler's occupancy estimate
     // (made against 64 KiB) drops and it stops holding the kernel to its register budget; the hardware has 160 KiB per CU.
     extern __shared__ int v_key_dyn[];
@@ -640,7 +499,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
     long long edges_acc = 0;
     int ring_acc = 0;
     const int M = *m_ptr;
-    // timestamps out of order: sources may sit in any later bucket -- k_search_dense takes every node in its generic form
+    // timestamps out of order: ids do not order time -- k_search_dense takes every node in its generic form
     if (M <= 0 || status[6] != 0) return;
     const int Gd = gridDim.x, nx = (Gd % 8 == 0) ? 8 : 1;
     const int xcd = blockIdx.x % nx, lb = blockIdx.x / nx, bpx = Gd / nx;
@@ -655,46 +514,39 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
         me = slot_it[nn];
         c = slot_xyb[nn];
     };
-    auto load_rows = [&](int c, int t, int &lo0, int &len0, int &lo1, int &len1) {
+    auto load_rows = [&](int c, int &lo0, int &len0) {
         const int x = c & 4095, y = (c >> 12) & 4095, b = (c >> 24) & 127;
         const int yn = y + l - r;
-        lo0 = 0; len0 = 0; lo1 = 0; len1 = 0;
+        lo0 = 0; len0 = 0;
         if (l < side && yn >= 0 && yn < H) {
-            const int tb = bucket_of(tk, t);
-            const int base = W * (tb + tk.nb * (yn + H * b));
-            const int xl = max(x - r, 0), xh = min(x + r, W - 1) + 1;
-            lo0 = start[base + xl];
-            len0 = start[base + xh] - lo0;
-            if (TWO && tb > 0) {
-                lo1 = start[base - W + xl];
-                len1 = start[base - W + xh] - lo1;
-            }
+            const int base = W * (yn + H * b);
+            lo0 = start[base + max(x - r, 0)];
+            len0 = start[base + min(x + r, W - 1) + 1] - lo0;
         }
     };
     int2 me, me1;
-    int c, c1, lo0, len0, lo1, len1;
+    int c, c1, lo0, len0;
     if (n_begin + grp < n_end) {
         load_node(n_begin + grp, me, c);
         load_node(n_begin + grp + G, me1, c1);
-        load_rows(c, me.y, lo0, len0, lo1, len1);
+        load_rows(c, lo0, len0);
     }
     for (int ni = n_begin + grp; ni < n_end; ni += G) {
         const int n = ni;
         // next destinations' loads (results are used one iteration later)
         int2 me2;
-        int c2, nlo0, nlen0, nlo1, nlen1;
+        int c2, nlo0, nlen0;
         load_node(ni + 2 * G, me2, c2);
-        load_rows(c1, me1.y, nlo0, nlen0, nlo1, nlen1);
+        load_rows(c1, nlo0, nlen0);
         const int e = me.x, t = me.y;
         const int x = c & 4095;
         const int64_t row = (int64_t)n * K;
-        // 1. row ranges: 2 x 15 lanes hold the row ranges of the two buckets, two 16-lane scans concatenate them
-        const int C0 = row16_sum(len0);
-        const int C = TWO ? C0 + row16_sum(len1) : C0;
-        const int cb0 = row16_inclusive_scan(len0) - len0, cb1 = TWO ? C0 + row16_inclusive_scan(len1) - len1 : 0;
-        const int clo0 = lo0, clo1 = lo1, cl0 = len0, cl1 = len1;
+        // 1. row ranges: 15 lanes hold them, a 16-lane scan concatenates them
+        const int C = row16_sum(len0);
+        const int cb0 = row16_inclusive_scan(len0) - len0;
+        const int clo0 = lo0, cl0 = len0;
         const int c_dst = c;
-        me = me1; c = c1; me1 = me2; c1 = c2; lo0 = nlo0; len0 = nlen0; lo1 = nlo1; len1 = nlen1;   // rotate the pipeline
+        me = me1; c = c1; me1 = me2; c1 = c2; lo0 = nlo0; len0 = nlen0;   // rotate the pipeline
         // Dense neighbourhoods are deferred to the position-centric kernel.  The list append is aggregated per wave
         // (LDS buffer, one global atomic per ~48 entries): one atomicAdd per destination on a single counter
         // serialises at ~350 M/s and was the whole cost of this kernel on dense windows (4.5 ms at 1.6 M deferrals).
@@ -720,7 +572,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
             }
         }
         if (defer) continue;
-        // Ring limit (one bucket).  The walk keeps the first K - 1 admissible sources in spiral order and the spiral runs
+        // Ring limit.  The walk keeps the first K - 1 admissible sources in spiral order and the spiral runs
         // ring by ring (Chebyshev distance), so once the rings <= rho hold K - 1 admissible sources nothing outside them is
         // kept: a neighbourhood with many candidates is searched in its inner (2 rho + 1)^2 window first -- exact when that
         // yields K - 1 sources, otherwise the full window is searched as before (the inner pass is then lost work).
@@ -734,7 +586,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
         int in_off = cl0, in_len = 0;          // (a row outside the window: everything is "left")
         int Cu = C, pb = cb0, p_off = 0;
         bool inner = false;
-        if constexpr (!TWO) {
+        {
             if ((ring_thr & 0xffff) > 0 && C > (ring_thr & 0xffff)) {
                 const int xd = c_dst & 4095, yd = (c_dst >> 12) & 4095, bd = (c_dst >> 24) & 127;
                 const int yn = yd + l - r;
@@ -768,21 +620,10 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
         }
         int V = 0;
         row_lo[grp][l] = clo0;
-        if constexpr (TWO) {
-            row_lo[grp][16 + l] = clo1;
-            // every range writes its events into the candidate list: (range << 16) | position in the range
-            const int mx = max(cl0, cl1);
-            for (int k = 0; k < mx; k++) {
-                if (k < cl0) v_keys[cb0 + k] = (l << 16) | k;
-                if (k < cl1) v_keys[cb1 + k] = ((16 + l) << 16) | k;
-            }
-        }
         for (int pass = 0;; pass++) {       // one pass, or up to three for a ring-limited destination
-        if constexpr (!TWO) {
-            row_base[grp][l] = pb;
-            row_sub[grp][l] = pb - p_off;
-            if (l == 15) row_base[grp][16] = Cu;
-        }
+        row_base[grp][l] = pb;
+        row_sub[grp][l] = pb - p_off;
+        if (l == 15) row_base[grp][16] = Cu;
         __builtin_amdgcn_wave_barrier();
         // 2. candidates, 16 per round, ROUNDS rounds of loads in flight.  The admissible ones are compacted into the SAME
         //    list: their number never exceeds the number of candidates read so far, and a batch reads all of its list
@@ -796,16 +637,12 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
                 it[q] = make_int2(0, 0);
                 cxv[q] = 0; rpv[q] = 0;
                 if (ci < Cu) {
-                    if constexpr (TWO) {
-                        rpv[q] = v_keys[ci];
-                    } else {
-                        int rr = 0;
-                        if (row_base[grp][rr + 8] <= ci) rr += 8;
-                        if (row_base[grp][rr + 4] <= ci) rr += 4;
-                        if (row_base[grp][rr + 2] <= ci) rr += 2;
-                        if (row_base[grp][rr + 1] <= ci) rr += 1;
-                        rpv[q] = (rr << 16) | (ci - row_sub[grp][rr]);
-                    }
+                    int rr = 0;
+                    if (row_base[grp][rr + 8] <= ci) rr += 8;
+                    if (row_base[grp][rr + 4] <= ci) rr += 4;
+                    if (row_base[grp][rr + 2] <= ci) rr += 2;
+                    if (row_base[grp][rr + 1] <= ci) rr += 1;
+                    rpv[q] = (rr << 16) | (ci - row_sub[grp][rr]);
                     const int sv = row_lo[grp][rpv[q] >> 16] + (rpv[q] & 0xffff);
                     it[q] = slot_it[sv];
                     cxv[q] = slot_xyb[sv];
@@ -822,10 +659,9 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
                         valid = ((cxv[q] < 0) && it[q].x < e && !((float)(t - it[q].y) > delta_t)) ? 1 : 0;
                         const int dx = (cxv[q] & 4095) - x;
                         const int rr = rpv[q] >> 16;
-                        const int rank = sp_rank[(rr & 15) * 16 + (dx + r)];
-                        // spiral rank first, then newest first inside the pixel: the destination's own bucket before the
-                        // older one, larger slot = newer inside a range
-                        key = (rank << 20) | ((rr >> 4) << 19) | (0x7FFFF - (rpv[q] & 0xffff));
+                        const int rank = sp_rank[rr * 16 + (dx + r)];
+                        // spiral rank first, then newest first inside the pixel: larger slot = newer inside a row's range
+                        key = (rank << 20) | (0x7FFFF - (rpv[q] & 0xffff));
                     }
                     const unsigned bits = (unsigned)(__ballot(valid != 0) >> gshift) & 0xffffu;
                     if (valid) v_keys[V + __popc(bits & lt_mask)] = key;
@@ -834,7 +670,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
             }
         }
         __builtin_amdgcn_wave_barrier();
-        if (TWO || !inner || pass == 2) break;
+        if (!inner || pass == 2) break;
         if (pass == 0 && V >= K - 1) { ring_acc += (l == 0) ? 1 : 0; break; }
         // the inner window fell short: the left parts (whole rows outside the window), then the right parts
         const int p_len = pass == 0 ? in_off : cl0 - (in_off + in_len);
@@ -849,8 +685,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
         }
         auto emit = [&](int mk, int rk) {
             const int dec = sp_dec[mk >> 20];
-            const int rr = (dec >> 12) + ((mk >> 19) & 1) * 16;
-            nbr_src[row + 1 + rk] = row_lo[grp][rr] + (0x7FFFF - (mk & 0x7FFFF));   // range start + position
+            nbr_src[row + 1 + rk] = row_lo[grp][dec >> 12] + (0x7FFFF - (mk & 0x7FFFF));   // range start + position
             nbr_code[row + 1 + rk] = (int16_t)(dec & 0xfff);
         };
         // Dense neighbourhoods hold far more admissible candidates than the K-1 that survive, and the rank counting
@@ -915,18 +750,16 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_search_rows(const int32_t *__
 }
 
 // ---------------------------------------------------------------------------------------------
-// K6, the destinations the row kernel left: the position-centric walk of the reference (ev_graph.cu:48-78) on the
-// bucketed index, 16 lanes per destination, one spiral position per lane and round.  A position is one pixel = two
-// segments (the destination's bucket and the one before); timestamps being sorted, the admissible entries of a segment are
-// a slot range found by binary searches (admissible_range), the newer bucket's entries precede the older one's, a 16-lane
+// K6, everything the row kernel left.
+// LIST mode (the usual call): the position-centric walk of the reference (ev_graph.cu:48-78) for the deferred destinations,
+// 16 lanes per destination, one spiral position per lane and round.  A position is one pixel = one segment; timestamps being
+// sorted, the admissible entries of a segment are a slot range found by binary searches (admissible_range), a 16-lane
 // prefix sum reproduces the sequential "first K in spiral order" cut, and the walk ends with the round that fills K --
 // event-dense neighbourhoods (the ones deferred here: more than kRowCap candidates) end in the first rings.
-//
 // GENERIC form (every node of the window; chosen on the device when the timestamps are not sorted, status[6], and by the
-// host for radii beyond 7 pixels): candidate-centric over every row range that can hold a source -- all (2r+1) rows of
-// the buckets tb - 1 .. tb (sorted) or tb - 1 .. nb - 1 (unsorted: a source is OLDER BY ID, its timestamp may be later) --
-// every candidate tested on its own, keyed by (spiral rank, id descending) in 64 bits: exact whatever the order of the
-// timestamps, with the K - 1 smallest keys kept in a small LDS list that is compacted as it fills.  Slow and rare.
+// host for radii beyond 7 pixels): 16 lanes per destination, candidate-centric over all (2r+1) row ranges, every candidate
+// tested on its own, keyed by (spiral rank, id descending) in 64 bits: exact whatever the order of the timestamps, with the
+// K - 1 smallest keys kept in a small LDS list that is compacted as it fills.  Slow and rare.
 __host__ __device__ inline int dense_gen_cap(int K) { return (K - 1 + 16 + 15) / 16 * 16; }
 __host__ __device__ inline size_t dense_lds_bytes(int K, int r) {
     const int S = (2 * r + 1) * (2 * r + 1);
@@ -934,7 +767,7 @@ __host__ __device__ inline size_t dense_lds_bytes(int K, int r) {
 }
 
 __global__ __launch_bounds__(kBlock) void k_search_dense(const int32_t *__restrict__ m_ptr, int W, int H, int K, int r,
-                                                        float delta_t, const TimeKey tk,
+                                                        float delta_t,
                                                         const int32_t *__restrict__ slot_xyb,
                                                         const int32_t *__restrict__ start,
                                                         const int2 *__restrict__ slot_it,
@@ -983,110 +816,109 @@ __global__ __launch_bounds__(kBlock) void k_search_dense(const int32_t *__restri
     const int per_block = (chunk + bpx - 1) / bpx;
     const int n_begin = xcd * chunk + lb * per_block;
     const int n_end = min(min(M, (xcd + 1) * chunk), n_begin + per_block);
-    for (int ni = n_begin + grp; ni < n_end; ni += G) {
-        const int n = generic ? ni : node_list[ni];
-        const int2 me = slot_it[n];
-        const int e = me.x, t = me.y;
-        const int c = slot_xyb[n];
-        const int x = c & 4095, y = (c >> 12) & 4095, b = (c >> 24) & 127;
-        const int tb = bucket_of(tk, t);
-        const int64_t row = (int64_t)n * K;
-        if (l == 0) {
-            nbr_src[row] = n;  // self loop first (ev_graph.cu:44-46)
-            nbr_code[row] = (int16_t)(r * side + r);
-        }
-        int total = 1;
-        if (!generic) {
+    if (!generic) {
+        for (int ni = n_begin + grp; ni < n_end; ni += G) {
+            const int n = node_list[ni];
+            const int2 me = slot_it[n];
+            const int e = me.x, t = me.y;
+            const int c = slot_xyb[n];
+            const int x = c & 4095, y = (c >> 12) & 4095, b = (c >> 24) & 127;
+            const int64_t row = (int64_t)n * K;
+            if (l == 0) {
+                nbr_src[row] = n;  // self loop first (ev_graph.cu:44-46)
+                nbr_code[row] = (int16_t)(r * side + r);
+            }
+            int total = 1;
             for (int s0 = 0; s0 < S && total < K; s0 += 16) {
                 const int s = s0 + l;
-                int code = 0, loN = 0, hiN = 0, loO = 0, hiO = 0;
+                int code = 0, lo = 0, hi = 0;
                 if (s < S) {
                     const int sc = sp_tab[s];
                     const int sx = (sc & 255) - 64, sy = ((sc >> 8) & 255) - 64;
                     code = (sx + r) * side + (sy + r);
                     const int xn = x + sx, yn = y + sy;
                     if (xn >= 0 && yn >= 0 && xn < W && yn < H) {          // out of FOV: skip this pixel only
-                        const int key = xn + W * (tb + tk.nb * (yn + H * b));
-                        const Pair sN = *reinterpret_cast<const Pair *>(start + key);      // one 8-byte load per segment
-                        const int aN = sN.a, bN = sN.b;
-                        int aO = 0, bO = 0;
-                        if (tb > 0) {
-                            const Pair sO = *reinterpret_cast<const Pair *>(start + key - W);
-                            aO = sO.a; bO = sO.b;
-                        }
-                        if (bN > aN) admissible_range(slot_it, slot_xyb, aN, bN, e, t, delta_t, true, hot, loN, hiN);
-                        if (bO > aO) admissible_range(slot_it, slot_xyb, aO, bO, e, t, delta_t, false, hot, loO, hiO);
+                        const Pair sN = *reinterpret_cast<const Pair *>(start + xn + W * (yn + H * b));   // one 8-byte load
+                        if (sN.b > sN.a) admissible_range(slot_it, slot_xyb, sN.a, sN.b, e, t, delta_t, hot, lo, hi);
                     }
                 }
-                const int nN = hiN - loN;
-                const int v = min(nN + (hiO - loO), K);
+                const int v = min(hi - lo, K);
                 int slot = total + row16_inclusive_scan(v) - v;
                 total += row16_sum(v);
                 for (int k = 0; k < v && slot < K; k++, slot++) {
-                    nbr_src[row + slot] = k < nN ? hiN - 1 - k : hiO - 1 - (k - nN);     // newest first
+                    nbr_src[row + slot] = hi - 1 - k;     // newest first
                     nbr_code[row + slot] = (int16_t)code;
                 }
             }
             if (total > K) total = K;
-        } else {
-            unsigned long long *k0 = gk + (size_t)grp * 2 * cap, *k1 = k0 + cap;
-            int *s0p = gs + (size_t)grp * 2 * cap, *s1p = s0p + cap;
-            int V = 0;
-            // keep the K - 1 smallest keys of the list, in key order (keys are distinct: they carry the event id)
-            auto compact = [&]() {
-                __builtin_amdgcn_wave_barrier();
-                for (int vi = l; vi < V; vi += 16) {
-                    const unsigned long long mk = k0[vi];
-                    int rk = 0;
-                    for (int j = 0; j < V; j++) rk += (k0[j] < mk) ? 1 : 0;
-                    if (rk < K - 1) { k1[rk] = mk; s1p[rk] = s0p[vi]; }
-                }
-                __builtin_amdgcn_wave_barrier();
-                V = min(V, K - 1);
-                unsigned long long *tk_ = k0; k0 = k1; k1 = tk_;
-                int *ts_ = s0p; s0p = s1p; s1p = ts_;
-            };
-            const int j_hi = unsorted ? tk.nb - 1 : tb;
-            for (int j = j_hi; j >= max(tb - 1, 0); j--) {
-                for (int dy = -r; dy <= r; dy++) {
-                    const int yn = y + dy;
-                    if (yn < 0 || yn >= H) continue;
-                    const int base = W * (j + tk.nb * (yn + H * b));
-                    const int lo = start[base + max(x - r, 0)], hi = start[base + min(x + r, W - 1) + 1];
-                    for (int c0 = lo; c0 < hi; c0 += 16) {
-                        const int sv = c0 + l;
-                        bool valid = false;
-                        unsigned long long key = 0;
-                        if (sv < hi) {
-                            const int2 it = slot_it[sv];
-                            const int cx = slot_xyb[sv];
-                            // visible in the FIFO; older than the destination (ev_graph.cu:64); dt <= delta (:69)
-                            valid = (cx < 0) && it.x < e && !((float)(t - it.y) > delta_t);
-                            const int dx = (cx & 4095) - x;
-                            key = ((unsigned long long)sp_rank[(dy + r) * side + (dx + r)] << 32) |
-                                  (unsigned long long)(0xFFFFFFFFu - (unsigned)it.x);       // newest (largest id) first
-                        }
-                        const unsigned bits = (unsigned)(__ballot(valid) >> gshift) & 0xffffu;
-                        if (valid) {
-                            const int pidx = V + __popc(bits & lt_mask);
-                            k0[pidx] = key;
-                            s0p[pidx] = sv;
-                        }
-                        V += __popc(bits);
-                        if (V > cap - 16) compact();      // (group-uniform)
-                    }
-                }
-            }
-            compact();
-            for (int vi = l; vi < V; vi += 16) {
-                int sx, sy;
-                spiral_offset((int)(k0[vi] >> 32), sx, sy);
-                nbr_src[row + 1 + vi] = s0p[vi];
-                nbr_code[row + 1 + vi] = (int16_t)((sx + r) * side + (sy + r));
-            }
-            total = 1 + V;
-            __builtin_amdgcn_wave_barrier();  // the lists are reused by the next destination
+            if (l == 0) { deg[n] = total; edges_acc += total; }
         }
+    } else
+    for (int ni = n_begin + grp; ni < n_end; ni += G) {
+        const int n = ni;
+        const int2 me = slot_it[n];
+        const int e = me.x, t = me.y;
+        const int c = slot_xyb[n];
+        const int x = c & 4095, y = (c >> 12) & 4095, b = (c >> 24) & 127;
+        const int64_t row = (int64_t)n * K;
+        if (l == 0) {
+            nbr_src[row] = n;  // self loop first (ev_graph.cu:44-46)
+            nbr_code[row] = (int16_t)(r * side + r);
+        }
+        unsigned long long *k0 = gk + (size_t)grp * 2 * cap, *k1 = k0 + cap;
+        int *s0p = gs + (size_t)grp * 2 * cap, *s1p = s0p + cap;
+        int V = 0;
+        // keep the K - 1 smallest keys of the list, in key order (keys are distinct: they carry the event id)
+        auto compact = [&]() {
+            __builtin_amdgcn_wave_barrier();
+            for (int vi = l; vi < V; vi += 16) {
+                const unsigned long long mk = k0[vi];
+                int rk = 0;
+                for (int j = 0; j < V; j++) rk += (k0[j] < mk) ? 1 : 0;
+                if (rk < K - 1) { k1[rk] = mk; s1p[rk] = s0p[vi]; }
+            }
+            __builtin_amdgcn_wave_barrier();
+            V = min(V, K - 1);
+            unsigned long long *tk_ = k0; k0 = k1; k1 = tk_;
+            int *ts_ = s0p; s0p = s1p; s1p = ts_;
+        };
+        for (int dy = -r; dy <= r; dy++) {
+            const int yn = y + dy;
+            if (yn < 0 || yn >= H) continue;
+            const int base = W * (yn + H * b);
+            const int lo = start[base + max(x - r, 0)], hi = start[base + min(x + r, W - 1) + 1];
+            for (int c0 = lo; c0 < hi; c0 += 16) {
+                const int sv = c0 + l;
+                bool valid = false;
+                unsigned long long key = 0;
+                if (sv < hi) {
+                    const int2 it = slot_it[sv];
+                    const int cx = slot_xyb[sv];
+                    // visible in the FIFO; older than the destination (ev_graph.cu:64); dt <= delta (:69)
+                    valid = (cx < 0) && it.x < e && !((float)(t - it.y) > delta_t);
+                    const int dx = (cx & 4095) - x;
+                    key = ((unsigned long long)sp_rank[(dy + r) * side + (dx + r)] << 32) |
+                          (unsigned long long)(0xFFFFFFFFu - (unsigned)it.x);       // newest (largest id) first
+                }
+                const unsigned bits = (unsigned)(__ballot(valid) >> gshift) & 0xffffu;
+                if (valid) {
+                    const int pidx = V + __popc(bits & lt_mask);
+                    k0[pidx] = key;
+                    s0p[pidx] = sv;
+                }
+                V += __popc(bits);
+                if (V > cap - 16) compact();      // (group-uniform)
+            }
+        }
+        compact();
+        for (int vi = l; vi < V; vi += 16) {
+            int sx, sy;
+            spiral_offset((int)(k0[vi] >> 32), sx, sy);
+            nbr_src[row + 1 + vi] = s0p[vi];
+            nbr_code[row + 1 + vi] = (int16_t)((sx + r) * side + (sy + r));
+        }
+        const int total = 1 + V;
+        __builtin_amdgcn_wave_barrier();  // the lists are reused by the next destination
         if (l == 0) { deg[n] = total; edges_acc += total; }
     }
     {   // one atomic per wave instead of one per lane group (same single-counter drain as in k_search_rows)
@@ -1187,7 +1019,6 @@ __global__ __launch_bounds__(kBlock) void k_stage_window(const float *__restrict
                                                         float *__restrict__ pos_out, float *__restrict__ feat_out,
                                                         int32_t *__restrict__ batch_out, int32_t *__restrict__ n_dev,
                                                         int32_t *__restrict__ status8, int W, int H, int B, float fT,
-                                                        const TimeKey tk,
                                                         int32_t *__restrict__ cnt, int32_t *__restrict__ ev_xyb,
                                                         int32_t *__restrict__ ev_t, int32_t *__restrict__ ev_rank) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -1196,7 +1027,7 @@ __global__ __launch_bounds__(kBlock) void k_stage_window(const float *__restrict
     if (i < N) {
         feat_out[i] = feat[i];
         batch_out[i] = (int32_t)batch[i];
-        count_event<BatchT, false>(i, pos, batch, W, H, B, (float)W, (float)H, fT, tk, cnt, ev_xyb, ev_t, ev_rank,
+        count_event<BatchT, false>(i, pos, batch, W, H, B, (float)W, (float)H, fT, cnt, ev_xyb, ev_t, ev_rank,
                                    status8 + 8, status8 + 9);
     }
     if (i < 3 * N) pos_out[i] = pos[i];
@@ -1222,7 +1053,7 @@ using namespace dagr;
 
 namespace dagr {
 // views into the builder workspace for the level-0 pooling kernel (pooling.hip) and the asynchronous update
-// (async_update.hip): the index is keyed (sample, y, time bucket, x) -- see PixelIndex in common.hpp
+// (async_update.hip): the index is keyed (sample, y, x) -- see PixelIndex in common.hpp
 void graph_ws_index(const dagr_graph_desc *desc, void *workspace, PixelIndex *out) {
     GraphWs ws;
     carve(*desc, (char *)workspace, &ws);
@@ -1233,7 +1064,6 @@ void graph_ws_index(const dagr_graph_desc *desc, void *workspace, PixelIndex *ou
     out->unsorted = ws.status + 6;
     out->W = desc->width;
     out->H = desc->height;
-    out->nb = ws.tk.nb;
 }
 const int32_t *graph_ws_node_count(const dagr_graph_desc *desc, void *workspace) {
     GraphWs ws;
@@ -1284,45 +1114,32 @@ static int launch_search(const dagr_graph_desc *desc, const GraphWs &ws, int64_t
     const bool rows = 2 * r + 2 <= 16;
     if (rows) {
         // fast path: candidate-centric row kernel; dense neighbourhoods are deferred (list in ev_rank, which is dead
-        // after k_scatter; counter in status[5]) to the position-centric kernel
+        // after k_scatter; counter in status[5]) to the position-centric walk of k_search_dense
         constexpr size_t rows_lds = (size_t)(kBlock / 16) * (kRowCap + 4) * 4;
-        // builder knob DAGR_ROWS_VARIANT = 10 * rounds + waves per SIMD (16 candidates per round)
-        static const int variant_env = [] { const char *e = getenv("DAGR_ROWS_VARIANT"); return e ? atoi(e) : 0; }();
-        // (registers: 88 / 78.  The block's 25 KB of LDS hold six workgroups per CU either way; the 72-register form of the
-        // one-bucket kernel, variant 47, spills three registers since the ring-limited passes and measures the same)
-        const int variant = variant_env ? variant_env : (ws.tk.nb > 1 ? 45 : 46);
-        // neighbourhoods beyond this many candidates go to the position-centric kernel (builder knob DAGR_DEFER_CAP).
-        // Measured (profiles/r5_search_buckets.md): with time buckets 128 is the best cut on event-dense streams (S-edges
-        // 8 x 200 k: 1.84 ms at 128, 2.07 at 192, 2.57 at 320), without them the list's capacity is.
-        static const int defer_env = [] { const char *e = getenv("DAGR_DEFER_CAP"); return e ? atoi(e) : 0; }();
-        const int defer_cap = std::min(kRowCap, std::max(16, defer_env ? defer_env : (ws.tk.nb > 1 ? 128 : kRowCap)));
-        // candidates from which a neighbourhood is searched in its inner rings first (k_search_rows; 0 = never)
-        static const int ring_env = [] { const char *e = getenv("DAGR_RING_THR"); return e ? atoi(e) : -1; }();
-        static const int want_env = [] { const char *e = getenv("DAGR_RING_WANT"); return e ? atoi(e) : 0; }();
-        // measured (whole build in us; threshold x candidates wanted per source): S-edges 8 x 100 k 833 -> 748, 8 x 200 k
-        // 1631 -> 1511, S-uniform 8 x 400 k 2761 -> 2449 at (200, 6); wanting 4 per source makes the inner pass fall short
-        // three times in four on uniform streams (2986: the extra passes are not free), thresholds below 200 cost sparse
-        // windows two loads for nothing (S-uniform 1 x 200 k: 150 -> 162 at 128)
-        const int ring_thr = (ring_env >= 0 ? ring_env : 200) | ((want_env > 0 ? want_env : 6) << 16);
+        // measurement knob DAGR_ROWS_VARIANT = 10 * rounds + waves per SIMD (16 candidates per round)
+        static const int variant = (int)knob("DAGR_ROWS_VARIANT", 46);
+        // neighbourhoods beyond this many candidates go to the position-centric walk (measurement knob DAGR_DEFER_CAP)
+        static const int defer_cap = std::min(kRowCap, std::max(16, (int)knob("DAGR_DEFER_CAP", kRowCap)));
+        // candidates from which a neighbourhood is searched in its inner rings first (k_search_rows; 0 = never) and
+        // candidates wanted per source.  Measured in round 5 (whole build in us, profiles/r5_ring_sweep.txt): S-edges
+        // 8 x 100 k 833 -> 748, 8 x 200 k 1631 -> 1511, S-uniform 8 x 400 k 2761 -> 2449 at (200, 6); wanting 4 per source
+        // makes the inner pass fall short three times in four on uniform streams, thresholds below 200 cost sparse windows
+        // two loads for nothing
+        static const int ring_thr = (int)knob("DAGR_RING_THR", 200) | ((int)knob("DAGR_RING_WANT", 6) << 16);
         auto launch_rows = [&](auto kern) {
             static thread_local unsigned res_rows = 0;
             if (!res_rows) res_rows = persistent_grid(kern, kBlock, rows_lds, 1 << 30);
             const unsigned gR = round_grid8(std::min<int64_t>(ceil_div(N * 16, kBlock), res_rows));
-            kern<<<gR, kBlock, rows_lds, stream>>>(ws.start + ws.PK, W, H, K, r, (float)desc->delta_t_us, ws.tk, defer_cap,
-                                                   ring_thr, ws.slot_xyb, ws.start, ws.slot_it, nbr_src, nbr_code, deg, ws.status,
+            kern<<<gR, kBlock, rows_lds, stream>>>(ws.start + ws.PK, W, H, K, r, (float)desc->delta_t_us, defer_cap, ring_thr,
+                                                   ws.slot_xyb, ws.start, ws.slot_it, nbr_src, nbr_code, deg, ws.status,
                                                    ws.ev_rank, ws.status + 5);
         };
-        const bool two = ws.tk.nb > 1;
-#define DAGR_ROWS(R, WV) do { if (two) launch_rows(k_search_rows<kRowCap, R, WV, true>); else launch_rows(k_search_rows<kRowCap, R, WV, false>); } while (0)
         switch (variant) {
-            case 47: DAGR_ROWS(4, 7); break;
-            case 46: DAGR_ROWS(4, 6); break;
-            case 44: DAGR_ROWS(4, 4); break;
-            case 35: DAGR_ROWS(3, 5); break;
-            case 25: DAGR_ROWS(2, 5); break;
-            default: DAGR_ROWS(4, 5); break;
+            case 47: launch_rows(k_search_rows<kRowCap, 4, 7>); break;
+            case 45: launch_rows(k_search_rows<kRowCap, 4, 5>); break;
+            case 36: launch_rows(k_search_rows<kRowCap, 3, 6>); break;
+            default: launch_rows(k_search_rows<kRowCap, 4, 6>); break;
         }
-#undef DAGR_ROWS
         DAGR_CHECK_LAUNCH();
     }
     const size_t dense_lds = dense_lds_bytes(K, r);
@@ -1333,7 +1150,7 @@ static int launch_search(const dagr_graph_desc *desc, const GraphWs &ws, int64_t
         res_dense_lds = dense_lds;
     }
     const unsigned gT = round_grid8(std::min<int64_t>(ceil_div(N * 16, kBlock), res_dense));
-    k_search_dense<<<gT, kBlock, dense_lds, stream>>>(ws.start + ws.PK, W, H, K, r, (float)desc->delta_t_us, ws.tk, ws.slot_xyb,
+    k_search_dense<<<gT, kBlock, dense_lds, stream>>>(ws.start + ws.PK, W, H, K, r, (float)desc->delta_t_us, ws.slot_xyb,
                                                      ws.start, ws.slot_it, nbr_src, nbr_code, deg, ws.status, ws.ev_rank,
                                                      ws.status + 5, rows ? 0 : 1, ga);
     DAGR_CHECK_LAUNCH();
@@ -1365,7 +1182,7 @@ static int build_window(const dagr_graph_desc *desc, void *workspace, const void
         DAGR_CHECK_HIP(hipMemsetAsync(ws.status, 0, 8 * 4, stream));
 #define DAGR_LAUNCH_COUNT(BT, IP)                                                                          \
     k_count<BT, IP><<<gN, kBlock, 0, stream>>>(pos, (const BT *)batch, n, W, H, B, (float)W, (float)H,        \
-                                               (float)desc->time_window, ws.tk, ws.cnt, ws.ev_xyb, ws.ev_t,  \
+                                               (float)desc->time_window, ws.cnt, ws.ev_xyb, ws.ev_t,         \
                                                ws.ev_rank, ws.status, xr)
         if (batch_is_int64) { if (pos_is_int32) DAGR_LAUNCH_COUNT(int64_t, true); else DAGR_LAUNCH_COUNT(int64_t, false); }
         else                { if (pos_is_int32) DAGR_LAUNCH_COUNT(int32_t, true); else DAGR_LAUNCH_COUNT(int32_t, false); }
@@ -1374,18 +1191,18 @@ static int build_window(const dagr_graph_desc *desc, void *workspace, const void
     }
     // start = exclusive_scan(cnt); cnt is re-zeroed in the same pass (invariant for the next window)
     DAGR_CHECK_HIP(exclusive_scan_i32_chained(ws.cnt, ws.start, ws.PK + 1, ws.scan_tmp, true, stream));
-    k_scatter<<<gN, kBlock, 0, stream>>>(n, n_dev, W, H, ws.tk, ws.ev_xyb, ws.ev_t, ws.ev_rank, ws.start, ws.slot_tmp,
+    k_scatter<<<gN, kBlock, 0, stream>>>(n, n_dev, W, H, ws.ev_xyb, ws.ev_rank, ws.start, ws.slot_tmp,
                                          ws.ev_slot, ws.status, xr);
     DAGR_CHECK_LAUNCH();
     // number of occupied CSR slots M = start[PK] <= N (dropped events excluded); slots are a
     // prefix [0, M) so launching N threads with an in-kernel bound read would need M on the host.
     // Out-of-FOV events are an error condition; we order all N slots but guard on start[PK].
     const int hot_cap = (int)(desc->max_events + 1);
-    const int hot_thr = std::min(kShortSeg, desc->queue_size / ws.tk.nb);
-    k_order<<<gN, kBlock, 0, stream>>>(n, ws.PK, W, H, ws.tk, hot_thr, ws.ev_xyb, ws.ev_t, ws.start, ws.slot_tmp, ws.slot_it,
+    const int hot_thr = std::min(kShortSeg, desc->queue_size);
+    k_order<<<gN, kBlock, 0, stream>>>(n, ws.PK, W, H, hot_thr, ws.ev_xyb, ws.ev_t, ws.start, ws.slot_tmp, ws.slot_it,
                                        ws.slot_xyb, ws.ev_slot, ws.hot_list, hot_cap, ws.status, xr);
     DAGR_CHECK_LAUNCH();
-    k_fix_pixels<<<1024, kBlock, 0, stream>>>(desc->queue_size, W, ws.tk, ws.ev_xyb, ws.slot_xyb, ws.ev_slot, ws.ev_t, ws.start,
+    k_fix_pixels<<<1024, kBlock, 0, stream>>>(desc->queue_size, ws.ev_xyb, ws.slot_xyb, ws.ev_slot, ws.ev_t, ws.start,
                                             ws.slot_tmp, ws.slot_it, ws.hot_list, hot_cap, ws.status);
     DAGR_CHECK_LAUNCH();
     return launch_search(desc, ws, N, nbr_src, nbr_code, deg, stream, gather);
@@ -1435,11 +1252,11 @@ int dagr_stage_window(const dagr_graph_desc *desc, void *workspace, const float 
     if (batch_is_int64)
         k_stage_window<int64_t><<<grid, kBlock, 0, (hipStream_t)stream>>>(
             pos, feat, (const int64_t *)batch, (int)N, pos_out, feat_out, batch_out, n_dev, ws.status, W, H, B,
-            (float)desc->time_window, ws.tk, ws.cnt, ws.ev_xyb, ws.ev_t, ws.ev_rank);
+            (float)desc->time_window, ws.cnt, ws.ev_xyb, ws.ev_t, ws.ev_rank);
     else
         k_stage_window<int32_t><<<grid, kBlock, 0, (hipStream_t)stream>>>(
             pos, feat, (const int32_t *)batch, (int)N, pos_out, feat_out, batch_out, n_dev, ws.status, W, H, B,
-            (float)desc->time_window, ws.tk, ws.cnt, ws.ev_xyb, ws.ev_t, ws.ev_rank);
+            (float)desc->time_window, ws.cnt, ws.ev_xyb, ws.ev_t, ws.ev_rank);
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;
 }

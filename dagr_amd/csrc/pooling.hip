@@ -964,7 +964,7 @@ int launch_pool_l0_slots(const dagr_pool_desc *desc, const dagr_graph_desc *gdes
     const int32_t *start = ix.start; const int2 *slot_it = ix.slot_it;
     const int32_t *slot_xyb = ix.slot_xyb;
     const int32_t *n_ptr = ix.n_nodes;
-    const int row_keys = ix.W * ix.nb;        // keys per pixel row: the band of a voxel row starts at a row's first key
+    const int row_keys = ix.W;                // keys per pixel row: the band of a voxel row starts at a row's first key
     const int C = desc->channels, W = gdesc->width, H = gdesc->height, K = gdesc->max_neighbors;
     const bool vec4 = C % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0;
     // LDS window: up to 60 KB of accumulators per (16-wave) workgroup, at least one voxel row, at most 1024 table slots
@@ -977,7 +977,7 @@ int launch_pool_l0_slots(const dagr_pool_desc *desc, const dagr_graph_desc *gdes
     DAGR_CHECK_ARG(desc->gx < 65536 && desc->gy < 65536 && VW < 32768, "voxel grid too large for the level-0 pooling kernel");
     // one 16-wave workgroup per CU is resident at a time (114 registers); wide rows run two rounds of shorter runs, which
     // overlaps one round's merge with the other's streaming (measured: 112 vs 127 us at 80 channels, 47 vs 44 us at 16)
-    static const int gmult_env = [] { const char *e = getenv("DAGR_POOL_GRID_MULT"); return e ? atoi(e) : 0; }();
+    static const int gmult_env = (int)knob("DAGR_POOL_GRID_MULT", 0);
     const int gmult = gmult_env > 0 ? gmult_env : (C > 32 ? 2 : 1);
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)gmult * device_cu_count(),
                                                                           ceil_div(n_cap, kPoolL0Block)));

@@ -345,7 +345,7 @@ hipError_t exclusive_scan_i32_chained(int32_t *in, int32_t *out, int64_t n, void
     unsigned long long *words = (unsigned long long *)((char *)state + 64);
     if (ceil_div(n, kScanTile) > 320) {
         // wider tiles keep the tile count (= the look-back's length) down: the narrowest tile that gives <= 320 of them
-        static const int force = [] { const char *e = getenv("DAGR_SCAN_EPT"); return e ? atoi(e) : 0; }();   // builder knob
+        static const int force = (int)knob("DAGR_SCAN_EPT", 0);   // measurement knob
         int ept = n <= 320ll * 1024 * 8 ? 8 : n <= 320ll * 1024 * 16 ? 16 : n <= 320ll * 1024 * 32 ? 32 : 48;
         if (force == 8 || force == 16 || force == 32 || force == 48) ept = force;
         if (force < 0 || ceil_div(n, 1024 * 48) > 2048)     // (far beyond any window: the three-launch form)

@@ -781,8 +781,11 @@ class WindowEngine:
 
     def _sample(self, n_ptr, n_max, pos, batch, b64, fmap, out, coff):
         """sample_features (net.py:193-221) of one channels-last feature map into out[:, coff:coff+C]."""
-        ready = self._feat_ready.get(id(fmap)) if self._feat_ready else None
-        if ready is not None:                       # pipelined window: the map comes from the image branch's stream
+        if self._feat_ready is not None:            # pipelined window: the map comes from the image branch's stream
+            ready = self._feat_ready.get(id(fmap))
+            if ready is None:
+                raise RuntimeError("pipelined window: a sampled feature map has no ready-event (the image branch did not "
+                                   "announce it) -- reading it would race with the image stream")
             torch.cuda.current_stream(self.device).wait_event(ready)
         Bf, C, h, w = fmap.shape
         nhwc = fmap.permute(0, 2, 3, 1)
@@ -871,6 +874,9 @@ class WindowEngine:
                 outs = [dconv(o) for o, dconv in zip(outs, net.output_dconv)]
         else:
             feats, outs = bb.net(x)
+            if on_feature is not None:              # unfolded trunk (DAGR_IMG_EPILOGUES=0): all maps exist only now
+                for j, f in enumerate(feats):
+                    on_feature(j, f)
         outs = outs[-self.num_scales:]
         resized = [torch.nn.functional.interpolate(f, o) for f, o in zip(outs, self.out_sizes)]
         return feats, head.cnn_head(resized)

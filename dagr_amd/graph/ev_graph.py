@@ -26,7 +26,7 @@ class WindowGraphBuilder:
 
     ``build(pos, batch)`` -> ``(nbr_src int32[N,K], nbr_code int16[N,K], deg int32[N])`` on the
     current stream, no host synchronisation.  The lists are in *node (slot) order*: node n is the n-th
-    event in (sample, y, x, time) order ((sample, y, time bucket, x, time) with DAGR_TIME_BUCKETS > 1); ``node_order()`` returns the permutation and ``edge_index``
+    event in (sample, y, x, time) order; ``node_order()`` returns the permutation and ``edge_index``
     the reference-shaped, event-ordered ``int64[2,E]``.
     """
 

@@ -157,8 +157,14 @@ class GNNHead(YOLOXHeadParams):
                     # a replayed graph hands out ITS buffers, rewritten by the next step: the caller gets values of its own
                     # (one small launch for the five scalars; `total` keeps its link to the graph's backward)
                     total, iou, obj, cls, ratio = torch.stack((total, iou, obj, cls, ratio)).unbind(0)
+                    # the mark lives as long as the AUTOGRAD NODE of this loss, not the Python tensor: the hybrid loss of a
+                    # --use_image step (`loss_image[i] + loss_events[i]`) and callers that sum losses drop `total` while its
+                    # backward is still pending; a sentinel in the node's metadata dies only when the graph itself is freed
                     import weakref
-                    mark = [weakref.ref(total), False]           # [the loss of this forward, its backward has run]
+                    alive = _Sentinel()
+                    total.grad_fn.metadata["dagr_loss_graph_pending"] = alive
+                    mark = [weakref.ref(alive), False]           # [this forward's graph is alive, its backward has run]
+                    del alive
                     self._loss_graph_pending[key] = mark
 
                     def _done(grad, mark=mark):
@@ -185,6 +191,11 @@ class GNNHead(YOLOXHeadParams):
         outputs[..., :2] = (outputs[..., :2] + grid) * stride
         outputs[..., 2:4] = torch.exp(outputs[..., 2:4]) * stride
         return outputs
+
+
+class _Sentinel:
+    """Weak-referenceable token kept in an autograd node's metadata (see ``GNNHead.forward``: the loss-graph guard)."""
+    __slots__ = ("__weakref__",)
 
 
 def _window_part(d):

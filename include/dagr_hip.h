@@ -154,10 +154,11 @@ int dagr_graph_search_window(const dagr_graph_desc *desc, void *workspace, int64
  * num_edges = sum(deg). */
 int dagr_graph_status(const dagr_graph_desc *desc, void *workspace, int64_t *num_edges /*host*/,
                       int32_t *flags /*host*/, void *stream);
-/* All eight status words of the last build (synchronises `stream`): [0] pixels with more than 64 events, [1] flags,
- * [2..3] num_edges (uint64), [5] destinations the row kernel deferred to the position-centric sweep (neighbourhoods of
- * more than 320 candidates), [6] 1 when timestamps were not non-decreasing inside a sample (linear FIFO walk,
- * ev_graph.cu:58-76, instead of the two binary searches).  Tests use it to show which paths a window took. */
+/* All eight status words of the last build (synchronises `stream`): [0] pixels with more than min(64, Q) events, [1] flags,
+ * [2..3] num_edges (uint64), [4] pixels beyond the FIFO depth, [5] destinations the row kernel deferred to the
+ * position-centric walk (neighbourhoods of more than 320 candidates), [6] 1 when timestamps were not non-decreasing inside
+ * a sample (every destination then takes the generic search), [7] destinations the row kernel answered from the inner rings
+ * of their neighbourhood.  Tests use it to show which paths a window took. */
 int dagr_graph_counters(const dagr_graph_desc *desc, void *workspace, int32_t *out8_host, void *stream);
 
 /* Reference-shaped output: edge_index int64[2,E] in the order of

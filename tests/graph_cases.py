@@ -82,3 +82,44 @@ def wide_radius_cases():
     cases.append(_case("r8_unsorted_k24", rng.integers(0, 64, n), rng.integers(0, 48, n), rng.integers(960000, 1000001, n),
                        np.zeros(n), 64, 48, 1, 8, 10000, K=24, Q=8))
     return cases
+
+
+def heavy_cases():
+    """Event-dense neighbourhoods (csrc/graph_build.hip: the row kernel's ring-limited passes for 200 .. 320 candidates, the
+    position-centric walk of k_search_dense beyond).  GPU suites only: the
+    expected graphs come from the oracle and, where it is built, from the reference's own kernels (oracle/_ref)."""
+    cases = []
+    rng = np.random.default_rng(29)
+    W, H = 96, 64
+
+    def around(cx, cy, n_core, core, n_halo, halo, t_lo, t_hi=1000001):
+        x = np.concatenate([rng.integers(cx, cx + core, n_core), rng.integers(cx - halo, cx + core + halo, n_halo)])
+        y = np.concatenate([rng.integers(cy, cy + core, n_core), rng.integers(cy - halo, cy + core + halo, n_halo)])
+        t = np.sort(rng.integers(t_lo, t_hi, n_core + n_halo))
+        perm = rng.permutation(n_core + n_halo)
+        return x[perm], y[perm], t
+    # 2400 events on 2 x 2 pixels + a halo: ring 0 alone overflows the key list -> position-centric walk; FIFO depth 128
+    x, y, t = around(40, 30, 2400, 2, 300, 4, 985000)
+    cases.append(_case("walk_2x2_q128", x, y, t, np.zeros(len(x)), W, H, 1, 4, 10000))
+    # the same without any pixel beyond the FIFO depth (every slot visible: no visibility searches)
+    cases.append(_case("walk_2x2_q1024", x, y, t, np.zeros(len(x)), W, H, 1, 4, 10000, Q=1024))
+    # at the sensor's corner: clipped windows, clamped offsets
+    x, y, t = around(0, 0, 1800, 2, 300, 3, 985000)
+    cases.append(_case("walk_corner", np.clip(x, 0, W - 1), np.clip(y, 0, H - 1), t, np.zeros(len(x)), W, H, 1, 4, 10000, Q=64))
+    # dense but mostly stale: few admissible sources per ring, the passes grow to the full window (and fall short of K - 1)
+    n = 6000
+    cases.append(_case("stale_block", rng.integers(20, 50, n), rng.integers(10, 40, n),
+                       np.sort(rng.integers(700000, 1000001, n)), np.zeros(n), W, H, 1, 4, 10000))
+    # radius 7 (15 x 15 windows), moving edges at a density where most destinations are heavy; K = 12 and K = 16
+    x, y, t, p, b = syn.batch_windows(syn.edges_window, 20000, 2, 160, 120, seed=51)
+    cases.append(_case("edges_r7_b2", x, y, t, b, 160, 120, 2, 7, 10000))
+    cases.append(_case("edges_r7_b2_k12_q16", x, y, t, b, 160, 120, 2, 7, 10000, K=12, Q=16))
+    # radius 5 and 6 (row matrices narrower than 16 columns), uniform at 6 events per pixel
+    x, y, t, p, b = syn.batch_windows(syn.uniform_window, 30000, 1, 80, 60, seed=61)
+    cases.append(_case("uniform_dense_r5", x, y, t, b, 80, 60, 1, 5, 10000))
+    cases.append(_case("uniform_dense_r6_k24", x, y, t, b, 80, 60, 1, 6, 10000, K=24))
+    # K = 64 (the interface's maximum) on a dense blob: more sources wanted than one round of candidates holds
+    n = 5000
+    cases.append(_case("blob_k64", rng.integers(30, 44, n), rng.integers(20, 34, n),
+                       np.sort(rng.integers(990000, 1000001, n)), np.zeros(n), W, H, 1, 4, 10000, K=64))
+    return cases

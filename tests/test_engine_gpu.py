@@ -82,7 +82,7 @@ def _log(name, rec):
 
 def _path_counters(eng):
     """Which paths the last window took (device-side counters): pixels handed to k_fix_pixels (a segment beyond 64 events or
-    beyond Q / buckets) and those among them that hold more than Q events, destinations deferred by the row kernel to the
+    beyond Q) and those among them that hold more than Q events, destinations deferred by the row kernel to the
     position-centric walk (> 320 candidates), destinations the row kernel answered from the inner rings of their
     neighbourhood (> 200 candidates), unsorted-timestamp fallback, and -- cumulative -- level-0 nodes the pooling merged
     through its global path."""
@@ -617,6 +617,35 @@ def test_window_graph_with_the_image_branch():
         for rep in range(5):
             assert _decoded_err(eng, runs[rep][k], eager[k].cpu()) < 1e-4, (rep, k)
     assert _decoded_err(eng, runs[-1][0], runs[-1][1].cpu()) > 1e-3      # the two windows are different windows
+
+
+def test_window_graph_with_the_unfolded_image_trunk(monkeypatch):
+    """``DAGR_IMG_EPILOGUES=0`` keeps torchvision's own trunk forward: the feature maps then exist only after the whole
+    branch, and the pipelined window must still order every sampler behind the image stream (the fallback
+    recorded no per-map event, so the graph levels read the maps without a dependency).  Same outputs as the default
+    (epilogue-folded) engine to the library kernels' rounding, and every sampled map had its event."""
+    W, H, B = 320, 215, 2
+    args, model, sd = _setup(W, H, B, seed=13, use_image=True, img_net="resnet18")
+    win = _dev_window(syn.uniform_window, 4000, B, W, H, 51)
+    img = torch.rand((B, 3, H, W), generator=torch.Generator().manual_seed(7)).cuda()
+    with torch.no_grad():
+        want = model.engine().forward_raw(*win, image=img, trace={}).clone()
+        monkeypatch.setenv("DAGR_IMG_EPILOGUES", "0")
+        from dagr_amd.engine import WindowEngine
+        eng = WindowEngine(model).set_low_latency(True)
+        assert not eng.fuse_image_epilogues and eng.pipeline_image
+        seen = []
+        sample0 = eng._sample
+
+        def spy(*a, **k):
+            seen.append(eng._feat_ready is not None and id(a[5]) in eng._feat_ready)
+            return sample0(*a, **k)
+        eng._sample = spy
+        runs = [eng.forward_raw(*win, image=img).clone() for _ in range(5)]
+    assert eng._wg is not None and seen and all(seen), seen
+    eng.check_status()
+    for r in runs:
+        assert _decoded_err(eng, r, want.cpu()) < 1e-4
 
 
 def test_tail_graph_replay_matches_eager_launches():

@@ -5,7 +5,7 @@ import torch
 
 from oracle import graph as og
 from dagr_amd.utils import synthetic as syn
-from tests.graph_cases import small_cases, medium_cases, wide_radius_cases
+from tests.graph_cases import heavy_cases, small_cases, medium_cases, wide_radius_cases
 
 pytestmark = pytest.mark.gpu
 
@@ -227,21 +227,42 @@ def test_staged_device_count_build_equals_host_count_build(mutate):
         assert torch.equal(_edges(g1, want, n), _edges(g2, out, n)), (mutate, n)
 
 
-def test_time_bucketed_index_builds_the_same_graphs():
-    """The builder's index can carry a time dimension (DAGR_TIME_BUCKETS = n: keys (sample, y, time bucket, x), buckets one
-    delta_t wide; csrc/graph_build.hip, profiles/r5_search_buckets.md) -- off by default, because it only pays on dense
-    uniform streams.  The knob is read once per process, so the graph, property and asynchronous-update suites are run
-    again in a child process with five buckets: same oracle, same bit-exact assertions (two-bucket row ranges, segments
-    per (pixel, bucket), the FIFO depth counted over a pixel's buckets, the generic walk for unsorted timestamps)."""
-    import os
-    import subprocess
-    import sys
-    if os.environ.get("DAGR_TIME_BUCKETS"):
-        pytest.skip("already inside the bucketed run")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DAGR_TIME_BUCKETS="5")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", "tests/test_graph_gpu.py",
-                        "tests/test_properties_gpu.py", "tests/test_async_update_gpu.py"], cwd=root, env=env,
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout
+def _search_counters(case):
+    """{deferred to the position-centric walk, answered from the inner rings, unsorted} of one more build of the case."""
+    import ctypes
+    from dagr_amd import _lib
+    N = len(case["x"])
+    g = _builder(case, max(N, 16))
+    dev = torch.device("cuda:0")
+    pos = torch.from_numpy(np.stack([case["x"], case["y"], case["t"]], -1).astype(np.int32).reshape(N, 3)).to(dev)
+    g.build(pos, torch.from_numpy(case["b"].astype(np.int64)).to(dev))
+    out = (ctypes.c_int32 * 8)()
+    _lib.check(_lib.lib().dagr_graph_counters(ctypes.byref(g.desc), _lib.ptr(g.workspace), ctypes.cast(out, ctypes.c_void_p),
+                                              _lib.cur_stream(dev)), "counters")
+    return dict(walked=int(out[5]), inner=int(out[7]), unsorted=int(out[6]))
+
+
+@pytest.mark.parametrize("case", heavy_cases(), ids=lambda c: c["name"])
+def test_heavy_neighbourhoods_bit_exact(case):
+    """Event-dense neighbourhoods -- the row kernel's ring-limited passes (inner window first, then the parts left and right
+    of it) and the position-centric walk of the deferred ones -- == the oracle == (where oracle/_ref is built) the
+    reference's own insert_in_queue + fill_edges kernels run on this GPU, edge for edge; the counters show that the
+    intended path ran."""
+    ei, nbr_src, nbr_code, deg, ne, flags = _run_hip(case)
+    ref = _oracle(case)
+    assert flags == 0
+    assert ei.shape == ref.shape, (ei.shape, ref.shape)
+    assert (ei == ref).all()
+    assert ne == ref.shape[1] and deg.max() <= case["K"]
+    _check_codes(case, nbr_src, nbr_code, deg)
+    from oracle import ref_harness
+    if ref_harness.available():
+        own = ref_harness.reference_window_graph(case["x"], case["y"], case["t"], case["b"], case["W"], case["H"], case["B"],
+                                                 case["r"], case["dt"], K=case["K"], Q=case["Q"])
+        assert own.shape == ei.shape and (own == ei).all()
+    cnt = _search_counters(case)
+    assert cnt["unsorted"] == 0
+    if case["name"].startswith(("walk", "blob", "uniform_dense", "stale")):
+        assert cnt["walked"] > 0, cnt
+    if case["name"].startswith("edges_r7"):
+        assert cnt["inner"] > 0, cnt

@@ -164,21 +164,44 @@ def test_training_backward_is_deterministic():
         assert torch.equal(snaps[0][1][k], snaps[1][1][k]), k
 
 
-def test_two_forwards_before_one_backward_do_not_share_the_loss_graph():
+@pytest.mark.parametrize("mode", ["outputs_kept", "outputs_dropped", "use_image_outputs_dropped"])
+def test_two_forwards_before_one_backward_do_not_share_the_loss_graph(mode):
     """Gradient accumulation: two forwards of the same call site, ONE backward over the sum.  The graphed YOLOX loss owns
     static buffers, so the second forward must not replay it while the first one's backward is pending (it
-    silently produced wrong gradients); it takes the launch-by-launch form, and the result equals the all-eager run."""
+    silently produced wrong gradients); it takes the launch-by-launch form, and the result equals the all-eager run.
+    ``outputs_dropped``: the caller keeps only the running sum, so the first forward's loss TENSORS are gone while their
+    backward is pending; with ``--use_image`` the hybrid sum (dagr.py:262-268) drops them inside forward itself (ADVICE r5:
+    the guard must follow the autograd node, not the Python tensor)."""
     import os
     W, H, B = 240, 180, 2
-    args, model, _, batch, _, _ = _training_case(W, H, B, 3000, seed=6)
+    over = dict(use_image=True, img_net="resnet18") if mode.startswith("use_image") else {}
+    args, model, _, batch, _, _ = _training_case(W, H, B, 3000, seed=6, **over)
+    if over:
+        batch.image = torch.randint(0, 256, (B, 3, H, W), generator=torch.Generator().manual_seed(6), dtype=torch.uint8)
+        batch.bbox0 = batch.bbox.clone()
+        batch.bbox0[:, :2] -= 3.0
+        batch.bbox0_batch = batch.bbox_batch.clone()
 
     def accumulate():
         model.zero_grad(set_to_none=True)
-        o1 = model(format_data(batch.clone().cuda()))
-        o2 = model(format_data(batch.clone().cuda()))
-        (o1["total_loss"] + o2["total_loss"]).backward()
-        return float(o1["total_loss"]), float(o2["total_loss"]), \
-            {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        if mode == "outputs_kept":
+            o1 = model(format_data(batch.clone().cuda()))
+            o2 = model(format_data(batch.clone().cuda()))
+            (o1["total_loss"] + o2["total_loss"]).backward()
+            l1, l2 = float(o1["total_loss"]), float(o2["total_loss"])
+        else:
+            vals = []
+            acc = None
+            for _ in range(2):
+                loss = model(format_data(batch.clone().cuda()))["total_loss"]      # the output dict dies here
+                vals.append(loss.detach().clone())
+                acc = loss if acc is None else acc + loss
+                del loss
+            import gc
+            gc.collect()
+            acc.backward()
+            l1, l2 = float(vals[0]), float(vals[1])
+        return l1, l2, {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
     old = os.environ.pop("DAGR_GRAPH_LOSS", None)
     try:
         a1, a2, ga = accumulate()                 # graph for the first forward, launch-by-launch for the second
@@ -189,12 +212,15 @@ def test_two_forwards_before_one_backward_do_not_share_the_loss_graph():
         os.environ.pop("DAGR_GRAPH_LOSS", None)
         if old is not None:
             os.environ["DAGR_GRAPH_LOSS"] = old
-    assert a1 == b1 and a2 == b2 and e1 == e2
-    assert abs(a1 - e1) <= 1e-6 * max(1.0, abs(e1)) and abs(a2 - e2) <= 1e-6 * max(1.0, abs(e2))
+    tol = 1e-5 if mode.startswith("use_image") else 1e-6
+    if not mode.startswith("use_image"):
+        assert a1 == b1 and a2 == b2 and e1 == e2
+    assert abs(a1 - e1) <= tol * max(1.0, abs(e1)) and abs(a2 - e2) <= tol * max(1.0, abs(e2))
     assert ga.keys() == ge.keys() and len(ga) >= 60
+    image = mode.startswith("use_image")        # (the image branch's convolutions are library kernels with atomics)
     for k in ga:
-        assert torch.equal(ga[k], gb[k]), k
-        assert _rel(ga[k], ge[k]) < 1e-6, (k, _rel(ga[k], ge[k]))
+        assert image or torch.equal(ga[k], gb[k]), k
+        assert _rel(ga[k], ge[k]) < (1e-4 if image else 1e-6), (k, _rel(ga[k], ge[k]))
     # and a forward whose loss was dropped without a backward does not block the graph for good
     model.zero_grad(set_to_none=True)
     model(format_data(batch.clone().cuda()))
