@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--no-latency", action="store_true", help="skip the per-window latency sweep")
     ap.add_argument("--no-rccl", action="store_true", help="world 1: no one-rank process group (plain barriers, local gather)")
     ap.add_argument("--no-events-only-leg", action="store_true", help="skip the events-only sub-measurement")
+    ap.add_argument("--no-side-legs", action="store_true", help="skip the other-stream and the H2D-inclusive legs")
     ap.add_argument("--events-only", action="store_true",
                     help="make the events-only model (BASELINE config 1 shape) the headline instead of config 2")
     ap.add_argument("--img-net", default="resnet50")
@@ -61,7 +62,8 @@ def parse():
                     help="independent engine instances (own buffers + stream) that consecutive window batches "
                          "rotate through; windows share no state, so batch i's latency-bound tail overlaps the level 0 "
                          "of batches i+1, i+2")
-    ap.add_argument("--cpu-steps", type=int, default=3, help="steps the CPU baseline legs time (median is reported)")
+    ap.add_argument("--cpu-steps", type=int, default=5, help="steps the CPU baseline legs time after one untimed warm-up "
+                                                             "step (median is reported; x --cpu-batch windows each)")
     ap.add_argument("--cpu-batch", type=int, default=2,
                     help="windows per CPU-baseline step (a bounded sample of the GPU step's --batch windows of the same "
                          "size; the oracle's cost is linear in the number of windows)")
@@ -184,8 +186,8 @@ def cpu_baseline(model_cpu, model_sd, W, H, B, n_events, n_steps, stream, use_im
     r, dt = og.graph_params(a.radius, W, 1000000)
     times, t_graph = [], []
     with torch.no_grad(), ThreadPoolExecutor(max_workers=min(B, os.cpu_count() or 1)) as pool:
-        for w in range(n_steps):
-            x, y, t, p, b = syn.batch_windows(gen, n_events, B, W, H, seed=1234 + 10 * w)
+        for w in range(-1, n_steps):          # step -1: one untimed warm-up step (allocator, thread pools, cold caches)
+            x, y, t, p, b = syn.batch_windows(gen, n_events, B, W, H, seed=1234 + 10 * max(w, 0))
             t0 = time.perf_counter()
             image_feat = cnn_out = None
             if use_image:
@@ -204,17 +206,21 @@ def cpu_baseline(model_cpu, model_sd, W, H, B, n_events, n_steps, stream, use_im
                 return og.build_window_graph(dpos[sl, 0], dpos[sl, 1], dpos[sl, 2], np.zeros(lo[s + 1] - lo[s], np.int32),
                                              W, H, 1, r, dt, K=a.max_neighbors, Q=128) + lo[s]
             ei = np.concatenate(list(pool.map(one, range(B))), axis=1)
-            t_graph.append(time.perf_counter() - tg)
+            tg = time.perf_counter() - tg
             om.forward_events(model_sd, a, H, W, x, y, t, p, b, B, image_feat=image_feat, cnn_out=cnn_out,
                               edge_index=torch.from_numpy(ei))
-            times.append(time.perf_counter() - t0)
+            if w >= 0:
+                t_graph.append(tg)
+                times.append(time.perf_counter() - t0)
     med = float(np.median(times))
     what = f"dagr-s + {img_net} image branch" if use_image else "events-only dagr-s"
     return dict(value=B * n_events / med, unit="events/s", cores=torch.get_num_threads(), kind="port",
                 windows_per_step=B, ms_per_window=round(1e3 * med / B, 1),   # (the GPU line's step holds gpu_windows_per_step)
                 step_ms_median=round(1e3 * med, 1), step_ms_all=[round(1e3 * t, 1) for t in times],
                 graph_ms_median=round(1e3 * float(np.median(t_graph)), 1), graph_threads=min(B, os.cpu_count() or 1),
-                sample=f"median of {n_steps} steps of B={B} windows x {n_events} events, {W}x{H}, {what} (the GPU line's "
+                windows_timed=B * n_steps,
+                sample=f"median of {n_steps} steps (after one untimed warm-up step) of B={B} windows x {n_events} events = "
+                       f"{B * n_steps} windows, {W}x{H}, {what} (the GPU line's "
                        f"windows and model, {B} windows per step instead of the GPU step's batch); oracle/model.py "
                        f"(torch-CPU fp32 on {torch.get_num_threads()} threads + C graph builder, one thread per sample), "
                        f"{sum(times):.1f} s of CPU work")
@@ -295,6 +301,78 @@ class Rig:
         cur = torch.cuda.current_stream(self.dev)
         for st in self.streams:
             cur.wait_stream(st)
+
+
+def h2d_run(rig, gen, npw, steps, warmup, seed):
+    """The step as ``utils/testing.py:29`` pays it: every window batch starts in HOST memory in the loader's dtypes (pos
+    int16[N,2], t int32[N], polarity int8[N], sample index int64[N], frame uint8[B,3,H,W]; pinned), is copied with
+    ``non_blocking`` copies on a copy stream into one of two device staging sets, formatted on the device
+    (``format_data``: dagr_format_events, frame / 255) and run through forward + post-processing.  The copy of batch i + 1
+    overlaps the compute of batch i.  Returns (elapsed seconds of `steps` steps, bytes copied per step)."""
+    from dagr_amd import _lib
+    from dagr_amd.model.utils import postprocess_device
+    from dagr_amd.utils import synthetic as syn
+    dev, B, W, H = rig.dev, rig.B, rig.W, rig.H
+    host = []
+    for s in range(4):
+        x, y, t, p, b = syn.batch_windows(gen, npw, B, W, H, seed=seed + 10 * s)
+        h = dict(xy=torch.from_numpy(np.stack([x, y], -1).astype(np.int16)).pin_memory(),
+                 t=torch.from_numpy(t.astype(np.int32)).pin_memory(), p=torch.from_numpy(p.astype(np.int8)).pin_memory(),
+                 b=torch.from_numpy(b.astype(np.int64)).pin_memory())
+        if rig.use_image:
+            h["img"] = torch.randint(0, 256, (B, 3, H, W), dtype=torch.uint8,
+                                     generator=torch.Generator().manual_seed(77 + s)).pin_memory()
+        host.append(h)
+    nbytes = sum(v.numel() * v.element_size() for v in host[0].values())
+    n_eng = len(rig.engines)
+    S = n_eng + 1                                # staging sets: one per engine in flight + the one being filled
+    stage = [{k: torch.empty_like(v, device=dev) for k, v in host[0].items()} for _ in range(S)]
+    copy_stream = torch.cuda.Stream(dev)
+    copied = [torch.cuda.Event() for _ in range(S)]
+    consumed = [torch.cuda.Event() for _ in range(S)]
+    L = _lib.lib()
+
+    def issue_copy(i):
+        st = stage[i % S]
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(consumed[i % S])          # the staging set's previous batch has been formatted
+            for k, v in host[i % len(host)].items():
+                st[k].copy_(v, non_blocking=True)
+            copied[i % S].record(copy_stream)
+
+    def step(i):
+        st = stage[i % S]
+        k = i % n_eng
+        eng, stream = rig.engines[k], rig.streams[k]
+        with torch.cuda.stream(stream):
+            stream.wait_event(copied[i % S])
+            N = st["t"].shape[0]
+            pos = torch.empty((N, 3), dtype=torch.float32, device=dev)
+            feat = torch.empty((N, 1), dtype=torch.float32, device=dev)
+            _lib.check(L.dagr_format_events(_lib.ptr(st["xy"]), _lib.ptr(st["t"]), _lib.ptr(st["p"]), N, W, H, 1000000,
+                                            _lib.ptr(pos), _lib.ptr(feat), _lib.cur_stream(dev)), "format_events")
+            image = st["img"].float() / 255.0 if rig.use_image else None
+            batch = st["b"].clone()
+            consumed[i % S].record(stream)
+            out = eng.forward_raw(pos, feat, batch, image=image, static_out=True)
+            return postprocess_device(out, rig.num_classes, rig.model.conf_threshold, rig.model.nms_threshold, H, W)
+    cur = torch.cuda.current_stream(dev)
+    for e in consumed:
+        e.record(cur)
+    torch.cuda.synchronize()
+    issue_copy(0)
+    for i in range(warmup):
+        issue_copy(i + 1)
+        step(i)
+    rig.drain()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(warmup, warmup + steps):
+        issue_copy(i + 1)
+        step(i)
+    rig.drain()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, nbytes
 
 
 def detections_rows(results, rank, B):
@@ -501,7 +579,6 @@ def latency_sweep(W, H, use_image, img_net, dev, Ns, n_warm, n_timed):
     """Per-window latency: one window batch at a time through ONE engine; the device is idle when a window starts
     (synchronize), HIP events bracket forward + post-processing on the engine's stream."""
     from dagr_amd.utils import synthetic as syn
-    from dagr_amd.model.utils import postprocess_device
     out = {}
     for B in (1, 8):
         rig = Rig(W, H, B, use_image, img_net, 1, dev, low_latency=True)
@@ -512,9 +589,9 @@ def latency_sweep(W, H, use_image, img_net, dev, Ns, n_warm, n_timed):
 
                 def window(i):
                     pos, feat, batch, image = slots[i % 2]
-                    # forward + post-processing as DAGR.forward runs them (the outputs are consumed at once)
-                    o = eng.forward_raw(pos, feat, batch, image=image, static_out=True)
-                    return postprocess_device(o, rig.num_classes, 0.001, 0.65, H, W)
+                    # forward + post-processing as DAGR.forward runs them in latency mode: ONE captured graph from the
+                    # staged events to det[B, A, 6] + n_keep[B] (engine.forward_detections; thresholds = the model's)
+                    return eng.forward_detections(pos, feat, batch, image=image)
                 for i in range(n_warm):
                     window(i)
                 torch.cuda.synchronize()
@@ -538,10 +615,13 @@ def latency_sweep(W, H, use_image, img_net, dev, Ns, n_warm, n_timed):
     return out
 
 
-def dry_run(a, world, rank):
+def dry_run(a, world, rank, rank_env, t_start):
     """--dry-run-gloo: every step of a multi-rank run except the model, on CPU."""
     import torch.distributed as dist
     dist.init_process_group("gloo")
+    envs = [None] * world
+    dist.all_gather_object(envs, dict(rank=rank, miopen_db=rank_env["miopen_db"], cores=rank_env["cores"],
+                                      startup_s=round(time.perf_counter() - t_start, 3)))
     run = timed_run(DryRunRig(rank), None, a.steps, a.warmup, dist, world, rank)
     if rank == 0:
         print(json.dumps({"metric": "events_per_sec", "value": None, "unit": "events/s", "n_gpus": world, "world": world,
@@ -549,7 +629,7 @@ def dry_run(a, world, rank):
                           "ms_per_step": round(1e3 * run["elapsed"] / a.steps, 4), "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "dry-run (gloo, no device)",
                           "config": {"workload": "control flow only: DryRunRig"},
-                          "gather": {"detections": run["n_detections"]},
+                          "gather": {"detections": run["n_detections"]}, "rank_env": envs,
                           "per_rank": [dict(compute_ms=round(1e3 * c, 3), gather_ms=round(1e3 * g, 3))
                                        for c, g in run["per_rank"]]}), flush=True)
     dist.barrier()
@@ -562,7 +642,6 @@ def async_update_leg(W, H, dev, n_window=25000, sizes=(1, 10, 100), n_updates=10
     device idle at the start of each update; beside it the re-evaluation of the whole window (what reset=False cost before
     the incremental update existed)."""
     from dagr_amd.utils import synthetic as syn
-    from dagr_amd.model.utils import postprocess_device
     rig = Rig(W, H, 1, False, "resnet50", 1, dev, low_latency=True)
     eng = rig.engines[0]
     n_extra = max(sizes) * (n_updates + n_warm)
@@ -583,18 +662,16 @@ def async_update_leg(W, H, dev, n_window=25000, sizes=(1, 10, 100), n_updates=10
             ms.append(e0.elapsed_time(e1))
         return np.array(ms)
 
-    def post(o):
-        return postprocess_device(o, rig.num_classes, 0.001, 0.65, H, W)
     out = {"window_events": n_window, "protocol": f"{n_warm} warm-up + {n_updates} timed updates per micro-batch size, one at "
                                                    "a time, HIP events around update + post-processing"}
-    full = timed(lambda i: post(eng.forward_raw(pos[:n_window], feat[:n_window], batch[:n_window], static_out=True)), 30)[10:]
+    full = timed(lambda i: eng.forward_detections(pos[:n_window], feat[:n_window], batch[:n_window]), 30)[10:]
     out["reevaluate_window_us"] = dict(p50=round(1e3 * float(np.median(full)), 1), p95=round(1e3 * float(np.percentile(full, 95)), 1))
     for m in sizes:
         eng.forward_raw(pos[:n_window], feat[:n_window], batch[:n_window])
 
         def upd(i, m=m):
             lo = n_window + i * m
-            post(eng.forward_append(pos[lo:lo + m], feat[lo:lo + m], batch[lo:lo + m], static_out=True))
+            eng.forward_detections(pos[lo:lo + m], feat[lo:lo + m], batch[lo:lo + m], append=True)
         us = 1e3 * timed(upd, n_warm + n_updates)[n_warm:]
         eng.check_status()
         out[f"update_{m}_events_us"] = dict(p50=round(float(np.median(us)), 1), p95=round(float(np.percentile(us, 95)), 1),
@@ -627,8 +704,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
+    t_start = time.perf_counter()
+    from dagr_amd import parallel as _parallel
+    rank_env = _parallel.rank_environment()         # per-rank MIOpen db + core slice, before anything touches the device
     if a.dry_run_gloo:
-        return dry_run(a, world, rank)
+        return dry_run(a, world, rank, rank_env, t_start)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
     real_out = _claim_stdout()
     if torch.cuda.device_count() <= local_rank:
@@ -674,6 +754,16 @@ def main():
         ev_slots = ev_rig.make_slots(gen, NPW, 4, seed=1234 + 1000 * rank)
         ev_leg = timed_run(ev_rig, ev_slots, a.steps, a.warmup, dist, world, rank)
 
+    # ---- the same step on the other synthetic stream (S-edges when the line is S-uniform and vice versa) and with the
+    # window batches starting in host memory (what the reference's loop pays per batch, utils/testing.py:29)
+    other = h2d = None
+    if world == 1 and not a.no_side_legs:
+        other_gen = syn.edges_window if a.stream == "uniform" else syn.uniform_window
+        o_slots = rig.make_slots(other_gen, NPW, 4, seed=1234 + 1000 * rank)
+        other = timed_run(rig, o_slots, a.steps, a.warmup, None, 1, rank)
+        del o_slots
+        h2d = h2d_run(rig, gen, NPW, a.steps, a.warmup, seed=1234 + 1000 * rank)
+
     result = None
     if rank == 0:
         ms_per_step = 1e3 * run["elapsed"] / a.steps
@@ -698,6 +788,17 @@ def main():
                        "backend": ("nccl (RCCL)" if dist is not None else "none"), "note": rccl_note},
             "roofline": st["roofline"], "stages": st["stages"],
         }
+        if other is not None:
+            oname = "edges" if a.stream == "uniform" else "uniform"
+            result["value_" + oname] = round(n_events_step * a.steps / other["elapsed"], 1)
+            result["ms_per_step_" + oname] = round(1e3 * other["elapsed"] / a.steps, 4)
+        if h2d is not None:
+            # the line's engines, copies on a copy stream under the previous batches' compute; `value` above has its inputs resident
+            result["value_h2d"] = round(n_events_step * a.steps / h2d[0], 1)
+            result["h2d"] = {"ms_per_step": round(1e3 * h2d[0] / a.steps, 4), "MB_per_step": round(h2d[1] / 1e6, 2),
+                             "engines": n_eng, "protocol": "pinned host batches in the loader's dtypes (int16 xy, int32 t, int8 "
+                             "polarity, int64 sample index, uint8 frames) -> non_blocking copies on a copy stream into two "
+                             "staging sets -> format_data on the device -> forward + post-processing; copy i+1 under compute i"}
         if st["image_branch"] is not None:
             ib = dict(st["image_branch"])
             ib["share_of_step"] = round(ib["ms"] / ms_per_step, 3)     # one engine's isolated stage time over the step time

@@ -338,6 +338,11 @@ class WindowEngine:
         self._cnn_out = None
         self._img_stream = None
         self._feat_ready = None                 # pipelined window: event per feature map (keyed by the map's id)
+        # detection post-processing captured with the window / tail graph (forward_detections): thresholds it was captured
+        # with, its static outputs, and whether the last forward ran it
+        self._post_key = None
+        self._det = self._n_keep = None
+        self._post_fresh = False
         self._cnn_ready = None
         # captured --use_image windows: graph levels start when THEIR feature map exists (builder knob to A/B)
         self.pipeline_image = os.environ.get("DAGR_PIPELINE_IMAGE", "1") != "0"
@@ -1226,6 +1231,43 @@ class WindowEngine:
             cur.wait_event(self._head_join)
         return self._heads_finish()
 
+    def _post_launch(self, out):
+        """``postprocess_network_output`` (model/utils.py:61-110; dagr.py:94-95) of the decoded outputs as the LAST launch of
+        a captured window / tail: det[B, A, 6] + n_keep[B] in static buffers.  Only when a caller asked for detections
+        (forward_detections): raw-output callers do not pay for it."""
+        if self._post_key is None:
+            return
+        B, A, C = out.shape
+        if self._det is None or tuple(self._det.shape) != (B, A, 6):
+            self._det = torch.empty((B, A, 6), dtype=torch.float32, device=self.device)
+            self._n_keep = torch.empty((B,), dtype=torch.int32, device=self.device)
+        conf, nms = self._post_key
+        _lib.check(self.L.dagr_postprocess(_lib.ptr(out), B, A, int(self.num_classes), conf, nms,
+                                           float(max(self.W, self.H) + 1), _lib.ptr(self._det), _lib.ptr(self._n_keep),
+                                           _lib.cur_stream(self.device)), "postprocess")
+        self._post_fresh = True
+
+    def forward_detections(self, pos, feat, batch, image=None, append=False):
+        """One window (``append``: one asynchronous update) through forward + post-processing: ``(det[B, A, 6], n_keep[B])``
+        as ``model.utils.postprocess_device`` returns them, valid until the engine's next call.  In latency mode the
+        post-processing is part of the captured graph: no launch, and no host time, between the heads and the NMS."""
+        from .model.utils import postprocess_device
+        key = (float(self.model.conf_threshold), float(self.model.nms_threshold))
+        if key != self._post_key:                   # (re)capture with these thresholds
+            self._post_key = key
+            self._wg = None
+            self._wg_warm = 0
+            self._graph = None
+            self._graph_warm = 0
+        self._post_fresh = False
+        if append:
+            out = self.forward_append(pos, feat, batch, static_out=True)
+        else:
+            out = self.forward_raw(pos, feat, batch, image=image, static_out=True)
+        if self._post_fresh:
+            return self._det, self._n_keep
+        return postprocess_device(out, self.num_classes, key[0], key[1], self.H, self.W)
+
     def forward_raw(self, pos, feat, batch, image=None, trace=None, image_handle=None, static_out=False):
         """pos fp32[N,3] normalised (format_data), feat fp32[N,1], batch int32/int64[N] on the device;
         image fp32[B,3,H,W] in [0,1] when the model was built with --use_image.
@@ -1321,7 +1363,9 @@ class WindowEngine:
             self.stage_l0_conv1()
             self.stage_l0_conv2()
             self.stage_pool1()
-            return self._tail_and_head()
+            out = self._tail_and_head()
+            self._post_launch(out)
+            return out
         finally:
             self._dev_mode = False
 
@@ -1360,6 +1404,7 @@ class WindowEngine:
         else:
             self._wg.replay()
             out = self._wg_out
+            self._post_fresh = self._post_key is not None
         # the resident window (what check_status / an asynchronous update / the probes look at): the actual count
         self._N = N
         self._n_rows = N
@@ -1377,12 +1422,16 @@ class WindowEngine:
         if self._graph is None:
             if self._graph_warm < 2:                 # lazy one-time work (function attributes, allocator) stays eager
                 self._graph_warm += 1
-                return self._tail_and_head()
+                out = self._tail_and_head()
+                self._post_launch(out)
+                return out
             g = torch.cuda.CUDAGraph()
             with _capture(g):
                 out = self._tail_and_head()
+                self._post_launch(out)
             self._graph, self._graph_out = g, out
         self._graph.replay()
+        self._post_fresh = self._post_key is not None
         return self._graph_out if static_out else self._graph_out.clone()   # rewritten by the next window
 
     def _decode_maps(self, dense_maps):
@@ -1454,6 +1503,13 @@ class WindowEngine:
                 v = int(v[0]) if hasattr(v, "__len__") else int(v)
                 if v != want:
                     raise RuntimeError(f"data.{name} = {v}, but the model was built for {want}")
+
+    def forward_detections_data(self, data):
+        """``forward_detections`` on ``DAGR.forward``'s input contract."""
+        batch = data.batch if getattr(data, "batch", None) is not None else \
+            torch.zeros(data.pos.shape[0], dtype=torch.int64, device=data.pos.device)
+        self.check_batch(data)
+        return self.forward_detections(data.pos.float(), data.x.float(), batch, image=getattr(data, "image", None))
 
     def forward_data(self, data, static_out=False):
         """``DAGR.forward`` input contract: ``data`` after ``format_data`` (pos fp32[N,3] normalised,

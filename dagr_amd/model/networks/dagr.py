@@ -8,7 +8,8 @@ import torch
 
 from ..layers.conv import ConvBlock
 from ..layers.spline_conv import SplineConvToDense
-from ..utils import voxel_size_to_params, postprocess_network_output, convert_to_evaluation_format
+from ..utils import (voxel_size_to_params, postprocess_network_output, convert_to_evaluation_format,
+                     detections_from_device)
 from .net import Net
 from .yolox_min import YOLOXHeadParams
 
@@ -351,9 +352,13 @@ class DAGR(torch.nn.Module):
         eng.check_batch(x)
         if reset:
             self._window = None                  # a new window: the running one is gone
+        det_dev = None           # (det, n_keep) when forward + post-processing ran as one captured graph
         if reset or self._window is None:
             # a window of its own (every evaluation script's call), or the first call of an asynchronous run
-            outputs = eng.forward_data(x, static_out=filtering)      # post-processed below, before the next window
+            if filtering and eng.window_graph:
+                det_dev = eng.forward_detections_data(x)
+            else:
+                outputs = eng.forward_data(x, static_out=filtering)  # post-processed below, before the next window
             # only remembered: a later reset=False call continues from it.  A running window keeps the FRAME of the call
             # that opened it (DSEC: the image at the start of the window, dsec_data.py:141-184); later micro-batches
             # bring events only, in the incremental and in the re-evaluating mode alike.
@@ -366,7 +371,10 @@ class DAGR(torch.nn.Module):
             # far -- the guarantee the reference's asynchronous model gives for its update (evaluate_flops.py:139-147).
             batch = x.batch if getattr(x, "batch", None) is not None else \
                 torch.zeros(x.pos.shape[0], dtype=torch.int64, device=x.pos.device)
-            outputs = eng.forward_append(x.pos, x.x, batch, static_out=filtering)
+            if filtering and eng.tail_graph:
+                det_dev = eng.forward_detections(x.pos, x.x, batch, append=True)
+            else:
+                outputs = eng.forward_append(x.pos, x.x, batch, static_out=filtering)
             self._window.append(_window_part(x))
             if len(self._window) > 64:           # bounded bookkeeping on long streams: one concatenated part
                 _concat_window(self._window)
@@ -378,9 +386,12 @@ class DAGR(torch.nn.Module):
             pos, feat, batch = _concat_window(self._window)
             outputs = eng.forward_raw(pos, feat, batch, image=self._window_image)
             eng._async_on = False
-        detections = postprocess_network_output(outputs, self.backbone.num_classes, self.conf_threshold,
-                                                self.nms_threshold, filtering=filtering, height=self.height,
-                                                width=self.width)
+        if det_dev is not None:
+            detections = detections_from_device(*det_dev)
+        else:
+            detections = postprocess_network_output(outputs, self.backbone.num_classes, self.conf_threshold,
+                                                    self.nms_threshold, filtering=filtering, height=self.height,
+                                                    width=self.width)
         if self.check_device_status:
             # sticky device-side flags (events outside the sensor / batch range, pooled-level capacity overflows,
             # to_dense cells outside the map): a window that tripped one was computed on a truncated graph.  The

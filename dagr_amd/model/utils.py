@@ -41,10 +41,15 @@ def postprocess_network_output(prediction, num_classes, conf_thre=0.01, nms_thre
         class_conf, class_pred = torch.max(prediction[..., 5:5 + num_classes], dim=-1)
         scores = prediction[..., 4] * class_conf                                       # image_pred[:, 4:5] *= class_conf
         return [{"boxes": boxes[b], "scores": scores[b], "labels": class_pred[b].long()} for b in range(B)]
-    det, n_keep = postprocess_device(prediction, num_classes, conf_thre, nms_thre, height, width)
-    # ONE D2H copy (the B survivor counts) cuts the per-image dicts: the reference's return type is variable-length,
-    # so one synchronisation is inherent
+    return detections_from_device(*postprocess_device(prediction, num_classes, conf_thre, nms_thre, height, width))
+
+
+def detections_from_device(det, n_keep):
+    """``(det[B, A, 6], n_keep[B])`` -> the reference's per-image dicts (model/utils.py:104-108).  ONE D2H copy (the B
+    survivor counts) cuts them: the return type is variable-length, so one synchronisation is inherent.  The rows are
+    copied out of `det` (a captured window hands out its static buffer, rewritten by the next one)."""
     counts = n_keep.tolist()
+    det = det.clone()
     return [{"boxes": det[b, :n, :4], "scores": det[b, :n, 4], "labels": det[b, :n, 5].long()}
             for b, n in enumerate(counts)]
 

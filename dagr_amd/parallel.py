@@ -10,6 +10,44 @@ import torch
 import torch.distributed as dist
 
 
+def rank_environment(local_rank=None, local_world=None, apply=True):
+    """What one process of an N-rank job on one node sets up BEFORE its first kernel, so that eight ranks starting together
+    do not step on each other (each call is a no-op at N = 1):
+      * ``MIOPEN_USER_DB_PATH`` / ``MIOPEN_CUSTOM_CACHE_DIR`` per rank: with ``cudnn.benchmark`` every rank runs MIOpen's
+        find at start-up and WRITES its user perf-db; eight processes would share one file otherwise;
+      * CPU affinity: rank r gets the r-th contiguous slice of the host cores this process may run on (launch-bound host
+        threads of eight ranks do not migrate over each other), and torch's intra-op pool is sized to the slice.
+    Reads LOCAL_RANK / LOCAL_WORLD_SIZE (``torch.distributed.run`` sets both).  Returns what it chose."""
+    import os
+    if local_rank is None:
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if local_world is None:
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    out = dict(local_rank=local_rank, local_world=local_world, miopen_db=None, cores=None)
+    if local_world <= 1:
+        return out
+    base = os.environ.get("DAGR_RANK_CACHE_DIR", os.path.join(os.environ.get("TMPDIR", "/tmp"), "dagr_rank_cache"))
+    db = os.path.join(base, f"miopen_rank{local_rank}")
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+    except AttributeError:                       # (not Linux)
+        avail = list(range(os.cpu_count() or 1))
+    per = max(1, len(avail) // local_world)
+    cores = avail[(local_rank * per) % len(avail):][:per] or avail
+    out.update(miopen_db=db, cores=cores)
+    if apply:
+        os.makedirs(db, exist_ok=True)
+        os.environ.setdefault("MIOPEN_USER_DB_PATH", db)
+        os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", db)
+        try:
+            os.sched_setaffinity(0, cores)
+        except (AttributeError, OSError):
+            pass
+        torch.set_num_threads(max(1, len(cores)))
+        out["miopen_db"] = os.environ["MIOPEN_USER_DB_PATH"]
+    return out
+
+
 def shard_indices(num_items, rank, world_size):
     """Window w -> rank w mod G; returns this rank's window indices in order."""
     return list(range(rank, num_items, world_size))

@@ -76,6 +76,7 @@ def distributed():
     """(world, rank, device) of a ``torch.distributed.run`` launch (one process per GPU); backend "nccl" = RCCL."""
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    parallel.rank_environment()      # N ranks on a node: a MIOpen perf-db and a slice of the host cores per rank
     if torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)

@@ -111,3 +111,27 @@ def test_eight_ranks_as_the_driver_launches_them():
     assert line["scaling"] == "weak" and line["steps"] == 3
     assert all(set(r) == {"compute_ms", "gather_ms"} for r in line["per_rank"])
     assert line["gather"]["detections"] == sum((r + i + b) % 4 for r in range(8) for i in range(3) for b in range(3))
+    # every rank set itself up apart from the others before touching anything: its own MIOpen user db (eight processes
+    # running the benchmark-mode find at start-up would otherwise write one file) and its own slice of the host cores
+    envs = sorted(line["rank_env"], key=lambda e: e["rank"])
+    assert [e["rank"] for e in envs] == list(range(8))
+    assert len({e["miopen_db"] for e in envs}) == 8 and all(e["miopen_db"].endswith(f"miopen_rank{e['rank']}") for e in envs)
+    cores = [tuple(e["cores"]) for e in envs]
+    n_host = len(os.sched_getaffinity(0))
+    assert all(len(c) == max(1, n_host // 8) for c in cores)
+    if n_host >= 8:
+        assert len(set(c for cs in cores for c in cs)) == sum(len(c) for c in cores)      # disjoint slices
+    # start-up (interpreter + imports + environment, to the first collective) of eight ranks started together
+    assert max(e["startup_s"] for e in envs) < 120
+
+
+def test_rank_environment_is_a_no_op_for_one_rank(monkeypatch):
+    from dagr_amd import parallel
+    for k in ("LOCAL_RANK", "LOCAL_WORLD_SIZE", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    before = os.sched_getaffinity(0)
+    out = parallel.rank_environment()
+    assert out["miopen_db"] is None and out["cores"] is None and os.sched_getaffinity(0) == before
+    plan = parallel.rank_environment(local_rank=3, local_world=8, apply=False)
+    assert plan["miopen_db"].endswith("miopen_rank3") and len(plan["cores"]) == max(1, len(before) // 8)
+    assert os.sched_getaffinity(0) == before

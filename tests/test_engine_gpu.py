@@ -188,7 +188,12 @@ def _compare(args, model, sd, W, H, B, x, y, t, p, b, pos, image=None, plain=Fal
     if log:
         _log(log, rec)
     assert rel < TOL, f"decoded outputs differ by {rel}"
-    assert _err(out_h.cpu()[..., :4], out_o[..., :4]) < 100 * TOL
+    # (the loose direct bound on the decoded boxes: wh = exp(logit) * stride overflows fp32 on some anchors of random-weight
+    # models at the largest windows -- there both sides must overflow alike, the finite entries are compared)
+    bh, bo = out_h.cpu()[..., :4], out_o[..., :4]
+    fin = torch.isfinite(bo)
+    assert torch.equal(torch.isfinite(bh), fin) and torch.equal(bh[~fin], bo[~fin])
+    assert _err(torch.where(fin, bh, torch.zeros_like(bh)), torch.where(fin, bo, torch.zeros_like(bo))) < 100 * TOL
     return out_h
 
 
@@ -425,6 +430,17 @@ def test_dagr_l_resnet50_b8():
                  image=_bench_image(B, H, W, 79), plain=True, log="dagr_l_resnet50_b8")
 
 
+def test_dagr_l_resnet50_vga_b8_100k():
+    """BASELINE config 4 at the size ``tools/config_probe.py`` reports it (profiles/*_config_probe.jsonl): dagr-l + --use_image
+    --img_net resnet50, 640x480, B = 8 x 100 k S-uniform events -- the deep, wide levels under the bench's own stream."""
+    W, H, B = 640, 480, 8
+    args, model, sd = _setup(W, H, B, seed=10, calibrate=syn.uniform_window, use_image=True, img_net="resnet50",
+                             net_stem_width=1.0, yolo_stem_width=1.0)
+    with torch.no_grad():
+        _compare(args, model, sd, W, H, B, *_events(syn.uniform_window, 100000, B, W, H, seed=1234),
+                 image=_bench_image(B, H, W, 80), plain=True, log="dagr_l_resnet50_vga_b8_100k")
+
+
 def _last_log(name):
     import json
     import os
@@ -462,18 +478,20 @@ def test_vga_b1_dense_windows(stream, n):
     assert paths["pool1_global_path"] > 0          # the window's t == 1.0 event (QUIRK-1) at least
 
 
-@pytest.mark.parametrize("stream,n", [("edges", 200000)])
+@pytest.mark.parametrize("stream,n", [("edges", 200000), ("uniform", 400000)])
 def test_vga_b8_dense_windows(stream, n):
     """The B = 8 columns of bench.py's latency table beyond 100 k events per window (1.6 M events per step): the same
-    stage-by-stage comparison as the B = 1 cases above, eight sample planes at once (VERDICT r4 missing #3; the 8 x 400 k
-    S-uniform column was run once the same way in round 5 -- 3.2 M events take the CPU oracle two minutes --
-    profiles/r5_parity_stage_errors.jsonl: every stage within 7.4e-5)."""
+    stage-by-stage comparison as the B = 1 cases above, eight sample planes at once -- the 8 x 200 k S-edges column and the
+    largest one, 8 x 400 k S-uniform (3.2 M events: the CPU oracle takes two minutes on it)."""
     W, H, B = 640, 480, 8
     gen = syn.uniform_window if stream == "uniform" else syn.edges_window
     args, model, sd = _setup(W, H, B, seed=3, calibrate=gen)
     name = f"vga_b8_{stream}_{n // 1000}k"
     _compare(args, model, sd, W, H, B, *_events(gen, n, B, W, H, seed=4234), plain=True, log=name)
-    assert _last_log(name)["paths"]["deferred"] > 0, "the dense-neighbourhood path did not run"
+    paths = _last_log(name)["paths"]
+    assert paths["deferred"] > 0, "the dense-neighbourhood path did not run"
+    if stream == "uniform":
+        assert paths["ring_limited"] > 0, "no neighbourhood was answered from its inner rings"
 
 
 def test_bench_workload_dagr_s_resnet50_vga_b8_100k_edges():
@@ -596,6 +614,54 @@ def test_window_graph_replay_matches_eager_launches():
         assert torch.equal(eng.forward_raw(*big), want)
     assert eng.max_events > cap0 and eng._wg is not None
     assert torch.equal(eng.forward_raw(*wins[0]), eager[0])
+
+
+def test_detections_come_out_of_the_captured_window():
+    """Latency mode: ``forward_detections`` replays forward + post-processing (confidence mask, class-offset NMS,
+    model/utils.py:61-110) as ONE captured graph -- det / n_keep bit-identical to the launch-by-launch forward followed by
+    ``postprocess_device``, for windows of different sizes through the same graph, after a change of the thresholds
+    (re-capture), and for asynchronous updates through the captured tail."""
+    from dagr_amd.model.utils import postprocess_device
+    W, H, B = 320, 215, 2
+    args, model, sd = _setup(W, H, B, seed=12)
+    eng = model.engine().set_low_latency(True)
+    wins = [_dev_window(syn.edges_window, n, B, W, H, seed) for n, seed in ((4000, 41), (2500, 43), (6000, 45))]
+
+    def want(w, conf, nms):
+        o = eng.forward_raw(*w, trace={})
+        det, nk = postprocess_device(o, eng.num_classes, conf, nms, H, W)
+        return det.clone(), nk.clone()
+    for conf, nms in ((0.001, 0.65), (0.05, 0.5)):
+        model.conf_threshold, model.nms_threshold = conf, nms
+        ref = [want(w, conf, nms) for w in wins]
+        for rep in range(3):
+            for k, w in enumerate(wins):
+                det, nk = eng.forward_detections(*w)
+                assert torch.equal(nk, ref[k][1]), (conf, rep, k)
+                for b in range(B):
+                    n = int(nk[b])
+                    assert torch.equal(det[b, :n], ref[k][0][b, :n]), (conf, rep, k, b)
+        assert eng._wg is not None and eng._post_fresh, "the window (with its post-processing) was not captured"
+        assert int(ref[0][1].sum()) > 0
+    # asynchronous updates: the captured tail ends with the post-processing too
+    model.conf_threshold, model.nms_threshold = 0.001, 0.65
+    upd = [_dev_window(syn.edges_window, 300, B, W, H, s) for s in (61, 62, 63)]
+    eng.tail_graph = False
+    eng.forward_raw(*wins[0])
+    ref = []
+    for u in upd:
+        o = eng.forward_append(*u)
+        det, nk = postprocess_device(o, eng.num_classes, 0.001, 0.65, H, W)
+        ref.append((det.clone(), nk.clone()))
+    eng.tail_graph = True
+    eng.forward_raw(*wins[0])
+    for k, u in enumerate(upd):
+        det, nk = eng.forward_detections(*u, append=True)
+        assert torch.equal(nk, ref[k][1])
+        for b in range(B):
+            assert torch.equal(det[b, :int(nk[b])], ref[k][0][b, :int(nk[b])])
+    # DAGR.forward takes the same path: its dicts == the launch-by-launch dicts
+    eng.check_status()
 
 
 def test_window_graph_with_the_image_branch():
