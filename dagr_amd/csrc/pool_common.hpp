@@ -21,9 +21,8 @@ struct PoolWs {
     long long *xacc;     // [T][C]: ordered-int max (low 32 bits) or fixed-point sum
     int32_t *rows;       // [T][64] source-cluster sets, -1 = empty (raw ids on the 3-launch path)
     int32_t *rowcnt;     // [T+1]
-    int32_t *status;     // [16]: 0 flags (sticky); 4 = epoch; 5 = level-0 nodes merged through the global path (sticky, cumulative);
-                         //      6 = launch tag of the chained scan; 7 = ticket counter of k_pool_scan_emit, 8 = its finished
-                         //      scan tiles, 9 = workgroups past its barrier (7 - 9 zero between launches)
+    int32_t *status;     // [8]: 0 flags (sticky); 4 = epoch; 5 = level-0 nodes merged through the global path (sticky, cumulative);
+                         //      6 = launch tag of the chained scan; 7 = its tile ticket counter (zero between launches)
     unsigned long long *tile_state;   // [ceil((T + 1) / kPoolScanTile) + 8] chained scan: tag | flag | clusters | edges
     unsigned long long *nbmask;  // [T] level 0: 5x5 bitmaps of source cells, zero between calls: bits 0-24 cells of the
                                  // slot's own sample plane, bits 32-56 cells of the plane below (sources of the slot's
@@ -49,7 +48,7 @@ __host__ __device__ inline size_t pool_carve(const dagr_pool_desc &d, char *base
     w.xacc = (long long *)take(T * (size_t)d.channels * 8);
     w.rows = (int32_t *)take(T * (size_t)kRowSlots * 4);
     w.rowcnt = (int32_t *)take((T + 32) * 4);
-    w.status = (int32_t *)take(64);
+    w.status = (int32_t *)take(32);
     w.tile_state = (unsigned long long *)take(((T + 1 + kPoolScanTile - 1) / kPoolScanTile + 8) * 8);
     w.nbmask = (unsigned long long *)take((T + 9) * 8);
     w.T = (int)T;

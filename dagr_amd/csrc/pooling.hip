@@ -638,16 +638,24 @@ __global__ __launch_bounds__(kBlock) void k_recode(const int32_t *__restrict__ n
 // it meets an inclusive one.  The tile that takes the last ticket writes the counts, the empty tail rows, closes the
 // epoch and re-arms ticket counter and tag.  Integers throughout: the result is the single-workgroup kernel's, bit for
 // bit.
-template <bool MASKS, bool KEEP>
-__device__ __forceinline__ void pool_scan_tile(const PoolWs &ws, int32_t *__restrict__ n_out, int32_t *__restrict__ rowptr_out,
-                                               int32_t *__restrict__ e_out, const int tile, const unsigned tag12) {
+template <bool MASKS, bool KEEP = false>
+__global__ __launch_bounds__(kBlock) void k_pool_scan_chained(PoolWs ws, int32_t *__restrict__ n_out,
+                                                             int32_t *__restrict__ rowptr_out,
+                                                             int32_t *__restrict__ e_out) {
     constexpr int PER = kPoolScanTile / kBlock;   // 8
     __shared__ __align__(16) unsigned char st_occ[kPoolScanTile], st_cnt[kPoolScanTile];
     __shared__ int sm_scan[8];
-    __shared__ int sh_base_occ, sh_base_cnt;
+    __shared__ int sh_tile, sh_base_occ, sh_base_cnt;
+    __shared__ unsigned sh_tag;
     const int n = ws.T + 1;
     const int ntiles = (n + kPoolScanTile - 1) / kPoolScanTile;
-    const unsigned long long tag = (unsigned long long)tag12 << 52;
+    if (threadIdx.x == 0) {
+        sh_tile = atomicAdd(&ws.status[7], 1);
+        sh_tag = (unsigned)__hip_atomic_load(&ws.status[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xfffu;
+    }
+    __syncthreads();
+    const int tile = sh_tile;
+    const unsigned long long tag = (unsigned long long)sh_tag << 52;
     const int base = tile * kPoolScanTile;
     // load phase, coalesced: thread t takes elements base + 256 j + t; parked as bytes in LDS (a flag is 0/1, a row size or
     // bitmap population is <= 64), then every thread scans 8 CONSECUTIVE slots
@@ -708,7 +716,7 @@ __device__ __forceinline__ void pool_scan_tile(const PoolWs &ws, int32_t *__rest
             while (!__all(ready)) {                // spin until every predecessor of the window has published
                 if (!ready) {
                     wd = __hip_atomic_load(&ws.tile_state[pidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ready = (wd >> 52) == (unsigned long long)tag12 && ((wd >> 50) & 3ull) != 0ull;
+                    ready = (wd >> 52) == (unsigned long long)sh_tag && ((wd >> 50) & 3ull) != 0ull;
                 }
             }
             const bool incl = pidx >= 0 && ((wd >> 50) & 3ull) == 2ull;
@@ -747,8 +755,9 @@ __device__ __forceinline__ void pool_scan_tile(const PoolWs &ws, int32_t *__rest
         if (threadIdx.x == 0) {
             *n_out = nc;
             *e_out = ne;
-            if (!KEEP) ws.status[4] ^= 1;   // the next call fills the other accumulator pair; the emit part reads the one just filled
-            ws.status[6] = (int)((tag12 + 1u) & 0xfffu);
+            if (!KEEP) ws.status[4] ^= 1;   // the next call fills the other accumulator pair; launch (C) reads the one just filled
+            ws.status[7] = 0;
+            ws.status[6] = (int)((sh_tag + 1u) & 0xfffu);
         }
     }
 }
@@ -758,15 +767,17 @@ __device__ __forceinline__ void pool_scan_tile(const PoolWs &ws, int32_t *__rest
 // source set -- 64 hashed raw ids (pooled levels) or the two cell bitmaps (level 0) -- into its sorted CSR row with the
 // LUT coordinate of every edge, and re-arms what the slot owns: its feature accumulators, perm, its set, and the
 // position/count accumulators of the OTHER pair (the one the previous call left behind).
-template <bool MASKS, bool KEEP>
-__device__ __forceinline__ void pool_emit_slot(const dagr_pool_desc &d, const PoolWs &ws, const int32_t *__restrict__ batch32,
-                                               const int64_t *__restrict__ batch64, float *__restrict__ x_out, int ldo,
-                                               int xoff, float *__restrict__ pos_out, int32_t *__restrict__ batch_out,
-                                               const int32_t *__restrict__ rowptr_out, int32_t *__restrict__ col,
-                                               int32_t *__restrict__ code, int e_cap, const int raw, const int epoch) {
+template <bool MASKS, bool KEEP = false>
+__global__ __launch_bounds__(kBlock) void k_pool_emit(dagr_pool_desc d, PoolWs ws, const int32_t *__restrict__ batch32,
+                                                     const int64_t *__restrict__ batch64, float *__restrict__ x_out,
+                                                     int ldo, int xoff, float *__restrict__ pos_out,
+                                                     int32_t *__restrict__ batch_out,
+                                                     const int32_t *__restrict__ rowptr_out, int32_t *__restrict__ col,
+                                                     int32_t *__restrict__ code, int e_cap) {
     const int lane = threadIdx.x & 63;
+    const int raw = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     if (raw >= ws.T) return;
-    const int pair = KEEP ? epoch : epoch ^ 1;                 // the scan has closed the epoch (KEEP: it stays open)
+    const int pair = KEEP ? ws_pair(ws) : ws_pair(ws) ^ 1;     // the scan has closed the epoch (KEEP: it stays open)
     const int cnt = ws_cnt(ws, pair)[raw];
     if (!KEEP) {
         if (lane == 0) ws_cnt(ws, pair ^ 1)[raw] = 0;
@@ -837,56 +848,6 @@ __device__ __forceinline__ void pool_emit_slot(const dagr_pool_desc &d, const Po
     if (ix < 0 || ix > 2 * d.rx || iy < 0 || iy > 2 * d.ry) atomicOr(ws.status, 8);
     col[o] = ws.newid[v];
     code[o] = (ix & 0xffff) | (iy << 16);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Launches (S) and (C) as ONE launch (round 6: a B = 1 window is a chain of ~30 dependent launches of ~5 us each, and the
-// four poolings were eight of them).  The grid is (C)'s -- one wave per table slot -- and the first ceil((T + 1) / 2048)
-// workgroups TO START (ticket order) run the scan tiles first; every workgroup then waits until all tiles have written
-// their ids and row pointers (a counter the tiles bump after a release fence) and emits its slots.  No deadlock: a waiting
-// workgroup waits for tiles only, a tile waits for lower tiles only, and tickets are handed out in start order, so
-// whatever is waited for is running.  The last workgroup to pass re-arms ticket and counters for the next launch.
-template <bool MASKS, bool KEEP = false>
-__global__ __launch_bounds__(kBlock) void k_pool_scan_emit(dagr_pool_desc d, PoolWs ws, const int32_t *__restrict__ batch32,
-                                                          const int64_t *__restrict__ batch64, float *__restrict__ x_out,
-                                                          int ldo, int xoff, float *__restrict__ pos_out,
-                                                          int32_t *__restrict__ batch_out, int32_t *__restrict__ n_out,
-                                                          int32_t *__restrict__ rowptr_out, int32_t *__restrict__ col,
-                                                          int32_t *__restrict__ code, int32_t *__restrict__ e_out, int e_cap) {
-    __shared__ int sh_ticket, sh_epoch;
-    __shared__ unsigned sh_tag;
-    const int ntiles = (ws.T + 1 + kPoolScanTile - 1) / kPoolScanTile;
-    if (threadIdx.x == 0) {
-        sh_ticket = atomicAdd(&ws.status[7], 1);
-        sh_tag = (unsigned)__hip_atomic_load(&ws.status[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xfffu;
-    }
-    __syncthreads();
-    const int ticket = sh_ticket;
-    if (ticket < ntiles) {
-        pool_scan_tile<MASKS, KEEP>(ws, n_out, rowptr_out, e_out, ticket, sh_tag);
-        __threadfence();                     // this tile's ids / row pointers (and the last tile's epoch flip) before the count
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(&ws.status[8], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (threadIdx.x == 0) {
-        while (__hip_atomic_load(&ws.status[8], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < ntiles)
-            __builtin_amdgcn_s_sleep(1);
-        sh_epoch = __hip_atomic_load(&ws.status[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1;
-    }
-    __syncthreads();
-    __threadfence();                         // (acquire for every thread of the workgroup: no stale L1 lines below)
-    const int epoch = sh_epoch;
-    pool_emit_slot<MASKS, KEEP>(d, ws, batch32, batch64, x_out, ldo, xoff, pos_out, batch_out, rowptr_out, col, code, e_cap,
-                                (int)blockIdx.x * (kBlock / 64) + (int)(threadIdx.x >> 6), epoch);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        // every workgroup has read the counters it needs once it is here; the last one re-arms them
-        if (atomicAdd(&ws.status[9], 1) == (int)gridDim.x - 1) {
-            ws.status[7] = 0;
-            ws.status[8] = 0;
-            ws.status[9] = 0;
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1057,7 +1018,7 @@ int dagr_pool_workspace_init(const dagr_pool_desc *desc, void *workspace, size_t
     DAGR_CHECK_HIP(hipMemsetAsync(ws.perm, 0xff, T * 4, stream));
     DAGR_CHECK_HIP(hipMemsetAsync(ws.rows, 0xff, T * (size_t)kRowSlots * 4, stream));
     DAGR_CHECK_HIP(hipMemsetAsync(ws.rowcnt, 0, (T + 32) * 4, stream));
-    DAGR_CHECK_HIP(hipMemsetAsync(ws.status, 0, 64, stream));
+    DAGR_CHECK_HIP(hipMemsetAsync(ws.status, 0, 32, stream));
     DAGR_CHECK_HIP(hipMemsetAsync(ws.tile_state, 0, ((T + 1 + kPoolScanTile - 1) / kPoolScanTile + 8) * 8, stream));
     DAGR_CHECK_HIP(hipMemsetAsync(ws.nbmask, 0, (T + 9) * 8, stream));
     // feature accumulators: ordered-int minimum for max, 0 for mean
@@ -1074,8 +1035,9 @@ int dagr_pool_workspace_init(const dagr_pool_desc *desc, void *workspace, size_t
 }
 
 
-// launches (S) + (C) as one: one wave per table slot, the first workgroups scan first (k_pool_scan_emit)
-static_assert(kPoolScanTile >= kBlock / 64, "the emit-shaped grid holds at least one workgroup per scan tile");
+// launch (S): one workgroup per 2048 table slots
+#define DAGR_POOL_SCAN(MASKS, KEEP)                                                                                   \
+    k_pool_scan_chained<MASKS, KEEP><<<(unsigned)ceil_div(T + 1, kPoolScanTile), kBlock, 0, stream>>>(ws, n_out, rowptr_out, e_out)
 
 static int pool_tail(const dagr_pool_desc *d, PoolWs &ws, const int32_t *batch32, const int64_t *batch64,
                      float *x_out, int ldo, int xoff, float *pos_out, int32_t *batch_out, int32_t *n_out,
@@ -1128,8 +1090,10 @@ int dagr_pool_l0(const dagr_pool_desc *desc, void *pool_ws, const dagr_graph_des
     }
     if (fast_edges) {
         // (S) ids + row pointers from the occupancy flags and the bitmap populations, (C) nodes + CSR rows
-        k_pool_scan_emit<true><<<(unsigned)ceil_div(T + 1, kBlock / 64), kBlock, 0, stream>>>(
-            *desc, ws, b32, b64, x_out, ldo, xoff, pos_out, batch_out, n_out, rowptr_out, col_out, code_out, e_out, e_cap);
+        DAGR_POOL_SCAN(true, false);
+        DAGR_CHECK_LAUNCH();
+        k_pool_emit<true><<<(unsigned)ceil_div(T, kBlock / 64), kBlock, 0, stream>>>(
+            *desc, ws, b32, b64, x_out, ldo, xoff, pos_out, batch_out, rowptr_out, col_out, code_out, e_cap);
         DAGR_CHECK_LAUNCH();
         return DAGR_OK;
     }
@@ -1211,9 +1175,10 @@ int dagr_pool_l0_stream(const dagr_pool_desc *desc, void *pool_ws, int32_t rebui
             nbr_src, deg, K, gdesc->radius);
         DAGR_CHECK_LAUNCH();
     }
-    k_pool_scan_emit<true, true><<<(unsigned)ceil_div(T + 1, kBlock / 64), kBlock, 0, stream>>>(
-        *desc, ws, batch_events, nullptr, x_out, ldo, xoff, pos_out, batch_out, n_out, rowptr_out, col_out, code_out, e_out,
-        e_cap);
+    DAGR_POOL_SCAN(true, true);
+    DAGR_CHECK_LAUNCH();
+    k_pool_emit<true, true><<<(unsigned)ceil_div(T, kBlock / 64), kBlock, 0, stream>>>(
+        *desc, ws, batch_events, nullptr, x_out, ldo, xoff, pos_out, batch_out, rowptr_out, col_out, code_out, e_cap);
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;
 }
@@ -1237,8 +1202,10 @@ int dagr_pool_csr(const dagr_pool_desc *desc, void *pool_ws, const int32_t *n_pt
             *desc, n_ptr, n_max, x, ldx, pos, batch, rowptr, col, ws, cluster_scratch);
         DAGR_CHECK_LAUNCH();
     }
-    k_pool_scan_emit<false><<<(unsigned)ceil_div(T + 1, kBlock / 64), kBlock, 0, stream>>>(
-        *desc, ws, batch, nullptr, x_out, ldo, xoff, pos_out, batch_out, n_out, rowptr_out, col_out, code_out, e_out, e_cap);
+    DAGR_POOL_SCAN(false, false);
+    DAGR_CHECK_LAUNCH();
+    k_pool_emit<false><<<(unsigned)ceil_div(T, kBlock / 64), kBlock, 0, stream>>>(
+        *desc, ws, batch, nullptr, x_out, ldo, xoff, pos_out, batch_out, rowptr_out, col_out, code_out, e_cap);
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;
 }

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(1024) void scan_single_block(int32_t *__restrict__ 
     }
 }
 
-// The same scan in ONE launch (decoupled look-back, as pool_scan_tile in pooling.hip): a workgroup takes the next tile
+// The same scan in ONE launch (decoupled look-back, as k_pool_scan_chained in pooling.hip): a workgroup takes the next tile
 // (ticket counter: a tile's predecessors are always running or done), scans it, publishes its total in a 64-bit word --
 // launch tag (24 bits) | flag (1 = tile total, 2 = total of all tiles up to here) | value -- and one wave looks back over
 // the predecessors' words until it meets an inclusive one.  The last ticket re-arms the counter and bumps the tag.  The

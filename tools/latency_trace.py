@@ -11,7 +11,6 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
-from dagr_amd.model.utils import postprocess_device  # noqa: E402
 from dagr_amd.utils import synthetic as syn  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
@@ -26,7 +25,7 @@ with torch.no_grad():
 
     def window(i):
         pos, feat, batch, image = slots[i % 2]
-        return postprocess_device(eng.forward_raw(pos, feat, batch, image=image), rig.num_classes, 0.001, 0.65, 480, 640)
+        return eng.forward_detections(pos, feat, batch, image=image)     # as bench.py's latency sweep runs a window
     for i in range(20):
         window(i)
     torch.cuda.synchronize()
