@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 run_pass() {
   local name=$1; shift
   timeout 400 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- \
-      python "$ROOT/bench.py" --no-cpu-baseline --no-latency --steps 3 --warmup 1 --engines 1 $EXTRA > "$OUT/$name.log" 2>&1 < /dev/null
+      python "$ROOT/bench.py" --no-cpu-baseline --no-latency --no-side-legs --steps 3 --warmup 1 --engines 1 $EXTRA > "$OUT/$name.log" 2>&1 < /dev/null
   echo "pass $name rc=$?"
   local f=$(find "$OUT/$name" -name "*counter_collection.csv" 2>/dev/null | head -1)
   if [ -n "$f" ]; then python "$ROOT/tools/pmc_agg.py" "$f" > "$OUT/pmc_$name.csv"; head -14 "$OUT/pmc_$name.csv" | cut -c1-220; else echo "no counter csv"; tail -5 "$OUT/$name.log"; fi

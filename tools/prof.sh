@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- \
-    python "$ROOT/bench.py" --no-cpu-baseline --no-latency "$@" > "$OUT/bench.log" 2>&1 < /dev/null
+    python "$ROOT/bench.py" --no-cpu-baseline --no-latency --no-side-legs "$@" > "$OUT/bench.log" 2>&1 < /dev/null
 echo "rocprofv3 rc=$?"
 F=$(find "$OUT/trace" -name "*kernel_stats.csv" 2>/dev/null | head -1)
 if [ -n "$F" ]; then cp "$F" "$OUT/kernel_stats.csv"; head -45 "$OUT/kernel_stats.csv"; else echo "no kernel_stats.csv"; tail -20 "$OUT/bench.log"; fi

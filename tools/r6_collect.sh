@@ -4,9 +4,9 @@ set -eu
 cd "$(dirname "$0")/.."
 G=gpurun_out
 cp $G/r6_final/r6_traffic.json profiles/r6_traffic.json
-python tools/stats_md.py $G/r6_img_e1/kernel_stats.csv profiles/r6_image_e1_kernel_stats.md "python bench.py --no-cpu-baseline --no-latency --engines 1 --no-events-only-leg" "single engine (end of round 6)"
-python tools/stats_md.py $G/r6_ev_e1/kernel_stats.csv profiles/r6_events_only_e1_kernel_stats.md "python bench.py --no-cpu-baseline --no-latency --events-only --engines 1" "single engine: isolated per-launch times (end of round 6)"
-python tools/stats_md.py $G/r6_default/kernel_stats.csv profiles/r6_default3eng_kernel_stats.md "python bench.py --no-cpu-baseline --no-latency" "the driver's command (3 engines in flight), end of round 6"
+python tools/stats_md.py $G/r6_img_e1/kernel_stats.csv profiles/r6_image_e1_kernel_stats.md "python bench.py --no-cpu-baseline --no-latency --no-side-legs --engines 1 --no-events-only-leg" "single engine (end of round 6)"
+python tools/stats_md.py $G/r6_ev_e1/kernel_stats.csv profiles/r6_events_only_e1_kernel_stats.md "python bench.py --no-cpu-baseline --no-latency --no-side-legs --events-only --engines 1" "single engine: isolated per-launch times (end of round 6)"
+python tools/stats_md.py $G/r6_default/kernel_stats.csv profiles/r6_default3eng_kernel_stats.md "python bench.py --no-cpu-baseline --no-latency --no-side-legs" "the driver's command (3 engines in flight), end of round 6"
 python tools/stats_md.py $G/r6_edges/kernel_stats.csv profiles/r6_edges_stage_probe_kernel_stats.md "python tools/stage_probe.py edges:8:100000" "S-edges stream, B = 8 x 100 k (end of round 6)"
 cp $G/r6_img_e1/kernel_stats.csv profiles/r6_image_e1_kernel_stats.csv
 cp $G/r6_ev_e1/kernel_stats.csv profiles/r6_events_only_e1_kernel_stats.csv
