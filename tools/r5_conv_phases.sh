@@ -1,6 +1,7 @@
 #!/bin/bash
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+export DAGR_HIP_LIB="$ROOT/dagr_amd/lib/libdagr_hip_measure.so"   # the knobs below exist in the measurement build only
 OUT=$ROOT/gpurun_out/r5c15
 mkdir -p "$OUT"
 cd "$ROOT"

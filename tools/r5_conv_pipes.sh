@@ -3,6 +3,7 @@
 # of a tile hidden under phase 1 of other waves' tiles?), (3) the new tests, (4) a short default bench line (one-rank RCCL group).
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+export DAGR_HIP_LIB="$ROOT/dagr_amd/lib/libdagr_hip_measure.so"   # the knobs below exist in the measurement build only
 OUT=$ROOT/gpurun_out/r5c1
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp

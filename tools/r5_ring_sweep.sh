@@ -2,6 +2,7 @@
 # sweeps of the row search's knobs on the graph build alone (digests must stay the same)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+export DAGR_HIP_LIB="$ROOT/dagr_amd/lib/libdagr_hip_measure.so"   # the knobs below exist in the measurement build only
 cd "$ROOT"
 SPECS=${SPECS:-"edges:8:100000 edges:8:200000 uniform:8:400000 uniform:1:200000 uniform:8:100000 edges:1:25000"}
 run() { env "$@" PROBE_CHECK=1 timeout 300 python tools/graph_probe.py $SPECS 2>/dev/null | python -c "
