@@ -199,26 +199,28 @@ def _compare(args, model, sd, W, H, B, x, y, t, p, b, pos, image=None, plain=Fal
 
 def test_small_uniform_b2():
     W, H, B = 320, 215, 2
-    args, model, sd = _setup(W, H, B)
-    _compare(args, model, sd, W, H, B, *_events(syn.uniform_window, 6000, B, W, H, seed=5))
+    args, model, sd = _setup(W, H, B, calibrate=syn.uniform_window)
+    _compare(args, model, sd, W, H, B, *_events(syn.uniform_window, 6000, B, W, H, seed=5), plain=True)
 
 
 def test_small_edges_b3_repeatable():
     W, H, B = 320, 215, 3
-    args, model, sd = _setup(W, H, B, seed=1)
+    args, model, sd = _setup(W, H, B, seed=1, calibrate=syn.edges_window)
     ev = _events(syn.edges_window, 8000, B, W, H, seed=7)
-    o1 = _compare(args, model, sd, W, H, B, *ev).clone()
-    o2 = _compare(args, model, sd, W, H, B, *ev)      # same buffers, second window: bit-identical
+    o1 = _compare(args, model, sd, W, H, B, *ev, plain=True).clone()
+    o2 = _compare(args, model, sd, W, H, B, *ev, plain=True)      # same buffers, second window: bit-identical
     assert torch.equal(o1, o2)
 
 
 def test_vga_uniform_b1():
     W, H, B = 640, 480, 1
-    args, model, sd = _setup(W, H, B, seed=2)
-    _compare(args, model, sd, W, H, B, *_events(syn.uniform_window, 25000, B, W, H, seed=9))
+    args, model, sd = _setup(W, H, B, seed=2, calibrate=syn.uniform_window)
+    _compare(args, model, sd, W, H, B, *_events(syn.uniform_window, 25000, B, W, H, seed=9), plain=True)
 
 
 def test_empty_and_tiny_windows():
+    """(The one engine case on RAW random BatchNorm statistics and the rms-scaled bar: three events cannot calibrate
+    anything; every other case runs on calibrated statistics against the plain 1e-4 (1 + |b|) bar.)"""
     W, H, B = 320, 215, 2
     args, model, sd = _setup(W, H, B, seed=3)
     dev = torch.device("cuda:0")
@@ -237,26 +239,26 @@ def test_empty_and_tiny_windows():
 def test_use_image_resnet18_b2():
     """--use_image: sample_features at every level, 19/82/130-channel convs, CNN-head logit fusion."""
     W, H, B = 320, 215, 2
-    args, model, sd = _setup(W, H, B, seed=4, use_image=True, img_net="resnet18")
+    args, model, sd = _setup(W, H, B, seed=4, calibrate=syn.edges_window, use_image=True, img_net="resnet18")
     image = torch.rand((B, 3, H, W), generator=torch.Generator().manual_seed(1)).cuda()
     with torch.no_grad():
-        _compare(args, model, sd, W, H, B, *_events(syn.edges_window, 5000, B, W, H, seed=13), image=image)
+        _compare(args, model, sd, W, H, B, *_events(syn.edges_window, 5000, B, W, H, seed=13), image=image, plain=True)
 
 
 def test_dagr_l_widths_events_only():
     """dagr-l (net_stem_width = yolo_stem_width = 1: 128-channel levels, N = 256 fused head GEMM)."""
     W, H, B = 320, 215, 2
-    args, model, sd = _setup(W, H, B, seed=6, net_stem_width=1.0, yolo_stem_width=1.0)
-    _compare(args, model, sd, W, H, B, *_events(syn.edges_window, 5000, B, W, H, seed=17))
+    args, model, sd = _setup(W, H, B, seed=6, calibrate=syn.edges_window, net_stem_width=1.0, yolo_stem_width=1.0)
+    _compare(args, model, sd, W, H, B, *_events(syn.edges_window, 5000, B, W, H, seed=17), plain=True)
 
 
 def test_max_neighbors_8_takes_the_generic_level0_kernel():
     """A checkpoint trained with max_neighbors != 16 (config key `max_neighbors`, dagr-s-dsec.yaml:10) runs on the generic
     level-0 kernel (k_conv_l0: any list length, 3x3 / 3x5 / 5x5 tap windows) instead of the 16-node tiles."""
     W, H, B = 320, 215, 2
-    args, model, sd = _setup(W, H, B, seed=21, max_neighbors=8)
+    args, model, sd = _setup(W, H, B, seed=21, calibrate=syn.edges_window, max_neighbors=8)
     assert not model.engine().l0_tiles
-    _compare(args, model, sd, W, H, B, *_events(syn.edges_window, 6000, B, W, H, seed=31))
+    _compare(args, model, sd, W, H, B, *_events(syn.edges_window, 6000, B, W, H, seed=31), plain=True)
 
 
 @pytest.mark.parametrize("name,width", [("dagr-m", 0.75), ("dagr-n", 0.25)])
