@@ -449,6 +449,143 @@ __global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(U 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Narrow inputs on large levels: level 1's first conv of a B = 8 batch is 18 -> 64 on ~18 k nodes.  In k_conv_fused a wave
+// aggregates ONE node with one lane per input channel -- 18 of 64 lanes -- and every 16-node workgroup reads the whole
+// weight matrix from L2.  Here a workgroup owns 48 nodes (three 16-row MFMA tiles): phase A puts THREE nodes on a wave
+// (21 lanes each, every lane walks its own node's edge list: the loads of a node's 21 lanes coalesce into one request), and
+// phase B uses every weight fragment for three row tiles.  K = 26 cin <= 546 keeps the 48-row A tile (+ the split-K
+// partials) at 142 KB.  Same arithmetic and order per output element as k_conv_fused (edge order, tap order, k-split of 4,
+// fixed-order reduction): bit-identical results.
+// RT = 16-row tiles per workgroup.  3: the form described above.  5 (N <= 64): the split-K partials alias the A tile (it is
+// dead once every wave has read it), so an 80-node tile fits the LDS (154 KB) and the level of a B = 8 batch is ONE round
+// of workgroups (252 on 256 CUs) instead of one and a half; a wave then aggregates its five nodes in two passes of three.
+// Measured (L1c1 18 -> 64, 17 922 nodes): 16-node tiles 43.0 us, RT = 3 34.4, RT = 2 with two workgroups per CU 35.9.
+constexpr int kNarrowSub = 21;        // lanes per node in phase A
+template <int kNarrowRT, bool ALIAS>
+__global__ __launch_bounds__(kGemmThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_conv_fused_narrow(
+    const int32_t *__restrict__ n_ptr, int n_max, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const int32_t *__restrict__ code, const float *__restrict__ x, int ldx, int cin, int rx, int ry, float den_x, float den_y,
+    const float *__restrict__ Wq, const float *__restrict__ bias, float *__restrict__ C, int ldc, int N, int relu, int KP) {
+    constexpr int ROWS = 16 * kNarrowRT;
+    extern __shared__ __align__(16) float fl[];
+    const int K = 26 * cin;
+    float *At = fl;                                  // [ROWS][KP], columns K..KP-1 zero
+    float *red = ALIAS ? fl : fl + ROWS * KP;        // [KSPLIT][ROWS][NB] split-K partials
+    const int m0 = blockIdx.x * ROWS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int M = n_ptr ? min(*n_ptr, n_max) : n_max;
+    if (m0 >= M) return;
+    // ---- phase A: wave wv aggregates nodes m0 + RT wv + {0 .. RT-1}, three at a time; lane = (node of the pass, input channel)
+    {
+        const int sub = lane / kNarrowSub, ch = lane - kNarrowSub * sub;
+#pragma unroll
+        for (int r3 = 0; r3 < kNarrowRT; r3++) {
+            float *zr = At + (kNarrowRT * wv + r3) * KP;
+            for (int i = lane; i < KP; i += 64) zr[i] = 0.0f;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int p0 = 0; p0 < kNarrowRT; p0 += 3) {
+            const int slot = p0 + sub;                   // this lane's node among the wave's RT
+            const int n = m0 + kNarrowRT * wv + slot;
+            const bool node_ok = sub < 3 && slot < kNarrowRT && n < M;
+            const bool act = node_ok && ch < cin;
+            float *row = At + (kNarrowRT * wv + min(slot, kNarrowRT - 1)) * KP;
+            int e0 = 0, ne = 0;
+            if (node_ok) {
+                e0 = rowptr[n];
+                ne = rowptr[n + 1] - e0;
+            }
+            if (act) row[25 * cin + ch] = x[(size_t)n * ldx + ch];
+            constexpr int UA = 4;
+            for (int j = 0; __any(j < ne); j += UA) {
+                int src[UA], cd[UA];
+                float v[UA];
+#pragma unroll
+                for (int u = 0; u < UA; u++) {           // a node's lanes read the same two words: one request each
+                    const bool ok = j + u < ne;
+                    src[u] = ok ? col[e0 + j + u] : 0;
+                    cd[u] = ok ? code[e0 + j + u] : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < UA; u++) v[u] = (act && j + u < ne) ? x[(size_t)src[u] * ldx + ch] : 0.0f;
+#pragma unroll
+                for (int u = 0; u < UA; u++) {
+                    if (act && j + u < ne) {
+                        const AxisF ax = spline_axis_f(cd[u] & 0xffff, rx, den_x);
+                        const AxisF ay = spline_axis_f(cd[u] >> 16, ry, den_y);
+                        const float b00 = ax.b0 * ay.b0, b10 = ax.b1 * ay.b0, b01 = ax.b0 * ay.b1, b11 = ax.b1 * ay.b1;
+                        float *a00 = row + (ax.k0 + 5 * ay.k0) * cin + ch;
+                        float *a10 = row + (ax.k1 + 5 * ay.k0) * cin + ch;
+                        float *a01 = row + (ax.k0 + 5 * ay.k1) * cin + ch;
+                        float *a11 = row + (ax.k1 + 5 * ay.k1) * cin + ch;
+                        // the four taps of one edge are distinct (k0 != k1 on both axes): read all, then write
+                        const float o00 = *a00, o10 = *a10, o01 = *a01, o11 = *a11;
+                        *a00 = o00 + b00 * v[u];
+                        *a10 = o10 + b10 * v[u];
+                        *a01 = o01 + b01 * v[u];
+                        *a11 = o11 + b11 * v[u];
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase B: [48 x K] . [K x N]; wave (ks, w): K quarter ks, 16-column tile w of a 64-column block, three row tiles
+    const int ks = wv >> 2, w = wv & 3;
+    const int kk = lane >> 4, nn = lane & 15;
+    const int G = (K + 15) / 16, Gq = (G + KSPLIT - 1) / KSPLIT;
+    const int gbeg = ks * Gq, gend = min(G, gbeg + Gq);
+    for (int n0 = 0; n0 < N; n0 += NB) {
+        f32x4 acc[kNarrowRT][2];
+#pragma unroll
+        for (int rt = 0; rt < kNarrowRT; rt++) { acc[rt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[rt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        if (n0 + w * 16 < N) {
+            const float4 *wq = reinterpret_cast<const float4 *>(Wq) + ((size_t)(n0 / 16 + w) * G) * 64 + lane;
+            constexpr int U = 2;                     // weight groups in flight
+            for (int g0 = gbeg; g0 < gend; g0 += U) {
+                float4 b[U];
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    b[u] = g0 + u < gend ? wq[(size_t)(g0 + u) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    if (g0 + u < gend) {             // (wave-uniform)
+#pragma unroll
+                        for (int rt = 0; rt < kNarrowRT; rt++) {
+                            const float *ap = At + (16 * rt + nn) * KP + kk + 16 * (g0 + u);
+                            // (two accumulators per row tile, alternating as in k_conv_fused: same k-order per output)
+                            acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[0], b[u].x, acc[rt][0], 0, 0, 0);
+                            acc[rt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4], b[u].y, acc[rt][1], 0, 0, 0);
+                            acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[8], b[u].z, acc[rt][0], 0, 0, 0);
+                            acc[rt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[12], b[u].w, acc[rt][1], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        if (ALIAS) __syncthreads();              // every wave is done with the A tile before the partials overwrite it
+        float *rd = red + ks * ROWS * NB;
+#pragma unroll
+        for (int rt = 0; rt < kNarrowRT; rt++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) rd[(16 * rt + kk * 4 + q) * NB + w * 16 + nn] = acc[rt][0][q] + acc[rt][1][q];
+        __syncthreads();
+        for (int idx = tid; idx < ROWS * NB; idx += kGemmThreads) {
+            const int orow = m0 + idx / NB, ocol = n0 + idx % NB;
+            if (orow < M && ocol < N) {
+                float v = red[idx];
+                for (int s = 1; s < KSPLIT; s++) v += red[s * ROWS * NB + idx];   // fixed order
+                v += bias ? bias[ocol] : 0.f;
+                if (relu) v = fmaxf(v, 0.f);
+                C[(size_t)orow * ldc + ocol] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // Tap range of a pass: K is cut at tap boundaries into P = ceil(25 / tp) passes of tp taps (tp * cin a multiple of 16,
 // so that a pass starts on a weight group); the pass that holds tap 24 also holds the root and skip columns.  tp >= 25:
 // the whole row in one pass (every level of dagr-s / dagr-n).  Wider rows (26 * cin + cskip > ~2270 floats: dagr-m's
@@ -866,6 +1003,41 @@ extern "C" int dagr_spline_conv_fused(const int32_t *n_nodes_ptr, int32_t n_node
                                       const float *xskip, int32_t ldskip, int32_t cskip, int32_t rx, int32_t ry,
                                       float den_x, float den_y, const float *Wq, const float *bias, float *C,
                                       int32_t ldc, int32_t N, int32_t relu, void *stream) {
+    using namespace dagr;
+    // narrow inputs on a level of several workgroup rounds: 48- / 80-node tiles, three nodes per wave and pass
+    // (k_conv_fused_narrow).  Measurement knob DAGR_CONV_NARROW: 0 = never, 3 / 5 = force that tile form
+    static const int narrow = (int)knob("DAGR_CONV_NARROW", 1);
+    if (narrow && cin >= 1 && cin <= kNarrowSub && cskip == 0 && N >= 1 &&
+        (int64_t)n_nodes_max >= (int64_t)48 * device_cu_count()) {
+        DAGR_CHECK_ARG(rowptr && col && code && x && Wq && C, "NULL pointer");
+        DAGR_CHECK_ARG(((uintptr_t)Wq % 16) == 0, "packed weights must be 16-byte aligned");
+        int tp = 25, KP = 0;
+        if (fused_plan(cin, 0, &tp, &KP) && tp >= 25) {
+            // 80-node tiles when that makes the level one round of workgroups and the tile fits (the aliased partials serve
+            // ONE 64-column block)
+            const size_t tile5 = (size_t)16 * 5 * KP * 4, part5 = (size_t)KSPLIT * 16 * 5 * NB * 4;
+            const bool two = narrow != 3 && N <= NB && std::max(tile5, part5) <= 160 * 1024 &&
+                             (narrow == 5 || ceil_div(n_nodes_max, 80) <= device_cu_count());
+            const int rt = two ? 5 : 3;
+            const size_t tile = (size_t)16 * rt * KP * 4, part = (size_t)KSPLIT * 16 * rt * NB * 4;
+            const size_t lds = two ? std::max(tile, part) : tile + part;
+            const void *fn = two ? (const void *)k_conv_fused_narrow<5, true> : (const void *)k_conv_fused_narrow<3, false>;
+            static thread_local size_t set_lds[2] = {0, 0};
+            if (lds > set_lds[two ? 1 : 0]) {
+                DAGR_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                set_lds[two ? 1 : 0] = lds;
+            }
+            const unsigned grid = (unsigned)ceil_div(n_nodes_max, 16 * rt);
+            if (two)
+                k_conv_fused_narrow<5, true><<<grid, kGemmThreads, lds, (hipStream_t)stream>>>(
+                    n_nodes_ptr, n_nodes_max, rowptr, col, code, x, ldx, cin, rx, ry, den_x, den_y, Wq, bias, C, ldc, N, relu, KP);
+            else
+                k_conv_fused_narrow<3, false><<<grid, kGemmThreads, lds, (hipStream_t)stream>>>(
+                    n_nodes_ptr, n_nodes_max, rowptr, col, code, x, ldx, cin, rx, ry, den_x, den_y, Wq, bias, C, ldc, N, relu, KP);
+            DAGR_CHECK_LAUNCH();
+            return DAGR_OK;
+        }
+    }
     const HostConvJob j{n_nodes_ptr, n_nodes_max, rowptr, col, code, x, ldx, cin, xskip, ldskip, cskip, rx, ry, den_x, den_y,
                         Wq, bias, C, ldc, N, relu};
     return launch_conv_jobs(&j, 1, nullptr, stream);

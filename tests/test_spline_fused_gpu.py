@@ -48,6 +48,9 @@ CASES = [  # T, cin, cskip, N, max_deg, relu
     (200, 64, 0, 200, 6, False),      # N > 128: four column blocks
     (6000, 18, 0, 32, 9, True),       # level 1 of a B = 8 batch: more workgroups than CUs, two tiles per CU (62-register form)
     (6000, 32, 18, 32, 9, True),
+    (20000, 18, 0, 64, 9, True),      # level 1 of a B = 8 batch at its size: 80-node tiles, three nodes per wave and pass (k_conv_fused_narrow<5>)
+    (13000, 3, 0, 40, 20, False),     # the same form on 3 input channels, ragged N, a last tile of 40 rows
+    (12500, 12, 0, 96, 6, True),      # ... and its 48-node form (N > 64: two column blocks over one A tile)
     # rows beyond the LDS tile: K cut at tap boundaries into passes (accumulators stay in registers across them)
     (300, 128, 0, 256, 9, True),      # head conv pair of dagr-s (cls_conv | reg_conv): 2 passes of 13 / 12 + root
     (1200, 130, 130, 64, 7, True),    # --use_image level >= 2: K = 3510, tap split must be a multiple of 8
