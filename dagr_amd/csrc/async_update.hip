@@ -7,13 +7,12 @@
 // events already in the window do not change: an update only APPENDS level-0 rows.
 //
 // Here there is no FIFO volume.  The window's events stay where dagr_graph_build_window left them -- the index keyed
-// (sample, y, time bucket, x), newest last inside a segment -- and the events appended since hang off per-pixel chains,
+// (sample, y, x), newest last inside a pixel's segment -- and the events appended since hang off per-pixel chains,
 // newest first:
 //   app_head[p]  newest appended event of pixel p (-1: none)           int32[B*H*W]
 //   app_next[k]  next older appended event of the same pixel           int32[capacity], k = id - n_static
 //   app_xytb[k]  {x, y, t, b} of appended event k                      int32[capacity][4]
-// The FIFO column of pixel p, newest first, is then: its chain, followed by its segments read backwards (newest bucket
-// first), cut at depth Q -- which is all the reference's walk looks at (ev_graph.cu:58-76).
+// The FIFO column of pixel p, newest first, is then: its chain, followed by its segment read backwards, cut at depth Q -- which is all the reference's walk looks at (ev_graph.cu:58-76).
 //   k_async_insert  one workgroup per chunk of <= 1024 new events: denormalise (ev_tgn.py:11-16), link every event to
 //                   the previous new event of its pixel (or the old head), publish the new heads.  No atomics: the
 //                   order inside a pixel is the event order, as the reference's stable sort gives it.

@@ -17,9 +17,9 @@
 //     ones -- what recordings look like -- lost.  Removed in round 6.)
 //   * the search is candidate-centric: the row ranges' events are tested and keyed by (spiral rank of their pixel,
 //     recency); the reference's sequential "first K in spiral order, newest first inside a pixel" cut is "the K-1
-//     smallest keys in key order".  Light neighbourhoods: k_search_rows, 16 lanes per destination.  Event-dense ones:
-//     one destination per wave over nested ring windows (search_heavy in k_search_dense), with the reference's
-//     position-centric walk as the last resort; unsorted timestamps and radii beyond 7 pixels: k_search_dense's generic form.
+//     smallest keys in key order" (k_search_rows, 16 lanes per destination; crowded neighbourhoods in their inner rings
+//     first).  Event-dense neighbourhoods (> 320 candidates) take the reference's position-centric walk on the same index
+//     (k_search_dense); unsorted timestamps and radii beyond 7 pixels its generic form.
 //   * output is a fixed-stride neighbour list [N, K] (int32 source + int16 offset code) + deg[N]:
 //     no -1 fill, no compaction pass, no host sync; the offset code is the SplineConv LUT index.
 #include "common.hpp"
@@ -368,7 +368,7 @@ __device__ __forceinline__ int group16_inclusive_scan(int v) {
 }
 
 // Level-0 node numbering.  The graph is emitted in *slot space*: node n is CSR slot n, i.e. events ordered by
-// (sample, y, time bucket, x) and by time inside a segment.  All events of a band of pixel rows are one contiguous run of
+// (sample, y, x) and by time inside a segment.  All events of a band of pixel rows are one contiguous run of
 // nodes (voxel pooling streams its members), destinations that follow each other share the row ranges they fetch, and
 // the source rows of a tile of nodes sit in a few narrow runs of memory.  Event-order views (edge_index, permutations) are
 // produced on demand by dagr_graph_edge_index / dagr_graph_node_order.

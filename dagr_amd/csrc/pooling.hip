@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_accumulate(dagr_pool_desc d, co
 }
 
 // ---------------------------------------------------------------------------------------------
-// level 0, streaming form.  Nodes are CSR slots in (sample, y, time bucket, x, time) order, so all voxels of one sample / voxel row
+// level 0, streaming form.  Nodes are CSR slots in (sample, y, x, time) order, so all voxels of one sample / voxel row
 // (a "band") own ONE contiguous run of slots, and their table ids are contiguous too (raw = cx + gx * (cy + gy * b)).
 // The kernel therefore never looks a member up: the slots are cut into EQUAL contiguous runs, one per workgroup (balanced
 // whatever the event density: S-edges puts thousands of members into a few voxels), and every workgroup streams its run

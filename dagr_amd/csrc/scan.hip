@@ -221,8 +221,8 @@ __global__ __launch_bounds__(kBlock) void scan_chained(int32_t *__restrict__ in,
     }
 }
 
-// The one-launch scan on WIDE tiles (THREADS x EPT elements): the window builder's key table (B * H * W * time buckets:
-// 12.3 M entries for a B = 8 batch of VGA samples) stays within a few hundred tiles, where the look-back of one wave per
+// The one-launch scan on WIDE tiles (THREADS x EPT elements): the window builder's key table (B * H * W keys:
+// 2.5 M entries for a B = 8 batch of VGA samples) stays within a few hundred tiles, where the look-back of one wave per
 // tile is short, and every element is read ONCE (the three-launch form reads the input twice).  A wave owns a contiguous
 // sub-tile of 64 * EPT elements and reads it as EPT / 4 fully coalesced 1-KiB pieces; per piece a wave scan, a running
 // carry across the pieces, one LDS word per wave for the tile's total.

@@ -106,8 +106,7 @@ size_t dagr_graph_workspace_bytes(const dagr_graph_desc *desc);
 int dagr_graph_workspace_init(const dagr_graph_desc *desc, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Node numbering: the graph comes out in *slot space* -- node n is the n-th event in (sample, y, x,
- * time) order (the builder's CSR-by-pixel order; with the optional time buckets of the index, builder
- * knob DAGR_TIME_BUCKETS: (sample, y, time bucket, x, time)), so that spatial neighbours are memory
+ * time) order (the builder's CSR-by-pixel order), so that spatial neighbours are memory
  * neighbours in every level-0 array and the events of a range of pixel rows are one run of nodes.  nbr_src holds node numbers.  dagr_graph_node_order exports the permutation,
  * dagr_graph_gather_inputs brings the per-event inputs into node order, dagr_graph_edge_index emits the
  * reference-shaped, event-ordered int64 edge_index.
