@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--no-rccl", action="store_true", help="world 1: no one-rank process group (plain barriers, local gather)")
     ap.add_argument("--no-events-only-leg", action="store_true", help="skip the events-only sub-measurement")
     ap.add_argument("--no-side-legs", action="store_true", help="skip the other-stream and the H2D-inclusive legs")
+    ap.add_argument("--repeats", type=int, default=1,
+                    help="builder's collections: time the headline region this many times more AFTER the line's own (the "
+                         "line's `value` stays the first, exactly --steps steps); the spread goes into `repeat_ms_per_step`")
     ap.add_argument("--events-only", action="store_true",
                     help="make the events-only model (BASELINE config 1 shape) the headline instead of config 2")
     ap.add_argument("--img-net", default="resnet50")
@@ -754,6 +757,9 @@ def main():
         ev_slots = ev_rig.make_slots(gen, NPW, 4, seed=1234 + 1000 * rank)
         ev_leg = timed_run(ev_rig, ev_slots, a.steps, a.warmup, dist, world, rank)
 
+    repeats = [timed_run(rig, slots, a.steps, a.warmup, None, 1, rank)["elapsed"] for _ in range(max(0, a.repeats - 1))] \
+        if world == 1 else []
+
     # ---- the same step on the other synthetic stream (S-edges when the line is S-uniform and vice versa) and with the
     # window batches starting in host memory (what the reference's loop pays per batch, utils/testing.py:29)
     other = h2d = None
@@ -788,6 +794,8 @@ def main():
                        "backend": ("nccl (RCCL)" if dist is not None else "none"), "note": rccl_note},
             "roofline": st["roofline"], "stages": st["stages"],
         }
+        if repeats:
+            result["repeat_ms_per_step"] = [round(ms_per_step, 4)] + [round(1e3 * r / a.steps, 4) for r in repeats]
         if other is not None:
             oname = "edges" if a.stream == "uniform" else "uniform"
             result["value_" + oname] = round(n_events_step * a.steps / other["elapsed"], 1)
