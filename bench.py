@@ -289,16 +289,14 @@ class Rig:
         return slots
 
     def step(self, i, slots):
-        """forward + device-side post-processing of window batch i on engine i % n; returns (det[B,A,6], n_keep[B])."""
-        from dagr_amd.model.utils import postprocess_device
+        """forward + device-side post-processing of window batch i on engine i % n (engine.forward_detections: every image's
+        confidence mask + NMS inside the heads' last launch); returns (det[B,A,6], n_keep[B])."""
         pos, feat, batch, image = slots[i % len(slots)]
         k = i % len(self.engines)
         e, st = self.engines[k], self.streams[k]
         with torch.cuda.stream(st):
             # (post-processed at once, on the engine's stream, before its next window: no copy of the output buffer)
-            out = e.forward_raw(pos, feat, batch, image=image, static_out=True)
-            return postprocess_device(out, self.num_classes, self.model.conf_threshold, self.model.nms_threshold,
-                                      self.H, self.W)
+            return e.forward_detections(pos, feat, batch, image=image)
 
     def drain(self):
         cur = torch.cuda.current_stream(self.dev)
@@ -313,7 +311,6 @@ def h2d_run(rig, gen, npw, steps, warmup, seed):
     (``format_data``: dagr_format_events, frame / 255) and run through forward + post-processing.  The copy of batch i + 1
     overlaps the compute of batch i.  Returns (elapsed seconds of `steps` steps, bytes copied per step)."""
     from dagr_amd import _lib
-    from dagr_amd.model.utils import postprocess_device
     from dagr_amd.utils import synthetic as syn
     dev, B, W, H = rig.dev, rig.B, rig.W, rig.H
     host = []
@@ -357,8 +354,7 @@ def h2d_run(rig, gen, npw, steps, warmup, seed):
             image = st["img"].float() / 255.0 if rig.use_image else None
             batch = st["b"].clone()
             consumed[i % S].record(stream)
-            out = eng.forward_raw(pos, feat, batch, image=image, static_out=True)
-            return postprocess_device(out, rig.num_classes, rig.model.conf_threshold, rig.model.nms_threshold, H, W)
+            return eng.forward_detections(pos, feat, batch, image=image)
     cur = torch.cuda.current_stream(dev)
     for e in consumed:
         e.record(cur)

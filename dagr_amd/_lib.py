@@ -161,6 +161,8 @@ SIGNATURES = {
                                         c_void_p, c_void_p, c_void_p]),
     "dagr_heads_finish": (ctypes.c_int, [ctypes.POINTER(HeadScale), ctypes.POINTER(HeadScale), c_i32, c_i32, c_void_p,
                                          c_void_p, c_void_p]),
+    "dagr_heads_finish_detect": (ctypes.c_int, [ctypes.POINTER(HeadScale), ctypes.POINTER(HeadScale), c_i32, c_i32, c_void_p,
+                                                c_void_p, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "dagr_decode_heads": (ctypes.c_int, [c_void_p, c_i32, c_i32, c_float, c_void_p, c_i32, c_i32, c_float, c_i32, c_i32,
                                          c_void_p, c_void_p]),
     "dagr_postprocess": (ctypes.c_int, [c_void_p, c_i32, c_i32, c_i32, c_float, c_float, c_float, c_void_p, c_void_p,

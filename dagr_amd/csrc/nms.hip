@@ -193,9 +193,11 @@ __global__ __launch_bounds__(kBlock) void k_nms(const float *__restrict__ boxes,
 // max / argmax, score = obj * class_conf, confidence mask (score * class_conf >= thr), class-offset greedy NMS, and
 // the survivors written front-compacted in descending-score order as rows (x1, y1, x2, y2, score, label).
 constexpr int kPostThreads = 1024;   // 16 waves: four per SIMD, so the pairwise-IoU phase hides its VALU latencies
-__global__ __launch_bounds__(kPostThreads) void k_postprocess(const float *__restrict__ pred, int A, int Apad, int ncls,
-                                                       float conf_thr, float nms_thr, float class_offset,
-                                                       float *__restrict__ det, int32_t *__restrict__ n_keep) {
+// one image: p = its decoded rows [A][5 + ncls], d = its det rows [A][6], n_keep_b = its survivor count.  All kPostThreads
+// threads of the workgroup call it (k_postprocess: one workgroup per image; k_heads_finish: right after the decode).
+__device__ __forceinline__ void postprocess_image(const float *__restrict__ p, int A, int Apad, int ncls, float conf_thr,
+                                                  float nms_thr, float class_offset, float *__restrict__ d,
+                                                  int32_t *__restrict__ n_keep_b) {
     __shared__ float s_key[kMaxAnchors];
     __shared__ int s_idx[kMaxAnchors];
     __shared__ float4 s_raw[kMaxAnchors];     // un-offset boxes, anchor order
@@ -206,9 +208,7 @@ __global__ __launch_bounds__(kPostThreads) void k_postprocess(const float *__res
     __shared__ unsigned long long s_mask[kMaskAnchors][kMaskWords];
     __shared__ float s_key2[kMaskAnchors];
     __shared__ int s_scan[kPostThreads / 64];
-    const int b = blockIdx.x;
     const int ld = 5 + ncls;
-    const float *p = pred + (size_t)b * A * ld;
     for (int i = threadIdx.x; i < Apad; i += kPostThreads) {
         bool ok = false;
         float sc = -INFINITY;
@@ -254,7 +254,6 @@ __global__ __launch_bounds__(kPostThreads) void k_postprocess(const float *__res
     }
     int total;
     int base = block_exclusive_scan(cnt, s_scan, total);
-    float *d = det + (size_t)b * A * 6;
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         const int i = 4 * threadIdx.x + u;
@@ -266,7 +265,15 @@ __global__ __launch_bounds__(kPostThreads) void k_postprocess(const float *__res
             base++;
         }
     }
-    if (threadIdx.x == 0) n_keep[b] = total;
+    if (threadIdx.x == 0) *n_keep_b = total;
+}
+
+__global__ __launch_bounds__(kPostThreads) void k_postprocess(const float *__restrict__ pred, int A, int Apad, int ncls,
+                                                       float conf_thr, float nms_thr, float class_offset,
+                                                       float *__restrict__ det, int32_t *__restrict__ n_keep) {
+    const int b = blockIdx.x;
+    postprocess_image(pred + (size_t)b * A * (5 + ncls), A, Apad, ncls, conf_thr, nms_thr, class_offset,
+                      det + (size_t)b * A * 6, n_keep + b);
 }
 // collect_outputs + decode_outputs of the eval head (model/networks/dagr.py:283-312) for up to two scales in one launch:
 // dense maps [B, 5+C, Hs, Ws] (reg 4 | obj 1 | cls C, raw logits) -> out[B, A, 5+C] with A = sum Hs*Ws, anchors of a scale
@@ -308,31 +315,47 @@ struct HeadScale {
     float *dense;                           // optional [B, 5 + C, Hc, Wc]: the (fused) logit maps
 };
 
-__global__ __launch_bounds__(1024) void k_heads_finish(HeadScale h0, HeadScale h1, int n_scales, int B, int CH,
-                                                      float *__restrict__ out, int32_t *__restrict__ status) {
+// One workgroup PER IMAGE (round 6; until then one workgroup walked all B images: 21.8 us at B = 8 against 6 at B = 1): the
+// image's winner table in LDS (every workgroup scans the -- few hundred -- head nodes and keeps its own image's), its A x CH
+// outputs decoded, and -- `post.det` given -- the image's post-processing (model/utils.py:61-110: confidence mask +
+// class-offset NMS, postprocess_image above) right behind, on the rows the workgroup has just written: the window's last
+// two launches are one, and the B images finish side by side.
+struct PostArgs {
+    float *det;            // [B, A, 6] or NULL (decode only)
+    int32_t *n_keep;       // [B]
+    int ncls, Apad;
+    float conf_thr, nms_thr, class_offset;
+};
+__global__ __launch_bounds__(kPostThreads) void k_heads_finish(HeadScale h0, HeadScale h1, int n_scales, int B, int CH,
+                                                              float *__restrict__ out, int32_t *__restrict__ status,
+                                                              PostArgs post) {
     extern __shared__ int winner[];
+    const int b = blockIdx.x;
     const int A0 = h0.Hc * h0.Wc, A1 = n_scales > 1 ? h1.Hc * h1.Wc : 0, A = A0 + A1;
-    for (int i = threadIdx.x; i < B * A; i += blockDim.x) winner[i] = -1;
+    for (int i = threadIdx.x; i < A; i += blockDim.x) winner[i] = -1;
     __syncthreads();
     for (int s = 0; s < n_scales; s++) {
         const HeadScale &h = s == 0 ? h0 : h1;
-        int32_t *w = winner + (s == 0 ? 0 : B * A0);
+        int32_t *w = winner + (s == 0 ? 0 : A0);
         const int n_nodes = h.n_ptr ? min(*h.n_ptr, h.n_max) : h.n_max;
         for (int n = threadIdx.x; n < n_nodes; n += blockDim.x) {
-            const int cx = (int)(h.pos[3 * n] / h.vx), cy = (int)(h.pos[3 * n + 1] / h.vy), b = h.batch[n];
-            if (cx < 0 || cx >= h.Wc || cy < 0 || cy >= h.Hc || b < 0 || b >= B) { atomicOr(status, 1); continue; }
-            atomicMax(&w[(b * h.Hc + cy) * h.Wc + cx], n);
+            const int cx = (int)(h.pos[3 * n] / h.vx), cy = (int)(h.pos[3 * n + 1] / h.vy), nb = h.batch[n];
+            if (cx < 0 || cx >= h.Wc || cy < 0 || cy >= h.Hc || nb < 0 || nb >= B) {
+                if (b == 0) atomicOr(status, 1);
+                continue;
+            }
+            if (nb == b) atomicMax(&w[cy * h.Wc + cx], n);
         }
     }
     __syncthreads();
-    const int total = B * A * CH;
-    for (int i = threadIdx.x; i < total; i += blockDim.x) {
-        const int ch = i % CH, a = (i / CH) % A, b = i / (CH * A);
+    float *out_b = out + (size_t)b * A * CH;
+    for (int i = threadIdx.x; i < A * CH; i += blockDim.x) {
+        const int ch = i % CH, a = i / CH;
         const bool first = a < A0;
         const HeadScale &h = first ? h0 : h1;
         const int cell = first ? a : a - A0;
         const int HW = first ? A0 : A1;
-        const int n = (first ? winner : winner + B * A0)[b * HW + cell];
+        const int n = winner[a];
         float v = n >= 0 ? h.pred[(size_t)n * h.ld + ch] : 0.0f;
         const int k = ch < 4 ? 0 : (ch == 4 ? 1 : 2);
         if (h.cnn[k]) {
@@ -345,7 +368,12 @@ __global__ __launch_bounds__(1024) void k_heads_finish(HeadScale h0, HeadScale h
         if (ch < 2) r = (v + (float)(ch == 0 ? cell % h.Wc : cell / h.Wc)) * h.stride;
         else if (ch < 4) r = expf(v) * h.stride;
         else r = 1.0f / (1.0f + expf(-v));
-        out[i] = r;
+        out_b[i] = r;
+    }
+    if (post.det) {
+        __syncthreads();         // this workgroup wrote the rows it now reads
+        postprocess_image(out_b, A, post.Apad, post.ncls, post.conf_thr, post.nms_thr, post.class_offset,
+                          post.det + (size_t)b * A * 6, post.n_keep + b);
     }
 }
 }  // namespace
@@ -353,8 +381,8 @@ __global__ __launch_bounds__(1024) void k_heads_finish(HeadScale h0, HeadScale h
 
 using namespace dagr;
 
-extern "C" int dagr_heads_finish(const dagr_head_scale *scale0, const dagr_head_scale *scale1, int32_t batch_size,
-                                 int32_t channels, float *out, int32_t *status, void *stream) {
+static int launch_heads_finish(const dagr_head_scale *scale0, const dagr_head_scale *scale1, int32_t batch_size,
+                               int32_t channels, float *out, int32_t *status, const PostArgs &post_in, void *stream) {
     DAGR_CHECK_ARG(scale0 && out && status && batch_size > 0 && channels >= 5, "bad arguments");
     HeadScale h[2] = {};
     const dagr_head_scale *in[2] = {scale0, scale1};
@@ -372,11 +400,33 @@ extern "C" int dagr_heads_finish(const dagr_head_scale *scale0, const dagr_head_
         }
         cells += d.Hc * d.Wc;
     }
-    const size_t lds = (size_t)batch_size * cells * 4;
-    DAGR_CHECK_ARG(lds <= 64 * 1024, "head maps too large for the one-workgroup finish kernel");
-    k_heads_finish<<<1, 1024, lds, (hipStream_t)stream>>>(h[0], h[1], scale1 ? 2 : 1, batch_size, channels, out, status);
+    const size_t lds = (size_t)cells * 4;
+    DAGR_CHECK_ARG(lds <= 16 * 1024, "head maps too large for the per-image finish kernel");
+    PostArgs post = post_in;
+    if (post.det) {
+        DAGR_CHECK_ARG(cells <= kMaxAnchors && post.n_keep && post.ncls == channels - 5, "bad post-processing arguments");
+        post.Apad = 1;
+        while (post.Apad < cells) post.Apad <<= 1;
+    }
+    k_heads_finish<<<(unsigned)batch_size, kPostThreads, lds, (hipStream_t)stream>>>(h[0], h[1], scale1 ? 2 : 1, batch_size,
+                                                                                    channels, out, status, post);
     DAGR_CHECK_LAUNCH();
     return DAGR_OK;
+}
+
+extern "C" int dagr_heads_finish(const dagr_head_scale *scale0, const dagr_head_scale *scale1, int32_t batch_size,
+                                 int32_t channels, float *out, int32_t *status, void *stream) {
+    return launch_heads_finish(scale0, scale1, batch_size, channels, out, status, PostArgs{}, stream);
+}
+
+extern "C" int dagr_heads_finish_detect(const dagr_head_scale *scale0, const dagr_head_scale *scale1, int32_t batch_size,
+                                        int32_t channels, float *out, int32_t *status, float conf_threshold,
+                                        float iou_threshold, float class_offset, float *det, int32_t *n_keep, void *stream) {
+    DAGR_CHECK_ARG(det && n_keep, "NULL detection buffers");
+    PostArgs post{};
+    post.det = det; post.n_keep = n_keep; post.ncls = channels - 5;
+    post.conf_thr = conf_threshold; post.nms_thr = iou_threshold; post.class_offset = class_offset;
+    return launch_heads_finish(scale0, scale1, batch_size, channels, out, status, post, stream);
 }
 
 extern "C" int dagr_nms_batched(const float *boxes, const float *scores, const int32_t *cls, const uint8_t *valid,

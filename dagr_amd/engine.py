@@ -342,6 +342,7 @@ class WindowEngine:
         # with, its static outputs, and whether the last forward ran it
         self._post_key = None
         self._det = self._n_keep = None
+        self._wg_post = self._graph_post = (None, None)
         self._post_fresh = False
         self._cnn_ready = None
         # captured --use_image windows: graph levels start when THEIR feature map exists (builder knob to A/B)
@@ -1180,8 +1181,21 @@ class WindowEngine:
         A = sum(int(h) * int(w) for h, w in self.out_sizes)
         CH = 5 + self.num_classes
         out = torch.empty((self.B, A, CH), dtype=torch.float32, device=self.device)
-        _lib.check(self.L.dagr_heads_finish(ctypes.byref(scales[0]), ctypes.byref(scales[1]) if len(scales) > 1 else None,
-                                            self.B, CH, P(out), P(self.status), _lib.cur_stream(self.device)), "heads_finish")
+        s0, s1 = ctypes.byref(scales[0]), ctypes.byref(scales[1]) if len(scales) > 1 else None
+        if self._post_key is not None:
+            # a caller wants detections (forward_detections): every image's post-processing runs inside the same launch,
+            # right behind its decode (dagr_heads_finish_detect) -- fresh buffers per call (inside a capture they belong
+            # to the graph and are remembered with it)
+            self._det = torch.empty((self.B, A, 6), dtype=torch.float32, device=self.device)
+            self._n_keep = torch.empty((self.B,), dtype=torch.int32, device=self.device)
+            conf, nms = self._post_key
+            _lib.check(self.L.dagr_heads_finish_detect(s0, s1, self.B, CH, P(out), P(self.status), conf, nms,
+                                                       float(max(self.W, self.H) + 1), P(self._det), P(self._n_keep),
+                                                       _lib.cur_stream(self.device)), "heads_finish_detect")
+            self._post_fresh = True
+        else:
+            _lib.check(self.L.dagr_heads_finish(s0, s1, self.B, CH, P(out), P(self.status), _lib.cur_stream(self.device)),
+                       "heads_finish")
         self._fused_dense = [hb["dense"] for hb in self.head_buf]
         return out
 
@@ -1232,15 +1246,14 @@ class WindowEngine:
         return self._heads_finish()
 
     def _post_launch(self, out):
-        """``postprocess_network_output`` (model/utils.py:61-110; dagr.py:94-95) of the decoded outputs as the LAST launch of
-        a captured window / tail: det[B, A, 6] + n_keep[B] in static buffers.  Only when a caller asked for detections
-        (forward_detections): raw-output callers do not pay for it."""
-        if self._post_key is None:
+        """``postprocess_network_output`` (model/utils.py:61-110; dagr.py:94-95) of the decoded outputs for the paths that do
+        not end in ``_heads_finish`` (``--no_events``: the image branch's own maps); everywhere else the heads' launch has
+        already run it (dagr_heads_finish_detect).  Only when a caller asked for detections (forward_detections)."""
+        if self._post_key is None or self._post_fresh:     # (nobody asked / the heads' own launch already did it)
             return
         B, A, C = out.shape
-        if self._det is None or tuple(self._det.shape) != (B, A, 6):
-            self._det = torch.empty((B, A, 6), dtype=torch.float32, device=self.device)
-            self._n_keep = torch.empty((B,), dtype=torch.int32, device=self.device)
+        self._det = torch.empty((B, A, 6), dtype=torch.float32, device=self.device)
+        self._n_keep = torch.empty((B,), dtype=torch.int32, device=self.device)
         conf, nms = self._post_key
         _lib.check(self.L.dagr_postprocess(_lib.ptr(out), B, A, int(self.num_classes), conf, nms,
                                            float(max(self.W, self.H) + 1), _lib.ptr(self._det), _lib.ptr(self._n_keep),
@@ -1399,11 +1412,12 @@ class WindowEngine:
                 g = torch.cuda.CUDAGraph()
                 with _capture(g):
                     out = self._forward_static()
-                self._wg, self._wg_out = g, out
+                self._wg, self._wg_out, self._wg_post = g, out, (self._det, self._n_keep)
                 g.replay()
         else:
             self._wg.replay()
             out = self._wg_out
+            self._det, self._n_keep = self._wg_post
             self._post_fresh = self._post_key is not None
         # the resident window (what check_status / an asynchronous update / the probes look at): the actual count
         self._N = N
@@ -1429,8 +1443,9 @@ class WindowEngine:
             with _capture(g):
                 out = self._tail_and_head()
                 self._post_launch(out)
-            self._graph, self._graph_out = g, out
+            self._graph, self._graph_out, self._graph_post = g, out, (self._det, self._n_keep)
         self._graph.replay()
+        self._det, self._n_keep = self._graph_post
         self._post_fresh = self._post_key is not None
         return self._graph_out if static_out else self._graph_out.clone()   # rewritten by the next window
 

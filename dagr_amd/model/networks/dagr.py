@@ -355,8 +355,8 @@ class DAGR(torch.nn.Module):
         det_dev = None           # (det, n_keep) when forward + post-processing ran as one captured graph
         if reset or self._window is None:
             # a window of its own (every evaluation script's call), or the first call of an asynchronous run
-            if filtering and eng.window_graph:
-                det_dev = eng.forward_detections_data(x)
+            if filtering:
+                det_dev = eng.forward_detections_data(x)     # every image's post-processing inside the heads' last launch
             else:
                 outputs = eng.forward_data(x, static_out=filtering)  # post-processed below, before the next window
             # only remembered: a later reset=False call continues from it.  A running window keeps the FRAME of the call
@@ -371,7 +371,7 @@ class DAGR(torch.nn.Module):
             # far -- the guarantee the reference's asynchronous model gives for its update (evaluate_flops.py:139-147).
             batch = x.batch if getattr(x, "batch", None) is not None else \
                 torch.zeros(x.pos.shape[0], dtype=torch.int64, device=x.pos.device)
-            if filtering and eng.tail_graph:
+            if filtering:
                 det_dev = eng.forward_detections(x.pos, x.x, batch, append=True)
             else:
                 outputs = eng.forward_append(x.pos, x.x, batch, static_out=filtering)

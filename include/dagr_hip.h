@@ -543,6 +543,12 @@ typedef struct dagr_head_scale {
 } dagr_head_scale;
 int dagr_heads_finish(const dagr_head_scale *scale0, const dagr_head_scale *scale1, int32_t batch_size, int32_t channels,
                       float *out, int32_t *status, void *stream);
+/* The same launch followed, inside it, by dagr_postprocess of every image (model/utils.py:61-110; dagr.py:94-95: the eval
+ * forward post-processes its decoded outputs at once): one workgroup per image decodes the image's rows and runs its
+ * confidence mask + class-offset NMS on them.  det[B, A, 6] / n_keep[B] as dagr_postprocess; `out` is still written. */
+int dagr_heads_finish_detect(const dagr_head_scale *scale0, const dagr_head_scale *scale1, int32_t batch_size,
+                             int32_t channels, float *out, int32_t *status, float conf_threshold, float iou_threshold,
+                             float class_offset, float *det, int32_t *n_keep, void *stream);
 /* collect_outputs + decode_outputs of the eval head (model/networks/dagr.py:283-312; grid/stride cache of
  * model/utils.py:119-134) for one or two scales in one launch: dense logit maps [B, channels = 5+C, Hs, Ws] (reg | obj |
  * cls) -> out[B, A, channels], A = H0*W0 (+ H1*W1), xy = (logit + cell) * stride, wh = exp(logit) * stride, the rest

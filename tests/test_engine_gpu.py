@@ -662,8 +662,19 @@ def test_detections_come_out_of_the_captured_window():
         assert torch.equal(nk, ref[k][1])
         for b in range(B):
             assert torch.equal(det[b, :int(nk[b])], ref[k][0][b, :int(nk[b])])
-    # DAGR.forward takes the same path: its dicts == the launch-by-launch dicts
     eng.check_status()
+    # throughput mode (no captured graphs): the heads' last launch post-processes every image all the same
+    from dagr_amd.engine import WindowEngine
+    eng2 = WindowEngine(model).set_low_latency(False)
+    assert not eng2.window_graph and not eng2.tail_graph
+    for k, w in enumerate(wins):
+        o = eng2.forward_raw(*w).clone()
+        want_det, want_nk = postprocess_device(o, eng2.num_classes, 0.001, 0.65, H, W)
+        det, nk = eng2.forward_detections(*w)
+        assert torch.equal(nk, want_nk)
+        for b in range(B):
+            assert torch.equal(det[b, :int(nk[b])], want_det[b, :int(nk[b])])
+        assert torch.equal(eng2.forward_raw(*w), o)            # the decoded outputs are written as before
 
 
 def test_window_graph_with_the_image_branch():
