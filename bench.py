@@ -105,12 +105,12 @@ def launch_ranks(a):
     return subprocess.call(cmd)
 
 
-def make_model(W, H, B, use_image=False, img_net="resnet50", name="dagr-s"):
+def make_model(W, H, B, use_image=False, img_net="resnet50", name="dagr-s", **over):
     from dagr_amd.utils.args import model_args   # config/dagr-s-dsec.yaml values (pinned to the reference's FLAGS())
     from dagr_amd.model.networks.dagr import DAGR
     from dagr_amd.utils.testing_weights import randomize_
     torch.manual_seed(0)
-    args = model_args(name, batch_size=B, use_image=use_image, img_net=img_net)
+    args = model_args(name, batch_size=B, use_image=use_image, img_net=img_net, **over)   # (`over`: probes of other YAML keys)
     model = randomize_(DAGR(args, height=H, width=W)).eval()
     return args, model
 
@@ -259,10 +259,10 @@ class DryRunRig:
 class Rig:
     """One model on the device + its engines / streams + resident synthetic slots."""
 
-    def __init__(self, W, H, B, use_image, img_net, n_eng, dev, low_latency=False, model_name="dagr-s"):
+    def __init__(self, W, H, B, use_image, img_net, n_eng, dev, low_latency=False, model_name="dagr-s", **over):
         from dagr_amd.engine import WindowEngine
         self.W, self.H, self.B, self.use_image, self.dev = W, H, B, use_image, dev
-        self.args, model = make_model(W, H, B, use_image=use_image, img_net=img_net, name=model_name)
+        self.args, model = make_model(W, H, B, use_image=use_image, img_net=img_net, name=model_name, **over)
         self.sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()}
         self.model = model.to(dev)
         self.model.cache_luts(width=W, height=H, radius=self.args.radius)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """tools/config_probe.py -- throughput of the other BASELINE.json configurations through bench.py's rig (three engines on
 three streams, detections on the device, inputs resident): events/s and ms per step of B windows.  Builder tool.
-usage: python tools/config_probe.py [model:use_image:stream:B:N ...]   (default: config 4 = dagr-l:1:uniform:8:100000)"""
+usage: python tools/config_probe.py [model:use_image:stream:B:N[:max_neighbors] ...]   (default: config 4 =
+dagr-l:1:uniform:8:100000; a sixth field sets the YAML key max_neighbors -- != 16 takes the generic level-0 kernel)"""
 import json
 import os
 import sys
@@ -18,9 +19,10 @@ torch.cuda.set_device(0)
 STEPS, WARM = int(os.environ.get("PROBE_STEPS", "30")), 8
 with torch.no_grad():
     for spec in (sys.argv[1:] or ["dagr-l:1:uniform:8:100000"]):
-        name, img, stream, B, N = spec.split(":")
+        name, img, stream, B, N, *rest = spec.split(":")
         B, N, img = int(B), int(N), img == "1"
-        rig = bench.Rig(640, 480, B, img, "resnet50", 3, dev, model_name=name)
+        over = dict(max_neighbors=int(rest[0])) if rest else {}
+        rig = bench.Rig(640, 480, B, img, "resnet50", 3, dev, model_name=name, **over)
         slots = rig.make_slots(syn.uniform_window if stream == "uniform" else syn.edges_window, N, 3, seed=4234)
         for i in range(WARM):
             rig.step(i, slots)
