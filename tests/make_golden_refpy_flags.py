@@ -11,7 +11,6 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, "/root/reference/src")
 
 # script -> argv as the readme gives it ("config/..." is relative to the reference's root there, to this repo's root here)
 README_LINES = {
@@ -36,6 +35,7 @@ README_LINES = {
 
 
 def main():
+    sys.path.insert(0, "/root/reference/src")             # (only here: importing this file for README_LINES must not shadow `dagr`)
     import dagr.utils.args as rargs                       # the reference's module
     out = {}
     argv0, cwd0 = list(sys.argv), os.getcwd()
